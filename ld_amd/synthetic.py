@@ -1,0 +1,203 @@
+"""Deterministic synthetic inputs for the LD train step.
+
+There is no dataset and no checkpoint on the GPU box, so the bench, the smoke
+test and the parity fixtures all use:
+
+* images: ``randn`` (normalised-image statistics), columns past ``img_shape``
+  zero-filled exactly as ``Pad(size_divisor=32)`` would
+  (reference: mmdet/datasets/pipelines/transforms.py:481-509);
+* GT boxes: centre uniform in the image, ``w, h = exp(U(log 16, log 600))``
+  clipped to the image, non-integer xyxy fp32 (avoids ATSS distance ties),
+  labels ``randint(0, 80)``;
+* weights: :func:`seeded_state_dict` -- every tensor of a ``state_dict`` is
+  filled from a CPU ``torch.Generator`` whose seed is derived from the *key
+  name*, so the reference model (under ``oracle/ref_shim``) and the HIP model
+  receive bit-identical parameters as long as their key names agree (which is
+  itself part of the drop-in contract, SURVEY.md section 5 "checkpoint").
+
+Everything is generated on the CPU generator (bit-reproducible across
+machines for one torch build) and moved to the device afterwards.
+"""
+import math
+import zlib
+from collections import OrderedDict
+
+import torch
+
+__all__ = ['synthetic_batch', 'seeded_state_dict', 'synthetic_head_inputs']
+
+
+def _gen(seed):
+    g = torch.Generator(device='cpu')
+    g.manual_seed(int(seed))
+    return g
+
+
+def synthetic_boxes(num_gt, img_h, img_w, gen, min_size=16.0, max_size=600.0):
+    """(num_gt, 4) xyxy fp32 boxes, (num_gt,) int64 labels."""
+    cx = torch.rand(num_gt, generator=gen) * img_w
+    cy = torch.rand(num_gt, generator=gen) * img_h
+    lo, hi = math.log(min_size), math.log(max_size)
+    w = torch.exp(torch.rand(num_gt, generator=gen) * (hi - lo) + lo)
+    h = torch.exp(torch.rand(num_gt, generator=gen) * (hi - lo) + lo)
+    x1 = (cx - w / 2).clamp(0.0, img_w - 2.0)
+    y1 = (cy - h / 2).clamp(0.0, img_h - 2.0)
+    x2 = torch.maximum((cx + w / 2).clamp(0.0, float(img_w)), x1 + 1.7)
+    y2 = torch.maximum((cy + h / 2).clamp(0.0, float(img_h)), y1 + 1.3)
+    boxes = torch.stack([x1, y1, x2, y2], dim=1).float()
+    # knock the coordinates off any integer/half-integer lattice
+    boxes = boxes + torch.rand(num_gt, 4, generator=gen) * 0.37 + 0.011
+    labels = torch.randint(0, 80, (num_gt, ), generator=gen)
+    return boxes.contiguous(), labels
+
+
+def synthetic_batch(num_imgs=2,
+                    img_shape=(800, 1333),
+                    pad_shape=(800, 1344),
+                    num_gt=7,
+                    seed=1234,
+                    device='cpu'):
+    """One LD training batch in the mmdet batch contract
+    (reference: mmdet/models/detectors/kd_one_stage.py:46-65).
+
+    ``num_gt`` may be an int or a per-image list.
+    """
+    gen = _gen(seed)
+    h, w = img_shape
+    hp, wp = pad_shape
+    img = torch.zeros(num_imgs, 3, hp, wp)
+    img[:, :, :h, :w] = torch.randn(num_imgs, 3, h, w, generator=gen)
+    if isinstance(num_gt, int):
+        num_gt = [num_gt] * num_imgs
+    gt_bboxes, gt_labels = [], []
+    for g in num_gt:
+        b, l = synthetic_boxes(g, h, w, gen)
+        gt_bboxes.append(b.to(device))
+        gt_labels.append(l.to(device))
+    img_metas = [
+        dict(
+            img_shape=(h, w, 3),
+            pad_shape=(hp, wp, 3),
+            ori_shape=(h, w, 3),
+            scale_factor=1.0,
+            flip=False) for _ in range(num_imgs)
+    ]
+    return dict(
+        img=img.to(device),
+        img_metas=img_metas,
+        gt_bboxes=gt_bboxes,
+        gt_labels=gt_labels)
+
+
+def _key_seed(key, seed):
+    return (zlib.crc32(key.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF
+
+
+def seeded_state_dict(reference_sd, seed=0, reg_std=0.05, cls_std=0.02):
+    """Fill every entry of ``reference_sd`` (name -> tensor, used for shape and
+    dtype only) with deterministic values keyed on the entry's *name*.
+
+    The value distributions keep activations of a randomly initialised
+    ResNet-FPN-GFL stack well conditioned (no overflow, non-degenerate
+    softmaxes) so fp32 parity thresholds stay meaningful.
+    """
+    out = OrderedDict()
+    for key, ref in reference_sd.items():
+        g = _gen(_key_seed(key, seed))
+        shape = tuple(ref.shape)
+        leaf = key.rsplit('.', 1)[-1]
+        parent = key.rsplit('.', 2)[-2] if key.count('.') >= 1 else ''
+        if leaf == 'num_batches_tracked':
+            v = torch.zeros(shape, dtype=ref.dtype)
+        elif leaf == 'running_mean':
+            v = torch.rand(shape, generator=g) * 0.2 - 0.1
+        elif leaf == 'running_var':
+            v = torch.rand(shape, generator=g) * 0.4 + 0.8
+        elif leaf == 'project':  # Integral buffer, gfl_head.py:29-30
+            v = torch.linspace(0, shape[0] - 1, shape[0])
+        elif leaf == 'scale':  # mmcv Scale
+            v = torch.rand(shape, generator=g) * 0.4 + 0.8
+        elif len(shape) == 4:  # conv weight
+            fan_in = shape[1] * shape[2] * shape[3]
+            if parent == 'gfl_cls':
+                std = cls_std
+            elif parent in ('gfl_reg', 'reg_conf'):
+                std = reg_std
+            elif 'lateral_convs' in key:
+                std = 0.5 * math.sqrt(1.0 / fan_in)
+            elif 'fpn_convs' in key:
+                std = math.sqrt(1.0 / fan_in)
+            else:
+                std = math.sqrt(2.0 / fan_in)
+            v = torch.randn(shape, generator=g) * std
+        elif leaf == 'weight':  # norm affine
+            block = key.rsplit('.', 2)[0]
+            last = 'bn3' if block + '.bn3.weight' in reference_sd else 'bn2'
+            is_last_bn = ('.layer' in key and parent == last) or \
+                key.endswith('downsample.1.weight')
+            if is_last_bn:
+                v = torch.rand(shape, generator=g) * 0.2 + 0.2
+            else:
+                v = torch.rand(shape, generator=g) * 0.4 + 0.8
+        elif leaf == 'bias':
+            if parent == 'gfl_cls':
+                v = torch.rand(shape, generator=g) * 0.5 - 3.5
+            else:
+                v = torch.rand(shape, generator=g) * 0.2 - 0.1
+        else:
+            v = torch.randn(shape, generator=g) * 0.1
+        out[key] = v.to(ref.dtype).reshape(shape)
+    return out
+
+
+def level_shapes(pad_shape, strides=(8, 16, 32, 64, 128)):
+    """Feature-map sizes of FPN P3..P7 for a padded input. P3..P5 follow the
+    ResNet stride-2 convs (ceil for even pads), P6/P7 the 3x3 s2 pad-1 extra
+    convs (reference: mmdet/models/necks/fpn.py:129-160)."""
+    hp, wp = pad_shape
+
+    def down(x):  # 3x3 stride 2 pad 1  ==  ceil(x / 2)
+        return (x + 1) // 2
+
+    h, w = hp, wp
+    sizes = []
+    for i in range(7):
+        h, w = down(h), down(w)
+        if i >= 2:
+            sizes.append((h, w))
+    assert len(sizes) == len(strides)
+    return sizes
+
+
+def synthetic_head_inputs(num_imgs,
+                          featmap_sizes,
+                          seed=0,
+                          num_classes=80,
+                          reg_max=16,
+                          feat_channels=256,
+                          device='cpu'):
+    """Random student/teacher head outputs and FPN features for loss-block
+    parity tests: logits ~ 3*randn (reg), cls ~ 1.2*randn - 4, features ~ randn.
+
+    Returns dict of lists (one tensor per level, NCHW).
+    """
+    gen = _gen(seed)
+    out = dict(cls=[], reg=[], t_cls=[], t_reg=[], x=[], t_x=[])
+    for (h, w) in featmap_sizes:
+        out['cls'].append(
+            torch.randn(num_imgs, num_classes, h, w, generator=gen) * 1.2 -
+            4.0)
+        out['reg'].append(
+            torch.randn(num_imgs, 4 * (reg_max + 1), h, w, generator=gen) *
+            3.0)
+        out['t_cls'].append(
+            torch.randn(num_imgs, num_classes, h, w, generator=gen) * 1.2 -
+            4.0)
+        out['t_reg'].append(
+            torch.randn(num_imgs, 4 * (reg_max + 1), h, w, generator=gen) *
+            3.0)
+        out['x'].append(
+            torch.randn(num_imgs, feat_channels, h, w, generator=gen))
+        out['t_x'].append(
+            torch.randn(num_imgs, feat_channels, h, w, generator=gen))
+    return {k: [t.to(device) for t in v] for k, v in out.items()}

@@ -1,0 +1,500 @@
+"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.npz by EXECUTING THE
+REFERENCE CODE at /root/reference (unmodified, imported through
+oracle/ref_shim.py) on CPU in fp32.  Run from the repo root in the build
+container:
+
+    python oracle/gen_golden.py [--only kat,anchors,targets,lossblock,e2e]
+
+The fixtures it writes are committed; the GPU box has no /root/reference and
+only ever reads the .npz files.  Inputs that can be regenerated from a seed
+(`ld_amd.synthetic`) are NOT stored, only the seeds and the reference outputs.
+
+Reference entry points exercised (file:line under /root/reference):
+  mmdet/models/losses/kd_loss.py:10-88          KnowledgeDistillationKLDivLoss
+  mmdet/models/losses/gfocal_loss.py:8-179      QFL / DFL
+  mmdet/models/losses/iou_loss.py:85-102,325-360 GIoULoss
+  mmdet/models/dense_heads/gfl_head.py:15-44    Integral
+  mmdet/core/bbox/iou_calculators/iou2d_calculator.py:43-188 bbox_overlaps
+  mmdet/core/anchor/anchor_generator.py:9-346   AnchorGenerator
+  mmdet/core/bbox/assigners/atss_assigner.py:33-298 assign / get_vlr_region
+  mmdet/models/dense_heads/ld_head.py:116-611   LDHead.loss / get_targets
+  mmdet/models/detectors/kd_one_stage.py:46-81  forward_train
+  mmdet/models/detectors/base.py:185-218        _parse_losses
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+
+from ld_amd import synthetic  # noqa: E402
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+LOSS_KEYS = [
+    'loss_cls', 'loss_bbox', 'loss_dfl', 'loss_ld', 'loss_ld_vlr', 'loss_kd',
+    'loss_kd_neg', 'loss_im'
+]
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ---------------------------------------------------------------- KATs ----
+def gen_kat():
+    from mmdet.core.bbox.iou_calculators import bbox_overlaps
+    from mmdet.core.bbox.transforms import bbox2distance, distance2bbox
+    from mmdet.models.dense_heads.gfl_head import Integral
+    from mmdet.models.losses import (DistributionFocalLoss, GIoULoss,
+                                     KnowledgeDistillationKLDivLoss,
+                                     QualityFocalLoss)
+    from mmdet.models.losses.kd_loss import IMLoss
+    d = {}
+    i = torch.arange(4, dtype=torch.float32)[:, None]
+    j = torch.arange(17, dtype=torch.float32)[None, :]
+    pred = (3 * torch.sin(0.37 * i + 0.11 * j)).requires_grad_(True)
+    soft = 3 * torch.cos(0.23 * i + 0.19 * j)
+    w = torch.tensor([1, .5, .25, 2.])
+    d['kl_pred'], d['kl_soft'], d['kl_w'] = _np(pred), _np(soft), _np(w)
+    # KAT1: LD KL, T=10, lw .25
+    kl = KnowledgeDistillationKLDivLoss(loss_weight=0.25, T=10)
+    d['kat1_none'] = _np(kl(pred, soft, reduction_override='none'))
+    l = kl(pred, soft, weight=w, avg_factor=4.0)
+    d['kat1_mean'] = _np(l)
+    g, = torch.autograd.grad(l, pred)
+    d['kat1_grad'] = _np(g)
+    # KAT1b: KD T=2 lw 10
+    kd = KnowledgeDistillationKLDivLoss(loss_weight=10, T=2)
+    l = kd(pred, soft, weight=torch.ones(4), avg_factor=4)
+    d['kat1b_mean'] = _np(l)
+    d['kat1b_grad'] = _np(torch.autograd.grad(l, pred)[0])
+    # KAT2: DFL
+    dfl = DistributionFocalLoss(loss_weight=0.25)
+    lab = torch.tensor([0, 3.25, 15.9, 7.5])
+    d['dfl_label'] = _np(lab)
+    d['kat2_none'] = _np(dfl(pred, lab, reduction_override='none'))
+    l = dfl(pred, lab, weight=w, avg_factor=4.0)
+    d['kat2_mean'] = _np(l)
+    d['kat2_grad'] = _np(torch.autograd.grad(l, pred)[0])
+    # KAT3: Integral
+    integ = Integral(16)
+    e = integ(pred.reshape(1, 68))
+    d['kat3_integral'] = _np(e)
+    d['kat3_grad'] = _np(
+        torch.autograd.grad((e * torch.tensor([1., 2., 3., 4.])).sum(),
+                            pred)[0])
+    # KAT4: QFL
+    cp = (2 * torch.sin(0.5 * torch.arange(6.)[:, None] +
+                        0.3 * torch.arange(5.)[None, :])).requires_grad_(True)
+    labels = torch.tensor([0, 5, 2, 5, 4, 5])
+    score = torch.tensor([.7, 0, .3, 0, .9, 0])
+    d['qfl_pred'], d['qfl_labels'], d['qfl_score'] = _np(cp), _np(
+        labels), _np(score)
+    qfl = QualityFocalLoss(use_sigmoid=True, beta=2.0, loss_weight=1.0)
+    d['kat4_none'] = _np(qfl(cp, (labels, score), reduction_override='none'))
+    l = qfl(cp, (labels, score), weight=torch.ones(6), avg_factor=2.5)
+    d['kat4_mean'] = _np(l)
+    d['kat4_grad'] = _np(torch.autograd.grad(l, cp)[0])
+    # KAT5: GIoU
+    b1 = torch.tensor([[10., 10, 30, 40], [5, 5, 15, 25],
+                       [0, 0, 8, 8]]).requires_grad_(True)
+    b2 = torch.tensor([[12., 8, 28, 36], [10, 10, 20, 20], [20, 20, 30, 30]])
+    gw = torch.tensor([.5, .2, .9])
+    d['giou_b1'], d['giou_b2'], d['giou_w'] = _np(b1), _np(b2), _np(gw)
+    giou = GIoULoss(loss_weight=2.0)
+    d['kat5_none'] = _np(giou(b1, b2, reduction_override='none'))
+    l = giou(b1, b2, weight=gw, avg_factor=1.0)
+    d['kat5_mean'] = _np(l)
+    d['kat5_grad'] = _np(torch.autograd.grad(l, b1)[0])
+    # KAT6: IoU aligned, pairwise iou / iof / giou / diou
+    d['kat6_iou_aligned'] = _np(bbox_overlaps(b1, b2, is_aligned=True))
+    for mode in ('iou', 'iof', 'giou', 'diou'):
+        d['kat6_pair_' + mode] = _np(bbox_overlaps(b1, b2, mode=mode))
+    # distance2bbox / bbox2distance
+    pts = torch.tensor([[10.5, 20.25], [3., 4.]])
+    dist = torch.tensor([[1.5, 2.5, 3.5, 4.5], [0.1, 20., 7.7, 0.]])
+    d['d2b_points'], d['d2b_dist'] = _np(pts), _np(dist)
+    bx = distance2bbox(pts, dist)
+    d['d2b_out'] = _np(bx)
+    d['b2d_out'] = _np(bbox2distance(pts, bx, max_dis=16))
+    # IMLoss
+    g = torch.Generator().manual_seed(3)
+    xa = torch.randn(7, 256, generator=g).requires_grad_(True)
+    xb = torch.randn(7, 256, generator=g)
+    im = IMLoss(loss_weight=2.0)
+    l = im(xa, xb)
+    d['im_a'], d['im_b'], d['im_loss'] = _np(xa), _np(xb), _np(l)
+    d['im_grad'] = _np(torch.autograd.grad(l, xa)[0])
+    # weighted_loss doctest semantics (losses/utils.py:68-85)
+    np.savez_compressed(os.path.join(OUT, 'kat_losses.npz'), **d)
+    print('kat_losses.npz', len(d), 'arrays')
+
+
+# -------------------------------------------------------------- anchors ----
+def _anchor_generator():
+    from mmdet.core.anchor import build_anchor_generator
+    return build_anchor_generator(
+        dict(
+            type='AnchorGenerator',
+            ratios=[1.0],
+            octave_base_scale=8,
+            scales_per_octave=1,
+            strides=[8, 16, 32, 64, 128]))
+
+
+def gen_anchors():
+    ag = _anchor_generator()
+    d = {}
+    d['base_anchors'] = np.stack([_np(b) for b in ag.base_anchors])
+    for name, sizes, pad in [
+        ('kat7', [(8, 8), (4, 4), (2, 2), (1, 1), (1, 1)], (64, 64)),
+        ('small', synthetic.level_shapes((160, 224)), (160, 224)),
+        ('c1', synthetic.level_shapes((800, 800)), (800, 800)),
+        ('c2', synthetic.level_shapes((800, 1344)), (800, 1344)),
+    ]:
+        anchors = ag.grid_anchors(sizes, device='cpu')
+        flat = torch.cat(anchors)
+        d[name + '_sizes'] = np.array(sizes)
+        if flat.shape[0] < 2000:
+            d[name + '_anchors'] = _np(flat)
+        else:  # big grids: store strided samples + a float64 checksum
+            idx = np.arange(0, flat.shape[0], 97)
+            d[name + '_anchor_idx'] = idx
+            d[name + '_anchor_samples'] = _np(flat)[idx]
+            d[name + '_anchor_sum'] = _np(flat).astype(np.float64).sum(0)
+        # valid flags for an image narrower than the pad (real-batch case)
+        vf = ag.valid_flags(sizes, (pad[0] - 40, pad[1] - 70), device='cpu')
+        d[name + '_valid_counts'] = np.array([int(v.sum()) for v in vf])
+        d[name + '_valid_pad'] = np.array([pad[0] - 40, pad[1] - 70])
+    np.savez_compressed(os.path.join(OUT, 'anchors.npz'), **d)
+    print('anchors.npz')
+
+
+# -------------------------------------------------------------- targets ----
+def _ld_head(imitation_method='finegrained'):
+    from mmdet.models import build_head
+    cfg = dict(
+        type='LDHead',
+        num_classes=80,
+        in_channels=256,
+        stacked_convs=4,
+        feat_channels=256,
+        anchor_generator=dict(
+            type='AnchorGenerator',
+            ratios=[1.0],
+            octave_base_scale=8,
+            scales_per_octave=1,
+            strides=[8, 16, 32, 64, 128]),
+        loss_cls=dict(
+            type='QualityFocalLoss',
+            use_sigmoid=True,
+            beta=2.0,
+            loss_weight=1.0),
+        loss_dfl=dict(type='DistributionFocalLoss', loss_weight=0.25),
+        loss_ld=dict(
+            type='KnowledgeDistillationKLDivLoss', loss_weight=0.25, T=10),
+        loss_ld_vlr=dict(
+            type='KnowledgeDistillationKLDivLoss', loss_weight=0.25, T=10),
+        loss_kd=dict(
+            type='KnowledgeDistillationKLDivLoss', loss_weight=10, T=2),
+        loss_im=dict(type='IMLoss', loss_weight=2.0),
+        reg_max=16,
+        loss_bbox=dict(type='GIoULoss', loss_weight=2.0),
+        imitation_method=imitation_method,
+        train_cfg=ref_shim.ConfigDict(
+            assigner=dict(type='ATSSAssigner', topk=9),
+            allowed_border=-1,
+            pos_weight=-1,
+            debug=False),
+        test_cfg=ref_shim.ConfigDict(
+            nms_pre=1000,
+            min_bbox_size=0,
+            score_thr=0.05,
+            nms=dict(type='nms', iou_threshold=0.6),
+            max_per_img=100))
+    return build_head(cfg)
+
+
+TARGET_CASES = [
+    # name, pad_shape, img_shape, num_gt per image, seed
+    ('small_g3', (160, 224), (160, 224), [3, 1], 11),
+    ('small_g20', (160, 224), (150, 200), [20, 7], 12),
+    ('c1_g7', (800, 800), (800, 800), [7, 7], 13),
+    ('c2_g7', (800, 1344), (800, 1333), [7, 7], 1234),
+    ('c2_g1_g40', (800, 1344), (800, 1333), [1, 40], 15),
+    ('c2_g100', (800, 1344), (800, 1333), [100, 3], 16),
+]
+
+
+def _targets_reference(head, sizes, batch):
+    """Run the reference get_anchors/get_targets on CPU."""
+    anchor_list, valid_flag_list = head.get_anchors(
+        sizes, batch['img_metas'], device='cpu')
+    res = head.get_targets(
+        anchor_list,
+        valid_flag_list,
+        batch['gt_bboxes'],
+        batch['img_metas'],
+        gt_bboxes_ignore_list=None,
+        gt_labels_list=batch['gt_labels'],
+        label_channels=head.cls_out_channels)
+    return res
+
+
+def gen_targets():
+    head = _ld_head()
+    d = {}
+    # KAT7: tiny grid with grid-aligned GTs, CPU-vs-CPU only
+    from mmdet.core.bbox.assigners import ATSSAssigner
+    ag = _anchor_generator()
+    sizes = [(8, 8), (4, 4), (2, 2), (1, 1), (1, 1)]
+    anchors = torch.cat(ag.grid_anchors(sizes, device='cpu'))
+    gts = torch.tensor([[10., 12, 40, 44], [30, 5, 60, 30]])
+    gl = torch.tensor([3, 17])
+    assigner = ATSSAssigner(topk=9)
+    nl = [64, 16, 4, 1, 1]
+    ar = assigner.assign(anchors, nl, gts, None, gl)
+    d['kat7_gt'], d['kat7_labels'] = _np(gts), _np(gl)
+    d['kat7_gt_inds'] = _np(ar.gt_inds)
+    d['kat7_max_overlaps'] = _np(ar.max_overlaps)
+    d['kat7_vlr'] = _np(assigner.get_vlr_region(anchors, nl, gts, None, gl))
+    d['kat7_im'] = _np(head.get_im_region(anchors, gts, mode='finegrained'))
+
+    for name, pad, img_shape, num_gt, seed in TARGET_CASES:
+        batch = synthetic.synthetic_batch(
+            num_imgs=len(num_gt),
+            img_shape=img_shape,
+            pad_shape=pad,
+            num_gt=num_gt,
+            seed=seed)
+        sizes = synthetic.level_shapes(pad)
+        t0 = time.time()
+        (anchors_l, labels_l, lw_l, bt_l, bw_l, num_pos, num_neg, vlr_l,
+         im_l) = _targets_reference(head, sizes, batch)
+        labels = torch.cat(labels_l, 1)  # (N, A)
+        lw = torch.cat(lw_l, 1)
+        bt = torch.cat(bt_l, 1)
+        vlr = torch.cat(vlr_l, 1)
+        im = torch.cat(im_l, 1)
+        d[name + '_cfg'] = np.array(list(pad) + list(img_shape) + [seed])
+        d[name + '_num_gt'] = np.array(num_gt)
+        d[name + '_num_total_pos'] = np.array(num_pos)
+        for n in range(labels.shape[0]):
+            pos = ((labels[n] >= 0) & (labels[n] < 80)).nonzero().squeeze(1)
+            d[f'{name}_{n}_pos_inds'] = _np(pos).astype(np.int32)
+            d[f'{name}_{n}_pos_labels'] = _np(labels[n][pos]).astype(np.int32)
+            d[f'{name}_{n}_pos_bbox_targets'] = _np(bt[n][pos])
+            d[f'{name}_{n}_lw_zero_inds'] = _np(
+                (lw[n] == 0).nonzero().squeeze(1)).astype(np.int32)
+            vi = (vlr[n] > 0).nonzero().squeeze(1)
+            d[f'{name}_{n}_vlr_inds'] = _np(vi).astype(np.int32)
+            d[f'{name}_{n}_vlr_vals'] = _np(vlr[n][vi])
+            d[f'{name}_{n}_im_inds'] = _np(
+                (im[n] > 0).nonzero().squeeze(1)).astype(np.int32)
+        print(f'  targets {name}: {time.time() - t0:.2f}s  num_total_pos='
+              f'{num_pos}')
+    np.savez_compressed(os.path.join(OUT, 'targets.npz'), **d)
+    print('targets.npz')
+
+
+# ------------------------------------------------------------ lossblock ----
+LOSSBLOCK_CASES = [
+    # name, pad_shape, img_shape, num_gt, batch seed, head-input seed, store grads
+    ('small', (160, 224), (160, 224), [3, 1], 11, 101, True),
+    ('small_crowd', (160, 224), (150, 200), [20, 7], 12, 102, True),
+    ('c2', (800, 1344), (800, 1333), [7, 7], 1234, 103, False),
+    ('c2_crowd', (800, 1344), (800, 1333), [1, 40], 15, 104, False),
+]
+
+
+def gen_lossblock():
+    head = _ld_head()
+    d = {}
+    for name, pad, img_shape, num_gt, bseed, hseed, store in LOSSBLOCK_CASES:
+        batch = synthetic.synthetic_batch(
+            num_imgs=len(num_gt),
+            img_shape=img_shape,
+            pad_shape=pad,
+            num_gt=num_gt,
+            seed=bseed)
+        sizes = synthetic.level_shapes(pad)
+        hi = synthetic.synthetic_head_inputs(len(num_gt), sizes, seed=hseed)
+        for k in ('cls', 'reg', 'x'):
+            for t in hi[k]:
+                t.requires_grad_(True)
+        t0 = time.time()
+        losses = head.loss(hi['cls'], hi['reg'], batch['gt_bboxes'],
+                           batch['gt_labels'], (hi['t_cls'], hi['t_reg']),
+                           hi['x'], hi['t_x'], batch['img_metas'])
+        table = np.stack(
+            [np.array([float(v.detach()) for v in losses[k]]) for k in LOSS_KEYS])
+        total = sum(sum(v) for v in losses.values())
+        total.backward()
+        d[name + '_cfg'] = np.array(
+            list(pad) + list(img_shape) + [bseed, hseed])
+        d[name + '_num_gt'] = np.array(num_gt)
+        d[name + '_losses'] = table.astype(np.float64)  # (8 keys, 5 levels)
+        for k in ('cls', 'reg', 'x'):
+            gs = [
+                t.grad if t.grad is not None else torch.zeros_like(t)
+                for t in hi[k]
+            ]
+            d[f'{name}_g{k}_abs_sum'] = np.array(
+                [float(g.double().abs().sum()) for g in gs])
+            d[f'{name}_g{k}_sum'] = np.array(
+                [float(g.double().sum()) for g in gs])
+            if store:
+                for l, g in enumerate(gs):
+                    d[f'{name}_g{k}_{l}'] = _np(g)
+            else:  # deterministic sparse sample of the full-size gradient
+                for l, g in enumerate(gs):
+                    flat = _np(g).reshape(-1)
+                    idx = np.arange(0, flat.size, 1009)
+                    d[f'{name}_g{k}_{l}_sample'] = flat[idx]
+        print(f'  lossblock {name}: {time.time() - t0:.2f}s  total='
+              f'{float(total):.6f}')
+    np.savez_compressed(os.path.join(OUT, 'lossblock.npz'), **d)
+    print('lossblock.npz')
+
+
+# ------------------------------------------------------------------ e2e ----
+E2E_CASES = [
+    # name, student cfg, pad, img_shape, num_gt, batch seed
+    ('tiny_r18', 'configs/ld/ld_r18_gflv1_r101_fpn_coco_1x.py', (128, 160),
+     (128, 150), [3, 2], 21),
+    ('small_r50', 'configs/ld/ld_r50_gflv1_r101_fpn_coco_1x.py', (256, 320),
+     (256, 320), [5, 2], 22),
+    ('c1_r18', 'configs/ld/ld_r18_gflv1_r101_fpn_coco_1x.py', (800, 800),
+     (800, 800), [7, 7], 13),
+    ('c2_r50', 'configs/ld/ld_r50_gflv1_r101_fpn_coco_1x.py', (800, 1344),
+     (800, 1333), [7, 7], 1234),
+]
+
+
+def build_reference_detector(cfg_path, imitation_method=None):
+    import mmcv
+    from mmdet.models import build_detector
+    cwd = os.getcwd()
+    os.chdir(ref_shim.REFERENCE_ROOT)  # teacher_config is a relative path
+    try:
+        cfg = mmcv.Config.fromfile(cfg_path)
+        m = dict(cfg.model)
+        m['pretrained'] = None
+        m['teacher_ckpt'] = None
+        t = mmcv.Config.fromfile(m['teacher_config'])
+        tm = dict(t.model)
+        tm['pretrained'] = None
+        m['teacher_config'] = {'model': tm}
+        if imitation_method is not None:
+            m['bbox_head'] = dict(m['bbox_head'])
+            m['bbox_head']['imitation_method'] = imitation_method
+            m['bbox_head'].setdefault('loss_im',
+                                      dict(type='IMLoss', loss_weight=2.0))
+        det = build_detector(m)
+    finally:
+        os.chdir(cwd)
+    return det
+
+
+def gen_e2e(cases=None):
+    d = {}
+    path = os.path.join(OUT, 'e2e.npz')
+    if os.path.exists(path) and cases:
+        d = dict(np.load(path))
+    for name, cfg_path, pad, img_shape, num_gt, bseed in E2E_CASES:
+        if cases and name not in cases:
+            continue
+        torch.manual_seed(0)
+        # config 1 as shipped has imitation_method='gibox' (CUDA-only, weight
+        # 0) -> evaluate it as 'finegrained' with weight 0,
+        # numerically identical (0 * finite).
+        method = 'finegrained'
+        det = build_reference_detector(cfg_path, imitation_method=method)
+        if 'r18' in name:
+            det.bbox_head.loss_im.loss_weight = 0
+        det.load_state_dict(
+            synthetic.seeded_state_dict(det.state_dict(), seed=1))
+        det.teacher_model.load_state_dict(
+            synthetic.seeded_state_dict(
+                det.teacher_model.state_dict(), seed=2))
+        det.train()
+        batch = synthetic.synthetic_batch(
+            num_imgs=len(num_gt),
+            img_shape=img_shape,
+            pad_shape=pad,
+            num_gt=num_gt,
+            seed=bseed)
+        t0 = time.time()
+        losses = det.forward_train(batch['img'], batch['img_metas'],
+                                   batch['gt_bboxes'], batch['gt_labels'])
+        table = np.stack(
+            [np.array([float(v.detach()) for v in losses[k]]) for k in LOSS_KEYS])
+        loss, log_vars = det._parse_losses(losses)
+        t1 = time.time()
+        loss.backward()
+        t2 = time.time()
+        d[name + '_cfg'] = np.array(list(pad) + list(img_shape) + [bseed])
+        d[name + '_num_gt'] = np.array(num_gt)
+        d[name + '_losses'] = table.astype(np.float64)
+        d[name + '_log_vars'] = np.array(
+            [log_vars[k] for k in LOSS_KEYS + ['loss']], dtype=np.float64)
+        # a few parameter-gradient fingerprints (L2 norms), key names are part
+        # of the contract
+        names, norms = [], []
+        for k, p in det.named_parameters():
+            if p.grad is not None:
+                names.append(k)
+                norms.append(float(p.grad.double().norm()))
+        d[name + '_grad_names'] = np.array(names)
+        d[name + '_grad_norms'] = np.array(norms)
+        d[name + '_num_trainable'] = np.array(
+            sum(p.numel() for p in det.parameters() if p.requires_grad))
+        # feature fingerprints
+        with torch.no_grad():
+            x = det.extract_feat(batch['img'])
+            d[name + '_feat_abs_mean'] = np.array(
+                [float(f.double().abs().mean()) for f in x])
+            cls, reg = det.bbox_head(x)
+            d[name + '_cls_abs_mean'] = np.array(
+                [float(f.double().abs().mean()) for f in cls])
+            d[name + '_reg_abs_mean'] = np.array(
+                [float(f.double().abs().mean()) for f in reg])
+        print(f'  e2e {name}: fwd {t1 - t0:.1f}s bwd {t2 - t1:.1f}s',
+              {k: round(v, 6) for k, v in log_vars.items()})
+    np.savez_compressed(path, **d)
+    print('e2e.npz')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default='kat,anchors,targets,lossblock,e2e')
+    ap.add_argument('--e2e-cases', default='')
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    only = args.only.split(',')
+    if 'kat' in only:
+        gen_kat()
+    if 'anchors' in only:
+        gen_anchors()
+    if 'targets' in only:
+        gen_targets()
+    if 'lossblock' in only:
+        gen_lossblock()
+    if 'e2e' in only:
+        gen_e2e([c for c in args.e2e_cases.split(',') if c])
+
+
+if __name__ == '__main__':
+    main()
