@@ -270,6 +270,18 @@ def gen_targets():
     d['kat7_max_overlaps'] = _np(ar.max_overlaps)
     d['kat7_vlr'] = _np(assigner.get_vlr_region(anchors, nl, gts, None, gl))
     d['kat7_im'] = _np(head.get_im_region(anchors, gts, mode='finegrained'))
+    # KAT7b: same tiny grid, tie-free float GTs (usable CPU-vs-GPU; KAT7's
+    # grid-aligned GTs have centre-distance ties whose order inside
+    # torch.topk is a libstdc++ nth_element/partial_sort artefact)
+    gts = torch.tensor([[10.3, 12.7, 40.9, 44.2], [30.1, 5.6, 60.7, 30.4],
+                        [3.3, 2.2, 9.1, 11.8]])
+    gl = torch.tensor([3, 17, 42])
+    ar = assigner.assign(anchors, nl, gts, None, gl)
+    d['kat7b_gt'], d['kat7b_labels'] = _np(gts), _np(gl)
+    d['kat7b_gt_inds'] = _np(ar.gt_inds)
+    d['kat7b_max_overlaps'] = _np(ar.max_overlaps)
+    d['kat7b_vlr'] = _np(assigner.get_vlr_region(anchors, nl, gts, None, gl))
+    d['kat7b_im'] = _np(head.get_im_region(anchors, gts, mode='finegrained'))
 
     for name, pad, img_shape, num_gt, seed in TARGET_CASES:
         batch = synthetic.synthetic_batch(

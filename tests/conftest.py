@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, 'oracle')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line(
+        'markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    import numpy as np
+
+    class _G:
+
+        def __getitem__(self, name):
+            return np.load(os.path.join(GOLDEN, name + '.npz'),
+                           allow_pickle=False)
+
+    return _G()
