@@ -1,0 +1,224 @@
+/* ld_hip.h -- C ABI of libldhip.so, the MI355X (gfx950) implementation of the
+ * HikariTJU/LD training hot path.
+ *
+ * The reference (an MMDetection 2.10 fork, pure Python) has no native
+ * boundary of its own: its drop-in boundary is the mmdet registry API
+ * (SURVEY.md section 8b).  The host-side mirror of that API lives in the
+ * Python package `ld_amd`; every arithmetic step underneath it goes through
+ * the entry points declared here.  Each entry point cites the reference
+ * function it replaces (file:line relative to the reference checkout).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all pointers are DEVICE pointers unless the
+ *    parameter is a `const ld_*_t*` descriptor struct (host memory, read
+ *    during the call) or says "host";
+ *  - no allocation, no synchronisation and no host read-back inside: callers
+ *    pass workspaces; every launch goes to `stream` (a hipStream_t);
+ *  - return 0 on success, a negative LD_E* code on a bad argument, or the
+ *    positive hipError_t of a failed launch.  Nothing throws.
+ *  - tensors are fp32 unless stated; label tensors are int64 as in the
+ *    reference (ld_head.py:522-530).
+ */
+#ifndef LD_HIP_H_
+#define LD_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LD_MAX_LEVELS 8
+#define LD_NUM_LOSS_KEYS 8 /* loss_cls,bbox,dfl,ld,ld_vlr,kd,kd_neg,im */
+
+#define LD_EINVAL (-1)   /* bad argument */
+#define LD_ENOSPACE (-2) /* workspace too small */
+#define LD_EUNSUPPORTED (-3)
+
+typedef void* ld_stream_t; /* hipStream_t */
+
+/* ---- geometry of the FPN pyramid ------------------------------------- */
+/* One anchor per feature-map cell, anchors ordered level-major then row-major
+ * (x fastest): anchor_generator.py:229-270, ld_head.py:396-403. */
+typedef struct {
+  int32_t H, W;     /* feature-map size of this level            */
+  int32_t stride;   /* anchor stride (8,16,32,64,128)            */
+  int32_t offset;   /* index of the level's first anchor         */
+} ld_level_t;
+
+typedef struct {
+  int32_t num_levels;
+  int32_t num_anchors;      /* sum of H*W over levels                */
+  int32_t num_imgs;         /* N                                     */
+  int32_t anchor_scale;     /* octave_base_scale (8): side = scale*stride */
+  ld_level_t lv[LD_MAX_LEVELS];
+} ld_geom_t;
+
+/* A per-level family of NCHW maps (N, C, H_l, W_l).  Element (n, c, y, x) of
+ * level l lives at ptr[l] + n*stride_n[l] + c*stride_c[l] + y*W_l + x, which
+ * covers both separately allocated level tensors and the level-concatenated
+ * (N, C, A) arena the head uses. */
+typedef struct {
+  float* ptr[LD_MAX_LEVELS];
+  int64_t stride_n[LD_MAX_LEVELS];
+  int64_t stride_c[LD_MAX_LEVELS];
+} ld_maps_t;
+
+/* Hyper-parameters of LDHead.loss (ld_head.py:47-71 and the loss modules'
+ * constructor arguments). */
+typedef struct {
+  int32_t num_classes; /* 80 */
+  int32_t reg_max;     /* 16 -> 17 bins; only 16 is compiled */
+  int32_t topk;        /* ATSS topk, 9 */
+  int32_t feat_channels; /* 256 (ld_head.py:153-154 hard-codes it) */
+  float lw_cls, qfl_beta;       /* QualityFocalLoss (beta must be 2) */
+  float lw_bbox, giou_eps;      /* GIoULoss        */
+  float lw_dfl;                 /* DistributionFocalLoss */
+  float lw_ld, T_ld;            /* KnowledgeDistillationKLDivLoss (main LD) */
+  float lw_ld_vlr, T_ld_vlr;    /* ... (VLR LD)    */
+  float lw_kd, T_kd;            /* ... (cls KD)    */
+  float lw_im;                  /* IMLoss          */
+} ld_loss_hp_t;
+
+/* ---- library ------------------------------------------------------------ */
+/* ABI version of this header; bump on any signature change. */
+int ld_abi_version(void);
+/* Name of the gfx target the kernels were compiled for ("gfx950"). */
+const char* ld_target_arch(void);
+
+/* ---- target assignment ---------------------------------------------------
+ * Replaces, for a whole batch in two launches:
+ *   AnchorHead.get_anchors            anchor_head.py:145-173 (anchors implicit)
+ *   anchor_inside_flags               core/anchor/utils.py:20-46
+ *   ATSSAssigner.assign               atss_assigner.py:33-181
+ *   PseudoSampler.sample              samplers/pseudo_sampler.py:24-41
+ *   ATSSAssigner.get_vlr_region       atss_assigner.py:183-298
+ *   LDHead.get_im_region('finegrained') ld_head.py:580-611
+ *   LDHead._get_target_single/unmap   ld_head.py:449-577
+ *
+ * gt_bboxes  (N, max_gt, 4) xyxy, rows >= num_gt[n] ignored
+ * gt_labels  (N, max_gt) int64
+ * num_gt     (N) int32
+ * valid_hw   (N, num_levels, 2) int32: valid_h, valid_w of each level from
+ *            img_meta['pad_shape'] (anchor_generator.py:293-300)
+ * outputs, dense (N, A): labels int64 (background = num_classes),
+ *   label_weights, bbox_targets (N, A, 4), vlr, im
+ * counts     int32 [N + 2*num_levels + 1]:
+ *            [0,N) positives per image; [N, N+L) positives per level (batch);
+ *            [N+L, N+2L) im-region anchors per level; [N+2L] = sum_i max(P_i,1)
+ * Tie rule: equal centre distances are ordered by lower anchor index (the
+ * reference's order is an artefact of torch.topk). */
+size_t ld_atss_targets_workspace_bytes(const ld_geom_t* geom, int max_gt);
+int ld_atss_targets(const ld_geom_t* geom, const ld_loss_hp_t* hp,
+                    const float* gt_bboxes, const int64_t* gt_labels,
+                    const int32_t* num_gt, int max_gt, const int32_t* valid_hw,
+                    int64_t* labels, float* label_weights, float* bbox_targets,
+                    float* vlr, float* im, int32_t* counts, void* workspace,
+                    size_t workspace_bytes, ld_stream_t stream);
+
+/* Materialise the anchors (A, 4) -- only for API compatibility
+ * (AnchorGenerator.grid_anchors, anchor_generator.py:207-270); the kernels
+ * never read them. */
+int ld_grid_anchors(const ld_geom_t* geom, float* anchors, ld_stream_t stream);
+
+/* ---- fused loss block ----------------------------------------------------
+ * Replaces LDHead.loss_single for all levels and images, forward AND gradient
+ * (ld_head.py:116-282), reading the head outputs NCHW-direct (no permute).
+ *
+ * Call order on one stream:
+ *   ld_loss_prepass   -> weight_targets, IoU score, partial normalisers
+ *   (optional cross-rank all-reduce of norm_partial[0..1])
+ *   ld_loss_main      -> loss partials + gradients
+ *   ld_loss_finalize  -> the (8, L) loss table
+ *
+ * norm (device, float[4]): [0] sum_i max(P_i,1) (this rank), [1] sum of
+ *   weight_targets (this rank); after the caller's optional mean over ranks
+ *   ld_loss_main reads NTS = max(norm[0],1) and AVG = norm[1] + 1e-6 from it
+ *   (ld_head.py:338-341,362-365).
+ */
+size_t ld_loss_workspace_bytes(const ld_geom_t* geom);
+
+/* weight_targets = max_c sigmoid(cls) at positives (ld_head.py:198-199),
+ * score = IoU(decoded box, target) (ld_head.py:200-207) written dense (N, A)
+ * (zero elsewhere); norm[0], norm[1] as above. */
+int ld_loss_prepass(const ld_geom_t* geom, const ld_loss_hp_t* hp,
+                    const ld_maps_t* cls, const ld_maps_t* reg,
+                    const int64_t* labels, const float* bbox_targets,
+                    const int32_t* counts, float* weight_targets, float* score,
+                    float* norm, void* workspace, size_t workspace_bytes,
+                    ld_stream_t stream);
+
+/* Forward + gradient of every loss term.  grad_* have the same descriptors
+ * as their inputs and are fully overwritten.  `upstream` (device,
+ * float[8 * num_levels] key-major like `losses`, may be NULL = all ones) is
+ * d total / d loss[key][level] (base.py:197-210 sums them, so it is 1). */
+int ld_loss_main(const ld_geom_t* geom, const ld_loss_hp_t* hp,
+                 const ld_maps_t* cls, const ld_maps_t* reg,
+                 const ld_maps_t* t_cls, const ld_maps_t* t_reg,
+                 const ld_maps_t* x, const ld_maps_t* t_x,
+                 const int64_t* labels, const float* label_weights,
+                 const float* bbox_targets, const float* vlr, const float* im,
+                 const int32_t* counts, const float* weight_targets,
+                 const float* score, const float* norm, const float* upstream,
+                 const ld_maps_t* grad_cls, const ld_maps_t* grad_reg,
+                 const ld_maps_t* grad_x, void* workspace,
+                 size_t workspace_bytes, ld_stream_t stream);
+
+/* losses: device float[8 * num_levels], key-major (loss_cls[0..L), ...). */
+int ld_loss_finalize(const ld_geom_t* geom, const ld_loss_hp_t* hp,
+                     const int32_t* counts, const float* norm,
+                     const void* workspace, float* losses, ld_stream_t stream);
+
+/* The north-star kernel on its own, at any size: LD KL (T) + Integral
+ * (+ fused gradient) over `rows`-many anchors x 4 sides, channel-major
+ * (68, rows) student and teacher logits, weight (rows).
+ *   integral (4, rows) out, loss_rows (rows) out = weight * sum_sides KL,
+ *   grad (68, rows) out or NULL (forward only).
+ * Replaces Integral.forward (gfl_head.py:32-44) +
+ * knowledge_distillation_kl_div_loss (kd_loss.py:10-36) on the dense map. */
+int ld_kl_integral_dense(const float* s_reg, const float* t_reg,
+                         const float* weight, int64_t rows, float T,
+                         float scale, float* integral, float* loss_rows,
+                         float* grad, ld_stream_t stream);
+
+/* ---- reference-layout loss operators (row-major (rows, K) tensors) -------
+ * These back the registry loss modules when they are called on their own,
+ * with the reference's tensor layout.  Each computes the per-row loss
+ * (already multiplied by weight[row] if weight != NULL) and, if grad != NULL,
+ * d(sum_rows loss_rows * gscale)/d pred. */
+/* knowledge_distillation_kl_div_loss, kd_loss.py:10-36 */
+int ld_kd_kl_rows(const float* pred, const float* soft, const float* weight,
+                  int64_t rows, int K, float T, float gscale, float* loss_rows,
+                  float* grad, ld_stream_t stream);
+/* quality_focal_loss, gfocal_loss.py:8-50 (beta = 2) */
+int ld_qfl_rows(const float* pred, const int64_t* label, const float* score,
+                const float* weight, int64_t rows, int C, float gscale,
+                float* loss_rows, float* grad, ld_stream_t stream);
+/* distribution_focal_loss, gfocal_loss.py:53-74 */
+int ld_dfl_rows(const float* pred, const float* target, const float* weight,
+                int64_t rows, int K, float gscale, float* loss_rows,
+                float* grad, ld_stream_t stream);
+/* giou_loss, iou_loss.py:85-102 (aligned boxes (rows, 4)) */
+int ld_giou_rows(const float* pred, const float* target, const float* weight,
+                 int64_t rows, float eps, float gscale, float* loss_rows,
+                 float* grad, ld_stream_t stream);
+/* Integral.forward, gfl_head.py:32-44: (rows, 4*(reg_max+1)) -> (rows, 4);
+ * backward: grad_in (rows,4) -> grad (rows, 68) */
+int ld_integral_rows(const float* x, int64_t rows, float* out,
+                     ld_stream_t stream);
+int ld_integral_rows_bwd(const float* x, const float* grad_out, int64_t rows,
+                         float* grad_x, ld_stream_t stream);
+/* bbox_overlaps, iou2d_calculator.py:43-188; mode 0 iou, 1 iof, 2 giou,
+ * 3 diou; pairwise (m, n) or aligned (m). */
+int ld_bbox_overlaps(const float* b1, const float* b2, int64_t m, int64_t n,
+                     int mode, int aligned, float eps, float* out,
+                     ld_stream_t stream);
+/* sum of a float vector into out[0] (deterministic two-stage) */
+int ld_sum(const float* x, int64_t n, float* out, void* workspace,
+           size_t workspace_bytes, ld_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LD_HIP_H_ */

@@ -1,0 +1,672 @@
+// Fused LD loss block for gfx950: forward + gradient of every term of
+// LDHead.loss_single (mmdet/models/dense_heads/ld_head.py:116-282), for all
+// FPN levels and all images of the rank's batch, read NCHW-direct.
+//
+// Reference ops replaced (each was 5-15 ATen launches per level):
+//   Integral                      gfl_head.py:32-44
+//   distance2bbox / bbox2distance core/bbox/transforms.py:119-180
+//   bbox_overlaps(aligned)        iou2d_calculator.py:111-171
+//   GIoULoss                      losses/iou_loss.py:85-102,334-360
+//   DistributionFocalLoss         losses/gfocal_loss.py:53-74
+//   QualityFocalLoss              losses/gfocal_loss.py:8-50
+//   KnowledgeDistillationKLDivLoss losses/kd_loss.py:10-88  (LD, VLR-LD, KD)
+//   IMLoss                        losses/kd_loss.py:91-120
+//
+// Layout: thread <-> anchor (one spatial cell of one level of one image); the
+// channel stride of an NCHW map is H*W, so the 64 lanes of a wavefront read 64
+// consecutive floats of every channel they touch: perfectly coalesced with no
+// NCHW->NHWC permute (the reference materialises six permuted copies per
+// level, ld_head.py:143-154).  Per-anchor softmax / KL over 17 bins runs
+// serially in registers; cross-lane traffic is only the final wave reduction
+// of the loss partial sums, which are written per block and summed in a fixed
+// order by the finalise kernel (bitwise run-to-run reproducible, no float
+// atomics).
+#include <hip/hip_runtime.h>
+
+#include "../../include/ld_hip.h"
+#include "ld_math.h"
+
+namespace {
+
+using ld::Box;
+constexpr int K17 = ld::kRegBins;
+constexpr int kWave = 64;
+
+// loss partial-sum slots (workspace rows)
+enum { S_BBOX = 0, S_DFL, S_LD, S_VLR, S_CLS, S_KD, S_IM, S_WSUM, S_COUNT };
+
+struct BlockMap {  // level-aligned chunking of the anchor axis
+  int32_t blk_start[LD_MAX_LEVELS + 1];
+  int32_t blocks_per_img;
+};
+
+BlockMap make_block_map(const ld_geom_t& g, int per_block) {
+  BlockMap m;
+  int s = 0;
+  for (int l = 0; l < LD_MAX_LEVELS + 1; ++l) m.blk_start[l] = 0;
+  for (int l = 0; l < g.num_levels; ++l) {
+    m.blk_start[l] = s;
+    s += (g.lv[l].H * g.lv[l].W + per_block - 1) / per_block;
+  }
+  for (int l = g.num_levels; l < LD_MAX_LEVELS + 1; ++l) m.blk_start[l] = s;
+  m.blocks_per_img = s;
+  return m;
+}
+
+__device__ __forceinline__ int block_level(const BlockMap& m, int nl, int b) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < LD_MAX_LEVELS; ++i)
+    if (i < nl && b >= m.blk_start[i]) l = i;
+  return l;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+struct Cell {  // where this thread sits
+  int n, l, r, a, x, y;
+  bool active;
+  size_t o;  // n * A + a
+};
+
+__device__ __forceinline__ Cell locate(const ld_geom_t& g, const BlockMap& bm) {
+  Cell c;
+  c.n = blockIdx.y;
+  c.l = block_level(bm, g.num_levels, blockIdx.x);
+  const ld_level_t lv = g.lv[c.l];
+  c.r = (blockIdx.x - bm.blk_start[c.l]) * kWave + threadIdx.x;
+  c.active = c.r < lv.H * lv.W;
+  c.a = lv.offset + c.r;
+  c.y = c.r / lv.W;
+  c.x = c.r - c.y * lv.W;
+  c.o = (size_t)c.n * g.num_anchors + c.a;
+  return c;
+}
+
+__device__ __forceinline__ const float* chan_ptr(const ld_maps_t& m, const Cell& c,
+                                                 int ch) {
+  return m.ptr[c.l] + (size_t)c.n * m.stride_n[c.l] + (size_t)ch * m.stride_c[c.l] + c.r;
+}
+__device__ __forceinline__ float* chan_ptr_w(const ld_maps_t& m, const Cell& c,
+                                             int ch) {
+  return m.ptr[c.l] + (size_t)c.n * m.stride_n[c.l] + (size_t)ch * m.stride_c[c.l] + c.r;
+}
+
+__device__ __forceinline__ void load_side(const ld_maps_t& m, const Cell& c,
+                                          int side, float* v) {
+#pragma unroll
+  for (int k = 0; k < K17; ++k) v[k] = *chan_ptr(m, c, side * K17 + k);
+}
+
+// ------------------------------------------------------------- prepass ----
+__global__ __launch_bounds__(kWave) void loss_prepass_kernel(
+    ld_geom_t geom, ld_loss_hp_t hp, BlockMap bm, ld_maps_t cls, ld_maps_t reg,
+    const int64_t* __restrict__ labels, const float* __restrict__ bbox_targets,
+    float* __restrict__ weight_targets, float* __restrict__ score,
+    float* __restrict__ partial) {
+  const Cell c = locate(geom, bm);
+  float wt = 0.0f, sc = 0.0f;
+  if (c.active) {
+    const int64_t lab = labels[c.o];
+    if (lab >= 0 && lab < hp.num_classes) {
+      float m = *chan_ptr(cls, c, 0);
+      for (int ch = 1; ch < hp.num_classes; ++ch)
+        m = fmaxf(m, *chan_ptr(cls, c, ch));
+      wt = ld::sigmoidf_(m);  // max_c sigmoid(x_c) == sigmoid(max_c x_c)
+      float e[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float v[K17], p[K17];
+        load_side(reg, c, s, v);
+        e[s] = ld::softmax_expect<K17>(v, p);
+      }
+      const float stride = (float)geom.lv[c.l].stride;
+      // anchor centre / stride == (x, y) exactly (ld_head.py:196)
+      const float cx = (float)c.x, cy = (float)c.y;
+      const Box box{cx - e[0], cy - e[1], cx + e[2], cy + e[3]};
+      const float4 t = reinterpret_cast<const float4*>(bbox_targets)[c.o];
+      const Box tgt{t.x / stride, t.y / stride, t.z / stride, t.w / stride};
+      sc = ld::iou_pair(box, tgt);
+    }
+    weight_targets[c.o] = wt;
+    score[c.o] = sc;
+  }
+  const float s = wave_sum(wt);
+  if (threadIdx.x == 0)
+    partial[(size_t)S_WSUM * gridDim.y * bm.blocks_per_img +
+            (size_t)c.n * bm.blocks_per_img + blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void loss_norm_kernel(
+    int nparts, const float* __restrict__ partial_wsum,
+    const int32_t* __restrict__ counts, int idx_total_pos,
+    float* __restrict__ norm) {
+  __shared__ float s[256];
+  float acc = 0.0f;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += partial_wsum[i];
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if (threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    norm[0] = (float)counts[idx_total_pos];
+    norm[1] = s[0];
+  }
+}
+
+// ------------------------------------------- reg side: LD + VLR + DFL + GIoU
+__global__ __launch_bounds__(kWave) void loss_reg_kernel(
+    ld_geom_t geom, ld_loss_hp_t hp, BlockMap bm, ld_maps_t reg, ld_maps_t t_reg,
+    const int64_t* __restrict__ labels, const float* __restrict__ bbox_targets,
+    const float* __restrict__ vlr, const float* __restrict__ weight_targets,
+    const float* __restrict__ norm, const float* __restrict__ upstream,
+    ld_maps_t grad_reg, float* __restrict__ partial) {
+  const Cell c = locate(geom, bm);
+  float s_bbox = 0.0f, s_dfl = 0.0f, s_ld = 0.0f, s_vlr = 0.0f;
+  if (c.active) {
+    const int64_t lab = labels[c.o];
+    const bool pos = lab >= 0 && lab < hp.num_classes;
+    const float v = vlr[c.o];
+    const bool rem = v > 0.0f;
+    if (!pos && !rem) {
+#pragma unroll 4
+      for (int ch = 0; ch < 4 * K17; ++ch) *chan_ptr_w(grad_reg, c, ch) = 0.0f;
+    } else {
+      const int L = geom.num_levels;
+      const float up_bbox = upstream ? upstream[1 * L + c.l] : 1.0f;
+      const float up_dfl = upstream ? upstream[2 * L + c.l] : 1.0f;
+      const float up_ld = upstream ? upstream[3 * L + c.l] : 1.0f;
+      const float up_vlr = upstream ? upstream[4 * L + c.l] : 1.0f;
+      const float inv_avg = 1.0f / (norm[1] + 1e-6f);
+      const float wt = pos ? weight_targets[c.o] : 0.0f;
+      // per-anchor coefficients of d(total)/d(term)
+      const float c_ld = up_ld * hp.lw_ld * wt * 0.25f;           // /4.0
+      const float c_vlr = up_vlr * hp.lw_ld_vlr * v * 0.0625f;    // /16.0
+      const float c_dfl = up_dfl * hp.lw_dfl * wt * 0.25f * inv_avg;
+      const float c_bbox = up_bbox * hp.lw_bbox * wt * inv_avg;
+      float gd[4] = {0, 0, 0, 0};  // d(total)/d(E_side) through GIoU
+      float ytgt[4] = {0, 0, 0, 0};
+      if (pos) {
+        float e[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          float sv[K17], p[K17];
+          load_side(reg, c, s, sv);
+          e[s] = ld::softmax_expect<K17>(sv, p);
+        }
+        const float stride = (float)geom.lv[c.l].stride;
+        const float cx = (float)c.x, cy = (float)c.y;
+        const Box box{cx - e[0], cy - e[1], cx + e[2], cy + e[3]};
+        const float4 t = reinterpret_cast<const float4*>(bbox_targets)[c.o];
+        const Box tgt{t.x / stride, t.y / stride, t.z / stride, t.w / stride};
+        float iou, g[4];
+        const float gl = ld::giou_loss_grad(box, tgt, hp.giou_eps, &iou, g);
+        s_bbox = wt * gl;
+        gd[0] = -g[0] * c_bbox;
+        gd[1] = -g[1] * c_bbox;
+        gd[2] = g[2] * c_bbox;
+        gd[3] = g[3] * c_bbox;
+        const float rm = (float)hp.reg_max;
+        ytgt[0] = ld::clamp_dist(cx - tgt.x1, rm);
+        ytgt[1] = ld::clamp_dist(cy - tgt.y1, rm);
+        ytgt[2] = ld::clamp_dist(tgt.x2 - cx, rm);
+        ytgt[3] = ld::clamp_dist(tgt.y2 - cy, rm);
+      }
+      const bool same_T = hp.T_ld == hp.T_ld_vlr;
+#pragma unroll 1
+      for (int s = 0; s < 4; ++s) {
+        float sv[K17], tv[K17], d[K17], gr[K17];
+        load_side(reg, c, s, sv);
+        load_side(t_reg, c, s, tv);
+#pragma unroll
+        for (int k = 0; k < K17; ++k) gr[k] = 0.0f;
+        if (same_T) {
+          const float T = hp.T_ld;
+          const float kl = ld::kl_rows<K17>(sv, tv, 1.0f / T, T, d);
+          s_ld += wt * kl;
+          s_vlr += v * kl;
+          const float cg = (c_ld + (rem ? c_vlr : 0.0f)) * (T / (float)K17);
+#pragma unroll
+          for (int k = 0; k < K17; ++k) gr[k] = cg * d[k];
+        } else {
+          if (pos) {
+            const float T = hp.T_ld;
+            const float kl = ld::kl_rows<K17>(sv, tv, 1.0f / T, T, d);
+            s_ld += wt * kl;
+            const float cg = c_ld * (T / (float)K17);
+#pragma unroll
+            for (int k = 0; k < K17; ++k) gr[k] += cg * d[k];
+          }
+          if (rem) {
+            const float T = hp.T_ld_vlr;
+            const float kl = ld::kl_rows<K17>(sv, tv, 1.0f / T, T, d);
+            s_vlr += v * kl;
+            const float cg = c_vlr * (T / (float)K17);
+#pragma unroll
+            for (int k = 0; k < K17; ++k) gr[k] += cg * d[k];
+          }
+        }
+        if (pos) {
+          float p[K17];
+          const float e = ld::softmax_expect<K17>(sv, p);
+          float wl, wr;
+          int yl;
+          const float dl = ld::dfl_side<K17>(sv, p, ytgt[s], &wl, &wr, &yl);
+          s_dfl += wt * dl;
+#pragma unroll
+          for (int k = 0; k < K17; ++k) {
+            float gk = p[k] - (k == yl ? wl : 0.0f) - (k == yl + 1 ? wr : 0.0f);
+            gr[k] += c_dfl * gk + gd[s] * p[k] * ((float)k - e);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < K17; ++k) *chan_ptr_w(grad_reg, c, s * K17 + k) = gr[k];
+      }
+    }
+  }
+  const size_t nb = (size_t)gridDim.y * bm.blocks_per_img;
+  const size_t bi = (size_t)c.n * bm.blocks_per_img + blockIdx.x;
+  s_bbox = wave_sum(s_bbox);
+  s_dfl = wave_sum(s_dfl);
+  s_ld = wave_sum(s_ld);
+  s_vlr = wave_sum(s_vlr);
+  if (threadIdx.x == 0) {
+    partial[S_BBOX * nb + bi] = s_bbox;
+    partial[S_DFL * nb + bi] = s_dfl;
+    partial[S_LD * nb + bi] = s_ld;
+    partial[S_VLR * nb + bi] = s_vlr;
+  }
+}
+
+// ------------------------------------------------- cls side: QFL + KD -------
+__global__ __launch_bounds__(kWave) void loss_cls_kernel(
+    ld_geom_t geom, ld_loss_hp_t hp, BlockMap bm, ld_maps_t cls, ld_maps_t t_cls,
+    const int64_t* __restrict__ labels, const float* __restrict__ label_weights,
+    const float* __restrict__ score, const int32_t* __restrict__ counts,
+    const float* __restrict__ norm, const float* __restrict__ upstream,
+    ld_maps_t grad_cls, float* __restrict__ partial) {
+  const Cell c = locate(geom, bm);
+  float s_cls = 0.0f, s_kd = 0.0f;
+  const int C = hp.num_classes;
+  if (c.active) {
+    const float lw = label_weights[c.o];
+    if (lw == 0.0f) {  // outside the image's valid region
+#pragma unroll 4
+      for (int ch = 0; ch < C; ++ch) *chan_ptr_w(grad_cls, c, ch) = 0.0f;
+    } else {
+      const int64_t lab = labels[c.o];
+      const bool pos = lab >= 0 && lab < C;
+      const float up_cls = upstream ? upstream[0 * geom.num_levels + c.l] : 1.0f;
+      const float up_kd = upstream ? upstream[5 * geom.num_levels + c.l] : 1.0f;
+      const float nts = fmaxf(norm[0], 1.0f);  // ld_head.py:341
+      const float c_cls = up_cls * hp.lw_cls * lw / nts;
+      const float sc = pos ? score[c.o] : 0.0f;
+      // KD statistics over the 80 class logits (positives only)
+      float ms = 0, mt = 0, rzs = 0, rzt = 0, lzs = 0, lzt = 0, c_kd = 0;
+      const float T = hp.T_kd, invT = 1.0f / hp.T_kd;
+      if (pos) {
+        ms = *chan_ptr(cls, c, 0);
+        mt = *chan_ptr(t_cls, c, 0);
+        for (int ch = 1; ch < C; ++ch) {
+          ms = fmaxf(ms, *chan_ptr(cls, c, ch));
+          mt = fmaxf(mt, *chan_ptr(t_cls, c, ch));
+        }
+        float zs = 0.0f, zt = 0.0f;
+        for (int ch = 0; ch < C; ++ch) {
+          zs += expf((*chan_ptr(cls, c, ch) - ms) * invT);
+          zt += expf((*chan_ptr(t_cls, c, ch) - mt) * invT);
+        }
+        rzs = 1.0f / zs;
+        rzt = 1.0f / zt;
+        lzs = logf(zs);
+        lzt = logf(zt);
+        const int P_l = counts[geom.num_imgs + c.l];  // >= 1 here
+        c_kd = up_kd * hp.lw_kd * lw / (float)P_l * (T / (float)C);
+      }
+      float rowsum = 0.0f, kl = 0.0f;
+#pragma unroll 4
+      for (int ch = 0; ch < C; ++ch) {
+        const float x = *chan_ptr(cls, c, ch);
+        float dq;
+        float q;
+        if (pos && ch == (int)lab)
+          q = ld::qfl_pos(x, sc, &dq);
+        else
+          q = ld::qfl_neg(x, &dq);
+        rowsum += q;
+        float g = c_cls * dq;
+        if (pos) {
+          const float t = *chan_ptr(t_cls, c, ch);
+          const float ps = expf((x - ms) * invT) * rzs;
+          const float pt = expf((t - mt) * invT) * rzt;
+          kl += pt * (((t - mt) * invT - lzt) - ((x - ms) * invT - lzs));
+          g += c_kd * (ps - pt);
+        }
+        *chan_ptr_w(grad_cls, c, ch) = g;
+      }
+      s_cls = lw * rowsum;
+      if (pos) s_kd = lw * kl * (T * T) / (float)C;
+    }
+  }
+  const size_t nb = (size_t)gridDim.y * bm.blocks_per_img;
+  const size_t bi = (size_t)c.n * bm.blocks_per_img + blockIdx.x;
+  s_cls = wave_sum(s_cls);
+  s_kd = wave_sum(s_kd);
+  if (threadIdx.x == 0) {
+    partial[S_CLS * nb + bi] = s_cls;
+    partial[S_KD * nb + bi] = s_kd;
+  }
+}
+
+// ------------------------------------------------------------- IM (MSE) -----
+__global__ __launch_bounds__(kWave) void loss_im_kernel(
+    ld_geom_t geom, ld_loss_hp_t hp, BlockMap bm, ld_maps_t x, ld_maps_t t_x,
+    const float* __restrict__ im, const int32_t* __restrict__ counts,
+    const float* __restrict__ upstream, ld_maps_t grad_x,
+    float* __restrict__ partial) {
+  const Cell c = locate(geom, bm);
+  float s_im = 0.0f;
+  const int CH = hp.feat_channels;
+  if (c.active) {
+    const int P_l = counts[geom.num_imgs + c.l];
+    const int F_l = counts[geom.num_imgs + geom.num_levels + c.l];
+    // ld_head.py:186-191 and :246-252 (quirk Q5: no positives -> loss_im = 0)
+    const bool enabled = P_l > 0 && F_l > 0 && hp.lw_im != 0.0f;
+    const bool sel = enabled && im[c.o] > 0.0f;
+    if (!sel) {
+#pragma unroll 8
+      for (int ch = 0; ch < CH; ++ch) *chan_ptr_w(grad_x, c, ch) = 0.0f;
+    } else {
+      const float up = upstream ? upstream[7 * geom.num_levels + c.l] : 1.0f;
+      const float cg = up * hp.lw_im * 2.0f / ((float)F_l * (float)CH);
+#pragma unroll 8
+      for (int ch = 0; ch < CH; ++ch) {
+        const float d = *chan_ptr(x, c, ch) - *chan_ptr(t_x, c, ch);
+        s_im += d * d;
+        *chan_ptr_w(grad_x, c, ch) = cg * d;
+      }
+    }
+  }
+  const size_t nb = (size_t)gridDim.y * bm.blocks_per_img;
+  const size_t bi = (size_t)c.n * bm.blocks_per_img + blockIdx.x;
+  s_im = wave_sum(s_im);
+  if (threadIdx.x == 0) partial[S_IM * nb + bi] = s_im;
+}
+
+// ------------------------------------------------------------ finalise ------
+__global__ __launch_bounds__(kWave) void loss_finalize_kernel(
+    ld_geom_t geom, ld_loss_hp_t hp, BlockMap bm,
+    const int32_t* __restrict__ counts, const float* __restrict__ norm,
+    const float* __restrict__ partial, float* __restrict__ losses) {
+  const int L = geom.num_levels, N = geom.num_imgs;
+  const int l = blockIdx.x;
+  const size_t nb = (size_t)N * bm.blocks_per_img;
+  const int b0 = bm.blk_start[l], b1 = bm.blk_start[l + 1];
+  const int per = b1 - b0;
+  float acc[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    float a = 0.0f;
+    for (int i = threadIdx.x; i < per * N; i += kWave) {
+      const int n = i / per, b = b0 + (i - n * per);
+      a += partial[(size_t)k * nb + (size_t)n * bm.blocks_per_img + b];
+    }
+    acc[k] = wave_sum(a);
+  }
+  if (threadIdx.x == 0) {
+    const float nts = fmaxf(norm[0], 1.0f);
+    const float avg = norm[1] + 1e-6f;
+    const int P_l = counts[N + l], F_l = counts[N + L + l];
+    losses[0 * L + l] = hp.lw_cls * acc[S_CLS] / nts;
+    losses[1 * L + l] = hp.lw_bbox * acc[S_BBOX] / avg;
+    losses[2 * L + l] = hp.lw_dfl * acc[S_DFL] / 4.0f / avg;
+    losses[3 * L + l] = hp.lw_ld * acc[S_LD] / 4.0f;
+    losses[4 * L + l] = hp.lw_ld_vlr * acc[S_VLR] / 16.0f;
+    losses[5 * L + l] = P_l > 0 ? hp.lw_kd * acc[S_KD] / (float)P_l : 0.0f;
+    losses[6 * L + l] = 0.0f;  // loss_kd_neg = 0 * KD (ld_head.py:267-271)
+    losses[7 * L + l] = (P_l > 0 && F_l > 0)
+                            ? hp.lw_im * acc[S_IM] / ((float)F_l * (float)hp.feat_channels)
+                            : 0.0f;
+  }
+}
+
+// ------------------------------------ the north-star kernel, stand-alone ----
+// LD KL + Integral (+ gradient) over a dense channel-major (68, rows) map.
+// R consecutive rows per thread, loaded as float / float2 / float4.
+template <int R>
+struct VecT;
+template <>
+struct VecT<1> { using T = float; };
+template <>
+struct VecT<2> { using T = float2; };
+template <>
+struct VecT<4> { using T = float4; };
+
+template <int R, bool GRAD>
+__global__ __launch_bounds__(256) void kl_integral_dense_kernel(
+    const float* __restrict__ s_reg, const float* __restrict__ t_reg,
+    const float* __restrict__ weight, int64_t rows, float T, float scale,
+    float* __restrict__ integral, float* __restrict__ loss_rows,
+    float* __restrict__ grad) {
+  using V = typename VecT<R>::T;
+  const int64_t r0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * R;
+  if (r0 >= rows) return;
+  const float invT = 1.0f / T;
+  float w[R], lsum[R];
+  {
+    V wv = *reinterpret_cast<const V*>(weight + r0);
+    const float* wp = reinterpret_cast<const float*>(&wv);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      w[j] = wp[j];
+      lsum[j] = 0.0f;
+    }
+  }
+#pragma unroll 1
+  for (int s = 0; s < 4; ++s) {
+    float sv[R][K17], tv[R][K17];
+#pragma unroll
+    for (int k = 0; k < K17; ++k) {
+      V a = *reinterpret_cast<const V*>(s_reg + (int64_t)(s * K17 + k) * rows + r0);
+      V b = *reinterpret_cast<const V*>(t_reg + (int64_t)(s * K17 + k) * rows + r0);
+      const float* ap = reinterpret_cast<const float*>(&a);
+      const float* bp = reinterpret_cast<const float*>(&b);
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        sv[j][k] = ap[j];
+        tv[j][k] = bp[j];
+      }
+    }
+    float e[R];
+    float gr[R][K17];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      float d[K17], p[K17];
+      const float kl = ld::kl_rows<K17>(sv[j], tv[j], invT, T, d);
+      e[j] = ld::softmax_expect<K17>(sv[j], p);
+      lsum[j] += kl;
+      if (GRAD) {
+        const float cg = scale * w[j] * (T / (float)K17);
+#pragma unroll
+        for (int k = 0; k < K17; ++k) gr[j][k] = cg * d[k];
+      }
+    }
+    {
+      V ev;
+      float* ep = reinterpret_cast<float*>(&ev);
+#pragma unroll
+      for (int j = 0; j < R; ++j) ep[j] = e[j];
+      *reinterpret_cast<V*>(integral + (int64_t)s * rows + r0) = ev;
+    }
+    if (GRAD) {
+#pragma unroll
+      for (int k = 0; k < K17; ++k) {
+        V gv;
+        float* gp = reinterpret_cast<float*>(&gv);
+#pragma unroll
+        for (int j = 0; j < R; ++j) gp[j] = gr[j][k];
+        *reinterpret_cast<V*>(grad + (int64_t)(s * K17 + k) * rows + r0) = gv;
+      }
+    }
+  }
+  {
+    V lv;
+    float* lp = reinterpret_cast<float*>(&lv);
+#pragma unroll
+    for (int j = 0; j < R; ++j) lp[j] = w[j] * lsum[j];
+    *reinterpret_cast<V*>(loss_rows + r0) = lv;
+  }
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int check_geom(const ld_geom_t* g) {
+  if (!g || g->num_levels < 1 || g->num_levels > LD_MAX_LEVELS ||
+      g->num_imgs < 1 || g->num_anchors < 1)
+    return LD_EINVAL;
+  return 0;
+}
+
+int check_hp(const ld_loss_hp_t* hp) {
+  if (!hp) return LD_EINVAL;
+  if (hp->reg_max != 16 || hp->qfl_beta != 2.0f) return LD_EUNSUPPORTED;
+  if (hp->num_classes < 1 || hp->feat_channels < 1) return LD_EINVAL;
+  if (hp->T_ld < 1.0f || hp->T_ld_vlr < 1.0f || hp->T_kd < 1.0f)
+    return LD_EINVAL;  // kd_loss.py:51 assert T >= 1
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t ld_loss_workspace_bytes(const ld_geom_t* geom) {
+  if (check_geom(geom) != 0) return 0;
+  const BlockMap bm = make_block_map(*geom, kWave);
+  return align_up((size_t)S_COUNT * geom->num_imgs * bm.blocks_per_img * sizeof(float),
+                  256);
+}
+
+extern "C" int ld_loss_prepass(const ld_geom_t* geom, const ld_loss_hp_t* hp,
+                               const ld_maps_t* cls, const ld_maps_t* reg,
+                               const int64_t* labels, const float* bbox_targets,
+                               const int32_t* counts, float* weight_targets,
+                               float* score, float* norm, void* workspace,
+                               size_t workspace_bytes, ld_stream_t stream_) {
+  if (int e = check_geom(geom)) return e;
+  if (int e = check_hp(hp)) return e;
+  if (!cls || !reg || !labels || !bbox_targets || !counts || !weight_targets ||
+      !score || !norm)
+    return LD_EINVAL;
+  if (!workspace || workspace_bytes < ld_loss_workspace_bytes(geom))
+    return LD_ENOSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const BlockMap bm = make_block_map(*geom, kWave);
+  float* partial = (float*)workspace;
+  dim3 grid(bm.blocks_per_img, geom->num_imgs);
+  hipLaunchKernelGGL(loss_prepass_kernel, grid, dim3(kWave), 0, stream, *geom,
+                     *hp, bm, *cls, *reg, labels, bbox_targets, weight_targets,
+                     score, partial);
+  const int nparts = geom->num_imgs * bm.blocks_per_img;
+  hipLaunchKernelGGL(loss_norm_kernel, dim3(1), dim3(256), 0, stream, nparts,
+                     partial + (size_t)S_WSUM * nparts, counts,
+                     geom->num_imgs + 2 * geom->num_levels, norm);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_loss_main(const ld_geom_t* geom, const ld_loss_hp_t* hp,
+                            const ld_maps_t* cls, const ld_maps_t* reg,
+                            const ld_maps_t* t_cls, const ld_maps_t* t_reg,
+                            const ld_maps_t* x, const ld_maps_t* t_x,
+                            const int64_t* labels, const float* label_weights,
+                            const float* bbox_targets, const float* vlr,
+                            const float* im, const int32_t* counts,
+                            const float* weight_targets, const float* score,
+                            const float* norm, const float* upstream,
+                            const ld_maps_t* grad_cls, const ld_maps_t* grad_reg,
+                            const ld_maps_t* grad_x, void* workspace,
+                            size_t workspace_bytes, ld_stream_t stream_) {
+  if (int e = check_geom(geom)) return e;
+  if (int e = check_hp(hp)) return e;
+  if (!cls || !reg || !t_cls || !t_reg || !x || !t_x || !labels ||
+      !label_weights || !bbox_targets || !vlr || !im || !counts ||
+      !weight_targets || !score || !norm || !grad_cls || !grad_reg || !grad_x)
+    return LD_EINVAL;
+  if (!workspace || workspace_bytes < ld_loss_workspace_bytes(geom))
+    return LD_ENOSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const BlockMap bm = make_block_map(*geom, kWave);
+  float* partial = (float*)workspace;
+  dim3 grid(bm.blocks_per_img, geom->num_imgs);
+  hipLaunchKernelGGL(loss_reg_kernel, grid, dim3(kWave), 0, stream, *geom, *hp,
+                     bm, *reg, *t_reg, labels, bbox_targets, vlr,
+                     weight_targets, norm, upstream, *grad_reg, partial);
+  hipLaunchKernelGGL(loss_cls_kernel, grid, dim3(kWave), 0, stream, *geom, *hp,
+                     bm, *cls, *t_cls, labels, label_weights, score, counts,
+                     norm, upstream, *grad_cls, partial);
+  hipLaunchKernelGGL(loss_im_kernel, grid, dim3(kWave), 0, stream, *geom, *hp,
+                     bm, *x, *t_x, im, counts, upstream, *grad_x, partial);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_loss_finalize(const ld_geom_t* geom, const ld_loss_hp_t* hp,
+                                const int32_t* counts, const float* norm,
+                                const void* workspace, float* losses,
+                                ld_stream_t stream_) {
+  if (int e = check_geom(geom)) return e;
+  if (int e = check_hp(hp)) return e;
+  if (!counts || !norm || !workspace || !losses) return LD_EINVAL;
+  const BlockMap bm = make_block_map(*geom, kWave);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(geom->num_levels), dim3(kWave),
+                     0, (hipStream_t)stream_, *geom, *hp, bm, counts, norm,
+                     (const float*)workspace, losses);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_kl_integral_dense(const float* s_reg, const float* t_reg,
+                                    const float* weight, int64_t rows, float T,
+                                    float scale, float* integral,
+                                    float* loss_rows, float* grad,
+                                    ld_stream_t stream_) {
+  if (!s_reg || !t_reg || !weight || !integral || !loss_rows || rows < 1 ||
+      T < 1.0f)
+    return LD_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  // widest vector the row count and the base alignment allow
+  auto aligned = [](const void* p, size_t a) { return ((uintptr_t)p % a) == 0; };
+  int R = 1;
+  if (rows % 4 == 0 && aligned(s_reg, 16) && aligned(t_reg, 16) &&
+      aligned(weight, 16) && aligned(integral, 16) && aligned(loss_rows, 16) &&
+      (!grad || aligned(grad, 16)))
+    R = 4;
+  else if (rows % 2 == 0 && aligned(s_reg, 8) && aligned(t_reg, 8) &&
+           aligned(weight, 8) && aligned(integral, 8) && aligned(loss_rows, 8) &&
+           (!grad || aligned(grad, 8)))
+    R = 2;
+  // LD_KL_VEC overrides the vector width (1/2/4) for benchmarking
+  if (const char* env = getenv("LD_KL_VEC")) {
+    int v = atoi(env);
+    if ((v == 1 || v == 2 || v == 4) && v <= R) R = v;
+  }
+  const int64_t threads = (rows + R - 1) / R;
+  const dim3 block(256), grid((unsigned)((threads + 255) / 256));
+#define LD_LAUNCH_KL(RR, GG)                                                      \
+  hipLaunchKernelGGL((kl_integral_dense_kernel<RR, GG>), grid, block, 0, stream,  \
+                     s_reg, t_reg, weight, rows, T, scale, integral, loss_rows,   \
+                     grad)
+  if (grad) {
+    if (R == 4) LD_LAUNCH_KL(4, true);
+    else if (R == 2) LD_LAUNCH_KL(2, true);
+    else LD_LAUNCH_KL(1, true);
+  } else {
+    if (R == 4) LD_LAUNCH_KL(4, false);
+    else if (R == 2) LD_LAUNCH_KL(2, false);
+    else LD_LAUNCH_KL(1, false);
+  }
+#undef LD_LAUNCH_KL
+  return (int)hipGetLastError();
+}

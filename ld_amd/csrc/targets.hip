@@ -1,0 +1,408 @@
+// ATSS target assignment + VLR region + IM region for a whole batch, on gfx950.
+//
+// Replaces (reference, mmdet 2.10 fork):
+//   ATSSAssigner.assign            mmdet/core/bbox/assigners/atss_assigner.py:33-181
+//   ATSSAssigner.get_vlr_region    ...atss_assigner.py:183-298
+//   LDHead.get_im_region           mmdet/models/dense_heads/ld_head.py:580-611
+//   LDHead._get_target_single      ...ld_head.py:449-577 (+ unmap, misc.py:32-42)
+//   PseudoSampler.sample           mmdet/core/bbox/samplers/pseudo_sampler.py:24-41
+//
+// Design (MI355X-first, not a translation of the ~40 ATen launches per image):
+//   kernel A  one 256-thread workgroup per (image, GT): streams every valid
+//             anchor of every level once, keeps a register-resident sorted
+//             top-k per thread, merges them with k rounds of wave-shuffle
+//             arg-min, derives the mean+std IoU threshold and publishes the
+//             positive candidates with a 64-bit atomicMax (IoU, lowest GT
+//             index) per anchor.  Anchors are never materialised: anchor a of
+//             level l is the square of side 8*stride centred on (x*s, y*s).
+//   kernel B  one thread per (image, anchor): loops over the image's GTs held
+//             in LDS, evaluates the IoU / IoF-"diou" tile ONCE (the reference
+//             evaluates it five times) and writes the dense label / weight /
+//             box-target / VLR / IM maps in level-major layout, i.e. already in
+//             the form `images_to_levels` would produce.
+// All integer results (labels, positive indices, masks) are bit-exact w.r.t.
+// the reference CPU path on tie-free inputs; fp32 op order follows the
+// reference (no FMA contraction in this file).
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <limits.h>
+
+#include "../../include/ld_hip.h"
+#include "ld_math.h"
+
+namespace {
+
+using ld::Box;
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kMaxCand = LD_MAX_LEVELS * 16;
+
+struct DistIdx {
+  float d;
+  int i;
+};
+
+__device__ __forceinline__ bool lex_less(float d0, int i0, float d1, int i1) {
+  return (d0 < d1) || (d0 == d1 && i0 < i1);
+}
+
+__device__ __forceinline__ DistIdx wave_argmin(DistIdx v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    float od = __shfl_xor(v.d, off);
+    int oi = __shfl_xor(v.i, off);
+    if (lex_less(od, oi, v.d, v.i)) {
+      v.d = od;
+      v.i = oi;
+    }
+  }
+  return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+
+__device__ __forceinline__ int level_of(const ld_geom_t& g, int a) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < LD_MAX_LEVELS; ++i)
+    if (i < g.num_levels && a >= g.lv[i].offset) l = i;
+  return l;
+}
+
+// ---------------------------------------------------------------- kernel A --
+// workspace: keys (N*A u64), thr (N*max_gt f32), colmax (N*max_gt f32)
+template <int KMAX>
+__global__ __launch_bounds__(kBlock) void atss_select_kernel(
+    ld_geom_t geom, int topk, const float* __restrict__ gt_bboxes,
+    const int32_t* __restrict__ num_gt, int max_gt,
+    const int32_t* __restrict__ valid_hw, unsigned long long* __restrict__ keys,
+    float* __restrict__ thr_out, float* __restrict__ colmax_out) {
+  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  if (g >= num_gt[n]) return;
+  const float* gp = gt_bboxes + ((size_t)n * max_gt + g) * 4;
+  const Box gt{gp[0], gp[1], gp[2], gp[3]};
+  const float gcx = (gt.x1 + gt.x2) / 2.0f, gcy = (gt.y1 + gt.y2) / 2.0f;
+
+  __shared__ DistIdx s_wave[kWaves];
+  __shared__ float s_wmax[kWaves];
+  __shared__ int s_cand[kMaxCand];
+  __shared__ float s_ciou[kMaxCand];
+  __shared__ float s_thr;
+  int ncand = 0;  // uniform across the block
+  float my_colmax = 0.0f;
+
+  for (int l = 0; l < geom.num_levels; ++l) {
+    const ld_level_t lv = geom.lv[l];
+    const int vh = valid_hw[((size_t)n * geom.num_levels + l) * 2 + 0];
+    const int vw = valid_hw[((size_t)n * geom.num_levels + l) * 2 + 1];
+    const int nvalid = vh * vw;
+    const int k = min(topk, nvalid);
+    const float half = 0.5f * (float)(geom.anchor_scale * lv.stride);
+    float ld_[KMAX];
+    int li_[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      ld_[j] = FLT_MAX;
+      li_[j] = INT_MAX;
+    }
+    for (int v = tid; v < nvalid; v += kBlock) {
+      const int y = v / vw, x = v - y * vw;
+      const int a = lv.offset + y * lv.W + x;
+      const Box ab = ld::anchor_box(x, y, lv.stride, half);
+      const float acx = (ab.x1 + ab.x2) / 2.0f, acy = (ab.y1 + ab.y2) / 2.0f;
+      float d = ld::centre_dist(acx, acy, gcx, gcy);
+      my_colmax = fmaxf(my_colmax, ld::iou_pair(ab, gt));
+      int ai = a;
+      if (lex_less(d, ai, ld_[KMAX - 1], li_[KMAX - 1])) {
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+          if (lex_less(d, ai, ld_[j], li_[j])) {
+            float td = ld_[j];
+            int ti = li_[j];
+            ld_[j] = d;
+            li_[j] = ai;
+            d = td;
+            ai = ti;
+          }
+        }
+      }
+    }
+    // merge: k rounds of block-wide lexicographic arg-min over the list heads
+    for (int r = 0; r < k; ++r) {
+      DistIdx w = wave_argmin(DistIdx{ld_[0], li_[0]});
+      if ((tid & 63) == 0) s_wave[tid >> 6] = w;
+      __syncthreads();
+      DistIdx best = s_wave[0];
+#pragma unroll
+      for (int q = 1; q < kWaves; ++q)
+        if (lex_less(s_wave[q].d, s_wave[q].i, best.d, best.i)) best = s_wave[q];
+      if (li_[0] == best.i && best.i != INT_MAX) {  // the unique owner pops
+#pragma unroll
+        for (int j = 0; j < KMAX - 1; ++j) {
+          ld_[j] = ld_[j + 1];
+          li_[j] = li_[j + 1];
+        }
+        ld_[KMAX - 1] = FLT_MAX;
+        li_[KMAX - 1] = INT_MAX;
+      }
+      if (tid == 0) s_cand[ncand + r] = best.i;
+      __syncthreads();
+    }
+    ncand += k;
+  }
+  // column max IoU over all valid anchors (for the IM region)
+  {
+    float m = wave_max(my_colmax);
+    if ((tid & 63) == 0) s_wmax[tid >> 6] = m;
+  }
+  __syncthreads();
+  // IoU of the candidates
+  Box cab{0, 0, 0, 0};
+  float ciou = 0.0f;
+  if (tid < ncand) {
+    const int a = s_cand[tid];
+    const int l = level_of(geom, a);
+    const ld_level_t lv = geom.lv[l];
+    const int r = a - lv.offset;
+    const int y = r / lv.W, x = r - y * lv.W;
+    cab = ld::anchor_box(x, y, lv.stride,
+                         0.5f * (float)(geom.anchor_scale * lv.stride));
+    ciou = ld::iou_pair(cab, gt);
+    s_ciou[tid] = ciou;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // mean + unbiased std (atss_assigner.py:126-131); float64 accumulate,
+    // one rounding each -- matches torch's fp32 mean/std on every fixture
+    double sum = 0.0;
+    for (int i = 0; i < ncand; ++i) sum += (double)s_ciou[i];
+    const double mean = sum / (double)ncand;
+    double ss = 0.0;
+    for (int i = 0; i < ncand; ++i) {
+      const double dd = (double)s_ciou[i] - mean;
+      ss += dd * dd;
+    }
+    const double sd = sqrt(ss / (double)(ncand - 1));  // NaN when ncand == 1
+    const float thr = (float)mean + (float)sd;
+    s_thr = thr;
+    thr_out[(size_t)n * max_gt + g] = thr;
+    float cm = s_wmax[0];
+#pragma unroll
+    for (int q = 1; q < kWaves; ++q) cm = fmaxf(cm, s_wmax[q]);
+    colmax_out[(size_t)n * max_gt + g] = cm;
+  }
+  __syncthreads();
+  if (tid < ncand) {
+    const float thr = s_thr;
+    const float acx = (cab.x1 + cab.x2) / 2.0f, acy = (cab.y1 + cab.y2) / 2.0f;
+    const float l_ = acx - gt.x1, t_ = acy - gt.y1;
+    const float r_ = gt.x2 - acx, b_ = gt.y2 - acy;
+    const float mn = fminf(fminf(l_, t_), fminf(r_, b_));
+    if (ciou >= thr && mn > 0.01f) {
+      // highest IoU wins, ties -> lowest GT index (torch.max(dim=1) on CPU)
+      const unsigned long long key =
+          ((unsigned long long)__float_as_uint(ciou) << 32) |
+          (unsigned long long)(0xFFFFFFFFu - (unsigned)g);
+      atomicMax(keys + (size_t)n * geom.num_anchors + s_cand[tid], key);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- kernel B --
+constexpr int kGtChunk = 128;
+
+__global__ __launch_bounds__(kBlock) void atss_dense_kernel(
+    ld_geom_t geom, int num_classes, const float* __restrict__ gt_bboxes,
+    const int64_t* __restrict__ gt_labels, const int32_t* __restrict__ num_gt,
+    int max_gt, const int32_t* __restrict__ valid_hw,
+    const unsigned long long* __restrict__ keys, const float* __restrict__ thr,
+    const float* __restrict__ colmax, int64_t* __restrict__ labels,
+    float* __restrict__ label_weights, float* __restrict__ bbox_targets,
+    float* __restrict__ vlr, float* __restrict__ im,
+    int32_t* __restrict__ counts) {
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const int a = blockIdx.x * kBlock + tid;
+  const int A = geom.num_anchors, L = geom.num_levels, N = geom.num_imgs;
+  const int G = num_gt[n];
+  __shared__ float4 s_gt[kGtChunk];
+  __shared__ float s_thr[kGtChunk];
+  __shared__ float s_cm[kGtChunk];
+
+  bool valid = false;
+  Box ab{0, 0, 0, 0};
+  int l = 0;
+  if (a < A) {
+    l = level_of(geom, a);
+    const ld_level_t lv = geom.lv[l];
+    const int r = a - lv.offset;
+    const int y = r / lv.W, x = r - y * lv.W;
+    const int vh = valid_hw[((size_t)n * L + l) * 2 + 0];
+    const int vw = valid_hw[((size_t)n * L + l) * 2 + 1];
+    valid = (y < vh) && (x < vw);
+    ab = ld::anchor_box(x, y, lv.stride,
+                        0.5f * (float)(geom.anchor_scale * lv.stride));
+  }
+  float vmax = ld::kNegInf;
+  bool is_im = false;
+  for (int g0 = 0; g0 < G; g0 += kGtChunk) {
+    const int gc = min(kGtChunk, G - g0);
+    __syncthreads();
+    if (tid < gc) {
+      const float* gp = gt_bboxes + ((size_t)n * max_gt + g0 + tid) * 4;
+      s_gt[tid] = make_float4(gp[0], gp[1], gp[2], gp[3]);
+      s_thr[tid] = thr[(size_t)n * max_gt + g0 + tid];
+      s_cm[tid] = colmax[(size_t)n * max_gt + g0 + tid];
+    }
+    __syncthreads();
+    if (valid) {
+      for (int j = 0; j < gc; ++j) {
+        const float4 q = s_gt[j];
+        const Box gt{q.x, q.y, q.z, q.w};
+        const float iou = ld::iou_pair(ab, gt);
+        const float di = ld::diou_pair(ab, gt);
+        const float t = s_thr[j];
+        // atss_assigner.py:271-272
+        if ((di < t) && (di >= 0.25f * t)) vmax = fmaxf(vmax, iou);
+        // ld_head.py:594-596
+        if (iou > 0.5f * s_cm[j]) is_im = true;
+      }
+    }
+  }
+  if (a >= A) return;
+  const size_t o = (size_t)n * A + a;
+  int64_t lab = num_classes;
+  float lw = 0.0f, bt[4] = {0, 0, 0, 0}, vl = 0.0f, imv = 0.0f;
+  if (valid) {
+    lw = 1.0f;  // pos_weight <= 0 -> 1.0 for positives, negatives 1.0
+    const unsigned long long key = keys[o];
+    if (key != 0ull) {
+      const int g = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+      const float* gp = gt_bboxes + ((size_t)n * max_gt + g) * 4;
+      bt[0] = gp[0];
+      bt[1] = gp[1];
+      bt[2] = gp[2];
+      bt[3] = gp[3];
+      lab = gt_labels[(size_t)n * max_gt + g];
+      atomicAdd(counts + n, 1);
+      atomicAdd(counts + N + l, 1);
+    }
+    vl = (vmax != ld::kNegInf) ? vmax : 0.0f;
+    imv = is_im ? 1.0f : 0.0f;
+    if (is_im) atomicAdd(counts + N + L + l, 1);
+  }
+  labels[o] = lab;
+  label_weights[o] = lw;
+  reinterpret_cast<float4*>(bbox_targets)[o] =
+      make_float4(bt[0], bt[1], bt[2], bt[3]);
+  vlr[o] = vl;
+  im[o] = imv;
+}
+
+__global__ void atss_counts_finalize(int N, int L, int32_t* counts) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int s = 0;
+    for (int i = 0; i < N; ++i) s += max(counts[i], 1);  // ld_head.py:428
+    counts[N + 2 * L] = s;
+  }
+}
+
+__global__ void grid_anchors_kernel(ld_geom_t geom, float* __restrict__ out) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= geom.num_anchors) return;
+  const int l = level_of(geom, a);
+  const ld_level_t lv = geom.lv[l];
+  const int r = a - lv.offset;
+  const int y = r / lv.W, x = r - y * lv.W;
+  const Box b = ld::anchor_box(x, y, lv.stride,
+                               0.5f * (float)(geom.anchor_scale * lv.stride));
+  reinterpret_cast<float4*>(out)[a] = make_float4(b.x1, b.y1, b.x2, b.y2);
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int check_geom(const ld_geom_t* g) {
+  if (!g || g->num_levels < 1 || g->num_levels > LD_MAX_LEVELS ||
+      g->num_imgs < 1 || g->num_anchors < 1)
+    return LD_EINVAL;
+  int off = 0;
+  for (int l = 0; l < g->num_levels; ++l) {
+    if (g->lv[l].offset != off || g->lv[l].H < 1 || g->lv[l].W < 1)
+      return LD_EINVAL;
+    off += g->lv[l].H * g->lv[l].W;
+  }
+  return off == g->num_anchors ? 0 : LD_EINVAL;
+}
+
+}  // namespace
+
+extern "C" size_t ld_atss_targets_workspace_bytes(const ld_geom_t* geom,
+                                                   int max_gt) {
+  if (check_geom(geom) != 0 || max_gt < 0) return 0;
+  size_t keys = align_up((size_t)geom->num_imgs * geom->num_anchors * 8, 256);
+  size_t per_gt = align_up((size_t)geom->num_imgs * (max_gt > 0 ? max_gt : 1) * 4, 256);
+  return keys + 2 * per_gt;
+}
+
+extern "C" int ld_atss_targets(const ld_geom_t* geom, const ld_loss_hp_t* hp,
+                               const float* gt_bboxes, const int64_t* gt_labels,
+                               const int32_t* num_gt, int max_gt,
+                               const int32_t* valid_hw, int64_t* labels,
+                               float* label_weights, float* bbox_targets,
+                               float* vlr, float* im, int32_t* counts,
+                               void* workspace, size_t workspace_bytes,
+                               ld_stream_t stream_) {
+  if (int e = check_geom(geom)) return e;
+  if (!hp || !labels || !label_weights || !bbox_targets || !vlr || !im ||
+      !counts || !num_gt || !valid_hw || max_gt < 0)
+    return LD_EINVAL;
+  if (max_gt > 0 && (!gt_bboxes || !gt_labels)) return LD_EINVAL;
+  if (hp->topk < 1 || hp->topk > 16) return LD_EUNSUPPORTED;
+  const size_t need = ld_atss_targets_workspace_bytes(geom, max_gt);
+  if (!workspace || workspace_bytes < need) return LD_ENOSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int N = geom->num_imgs, A = geom->num_anchors, L = geom->num_levels;
+  char* ws = (char*)workspace;
+  const size_t keys_b = align_up((size_t)N * A * 8, 256);
+  const size_t per_gt = align_up((size_t)N * (max_gt > 0 ? max_gt : 1) * 4, 256);
+  unsigned long long* keys = (unsigned long long*)ws;
+  float* thr = (float*)(ws + keys_b);
+  float* colmax = (float*)(ws + keys_b + per_gt);
+  hipError_t err;
+  if ((err = hipMemsetAsync(keys, 0, (size_t)N * A * 8, stream))) return (int)err;
+  if ((err = hipMemsetAsync(counts, 0, sizeof(int32_t) * (N + 2 * L + 1), stream)))
+    return (int)err;
+  if (max_gt > 0) {
+    dim3 grid(max_gt, N);
+    if (hp->topk <= 9)
+      hipLaunchKernelGGL(atss_select_kernel<9>, grid, dim3(kBlock), 0, stream,
+                         *geom, hp->topk, gt_bboxes, num_gt, max_gt, valid_hw,
+                         keys, thr, colmax);
+    else
+      hipLaunchKernelGGL(atss_select_kernel<16>, grid, dim3(kBlock), 0, stream,
+                         *geom, hp->topk, gt_bboxes, num_gt, max_gt, valid_hw,
+                         keys, thr, colmax);
+  }
+  dim3 gridb((A + kBlock - 1) / kBlock, N);
+  hipLaunchKernelGGL(atss_dense_kernel, gridb, dim3(kBlock), 0, stream, *geom,
+                     hp->num_classes, gt_bboxes, gt_labels, num_gt,
+                     max_gt > 0 ? max_gt : 1, valid_hw, keys, thr, colmax,
+                     labels, label_weights, bbox_targets, vlr, im, counts);
+  hipLaunchKernelGGL(atss_counts_finalize, dim3(1), dim3(64), 0, stream, N, L,
+                     counts);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_grid_anchors(const ld_geom_t* geom, float* anchors,
+                               ld_stream_t stream) {
+  if (int e = check_geom(geom)) return e;
+  if (!anchors) return LD_EINVAL;
+  hipLaunchKernelGGL(grid_anchors_kernel,
+                     dim3((geom->num_anchors + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, *geom, anchors);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,185 @@
+"""ctypes binding of libldhip.so (C ABI declared in include/ld_hip.h).
+
+There is no fallback: if the shared library is missing, or a tensor handed to
+an op is not a contiguous fp32/int64 tensor on a HIP device, the call raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, '_lib', 'libldhip.so')
+
+LD_MAX_LEVELS = 8
+LD_NUM_LOSS_KEYS = 8
+LOSS_KEYS = ('loss_cls', 'loss_bbox', 'loss_dfl', 'loss_ld', 'loss_ld_vlr',
+             'loss_kd', 'loss_kd_neg', 'loss_im')
+
+
+class LdError(RuntimeError):
+    pass
+
+
+class LevelT(C.Structure):
+    _fields_ = [('H', C.c_int32), ('W', C.c_int32), ('stride', C.c_int32),
+                ('offset', C.c_int32)]
+
+
+class GeomT(C.Structure):
+    _fields_ = [('num_levels', C.c_int32), ('num_anchors', C.c_int32),
+                ('num_imgs', C.c_int32), ('anchor_scale', C.c_int32),
+                ('lv', LevelT * LD_MAX_LEVELS)]
+
+
+class MapsT(C.Structure):
+    _fields_ = [('ptr', C.c_void_p * LD_MAX_LEVELS),
+                ('stride_n', C.c_int64 * LD_MAX_LEVELS),
+                ('stride_c', C.c_int64 * LD_MAX_LEVELS)]
+
+
+class LossHpT(C.Structure):
+    _fields_ = [('num_classes', C.c_int32), ('reg_max', C.c_int32),
+                ('topk', C.c_int32), ('feat_channels', C.c_int32),
+                ('lw_cls', C.c_float), ('qfl_beta', C.c_float),
+                ('lw_bbox', C.c_float), ('giou_eps', C.c_float),
+                ('lw_dfl', C.c_float), ('lw_ld', C.c_float),
+                ('T_ld', C.c_float), ('lw_ld_vlr', C.c_float),
+                ('T_ld_vlr', C.c_float), ('lw_kd', C.c_float),
+                ('T_kd', C.c_float), ('lw_im', C.c_float)]
+
+
+_lib = None
+
+
+def lib_available():
+    return os.path.exists(LIB_PATH)
+
+
+def get_lib():
+    """Load libldhip.so (once).  Raises LdError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LdError(
+            f'{LIB_PATH} not found: the HIP extension has not been built '
+            '(run `python -m ld_amd.build`); ld_amd has no fallback path')
+    lib = C.CDLL(LIB_PATH)
+    _declare(lib)
+    if lib.ld_abi_version() != ABI_VERSION:
+        raise LdError('libldhip.so ABI version mismatch; rebuild')
+    _lib = lib
+    return lib
+
+
+ABI_VERSION = 1
+_vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
+_G, _H, _M = C.POINTER(GeomT), C.POINTER(LossHpT), C.POINTER(MapsT)
+
+# name -> (restype, argtypes); kept in one table so the CPU test-suite can
+# check that every symbol include/ld_hip.h declares is exported.
+SIGNATURES = {
+    'ld_abi_version': (C.c_int, []),
+    'ld_target_arch': (C.c_char_p, []),
+    'ld_atss_targets_workspace_bytes': (_sz, [_G, _i32]),
+    'ld_atss_targets': (C.c_int, [_G, _H, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
+                                  _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'ld_grid_anchors': (C.c_int, [_G, _vp, _vp]),
+    'ld_loss_workspace_bytes': (_sz, [_G]),
+    'ld_loss_prepass': (C.c_int, [_G, _H, _M, _M, _vp, _vp, _vp, _vp, _vp,
+                                  _vp, _vp, _sz, _vp]),
+    'ld_loss_main': (C.c_int, [_G, _H, _M, _M, _M, _M, _M, _M, _vp, _vp, _vp,
+                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _M, _M, _M,
+                               _vp, _sz, _vp]),
+    'ld_loss_finalize': (C.c_int, [_G, _H, _vp, _vp, _vp, _vp, _vp]),
+    'ld_kl_integral_dense': (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _vp,
+                                       _vp, _vp, _vp]),
+    'ld_kd_kl_rows': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp,
+                                _vp, _vp]),
+    'ld_qfl_rows': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp,
+                              _vp]),
+    'ld_dfl_rows': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp,
+                              _vp]),
+    'ld_giou_rows': (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp,
+                               _vp]),
+    'ld_integral_rows': (C.c_int, [_vp, _i64, _vp, _vp]),
+    'ld_integral_rows_bwd': (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    'ld_bbox_overlaps': (C.c_int, [_vp, _vp, _i64, _i64, _i32, _i32, _f32,
+                                   _vp, _vp]),
+    'ld_sum': (C.c_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
+}
+
+
+def _declare(lib):
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+
+
+_ERR = {-1: 'LD_EINVAL (bad argument)', -2: 'LD_ENOSPACE (workspace too small)',
+        -3: 'LD_EUNSUPPORTED'}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise LdError(f'{what} failed: {_ERR.get(rc, "hipError_t %d" % rc)}')
+
+
+# ---------------------------------------------------------------------------
+# tensor plumbing
+# ---------------------------------------------------------------------------
+def require_device(t, dtype=None, name='tensor'):
+    """The product runs on the GPU only: refuse anything else, loudly."""
+    if not isinstance(t, torch.Tensor):
+        raise LdError(f'{name}: expected a torch.Tensor, got {type(t)}')
+    if not t.is_cuda:
+        raise LdError(
+            f'{name} is on {t.device}: ld_amd ops only run on a HIP device '
+            '(there is no CPU path)')
+    if dtype is not None and t.dtype != dtype:
+        raise LdError(f'{name}: expected {dtype}, got {t.dtype}')
+    return t
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def make_geom(featmap_sizes, strides, num_imgs, anchor_scale=8):
+    g = GeomT()
+    L = len(featmap_sizes)
+    if L > LD_MAX_LEVELS or L != len(strides):
+        raise LdError('bad pyramid geometry')
+    off = 0
+    for l, ((h, w), s) in enumerate(zip(featmap_sizes, strides)):
+        s = s[0] if isinstance(s, (tuple, list)) else s
+        g.lv[l].H, g.lv[l].W = int(h), int(w)
+        g.lv[l].stride, g.lv[l].offset = int(s), off
+        off += int(h) * int(w)
+    g.num_levels, g.num_anchors = L, off
+    g.num_imgs, g.anchor_scale = int(num_imgs), int(anchor_scale)
+    return g
+
+
+def make_maps(tensors):
+    """Per-level (N, C, H, W) fp32 device tensors -> MapsT.  Each tensor's
+    spatial block must be contiguous (stride (.., .., W, 1)); batch and
+    channel strides are free, so views into a level-concatenated (N, C, A)
+    arena work without copies."""
+    m = MapsT()
+    for l, t in enumerate(tensors):
+        require_device(t, torch.float32, f'level {l} map')
+        n, c, h, w = t.shape
+        sn, sc, sh, sw = t.stride()
+        if (w > 1 and sw != 1) or (h > 1 and sh != w):
+            raise LdError(f'level {l} map: spatial block is not contiguous')
+        m.ptr[l] = t.data_ptr()
+        m.stride_n[l] = sn
+        m.stride_c[l] = sc
+    return m

@@ -1,0 +1,239 @@
+"""Torch-facing wrappers of the fused target-assignment / loss-block kernels.
+
+Host code here only marshals device pointers into the C ABI
+(include/ld_hip.h); no arithmetic of the hot path happens in Python/ATen.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+
+_WS = {}
+
+
+def workspace(device, nbytes, tag='ws'):
+    """A cached per-device scratch buffer (never shrinks)."""
+    key = (str(device), tag)
+    t = _WS.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8,
+                        device=device)
+        _WS[key] = t
+    return t
+
+
+def make_hp(num_classes=80, reg_max=16, topk=9, feat_channels=256, lw_cls=1.0,
+            qfl_beta=2.0, lw_bbox=2.0, giou_eps=1e-6, lw_dfl=0.25, lw_ld=0.25,
+            T_ld=10.0, lw_ld_vlr=0.25, T_ld_vlr=10.0, lw_kd=10.0, T_kd=2.0,
+            lw_im=2.0):
+    hp = L.LossHpT()
+    hp.num_classes, hp.reg_max, hp.topk = num_classes, reg_max, topk
+    hp.feat_channels = feat_channels
+    hp.lw_cls, hp.qfl_beta, hp.lw_bbox, hp.giou_eps = (lw_cls, qfl_beta,
+                                                       lw_bbox, giou_eps)
+    hp.lw_dfl, hp.lw_ld, hp.T_ld = lw_dfl, lw_ld, T_ld
+    hp.lw_ld_vlr, hp.T_ld_vlr, hp.lw_kd, hp.T_kd = (lw_ld_vlr, T_ld_vlr,
+                                                     lw_kd, T_kd)
+    hp.lw_im = lw_im
+    return hp
+
+
+def valid_hw_from_metas(featmap_sizes, strides, img_metas):
+    """anchor_generator.py:293-300: valid_h = min(ceil(pad_h / stride), H)."""
+    rows = []
+    for meta in img_metas:
+        ph, pw = meta['pad_shape'][:2]
+        for (h, w), s in zip(featmap_sizes, strides):
+            s = s[0] if isinstance(s, (tuple, list)) else s
+            rows.append([min(int(math.ceil(ph / s)), h),
+                         min(int(math.ceil(pw / s)), w)])
+    return rows
+
+
+def atss_targets(featmap_sizes, strides, img_metas, gt_bboxes, gt_labels, hp,
+                 device, anchor_scale=8):
+    """Dense ATSS / VLR / IM targets for a batch (see ld_atss_targets in
+    include/ld_hip.h).  Returns a dict of device tensors + the geometry."""
+    lib = L.get_lib()
+    N = len(img_metas)
+    geom = L.make_geom(featmap_sizes, strides, N, anchor_scale)
+    A, nl = geom.num_anchors, geom.num_levels
+    num_gt = [int(b.shape[0]) for b in gt_bboxes]
+    max_gt = max(num_gt) if num_gt else 0
+    gtb = torch.zeros((N, max(max_gt, 1), 4), dtype=torch.float32,
+                      device=device)
+    gtl = torch.zeros((N, max(max_gt, 1)), dtype=torch.int64, device=device)
+    for i, (b, l) in enumerate(zip(gt_bboxes, gt_labels)):
+        if num_gt[i]:
+            L.require_device(b, torch.float32, 'gt_bboxes')
+            gtb[i, :num_gt[i]] = b
+            gtl[i, :num_gt[i]] = l
+    ng = torch.tensor(num_gt, dtype=torch.int32).to(device)
+    vhw = torch.tensor(valid_hw_from_metas(featmap_sizes, strides, img_metas),
+                       dtype=torch.int32).to(device)
+    out = dict(
+        labels=torch.empty((N, A), dtype=torch.int64, device=device),
+        label_weights=torch.empty((N, A), dtype=torch.float32, device=device),
+        bbox_targets=torch.empty((N, A, 4), dtype=torch.float32,
+                                 device=device),
+        vlr=torch.empty((N, A), dtype=torch.float32, device=device),
+        im=torch.empty((N, A), dtype=torch.float32, device=device),
+        counts=torch.empty(N + 2 * nl + 1, dtype=torch.int32, device=device),
+    )
+    need = lib.ld_atss_targets_workspace_bytes(C.byref(geom), max_gt)
+    ws = workspace(device, need, 'targets')
+    rc = lib.ld_atss_targets(
+        C.byref(geom), C.byref(hp), L.ptr(gtb), L.ptr(gtl), L.ptr(ng), max_gt,
+        L.ptr(vhw), L.ptr(out['labels']), L.ptr(out['label_weights']),
+        L.ptr(out['bbox_targets']), L.ptr(out['vlr']), L.ptr(out['im']),
+        L.ptr(out['counts']), L.ptr(ws), ws.numel(), L.stream_ptr(device))
+    L.check(rc, 'ld_atss_targets')
+    out['geom'] = geom
+    out['num_gt'] = num_gt
+    return out
+
+
+def grid_anchors(featmap_sizes, strides, device, anchor_scale=8):
+    lib = L.get_lib()
+    geom = L.make_geom(featmap_sizes, strides, 1, anchor_scale)
+    out = torch.empty((geom.num_anchors, 4), dtype=torch.float32,
+                      device=device)
+    L.check(lib.ld_grid_anchors(C.byref(geom), L.ptr(out),
+                                L.stream_ptr(device)), 'ld_grid_anchors')
+    return out
+
+
+class _LossState:
+    pass
+
+
+def loss_block_forward(hp, targets, cls, reg, t_cls, t_reg, x, t_x,
+                       reduce_norm=None, upstream=None):
+    """Run prepass -> (normaliser reduction) -> main -> finalise.
+
+    cls/reg/x: student per-level NCHW tensors; t_*: teacher's.
+    reduce_norm: optional callable(norm_tensor[2]) doing the cross-rank MEAN
+    in place (core/utils/dist_utils.py:63-69) -- device side, no host sync.
+    Returns (losses (8, L) tensor, grads dict of lists, norm tensor).
+    """
+    lib = L.get_lib()
+    geom = targets['geom']
+    device = cls[0].device
+    N, A = geom.num_imgs, geom.num_anchors
+    m_cls, m_reg = L.make_maps(cls), L.make_maps(reg)
+    m_tcls, m_treg = L.make_maps(t_cls), L.make_maps(t_reg)
+    m_x, m_tx = L.make_maps(x), L.make_maps(t_x)
+    g_cls = [torch.empty_like(t, memory_format=torch.contiguous_format)
+             for t in cls]
+    g_reg = [torch.empty_like(t, memory_format=torch.contiguous_format)
+             for t in reg]
+    g_x = [torch.empty_like(t, memory_format=torch.contiguous_format)
+           for t in x]
+    mg_cls, mg_reg, mg_x = L.make_maps(g_cls), L.make_maps(g_reg), \
+        L.make_maps(g_x)
+    wt = torch.empty((N, A), dtype=torch.float32, device=device)
+    score = torch.empty((N, A), dtype=torch.float32, device=device)
+    norm = torch.zeros(4, dtype=torch.float32, device=device)
+    losses = torch.empty((L.LD_NUM_LOSS_KEYS, geom.num_levels),
+                         dtype=torch.float32, device=device)
+    need = lib.ld_loss_workspace_bytes(C.byref(geom))
+    ws = workspace(device, need, 'loss')
+    st = L.stream_ptr(device)
+    L.check(lib.ld_loss_prepass(
+        C.byref(geom), C.byref(hp), C.byref(m_cls), C.byref(m_reg),
+        L.ptr(targets['labels']), L.ptr(targets['bbox_targets']),
+        L.ptr(targets['counts']), L.ptr(wt), L.ptr(score), L.ptr(norm),
+        L.ptr(ws), ws.numel(), st), 'ld_loss_prepass')
+    if reduce_norm is not None:
+        reduce_norm(norm)
+    up = None
+    if upstream is not None:
+        up = L.require_device(upstream.contiguous(), torch.float32,
+                              'upstream')
+    L.check(lib.ld_loss_main(
+        C.byref(geom), C.byref(hp), C.byref(m_cls), C.byref(m_reg),
+        C.byref(m_tcls), C.byref(m_treg), C.byref(m_x), C.byref(m_tx),
+        L.ptr(targets['labels']), L.ptr(targets['label_weights']),
+        L.ptr(targets['bbox_targets']), L.ptr(targets['vlr']),
+        L.ptr(targets['im']), L.ptr(targets['counts']), L.ptr(wt),
+        L.ptr(score), L.ptr(norm), L.ptr(up), C.byref(mg_cls),
+        C.byref(mg_reg), C.byref(mg_x), L.ptr(ws), ws.numel(), st),
+        'ld_loss_main')
+    L.check(lib.ld_loss_finalize(
+        C.byref(geom), C.byref(hp), L.ptr(targets['counts']), L.ptr(norm),
+        L.ptr(ws), L.ptr(losses), st), 'ld_loss_finalize')
+    return losses, dict(cls=g_cls, reg=g_reg, x=g_x), norm, dict(
+        weight_targets=wt, score=score)
+
+
+class LDLossBlock(torch.autograd.Function):
+    """losses(8, L) = f(student cls[L], reg[L], x[L]); teacher tensors and
+    targets are constants.  The gradient is produced by the same fused launch
+    as the forward (upstream = 1); if the incoming grad is not all-ones the
+    block is re-run with the actual upstream coefficients."""
+
+    @staticmethod
+    def forward(ctx, hp, targets, teacher, reduce_norm, unit_upstream,
+                *student):
+        nl = targets['geom'].num_levels
+        cls, reg, x = student[:nl], student[nl:2 * nl], student[2 * nl:]
+        t_cls, t_reg, t_x = teacher
+        losses, grads, norm, aux = loss_block_forward(
+            hp, targets, cls, reg, t_cls, t_reg, x, t_x, reduce_norm)
+        ctx.unit_upstream = unit_upstream
+        ctx.pack = (hp, targets, teacher, norm)
+        ctx.nl = nl
+        ctx.save_for_backward(*student)
+        ctx.grads = grads
+        ctx.mark_non_differentiable(norm)
+        return losses, norm
+
+    @staticmethod
+    def backward(ctx, g_losses, _g_norm):
+        grads = ctx.grads
+        if not ctx.unit_upstream:
+            hp, targets, teacher, norm = ctx.pack
+            student = ctx.saved_tensors
+            nl = ctx.nl
+            cls, reg, x = student[:nl], student[nl:2 * nl], student[2 * nl:]
+            # the normalisers are constants of the graph (the reference takes
+            # them through .item(), ld_head.py:340-341,363): reuse them
+            _, grads, _, _ = _rerun_with_upstream(hp, targets, teacher, norm,
+                                                  cls, reg, x, g_losses)
+        out = tuple(grads['cls']) + tuple(grads['reg']) + tuple(grads['x'])
+        return (None, None, None, None, None) + out
+
+
+def _rerun_with_upstream(hp, targets, teacher, norm, cls, reg, x, upstream):
+    t_cls, t_reg, t_x = teacher
+    fixed = norm.clone()
+
+    def _restore(n):
+        n.copy_(fixed)
+
+    return loss_block_forward(hp, targets, cls, reg, t_cls, t_reg, x, t_x,
+                              reduce_norm=_restore, upstream=upstream)
+
+
+# ---------------------------------------------------------------------------
+# the north-star kernel on its own
+# ---------------------------------------------------------------------------
+def kl_integral_dense(s_reg, t_reg, weight, T=10.0, scale=1.0, with_grad=True):
+    """(68, rows) student/teacher logits, (rows,) weight ->
+    integral (4, rows), loss_rows (rows,), grad (68, rows) | None."""
+    lib = L.get_lib()
+    for t in (s_reg, t_reg, weight):
+        L.require_device(t, torch.float32)
+    rows = s_reg.shape[1]
+    assert s_reg.shape[0] == 68 and s_reg.is_contiguous()
+    integral = torch.empty((4, rows), dtype=torch.float32,
+                           device=s_reg.device)
+    loss_rows = torch.empty(rows, dtype=torch.float32, device=s_reg.device)
+    grad = torch.empty_like(s_reg) if with_grad else None
+    L.check(lib.ld_kl_integral_dense(
+        L.ptr(s_reg), L.ptr(t_reg), L.ptr(weight), rows, T, scale,
+        L.ptr(integral), L.ptr(loss_rows), L.ptr(grad),
+        L.stream_ptr(s_reg.device)), 'ld_kl_integral_dense')
+    return integral, loss_rows, grad

@@ -1,0 +1,57 @@
+"""CPU-side checks of the drop-in boundary: libldhip.so loads (no GPU needed)
+and exports every symbol include/ld_hip.h declares; the product refuses CPU
+tensors loudly (no fallback path)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(REPO, 'include', 'ld_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    names = re.findall(r'\b(ld_[a-z0-9_]+)\s*\(', src)
+    return sorted(set(names))
+
+
+def test_header_symbols_exported():
+    from ld_amd import lib as L
+    if not L.lib_available():
+        import __graft_entry__
+        __graft_entry__.build()
+    names = _declared()
+    assert len(names) >= 15
+    so = ctypes.CDLL(L.LIB_PATH)
+    for n in names:
+        assert hasattr(so, n), f'{n} declared in ld_hip.h but not exported'
+        assert n in L.SIGNATURES, f'{n} has no ctypes signature in ld_amd.lib'
+    assert set(L.SIGNATURES) <= set(names)
+    lib = L.get_lib()
+    assert lib.ld_abi_version() == L.ABI_VERSION
+    assert lib.ld_target_arch() == b'gfx950'
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected before any launch: callable on CPU."""
+    from ld_amd import lib as L
+    lib = L.get_lib()
+    g = L.make_geom([(4, 4)], [8], 1)
+    assert lib.ld_loss_workspace_bytes(ctypes.byref(g)) > 0
+    assert lib.ld_atss_targets_workspace_bytes(ctypes.byref(g), 3) > 0
+    rc = lib.ld_kd_kl_rows(None, None, None, 4, 17, 10.0, 1.0, None, None,
+                           None)
+    assert rc == -1
+    bad = L.GeomT()
+    assert lib.ld_loss_workspace_bytes(ctypes.byref(bad)) == 0
+
+
+def test_no_cpu_fallback():
+    from ld_amd import lib as L
+    with pytest.raises(L.LdError):
+        L.require_device(torch.zeros(3), torch.float32, 'x')
+    with pytest.raises(L.LdError):
+        L.make_maps([torch.zeros(1, 2, 3, 4)])
