@@ -218,6 +218,130 @@ int ld_bbox_overlaps(const float* b1, const float* b2, int64_t m, int64_t n,
 int ld_sum(const float* x, int64_t n, float* out, void* workspace,
            size_t workspace_bytes, ld_stream_t stream);
 
+/* ---- convolution (fp32, implicit GEMM on the f32 matrix cores) -----------
+ * Replaces nn.Conv2d under ResNet / FPN / GFLHead:
+ *   backbones/resnet.py:35-46,163-183 (BasicBlock/Bottleneck convs),
+ *   models/utils/res_layer.py:38-59 (downsample), necks/fpn.py:121-160,
+ *   dense_heads/gfl_head.py:102-133.
+ * Activations are (N, C, P) fp32 with P = sum over levels of H_l*W_l: a plain
+ * NCHW tensor is the one-level case; the FPN/head use the level-concatenated
+ * form so weight-shared convs over all five levels are one launch. */
+typedef struct {
+  int32_t Hin, Win, Hout, Wout;
+  int32_t off_in, off_out; /* first position of the level inside Pin / Pout */
+} ld_conv_level_t;
+
+typedef struct {
+  int32_t N, Cin, Cout, KH, KW;
+  int32_t stride; /* 1 or 2 */
+  int32_t pad;
+  int32_t num_levels;
+  int32_t Pin, Pout;
+  ld_conv_level_t lv[LD_MAX_LEVELS];
+} ld_conv_t;
+
+/* Fused forward epilogue, applied in this order:
+ *   v = acc; if scale: v = v*scale[co] + shift[co]  (frozen/eval BatchNorm,
+ *   resnet.py:639-648); if bias: v += bias[co]; if residual: v += residual;
+ *   if relu: v = max(v, 0).  Any pointer may be NULL. */
+typedef struct {
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const float* residual; /* same shape as y */
+  int32_t relu;
+} ld_conv_epilogue_t;
+
+/* (Cout,Cin,KH,KW) parameter -> GEMM images: wt_fwd [tap][Cin][Cout] and/or
+ * wt_bwd [KH*KW-1-tap][Cout][Cin] (either may be NULL). */
+int ld_conv_weight_transform(const float* w, int Cout, int Cin, int KH, int KW,
+                             float* wt_fwd, float* wt_bwd, ld_stream_t stream);
+int ld_conv_forward(const ld_conv_t* c, const float* x, const float* wt_fwd,
+                    const ld_conv_epilogue_t* ep, float* y, ld_stream_t stream);
+/* dx (N,Cin,Pin) fully overwritten. */
+int ld_conv_dgrad(const ld_conv_t* c, const float* dy, const float* wt_bwd,
+                  float* dx, ld_stream_t stream);
+size_t ld_conv_wgrad_workspace_bytes(const ld_conv_t* c);
+/* dw (Cout,Cin,KH,KW): overwritten, or += if accumulate != 0. */
+int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy, float* dw,
+                  int accumulate, void* workspace, size_t workspace_bytes,
+                  ld_stream_t stream);
+
+/* Small-Cin variant (the 7x7 stride-2 stem, resnet.py:558-570): flat
+ * (ci,kh,kw) reduction; wt = [Cin*KH*KW][Cout] image obtained with
+ * ld_conv_weight_transform(w, Cout, Cin*KH*KW, 1, 1, wt, NULL). */
+int ld_conv_forward_smallc(const ld_conv_t* c, const float* x, const float* wt,
+                           const ld_conv_epilogue_t* ep, float* y,
+                           ld_stream_t stream);
+
+/* ---- normalisation / elementwise layers ----------------------------------
+ * Level list of a level-concatenated (N, C, P) tensor (P = sum H_l*W_l). */
+typedef struct {
+  int32_t num_levels;
+  int32_t H[LD_MAX_LEVELS];
+  int32_t W[LD_MAX_LEVELS];
+} ld_levels_t;
+
+/* BatchNorm2d in eval mode (running stats frozen, affine trainable:
+ * resnet.py:639-648, norm_cfg requires_grad=True): scale = gamma*rsqrt(var+eps),
+ * shift = beta - mean*scale, rstd = rsqrt(var+eps) (rstd may be NULL). */
+int ld_bn_prepare(const float* gamma, const float* beta, const float* mean,
+                  const float* var, float eps, int C, float* scale, float* shift,
+                  float* rstd, ld_stream_t stream);
+/* y = act(x*scale[c] + shift[c] (+ residual)) on (N, C, P)
+ * (Bottleneck/BasicBlock tails, resnet.py:65-92,260-299). */
+int ld_bn_act_forward(const float* x, const float* residual, const float* scale,
+                      const float* shift, int N, int C, int P, int relu, float* y,
+                      ld_stream_t stream);
+size_t ld_bn_act_backward_workspace_bytes(int N, int C, int P);
+/* dz = relu ? dy*(y>0) : dy; dx = dz*scale (may be NULL); dres = dz (may be
+ * NULL); dgamma = sum dz*(x-mean)*rstd, dbeta = sum dz (either may be NULL). */
+int ld_bn_act_backward(const float* dy, const float* y, const float* x,
+                       const float* scale, const float* mean, const float* rstd,
+                       int N, int C, int P, int relu, float* dx, float* dres,
+                       float* dgamma, float* dbeta, int accumulate,
+                       void* workspace, size_t workspace_bytes,
+                       ld_stream_t stream);
+/* db[c] = sum_{n,p} dy (conv bias gradient, fpn.py / gfl_cls / gfl_reg). */
+int ld_bias_grad(const float* dy, int N, int C, int P, float* db, int accumulate,
+                 ld_stream_t stream);
+/* GroupNorm(G) (+ReLU) applied per FPN level of a level-concatenated tensor
+ * (gfl_head.py:102-126: each level is normalised on its own).  mean/rstd:
+ * (N, G, num_levels) outputs kept for the backward. */
+int ld_gn_forward(const ld_levels_t* lv, const float* x, const float* gamma,
+                  const float* beta, int N, int C, int G, float eps, int relu,
+                  float* y, float* mean, float* rstd, ld_stream_t stream);
+size_t ld_gn_backward_workspace_bytes(const ld_levels_t* lv, int N, int C);
+int ld_gn_backward(const ld_levels_t* lv, const float* dy, const float* y,
+                   const float* x, const float* gamma, const float* mean,
+                   const float* rstd, int N, int C, int G, int relu, float* dx,
+                   float* dgamma, float* dbeta, int accumulate, void* workspace,
+                   size_t workspace_bytes, ld_stream_t stream);
+/* MaxPool2d(kernel 3, stride 2, pad 1) on rows = N*C planes (resnet.py:570);
+ * forward only (the stem is frozen, frozen_stages=1). */
+int ld_maxpool3x3s2(const float* x, int rows, int H, int W, float* y,
+                    ld_stream_t stream);
+/* FPN top-down step (fpn.py:182-191): out = fine + nearest_up(coarse) with the
+ * finer map's size as target; rows = N*C planes.  Backward: dfine = dout
+ * (identity), dcoarse[q] = sum of dout over the fine cells that read q. */
+int ld_upsample_add_forward(const float* fine, const float* coarse, int rows,
+                            int Hf, int Wf, int Hc, int Wc, float* out,
+                            ld_stream_t stream);
+int ld_upsample_add_backward(const float* dout, int rows, int Hf, int Wf, int Hc,
+                             int Wc, float* dcoarse, ld_stream_t stream);
+/* mmcv Scale per level (gfl_head.py:182): y = x * scales[level]. */
+int ld_scale_levels_forward(const ld_levels_t* lv, const float* x,
+                            const float* scales, int rows, float* y,
+                            ld_stream_t stream);
+int ld_scale_levels_backward(const ld_levels_t* lv, const float* dy, const float* x,
+                             const float* scales, int rows, float* dx,
+                             float* dscales, int accumulate, ld_stream_t stream);
+/* torch.optim.SGD(momentum, weight_decay) over a flat parameter arena
+ * (apis/train.py:88): d = g*grad_scale + wd*p; buf = mu*buf + d; p -= lr*buf. */
+int ld_sgd_step(float* params, const float* grads, float* momentum_buf, size_t n,
+                float lr, float momentum, float weight_decay, float grad_scale,
+                ld_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,653 @@
+// The non-GEMM layers of the LD train step on gfx950 -- all HBM-bound, so the
+// rules are: one pass per tensor, float4 where the row length allows,
+// per-channel / per-group reductions written as fixed-order two-stage sums
+// (deterministic), statistics accumulated in fp64.
+//
+// Replaces (reference, mmdet 2.10 fork / mmcv / torch):
+//   BatchNorm2d in eval mode with trainable affine   resnet.py:639-648
+//       (norm_eval=True: running stats frozen, gamma/beta still learn)
+//   ReLU / residual add                               resnet.py:65-92,260-299
+//   GroupNorm(32) + ReLU of the head towers           gfl_head.py:102-126
+//   MaxPool2d(3, 2, 1)                                resnet.py:570
+//   FPN top-down nearest upsample + add               fpn.py:182-191
+//   mmcv Scale                                        gfl_head.py:131-133,182
+//   SGD(momentum, weight_decay)                       apis/train.py:88
+#include <hip/hip_runtime.h>
+
+#include "../../include/ld_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// block-wide sum of two doubles (256 threads), result valid in thread 0
+__device__ __forceinline__ void block_sum2(double& a, double& b) {
+  __shared__ double sa[4], sb[4];
+  a = wave_sum_d(a);
+  b = wave_sum_d(b);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sa[w] = a;
+    sb[w] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = sa[0] + sa[1] + sa[2] + sa[3];
+    b = sb[0] + sb[1] + sb[2] + sb[3];
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------ BN (eval) ----
+// scale = gamma * rsqrt(var + eps); shift = beta - mean * scale
+__global__ void bn_prepare_kernel(const float* __restrict__ gamma,
+                                  const float* __restrict__ beta,
+                                  const float* __restrict__ mean,
+                                  const float* __restrict__ var, float eps, int C,
+                                  float* __restrict__ scale,
+                                  float* __restrict__ shift,
+                                  float* __restrict__ rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float r = 1.0f / sqrtf(var[c] + eps);
+  const float s = gamma[c] * r;
+  scale[c] = s;
+  shift[c] = beta[c] - mean[c] * s;
+  if (rstd) rstd[c] = r;
+}
+
+// y = act(x * scale[c] + shift[c] (+ residual)); rows = N*C, row length P
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ residual,
+    const float* __restrict__ scale, const float* __restrict__ shift, int C, int P,
+    int relu, float* __restrict__ y) {
+  const int row = blockIdx.y;
+  const int c = row % C;
+  const float s = scale[c], b = shift[c];
+  const size_t base = (size_t)row * P;
+  if (VEC) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= P) return;
+    float4 v = *reinterpret_cast<const float4*>(x + base + i);
+    v.x = v.x * s + b; v.y = v.y * s + b; v.z = v.z * s + b; v.w = v.w * s + b;
+    if (residual) {
+      const float4 r = *reinterpret_cast<const float4*>(residual + base + i);
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+      v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(y + base + i) = v;
+  } else {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float v = x[base + i] * s + b;
+    if (residual) v += residual[base + i];
+    if (relu) v = fmaxf(v, 0.f);
+    y[base + i] = v;
+  }
+}
+
+// backward of the above.  dz = relu ? dy*(y>0) : dy;  dx = dz*scale[c];
+// dres = dz (optional);  partial[c][split] = (sum dz, sum dz * xhat)
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y,
+    const float* __restrict__ x, const float* __restrict__ scale,
+    const float* __restrict__ mean, const float* __restrict__ rstd, int N, int C,
+    int P, int relu, float* __restrict__ dx, float* __restrict__ dres,
+    double* __restrict__ partial) {
+  const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+  const float s = scale[c], mu = mean ? mean[c] : 0.f, rs = rstd ? rstd[c] : 0.f;
+  const long long total = (long long)N * P;
+  const long long per = (total + nsplit - 1) / nsplit;
+  const long long beg = (long long)split * per, end = min(total, beg + per);
+  double s1 = 0.0, s2 = 0.0;
+  for (long long e = beg + threadIdx.x; e < end; e += 256) {
+    const int n = (int)(e / P);
+    const int p = (int)(e - (long long)n * P);
+    const size_t idx = ((size_t)n * C + c) * P + p;
+    float dz = dy[idx];
+    if (relu && !(y[idx] > 0.f)) dz = 0.f;
+    if (dx) dx[idx] = dz * s;
+    if (dres) dres[idx] = dz;
+    if (partial) {
+      s1 += (double)dz;
+      s2 += (double)(dz * ((x[idx] - mu) * rs));
+    }
+  }
+  if (partial) {
+    block_sum2(s1, s2);
+    if (threadIdx.x == 0) {
+      partial[((size_t)c * nsplit + split) * 2 + 0] = s1;
+      partial[((size_t)c * nsplit + split) * 2 + 1] = s2;
+    }
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int C,
+                                       int nsplit, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nsplit; ++k) {
+    s1 += partial[((size_t)c * nsplit + k) * 2 + 0];
+    s2 += partial[((size_t)c * nsplit + k) * 2 + 1];
+  }
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+}
+
+// per-channel sum of dy over (N, P): conv bias gradient
+__global__ __launch_bounds__(256) void bias_grad_kernel(
+    const float* __restrict__ dy, int N, int C, int P, float* __restrict__ db,
+    int accumulate) {
+  const int c = blockIdx.x;
+  double s = 0.0, z = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const float* r = dy + ((size_t)n * C + c) * P;
+    for (int p = threadIdx.x; p < P; p += 256) s += (double)r[p];
+  }
+  block_sum2(s, z);
+  if (threadIdx.x == 0) db[c] = accumulate ? db[c] + (float)s : (float)s;
+}
+
+// -------------------------------------------------------------- GroupNorm ---
+struct Levels {
+  int num_levels;
+  int P;  // positions per (n, c) row
+  int off[LD_MAX_LEVELS + 1];
+};
+
+__device__ __forceinline__ int level_of_pos(const Levels& lv, int p) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < LD_MAX_LEVELS; ++i)
+    if (i < lv.num_levels && p >= lv.off[i]) l = i;
+  return l;
+}
+
+// one block per (n, group, level): mean / rstd over (C/G channels) x A_l
+__global__ __launch_bounds__(256) void gn_stats_kernel(
+    const float* __restrict__ x, Levels lv, int C, int G, float eps,
+    float* __restrict__ mean, float* __restrict__ rstd) {
+  const int L = lv.num_levels;
+  const int l = blockIdx.x % L, g = (blockIdx.x / L) % G, n = blockIdx.x / (L * G);
+  const int cpg = C / G, A = lv.off[l + 1] - lv.off[l];
+  const float* base = x + ((size_t)n * C + (size_t)g * cpg) * lv.P + lv.off[l];
+  double s = 0.0, q = 0.0;
+  const int total = cpg * A;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int ch = e / A, p = e - ch * A;
+    const double v = (double)base[(size_t)ch * lv.P + p];
+    s += v;
+    q += v * v;
+  }
+  block_sum2(s, q);
+  if (threadIdx.x == 0) {
+    const double m = s / total;
+    double var = q / total - m * m;
+    if (var < 0.0) var = 0.0;
+    const size_t o = ((size_t)n * G + g) * L + l;
+    mean[o] = (float)m;
+    rstd[o] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+// y = relu?( (x - mean) * rstd * gamma[c] + beta[c] )
+__global__ __launch_bounds__(256) void gn_apply_kernel(
+    const float* __restrict__ x, Levels lv, int C, int G,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+    float* __restrict__ y) {
+  const int row = blockIdx.y;  // n*C + c
+  const int c = row % C, n = row / C;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= lv.P) return;
+  const int l = level_of_pos(lv, p);
+  const size_t o = ((size_t)n * G + c / (C / G)) * lv.num_levels + l;
+  const size_t idx = (size_t)row * lv.P + p;
+  float v = (x[idx] - mean[o]) * rstd[o] * gamma[c] + beta[c];
+  if (relu) v = fmaxf(v, 0.f);
+  y[idx] = v;
+}
+
+// backward pass A: per (n, c, level): s1 = sum dz, s2 = sum dz * xhat
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y,
+    const float* __restrict__ x, Levels lv, int C, int G,
+    const float* __restrict__ mean, const float* __restrict__ rstd, int relu,
+    double* __restrict__ sums) {
+  const int L = lv.num_levels;
+  const int l = blockIdx.x % L, row = blockIdx.x / L;  // row = n*C + c
+  const int c = row % C, n = row / C;
+  const int A = lv.off[l + 1] - lv.off[l];
+  const size_t o = ((size_t)n * G + c / (C / G)) * L + l;
+  const float mu = mean[o], rs = rstd[o];
+  const size_t base = (size_t)row * lv.P + lv.off[l];
+  double s1 = 0.0, s2 = 0.0;
+  for (int p = threadIdx.x; p < A; p += 256) {
+    float dz = dy[base + p];
+    if (relu && !(y[base + p] > 0.f)) dz = 0.f;
+    s1 += (double)dz;
+    s2 += (double)(dz * ((x[base + p] - mu) * rs));
+  }
+  block_sum2(s1, s2);
+  if (threadIdx.x == 0) {
+    sums[((size_t)row * L + l) * 2 + 0] = s1;
+    sums[((size_t)row * L + l) * 2 + 1] = s2;
+  }
+}
+
+// backward pass B: dx = rstd * (gamma*dz - m1 - xhat*m2),
+//   m1 = mean_group(gamma*dz), m2 = mean_group(gamma*dz*xhat)
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y,
+    const float* __restrict__ x, Levels lv, int C, int G,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const double* __restrict__ sums, int relu,
+    float* __restrict__ dx) {
+  const int row = blockIdx.y;
+  const int c = row % C, n = row / C;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= lv.P) return;
+  const int L = lv.num_levels, cpg = C / G, g = c / cpg;
+  const int l = level_of_pos(lv, p);
+  const int A = lv.off[l + 1] - lv.off[l];
+  double m1 = 0.0, m2 = 0.0;
+  for (int k = 0; k < cpg; ++k) {
+    const int cc = g * cpg + k;
+    const size_t r = ((size_t)(n * C + cc) * L + l) * 2;
+    m1 += (double)gamma[cc] * sums[r + 0];
+    m2 += (double)gamma[cc] * sums[r + 1];
+  }
+  const double cnt = (double)cpg * A;
+  const float fm1 = (float)(m1 / cnt), fm2 = (float)(m2 / cnt);
+  const size_t o = ((size_t)n * G + g) * L + l;
+  const float mu = mean[o], rs = rstd[o];
+  const size_t idx = (size_t)row * lv.P + p;
+  float dz = dy[idx];
+  if (relu && !(y[idx] > 0.f)) dz = 0.f;
+  const float xh = (x[idx] - mu) * rs;
+  dx[idx] = rs * (gamma[c] * dz - fm1 - xh * fm2);
+}
+
+// dgamma[c] = sum_{n,l} s2, dbeta[c] = sum_{n,l} s1
+__global__ void gn_bwd_param_kernel(const double* __restrict__ sums, int N, int C,
+                                    int L, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int n = 0; n < N; ++n)
+    for (int l = 0; l < L; ++l) {
+      const size_t r = ((size_t)(n * C + c) * L + l) * 2;
+      s1 += sums[r + 0];
+      s2 += sums[r + 1];
+    }
+  dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+  dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+}
+
+// --------------------------------------------------------------- max pool ---
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(
+    const float* __restrict__ x, int rows, int H, int W, int Ho, int Wo,
+    float* __restrict__ y) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)rows * Ho * Wo;
+  if (i >= total) return;
+  const int wo = (int)(i % Wo);
+  const size_t q = i / Wo;
+  const int ho = (int)(q % Ho);
+  const size_t r = q / Ho;
+  const float* xp = x + r * H * W;
+  float m = -INFINITY;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hi = ho * 2 - 1 + kh;
+    if (hi < 0 || hi >= H) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int wi = wo * 2 - 1 + kw;
+      if (wi < 0 || wi >= W) continue;
+      m = fmaxf(m, xp[(size_t)hi * W + wi]);
+    }
+  }
+  y[i] = m;
+}
+
+// ---------------------------------------------------- FPN top-down pathway --
+// out = fine + nearest_up(coarse), target size = the finer map's size
+// (fpn.py:182-191: laterals[i-1] += F.interpolate(laterals[i], size=prev)).
+__device__ __forceinline__ int nearest_src(int dst, int in, int out) {
+  // F.interpolate(mode='nearest'): min(floor(dst * in/out), in-1), fp32 scale
+  const float scale = (float)in / (float)out;
+  return min((int)floorf((float)dst * scale), in - 1);
+}
+
+__global__ __launch_bounds__(256) void upsample_add_fwd_kernel(
+    const float* __restrict__ fine, const float* __restrict__ coarse, int Hf, int Wf,
+    int Hc, int Wc, float* __restrict__ out) {
+  const int row = blockIdx.y;
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= Hf * Wf) return;
+  const int h = r / Wf, w = r - h * Wf;
+  const int hc = nearest_src(h, Hc, Hf), wc = nearest_src(w, Wc, Wf);
+  out[(size_t)row * Hf * Wf + r] =
+      fine[(size_t)row * Hf * Wf + r] + coarse[(size_t)row * Hc * Wc + hc * Wc + wc];
+}
+
+// dcoarse[q] = sum over fine cells mapping to q of dout
+__global__ __launch_bounds__(256) void upsample_add_bwd_kernel(
+    const float* __restrict__ dout, int Hf, int Wf, int Hc, int Wc,
+    float* __restrict__ dcoarse) {
+  const int row = blockIdx.y;
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= Hc * Wc) return;
+  const int h = r / Wc, w = r - h * Wc;
+  const int h0 = max(0, (int)((long long)h * Hf / Hc) - 2);
+  const int h1 = min(Hf - 1, (int)((long long)(h + 1) * Hf / Hc) + 2);
+  const int w0 = max(0, (int)((long long)w * Wf / Wc) - 2);
+  const int w1 = min(Wf - 1, (int)((long long)(w + 1) * Wf / Wc) + 2);
+  float acc = 0.f;
+  for (int hf = h0; hf <= h1; ++hf) {
+    if (nearest_src(hf, Hc, Hf) != h) continue;
+    for (int wf = w0; wf <= w1; ++wf) {
+      if (nearest_src(wf, Wc, Wf) != w) continue;
+      acc += dout[(size_t)row * Hf * Wf + hf * Wf + wf];
+    }
+  }
+  dcoarse[(size_t)row * Hc * Wc + r] = acc;
+}
+
+// ------------------------------------------------------------- Scale layer --
+// y[n,c,p] = x[n,c,p] * scale[level(p)]
+__global__ __launch_bounds__(256) void scale_levels_kernel(
+    const float* __restrict__ x, Levels lv, const float* __restrict__ scales,
+    float* __restrict__ y) {
+  const int row = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= lv.P) return;
+  const int l = level_of_pos(lv, p);
+  const size_t idx = (size_t)row * lv.P + p;
+  y[idx] = x[idx] * scales[l];
+}
+
+// dscale[l] = sum dy * x over level l (all rows); one block per level
+__global__ __launch_bounds__(256) void scale_levels_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, Levels lv, int rows,
+    float* __restrict__ dscale, int accumulate) {
+  const int l = blockIdx.x;
+  const int A = lv.off[l + 1] - lv.off[l];
+  double s = 0.0, z = 0.0;
+  const long long total = (long long)rows * A;
+  for (long long e = threadIdx.x; e < total; e += 256) {
+    const int r = (int)(e / A), p = (int)(e - (long long)r * A);
+    const size_t idx = (size_t)r * lv.P + lv.off[l] + p;
+    s += (double)(dy[idx] * x[idx]);
+  }
+  block_sum2(s, z);
+  if (threadIdx.x == 0) dscale[l] = accumulate ? dscale[l] + (float)s : (float)s;
+}
+
+// --------------------------------------------------------------------- SGD --
+// torch.optim.SGD: d = g + wd*p; buf = mu*buf + d; p -= lr*buf
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p,
+                                                  const float* __restrict__ g,
+                                                  float* __restrict__ buf, size_t n,
+                                                  float lr, float mu, float wd,
+                                                  float gscale) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    float4 pv = *reinterpret_cast<float4*>(p + i);
+    const float4 gv = *reinterpret_cast<const float4*>(g + i);
+    float4 bv = *reinterpret_cast<float4*>(buf + i);
+    bv.x = mu * bv.x + (gv.x * gscale + wd * pv.x);
+    bv.y = mu * bv.y + (gv.y * gscale + wd * pv.y);
+    bv.z = mu * bv.z + (gv.z * gscale + wd * pv.z);
+    bv.w = mu * bv.w + (gv.w * gscale + wd * pv.w);
+    pv.x -= lr * bv.x; pv.y -= lr * bv.y; pv.z -= lr * bv.z; pv.w -= lr * bv.w;
+    *reinterpret_cast<float4*>(p + i) = pv;
+    *reinterpret_cast<float4*>(buf + i) = bv;
+  } else {
+    for (size_t k = i; k < n; ++k) {
+      const float b = mu * buf[k] + (g[k] * gscale + wd * p[k]);
+      buf[k] = b;
+      p[k] -= lr * b;
+    }
+  }
+}
+
+Levels make_levels(const ld_levels_t* lv) {
+  Levels k;
+  k.num_levels = lv->num_levels;
+  int off = 0;
+  for (int l = 0; l < LD_MAX_LEVELS + 1; ++l) k.off[l] = 0;
+  for (int l = 0; l < lv->num_levels; ++l) {
+    k.off[l] = off;
+    off += lv->H[l] * lv->W[l];
+  }
+  for (int l = lv->num_levels; l < LD_MAX_LEVELS + 1; ++l) k.off[l] = off;
+  k.P = off;
+  return k;
+}
+
+int check_levels(const ld_levels_t* lv) {
+  if (!lv || lv->num_levels < 1 || lv->num_levels > LD_MAX_LEVELS) return LD_EINVAL;
+  for (int l = 0; l < lv->num_levels; ++l)
+    if (lv->H[l] < 1 || lv->W[l] < 1) return LD_EINVAL;
+  return 0;
+}
+
+constexpr int kBnSplitMax = 64;
+
+int bn_splits(int N, int C, int P) {
+  const long long per_c = (long long)N * P;
+  int s = (int)((2048 + C - 1) / C);  // aim at ~2048 blocks
+  const int max_by_work = (int)((per_c + 4095) / 4096);
+  if (s > max_by_work) s = max_by_work;
+  if (s < 1) s = 1;
+  if (s > kBnSplitMax) s = kBnSplitMax;
+  return s;
+}
+
+}  // namespace
+
+#define LD_STREAM ((hipStream_t)stream)
+
+extern "C" int ld_bn_prepare(const float* gamma, const float* beta,
+                             const float* mean, const float* var, float eps, int C,
+                             float* scale, float* shift, float* rstd,
+                             ld_stream_t stream) {
+  if (!gamma || !beta || !mean || !var || !scale || !shift || C < 1)
+    return LD_EINVAL;
+  hipLaunchKernelGGL(bn_prepare_kernel, dim3((C + 255) / 256), dim3(256), 0,
+                     LD_STREAM, gamma, beta, mean, var, eps, C, scale, shift, rstd);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_bn_act_forward(const float* x, const float* residual,
+                                 const float* scale, const float* shift, int N,
+                                 int C, int P, int relu, float* y,
+                                 ld_stream_t stream) {
+  if (!x || !scale || !shift || !y || N < 1 || C < 1 || P < 1) return LD_EINVAL;
+  const bool vec = (P % 4 == 0) && ((uintptr_t)x % 16 == 0) &&
+                   ((uintptr_t)y % 16 == 0) &&
+                   (!residual || (uintptr_t)residual % 16 == 0);
+  if (vec)
+    hipLaunchKernelGGL((bn_act_fwd_kernel<true>), dim3((P / 4 + 255) / 256, N * C),
+                       dim3(256), 0, LD_STREAM, x, residual, scale, shift, C, P,
+                       relu, y);
+  else
+    hipLaunchKernelGGL((bn_act_fwd_kernel<false>), dim3((P + 255) / 256, N * C),
+                       dim3(256), 0, LD_STREAM, x, residual, scale, shift, C, P,
+                       relu, y);
+  return (int)hipGetLastError();
+}
+
+extern "C" size_t ld_bn_act_backward_workspace_bytes(int N, int C, int P) {
+  if (N < 1 || C < 1 || P < 1) return 0;
+  return (size_t)C * kBnSplitMax * 2 * sizeof(double);
+}
+
+extern "C" int ld_bn_act_backward(const float* dy, const float* y, const float* x,
+                                  const float* scale, const float* mean,
+                                  const float* rstd, int N, int C, int P, int relu,
+                                  float* dx, float* dres, float* dgamma,
+                                  float* dbeta, int accumulate, void* workspace,
+                                  size_t workspace_bytes, ld_stream_t stream) {
+  if (!dy || !scale || N < 1 || C < 1 || P < 1) return LD_EINVAL;
+  if (relu && !y) return LD_EINVAL;
+  const bool params = dgamma || dbeta;
+  if (params && (!x || !mean || !rstd)) return LD_EINVAL;
+  if (params && (!workspace ||
+                 workspace_bytes < ld_bn_act_backward_workspace_bytes(N, C, P)))
+    return LD_ENOSPACE;
+  const int ns = bn_splits(N, C, P);
+  hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(C, ns), dim3(256), 0, LD_STREAM, dy, y,
+                     x, scale, mean, rstd, N, C, P, relu, dx, dres,
+                     params ? (double*)workspace : nullptr);
+  if (params)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0,
+                       LD_STREAM, (const double*)workspace, C, ns, dgamma, dbeta,
+                       accumulate);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_bias_grad(const float* dy, int N, int C, int P, float* db,
+                            int accumulate, ld_stream_t stream) {
+  if (!dy || !db || N < 1 || C < 1 || P < 1) return LD_EINVAL;
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, LD_STREAM, dy, N, C, P,
+                     db, accumulate);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_gn_forward(const ld_levels_t* lv, const float* x,
+                             const float* gamma, const float* beta, int N, int C,
+                             int G, float eps, int relu, float* y, float* mean,
+                             float* rstd, ld_stream_t stream) {
+  if (int e = check_levels(lv)) return e;
+  if (!x || !gamma || !beta || !y || !mean || !rstd || N < 1 || C < 1 || G < 1 ||
+      C % G)
+    return LD_EINVAL;
+  const Levels k = make_levels(lv);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(N * G * k.num_levels), dim3(256), 0,
+                     LD_STREAM, x, k, C, G, eps, mean, rstd);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((k.P + 255) / 256, N * C), dim3(256), 0,
+                     LD_STREAM, x, k, C, G, mean, rstd, gamma, beta, relu, y);
+  return (int)hipGetLastError();
+}
+
+extern "C" size_t ld_gn_backward_workspace_bytes(const ld_levels_t* lv, int N,
+                                                 int C) {
+  if (check_levels(lv) != 0 || N < 1 || C < 1) return 0;
+  return (size_t)N * C * lv->num_levels * 2 * sizeof(double);
+}
+
+extern "C" int ld_gn_backward(const ld_levels_t* lv, const float* dy, const float* y,
+                              const float* x, const float* gamma, const float* mean,
+                              const float* rstd, int N, int C, int G, int relu,
+                              float* dx, float* dgamma, float* dbeta, int accumulate,
+                              void* workspace, size_t workspace_bytes,
+                              ld_stream_t stream) {
+  if (int e = check_levels(lv)) return e;
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || N < 1 || C < 1 || G < 1 ||
+      C % G)
+    return LD_EINVAL;
+  if (relu && !y) return LD_EINVAL;
+  if (!workspace || workspace_bytes < ld_gn_backward_workspace_bytes(lv, N, C))
+    return LD_ENOSPACE;
+  const Levels k = make_levels(lv);
+  double* sums = (double*)workspace;
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(N * C * k.num_levels), dim3(256), 0,
+                     LD_STREAM, dy, y, x, k, C, G, mean, rstd, relu, sums);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((k.P + 255) / 256, N * C), dim3(256),
+                     0, LD_STREAM, dy, y, x, k, C, G, mean, rstd, gamma, sums, relu,
+                     dx);
+  if (dgamma && dbeta)
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0,
+                       LD_STREAM, sums, N, C, k.num_levels, dgamma, dbeta,
+                       accumulate);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_maxpool3x3s2(const float* x, int rows, int H, int W, float* y,
+                               ld_stream_t stream) {
+  if (!x || !y || rows < 1 || H < 1 || W < 1) return LD_EINVAL;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)rows * Ho * Wo;
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)((total + 255) / 256)),
+                     dim3(256), 0, LD_STREAM, x, rows, H, W, Ho, Wo, y);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_upsample_add_forward(const float* fine, const float* coarse,
+                                       int rows, int Hf, int Wf, int Hc, int Wc,
+                                       float* out, ld_stream_t stream) {
+  if (!fine || !coarse || !out || rows < 1 || Hf < 1 || Wf < 1 || Hc < 1 || Wc < 1)
+    return LD_EINVAL;
+  hipLaunchKernelGGL(upsample_add_fwd_kernel, dim3((Hf * Wf + 255) / 256, rows),
+                     dim3(256), 0, LD_STREAM, fine, coarse, Hf, Wf, Hc, Wc, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_upsample_add_backward(const float* dout, int rows, int Hf, int Wf,
+                                        int Hc, int Wc, float* dcoarse,
+                                        ld_stream_t stream) {
+  if (!dout || !dcoarse || rows < 1 || Hf < 1 || Wf < 1 || Hc < 1 || Wc < 1)
+    return LD_EINVAL;
+  hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3((Hc * Wc + 255) / 256, rows),
+                     dim3(256), 0, LD_STREAM, dout, Hf, Wf, Hc, Wc, dcoarse);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_scale_levels_forward(const ld_levels_t* lv, const float* x,
+                                       const float* scales, int rows, float* y,
+                                       ld_stream_t stream) {
+  if (int e = check_levels(lv)) return e;
+  if (!x || !scales || !y || rows < 1) return LD_EINVAL;
+  const Levels k = make_levels(lv);
+  hipLaunchKernelGGL(scale_levels_kernel, dim3((k.P + 255) / 256, rows), dim3(256),
+                     0, LD_STREAM, x, k, scales, y);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_scale_levels_backward(const ld_levels_t* lv, const float* dy,
+                                        const float* x, const float* scales,
+                                        int rows, float* dx, float* dscales,
+                                        int accumulate, ld_stream_t stream) {
+  if (int e = check_levels(lv)) return e;
+  if (!dy || !x || !scales || !dx || rows < 1) return LD_EINVAL;
+  const Levels k = make_levels(lv);
+  hipLaunchKernelGGL(scale_levels_kernel, dim3((k.P + 255) / 256, rows), dim3(256),
+                     0, LD_STREAM, dy, k, scales, dx);
+  if (dscales)
+    hipLaunchKernelGGL(scale_levels_bwd_kernel, dim3(k.num_levels), dim3(256), 0,
+                       LD_STREAM, dy, x, k, rows, dscales, accumulate);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_sgd_step(float* params, const float* grads, float* momentum_buf,
+                           size_t n, float lr, float momentum, float weight_decay,
+                           float grad_scale, ld_stream_t stream) {
+  if (!params || !grads || !momentum_buf) return LD_EINVAL;
+  if (n == 0) return 0;
+  if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)momentum_buf) % 16)
+    return LD_EINVAL;
+  const size_t threads = (n + 3) / 4;
+  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256),
+                     0, LD_STREAM, params, grads, momentum_buf, n, lr, momentum,
+                     weight_decay, grad_scale);
+  return (int)hipGetLastError();
+}

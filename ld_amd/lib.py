@@ -49,6 +49,31 @@ class LossHpT(C.Structure):
                 ('T_kd', C.c_float), ('lw_im', C.c_float)]
 
 
+class ConvLevelT(C.Structure):
+    _fields_ = [('Hin', C.c_int32), ('Win', C.c_int32), ('Hout', C.c_int32),
+                ('Wout', C.c_int32), ('off_in', C.c_int32),
+                ('off_out', C.c_int32)]
+
+
+class ConvT(C.Structure):
+    _fields_ = [('N', C.c_int32), ('Cin', C.c_int32), ('Cout', C.c_int32),
+                ('KH', C.c_int32), ('KW', C.c_int32), ('stride', C.c_int32),
+                ('pad', C.c_int32), ('num_levels', C.c_int32),
+                ('Pin', C.c_int32), ('Pout', C.c_int32),
+                ('lv', ConvLevelT * LD_MAX_LEVELS)]
+
+
+class ConvEpilogueT(C.Structure):
+    _fields_ = [('bias', C.c_void_p), ('scale', C.c_void_p),
+                ('shift', C.c_void_p), ('residual', C.c_void_p),
+                ('relu', C.c_int32)]
+
+
+class LevelsT(C.Structure):
+    _fields_ = [('num_levels', C.c_int32), ('H', C.c_int32 * LD_MAX_LEVELS),
+                ('W', C.c_int32 * LD_MAX_LEVELS)]
+
+
 _lib = None
 
 
@@ -76,6 +101,7 @@ def get_lib():
 ABI_VERSION = 1
 _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 _G, _H, _M = C.POINTER(GeomT), C.POINTER(LossHpT), C.POINTER(MapsT)
+_CV, _EP, _LV = C.POINTER(ConvT), C.POINTER(ConvEpilogueT), C.POINTER(LevelsT)
 
 # name -> (restype, argtypes); kept in one table so the CPU test-suite can
 # check that every symbol include/ld_hip.h declares is exported.
@@ -108,6 +134,38 @@ SIGNATURES = {
     'ld_bbox_overlaps': (C.c_int, [_vp, _vp, _i64, _i64, _i32, _i32, _f32,
                                    _vp, _vp]),
     'ld_sum': (C.c_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    'ld_conv_weight_transform': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp,
+                                           _vp, _vp]),
+    'ld_conv_forward': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
+    'ld_conv_forward_smallc': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
+    'ld_conv_dgrad': (C.c_int, [_CV, _vp, _vp, _vp, _vp]),
+    'ld_conv_wgrad_workspace_bytes': (_sz, [_CV]),
+    'ld_conv_wgrad': (C.c_int, [_CV, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
+    'ld_bn_prepare': (C.c_int, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp,
+                                _vp]),
+    'ld_bn_act_forward': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32,
+                                    _i32, _vp, _vp]),
+    'ld_bn_act_backward_workspace_bytes': (_sz, [_i32, _i32, _i32]),
+    'ld_bn_act_backward': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
+                                     _i32, _i32, _vp, _vp, _vp, _vp, _i32,
+                                     _vp, _sz, _vp]),
+    'ld_bias_grad': (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
+    'ld_gn_forward': (C.c_int, [_LV, _vp, _vp, _vp, _i32, _i32, _i32, _f32,
+                                _i32, _vp, _vp, _vp, _vp]),
+    'ld_gn_backward_workspace_bytes': (_sz, [_LV, _i32, _i32]),
+    'ld_gn_backward': (C.c_int, [_LV, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
+                                 _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp,
+                                 _sz, _vp]),
+    'ld_maxpool3x3s2': (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    'ld_upsample_add_forward': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32,
+                                          _i32, _vp, _vp]),
+    'ld_upsample_add_backward': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32,
+                                           _vp, _vp]),
+    'ld_scale_levels_forward': (C.c_int, [_LV, _vp, _vp, _i32, _vp, _vp]),
+    'ld_scale_levels_backward': (C.c_int, [_LV, _vp, _vp, _vp, _i32, _vp, _vp,
+                                           _i32, _vp]),
+    'ld_sgd_step': (C.c_int, [_vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32,
+                              _vp]),
 }
 
 
