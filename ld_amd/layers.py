@@ -1,0 +1,461 @@
+"""Autograd-facing layer functions over the HIP C ABI (include/ld_hip.h).
+
+Every arithmetic step is a libldhip.so launch on the current torch HIP stream;
+torch supplies device memory, the autograd tape and nothing else.  Tensors are
+handled in the (N, C, P) form: P = H*W for an ordinary NCHW map, or the sum of
+the per-level H_l*W_l of a level-concatenated FPN/head tensor (``levels`` is
+the tuple of (H, W) per level).
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .lossblock import workspace
+
+_PARAM_GEN = [0]
+
+
+def bump_param_generation():
+    """Called by the optimizer after it rewrites parameters in place (outside
+    torch's version counters) so cached GEMM weight images are refreshed."""
+    _PARAM_GEN[0] += 1
+
+
+def _dev_f32(t, name):
+    L.require_device(t, torch.float32, name)
+    if not t.is_contiguous():
+        raise L.LdError(f'{name} must be contiguous')
+    return t
+
+
+def out_size(h, k, s, p):
+    return (h + 2 * p - k) // s + 1
+
+
+def conv_desc(N, Cin, Cout, KH, KW, stride, pad, levels):
+    d = L.ConvT()
+    d.N, d.Cin, d.Cout, d.KH, d.KW = N, Cin, Cout, KH, KW
+    d.stride, d.pad, d.num_levels = stride, pad, len(levels)
+    pin = pout = 0
+    out_levels = []
+    for l, (h, w) in enumerate(levels):
+        ho, wo = out_size(h, KH, stride, pad), out_size(w, KW, stride, pad)
+        d.lv[l].Hin, d.lv[l].Win, d.lv[l].Hout, d.lv[l].Wout = h, w, ho, wo
+        d.lv[l].off_in, d.lv[l].off_out = pin, pout
+        pin += h * w
+        pout += ho * wo
+        out_levels.append((ho, wo))
+    d.Pin, d.Pout = pin, pout
+    return d, tuple(out_levels)
+
+
+def levels_desc(levels):
+    d = L.LevelsT()
+    d.num_levels = len(levels)
+    for l, (h, w) in enumerate(levels):
+        d.H[l], d.W[l] = h, w
+    return d
+
+
+# ---------------------------------------------------------------------------
+# GEMM weight images (cached on the parameter)
+# ---------------------------------------------------------------------------
+def weight_images(w, need_bwd, smallc=False):
+    """[tap][Cin][Cout] (and, on demand, [flipped tap][Cout][Cin]) images of a
+    conv parameter; rebuilt when the parameter changed."""
+    lib = L.get_lib()
+    _dev_f32(w, 'conv weight')
+    stamp = (w._version, _PARAM_GEN[0] if w.requires_grad else -1,
+             w.data_ptr(), smallc)
+    cache = getattr(w, '_ld_images', None)
+    if cache is None or cache['ident'] != stamp[2:]:
+        cache = dict(ident=stamp[2:], stamp=None, fwd=None, bwd=None,
+                     bwd_stamp=None)
+        w._ld_images = cache
+    cout, cin, kh, kw = w.shape
+    st = L.stream_ptr(w.device)
+    if cache['stamp'] != stamp:
+        if cache['fwd'] is None:
+            cache['fwd'] = torch.empty(w.numel(), dtype=torch.float32,
+                                       device=w.device)
+        if smallc:
+            rc = lib.ld_conv_weight_transform(L.ptr(w), cout, cin * kh * kw,
+                                              1, 1, L.ptr(cache['fwd']), None,
+                                              st)
+        else:
+            rc = lib.ld_conv_weight_transform(L.ptr(w), cout, cin, kh, kw,
+                                              L.ptr(cache['fwd']), None, st)
+        L.check(rc, 'ld_conv_weight_transform')
+        cache['stamp'] = stamp
+    if need_bwd and cache['bwd_stamp'] != stamp:
+        if smallc:
+            raise L.LdError('small-Cin (stem) conv has no data gradient')
+        if cache['bwd'] is None:
+            cache['bwd'] = torch.empty(w.numel(), dtype=torch.float32,
+                                       device=w.device)
+        L.check(lib.ld_conv_weight_transform(L.ptr(w), cout, cin, kh, kw, None,
+                                             L.ptr(cache['bwd']), st),
+                'ld_conv_weight_transform')
+        cache['bwd_stamp'] = stamp
+    return cache['fwd'], cache['bwd']
+
+
+def _epilogue(bias=None, scale=None, shift=None, residual=None, relu=False):
+    ep = L.ConvEpilogueT()
+    ep.bias = bias.data_ptr() if bias is not None else None
+    ep.scale = scale.data_ptr() if scale is not None else None
+    ep.shift = shift.data_ptr() if shift is not None else None
+    ep.residual = residual.data_ptr() if residual is not None else None
+    ep.relu = 1 if relu else 0
+    return ep
+
+
+def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
+                     shift=None, residual=None, relu=False):
+    """One implicit-GEMM launch.  Returns (y3, out_levels)."""
+    lib = L.get_lib()
+    _dev_f32(x3, 'conv input')
+    N, cin, P = x3.shape
+    cout, cin_w, kh, kw = w.shape
+    if cin_w != cin:
+        raise L.LdError('conv: channel mismatch')
+    d, out_levels = conv_desc(N, cin, cout, kh, kw, stride, pad, levels)
+    if d.Pin != P:
+        raise L.LdError(f'conv: input has {P} positions, levels say {d.Pin}')
+    smallc = cin < 16
+    wt_fwd, _ = weight_images(w, False, smallc)
+    y3 = torch.empty((N, cout, d.Pout), dtype=torch.float32, device=x3.device)
+    if residual is not None:
+        _dev_f32(residual, 'residual')
+        assert residual.shape == y3.shape
+    ep = _epilogue(bias, scale, shift, residual, relu)
+    fn = lib.ld_conv_forward_smallc if smallc else lib.ld_conv_forward
+    L.check(fn(C.byref(d), L.ptr(x3), L.ptr(wt_fwd), C.byref(ep), L.ptr(y3),
+               L.stream_ptr(x3.device)), 'ld_conv_forward')
+    return y3, out_levels
+
+
+class ConvFn(torch.autograd.Function):
+    """y = conv(x, w) (+ bias).  backward = MFMA dgrad + split-K wgrad."""
+
+    @staticmethod
+    def forward(ctx, x3, w, bias, stride, pad, levels):
+        y3, out_levels = conv_forward_raw(x3, w, stride, pad, levels,
+                                          bias=bias)
+        ctx.save_for_backward(x3, w)
+        ctx.meta = (stride, pad, levels, bias is not None)
+        return y3
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.get_lib()
+        x3, w = ctx.saved_tensors
+        stride, pad, levels, has_bias = ctx.meta
+        dy = dy.contiguous()
+        N, cin, _ = x3.shape
+        cout, _, kh, kw = w.shape
+        d, _ = conv_desc(N, cin, cout, kh, kw, stride, pad, levels)
+        st = L.stream_ptr(x3.device)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            _, wt_bwd = weight_images(w, True)
+            dx = torch.empty_like(x3)
+            L.check(lib.ld_conv_dgrad(C.byref(d), L.ptr(dy), L.ptr(wt_bwd),
+                                      L.ptr(dx), st), 'ld_conv_dgrad')
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            need = lib.ld_conv_wgrad_workspace_bytes(C.byref(d))
+            ws = workspace(x3.device, need, 'wgrad')
+            L.check(lib.ld_conv_wgrad(C.byref(d), L.ptr(x3), L.ptr(dy),
+                                      L.ptr(dw), 0, L.ptr(ws), ws.numel(),
+                                      st), 'ld_conv_wgrad')
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(cout, dtype=torch.float32, device=x3.device)
+            L.check(lib.ld_bias_grad(L.ptr(dy), N, cout, dy.shape[2],
+                                     L.ptr(db), 0, st), 'ld_bias_grad')
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x3, w, bias, stride, pad, levels):
+    """Differentiable conv on an (N, C, P) tensor.  Returns (y3, out_levels)."""
+    N, cin, _ = x3.shape
+    cout, _, kh, kw = w.shape
+    _, out_levels = conv_desc(N, cin, cout, kh, kw, stride, pad, levels)
+    if torch.is_grad_enabled() and (x3.requires_grad or w.requires_grad or
+                                    (bias is not None and bias.requires_grad)):
+        return ConvFn.apply(x3, w, bias, stride, pad, levels), out_levels
+    y3, _ = conv_forward_raw(x3, w, stride, pad, levels, bias=bias)
+    return y3, out_levels
+
+
+# ---------------------------------------------------------------------------
+# BatchNorm (eval statistics) + residual + ReLU
+# ---------------------------------------------------------------------------
+def bn_prepare(gamma, beta, mean, var, eps):
+    lib = L.get_lib()
+    c = gamma.numel()
+    buf = torch.empty((3, c), dtype=torch.float32, device=gamma.device)
+    L.check(lib.ld_bn_prepare(L.ptr(gamma), L.ptr(beta), L.ptr(mean),
+                              L.ptr(var), eps, c, L.ptr(buf[0]), L.ptr(buf[1]),
+                              L.ptr(buf[2]), L.stream_ptr(gamma.device)),
+            'ld_bn_prepare')
+    return buf[0], buf[1], buf[2]
+
+
+class BnActFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x3, gamma, beta, mean, var, eps, residual, relu):
+        lib = L.get_lib()
+        _dev_f32(x3, 'bn input')
+        N, c, P = x3.shape
+        scale, shift, rstd = bn_prepare(gamma, beta, mean, var, eps)
+        y = torch.empty_like(x3)
+        if residual is not None:
+            _dev_f32(residual, 'bn residual')
+        L.check(lib.ld_bn_act_forward(L.ptr(x3), L.ptr(residual), L.ptr(scale),
+                                      L.ptr(shift), N, c, P, 1 if relu else 0,
+                                      L.ptr(y), L.stream_ptr(x3.device)),
+                'ld_bn_act_forward')
+        ctx.save_for_backward(x3, y, scale, mean, rstd)
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.get_lib()
+        x3, y, scale, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, c, P = x3.shape
+        need_x = ctx.needs_input_grad[0]
+        need_g, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        need_res = ctx.has_res and ctx.needs_input_grad[6]
+        dx = torch.empty_like(x3) if need_x else None
+        dres = torch.empty_like(x3) if need_res else None
+        dgamma = torch.empty(c, dtype=torch.float32, device=x3.device) \
+            if need_g else None
+        dbeta = torch.empty(c, dtype=torch.float32, device=x3.device) \
+            if need_b else None
+        need = lib.ld_bn_act_backward_workspace_bytes(N, c, P)
+        ws = workspace(x3.device, need, 'bn')
+        L.check(lib.ld_bn_act_backward(
+            L.ptr(dy), L.ptr(y), L.ptr(x3), L.ptr(scale), L.ptr(mean),
+            L.ptr(rstd), N, c, P, 1 if ctx.relu else 0, L.ptr(dx),
+            L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), 0, L.ptr(ws),
+            ws.numel(), L.stream_ptr(x3.device)), 'ld_bn_act_backward')
+        return dx, dgamma, dbeta, None, None, None, dres, None
+
+
+def bn_act(x3, gamma, beta, mean, var, eps, residual=None, relu=True):
+    if torch.is_grad_enabled() and (x3.requires_grad or gamma.requires_grad or
+                                    (residual is not None and
+                                     residual.requires_grad)):
+        return BnActFn.apply(x3, gamma, beta, mean, var, eps, residual, relu)
+    lib = L.get_lib()
+    N, c, P = x3.shape
+    scale, shift, _ = bn_prepare(gamma, beta, mean, var, eps)
+    y = torch.empty_like(x3)
+    L.check(lib.ld_bn_act_forward(L.ptr(x3), L.ptr(residual), L.ptr(scale),
+                                  L.ptr(shift), N, c, P, 1 if relu else 0,
+                                  L.ptr(y), L.stream_ptr(x3.device)),
+            'ld_bn_act_forward')
+    return y
+
+
+def conv_bn_act_infer(x3, w, gamma, beta, mean, var, eps, stride, pad, levels,
+                      residual=None, relu=True):
+    """Inference-only conv -> BN(eval) -> (+residual) -> ReLU as ONE launch
+    (BN folded into the conv epilogue).  Used for the frozen student stem /
+    layer1 and the whole teacher."""
+    scale, shift, _ = bn_prepare(gamma, beta, mean, var, eps)
+    return conv_forward_raw(x3, w, stride, pad, levels, scale=scale,
+                            shift=shift, residual=residual, relu=relu)
+
+
+# ---------------------------------------------------------------------------
+# GroupNorm + ReLU on level-concatenated tensors
+# ---------------------------------------------------------------------------
+class GnActFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x3, gamma, beta, groups, eps, levels, relu):
+        lib = L.get_lib()
+        _dev_f32(x3, 'gn input')
+        N, c, P = x3.shape
+        lv = levels_desc(levels)
+        y = torch.empty_like(x3)
+        stats = torch.empty((2, N, groups, len(levels)), dtype=torch.float32,
+                            device=x3.device)
+        L.check(lib.ld_gn_forward(C.byref(lv), L.ptr(x3), L.ptr(gamma),
+                                  L.ptr(beta), N, c, groups, eps,
+                                  1 if relu else 0, L.ptr(y), L.ptr(stats[0]),
+                                  L.ptr(stats[1]), L.stream_ptr(x3.device)),
+                'ld_gn_forward')
+        ctx.save_for_backward(x3, y, gamma, stats)
+        ctx.meta = (groups, levels, relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.get_lib()
+        x3, y, gamma, stats = ctx.saved_tensors
+        groups, levels, relu = ctx.meta
+        dy = dy.contiguous()
+        N, c, P = x3.shape
+        lv = levels_desc(levels)
+        dx = torch.empty_like(x3)
+        dgamma = torch.empty(c, dtype=torch.float32, device=x3.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=x3.device)
+        need = lib.ld_gn_backward_workspace_bytes(C.byref(lv), N, c)
+        ws = workspace(x3.device, need, 'gn')
+        L.check(lib.ld_gn_backward(
+            C.byref(lv), L.ptr(dy), L.ptr(y), L.ptr(x3), L.ptr(gamma),
+            L.ptr(stats[0]), L.ptr(stats[1]), N, c, groups, 1 if relu else 0,
+            L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), 0, L.ptr(ws), ws.numel(),
+            L.stream_ptr(x3.device)), 'ld_gn_backward')
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+def gn_act(x3, gamma, beta, groups, eps, levels, relu=True):
+    if torch.is_grad_enabled() and (x3.requires_grad or gamma.requires_grad):
+        return GnActFn.apply(x3, gamma, beta, groups, eps, levels, relu)
+    lib = L.get_lib()
+    N, c, P = x3.shape
+    lv = levels_desc(levels)
+    y = torch.empty_like(x3)
+    stats = torch.empty((2, N, groups, len(levels)), dtype=torch.float32,
+                        device=x3.device)
+    L.check(lib.ld_gn_forward(C.byref(lv), L.ptr(x3), L.ptr(gamma),
+                              L.ptr(beta), N, c, groups, eps,
+                              1 if relu else 0, L.ptr(y), L.ptr(stats[0]),
+                              L.ptr(stats[1]), L.stream_ptr(x3.device)),
+            'ld_gn_forward')
+    return y
+
+
+# ---------------------------------------------------------------------------
+# small layers
+# ---------------------------------------------------------------------------
+def maxpool3x3s2(x4):
+    """MaxPool2d(3, 2, 1), forward only (frozen stem)."""
+    lib = L.get_lib()
+    _dev_f32(x4, 'maxpool input')
+    if x4.requires_grad and torch.is_grad_enabled():
+        raise L.LdError('maxpool3x3s2 has no backward (the stem is frozen: '
+                        'frozen_stages >= 0 is required)')
+    N, c, h, w = x4.shape
+    ho, wo = out_size(h, 3, 2, 1), out_size(w, 3, 2, 1)
+    y = torch.empty((N, c, ho, wo), dtype=torch.float32, device=x4.device)
+    L.check(lib.ld_maxpool3x3s2(L.ptr(x4), N * c, h, w, L.ptr(y),
+                                L.stream_ptr(x4.device)), 'ld_maxpool3x3s2')
+    return y
+
+
+class UpsampleAddFn(torch.autograd.Function):
+    """out = fine + nearest_up(coarse)  (FPN top-down step)."""
+
+    @staticmethod
+    def forward(ctx, fine, coarse):
+        lib = L.get_lib()
+        _dev_f32(fine, 'fine')
+        _dev_f32(coarse, 'coarse')
+        N, c, hf, wf = fine.shape
+        hc, wc = coarse.shape[2:]
+        out = torch.empty_like(fine)
+        L.check(lib.ld_upsample_add_forward(L.ptr(fine), L.ptr(coarse), N * c,
+                                            hf, wf, hc, wc, L.ptr(out),
+                                            L.stream_ptr(fine.device)),
+                'ld_upsample_add_forward')
+        ctx.shapes = (N, c, hf, wf, hc, wc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.get_lib()
+        N, c, hf, wf, hc, wc = ctx.shapes
+        dout = dout.contiguous()
+        dcoarse = None
+        if ctx.needs_input_grad[1]:
+            dcoarse = torch.empty((N, c, hc, wc), dtype=torch.float32,
+                                  device=dout.device)
+            L.check(lib.ld_upsample_add_backward(L.ptr(dout), N * c, hf, wf,
+                                                 hc, wc, L.ptr(dcoarse),
+                                                 L.stream_ptr(dout.device)),
+                    'ld_upsample_add_backward')
+        return (dout if ctx.needs_input_grad[0] else None), dcoarse
+
+
+def upsample_add(fine, coarse):
+    return UpsampleAddFn.apply(fine, coarse)
+
+
+class ScaleLevelsFn(torch.autograd.Function):
+    """y[:, :, level l] = x * scales[l]  (mmcv Scale per FPN level)."""
+
+    @staticmethod
+    def forward(ctx, x3, scales, levels):
+        lib = L.get_lib()
+        _dev_f32(x3, 'scale input')
+        N, c, P = x3.shape
+        lv = levels_desc(levels)
+        y = torch.empty_like(x3)
+        L.check(lib.ld_scale_levels_forward(C.byref(lv), L.ptr(x3),
+                                            L.ptr(scales), N * c, L.ptr(y),
+                                            L.stream_ptr(x3.device)),
+                'ld_scale_levels_forward')
+        ctx.save_for_backward(x3, scales)
+        ctx.levels = levels
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.get_lib()
+        x3, scales = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, c, P = x3.shape
+        lv = levels_desc(ctx.levels)
+        dx = torch.empty_like(x3)
+        ds = torch.empty_like(scales) if ctx.needs_input_grad[1] else None
+        L.check(lib.ld_scale_levels_backward(
+            C.byref(lv), L.ptr(dy), L.ptr(x3), L.ptr(scales), N * c, L.ptr(dx),
+            L.ptr(ds), 0, L.stream_ptr(x3.device)), 'ld_scale_levels_backward')
+        return dx, ds, None
+
+
+def scale_levels(x3, scales, levels):
+    return ScaleLevelsFn.apply(x3, scales, levels)
+
+
+def sgd_step(params_flat, grads_flat, momentum_flat, lr, momentum,
+             weight_decay, grad_scale=1.0):
+    lib = L.get_lib()
+    for t in (params_flat, grads_flat, momentum_flat):
+        _dev_f32(t, 'sgd arena')
+    L.check(lib.ld_sgd_step(L.ptr(params_flat), L.ptr(grads_flat),
+                            L.ptr(momentum_flat), params_flat.numel(), lr,
+                            momentum, weight_decay, grad_scale,
+                            L.stream_ptr(params_flat.device)), 'ld_sgd_step')
+    bump_param_generation()
+
+
+# ---------------------------------------------------------------------------
+# level packing (device-side copies only: plumbing)
+# ---------------------------------------------------------------------------
+def pack_levels(feats):
+    """tuple of (N, C, H_l, W_l) -> (N, C, P) level-concatenated tensor."""
+    levels = tuple((int(f.shape[2]), int(f.shape[3])) for f in feats)
+    if len(feats) == 1:
+        return feats[0].reshape(feats[0].shape[0], feats[0].shape[1], -1), levels
+    return torch.cat([f.flatten(2) for f in feats], dim=2), levels
+
+
+def split_levels(x3, levels):
+    """(N, C, P) -> list of (N, C, H_l, W_l) views (no copies)."""
+    N, c, _ = x3.shape
+    outs, off = [], 0
+    for h, w in levels:
+        outs.append(x3[:, :, off:off + h * w].view(N, c, h, w))
+        off += h * w
+    return outs

@@ -1,0 +1,251 @@
+"""GPU tests (-m gpu): every HIP layer kernel, called through the C ABI,
+against a plain PyTorch fp32 reference of the same op computed on the CPU."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def _close(got, ref, rtol=2e-4, atol_rel=2e-5, what=''):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, f'{what}: shape {got.shape} vs {ref.shape}'
+    scale = float(ref.abs().max()) + 1e-30
+    err = (got - ref).abs()
+    tol = atol_rel * scale + rtol * ref.abs()
+    bad = err > tol
+    if bad.any():
+        idx = np.unravel_index(int(err.argmax()), tuple(err.shape))
+        nbad = int(bad.sum())
+        raise AssertionError(
+            f'{what}: {nbad}/{bad.numel()} elements off; max err '
+            f'{float(err.max()):.3e} at {idx} (got {float(got[idx]):.6f} ref '
+            f'{float(ref[idx]):.6f}, scale {scale:.3e}); first bad idx '
+            f'{tuple(int(v) for v in bad.nonzero()[0])}')
+
+
+def test_mfma_layout_identity():
+    """1x1 conv with a permutation-like weight on an asymmetric input: catches
+    any row/col swap in the MFMA fragment or accumulator mapping."""
+    from ld_amd import layers as Y
+    dev = _dev()
+    N, C, H, W = 1, 64, 8, 40
+    x = (torch.arange(N * C * H * W, dtype=torch.float32).reshape(N, C, H, W)
+         % 977) / 97.0
+    w = torch.zeros(64, 64, 1, 1)
+    perm = (torch.arange(64) * 7 + 3) % 64
+    for co in range(64):
+        w[co, perm[co], 0, 0] = 1.0 + co / 64.0
+    y, _ = Y.conv_forward_raw(x.to(dev).reshape(N, C, -1), w.to(dev), 1, 0,
+                              ((H, W), ))
+    ref = F.conv2d(x, w)
+    _close(y.reshape(ref.shape), ref, what='identity conv')
+
+
+CONV_CASES = [
+    # name, N, Cin, Cout, k, stride, pad, levels
+    ('1x1_64_256', 2, 64, 256, 1, 1, 0, ((20, 34), )),
+    ('1x1_s2_256_512', 2, 256, 512, 1, 2, 0, ((20, 34), )),
+    ('1x1_s2_odd', 1, 64, 128, 1, 2, 0, ((13, 21), )),
+    ('3x3_64_64', 2, 64, 64, 3, 1, 1, ((24, 40), )),
+    ('3x3_s2_128', 2, 128, 128, 3, 2, 1, ((26, 42), )),
+    ('3x3_s2_odd', 1, 64, 64, 3, 2, 1, ((13, 21), )),
+    ('3x3_256_256_levels', 2, 256, 256, 3, 1, 1,
+     ((20, 28), (10, 14), (5, 7), (3, 4), (2, 2))),
+    ('3x3_256_80_levels', 2, 256, 80, 3, 1, 1,
+     ((12, 20), (6, 10), (3, 5), (2, 3), (1, 2))),
+    ('3x3_256_68_levels', 1, 256, 68, 3, 1, 1,
+     ((12, 20), (6, 10), (3, 5), (2, 3), (1, 2))),
+    ('1x1_2048_256', 1, 2048, 256, 1, 1, 0, ((7, 11), )),
+    ('3x3_512_512_tiny', 2, 512, 512, 3, 1, 1, ((4, 6), )),
+]
+
+
+def _ref_conv_levels(x3, w, b, stride, pad, levels):
+    outs, off = [], 0
+    for h, wd in levels:
+        xl = x3[:, :, off:off + h * wd].reshape(x3.shape[0], x3.shape[1], h, wd)
+        outs.append(F.conv2d(xl, w, b, stride=stride, padding=pad).flatten(2))
+        off += h * wd
+    return torch.cat(outs, 2)
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_bwd(case):
+    from ld_amd import layers as Y
+    dev = _dev()
+    name, N, cin, cout, k, stride, pad, levels = case
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    P = sum(h * w for h, w in levels)
+    x = torch.randn(N, cin, P, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k)**0.5
+    b = torch.randn(cout, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    ref = _ref_conv_levels(xr, wr, br, stride, pad, levels)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    y, out_levels = Y.conv2d(xd, wd, bd, stride, pad, levels)
+    assert sum(h * w for h, w in out_levels) == ref.shape[2]
+    _close(y, ref, what=name + ' fwd')
+    y.backward(go.to(dev))
+    _close(xd.grad, xr.grad, what=name + ' dgrad')
+    _close(wd.grad, wr.grad, what=name + ' wgrad')
+    _close(bd.grad, br.grad, what=name + ' bias grad')
+
+
+def test_conv_fused_epilogue_and_stem():
+    from ld_amd import layers as Y
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    # stem: 7x7 s2 p3, Cin=3, BN(eval)+ReLU folded
+    x = torch.randn(2, 3, 38, 50, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    gamma, beta = torch.rand(64, generator=g) + .5, torch.randn(64, generator=g)
+    mean, var = torch.randn(64, generator=g) * .1, torch.rand(64, generator=g) + .5
+    ref = F.relu(F.batch_norm(F.conv2d(x, w, stride=2, padding=3), mean, var,
+                              gamma, beta, False, 0.0, 1e-5))
+    y, lv = Y.conv_bn_act_infer(x.to(dev).reshape(2, 3, -1), w.to(dev),
+                                gamma.to(dev), beta.to(dev), mean.to(dev),
+                                var.to(dev), 1e-5, 2, 3, ((38, 50), ))
+    assert lv == ((19, 25), )
+    _close(y.reshape(ref.shape), ref, what='stem conv+bn+relu')
+    mp = Y.maxpool3x3s2(y.reshape(ref.shape))
+    _close(mp, F.max_pool2d(ref, 3, 2, 1), what='maxpool')
+    # bottleneck tail: conv1x1 -> BN -> + residual -> ReLU in one launch
+    x = torch.randn(2, 64, 10, 14, generator=g)
+    w = torch.randn(256, 64, 1, 1, generator=g) * 0.1
+    res = torch.randn(2, 256, 10, 14, generator=g)
+    gamma, beta = torch.rand(256, generator=g), torch.randn(256, generator=g)
+    mean, var = torch.randn(256, generator=g) * .1, torch.rand(256, generator=g) + .5
+    ref = F.relu(F.batch_norm(F.conv2d(x, w), mean, var, gamma, beta, False,
+                              0.0, 1e-5) + res)
+    y, _ = Y.conv_bn_act_infer(x.to(dev).reshape(2, 64, -1), w.to(dev),
+                               gamma.to(dev), beta.to(dev), mean.to(dev),
+                               var.to(dev), 1e-5, 1, 0, ((10, 14), ),
+                               residual=res.to(dev).reshape(2, 256, -1))
+    _close(y.reshape(ref.shape), ref, what='conv+bn+res+relu')
+
+
+@pytest.mark.parametrize('relu,with_res', [(True, False), (True, True),
+                                           (False, False)])
+def test_bn_act(relu, with_res):
+    from ld_amd import layers as Y
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    N, C, H, W = 2, 96, 13, 21
+    x = torch.randn(N, C, H * W, generator=g)
+    res = torch.randn(N, C, H * W, generator=g) if with_res else None
+    gamma = torch.rand(C, generator=g) + .5
+    beta = torch.randn(C, generator=g)
+    mean, var = torch.randn(C, generator=g), torch.rand(C, generator=g) + .5
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+    rr = res.clone().requires_grad_(True) if with_res else None
+    ref = F.batch_norm(xr.reshape(N, C, H, W), mean, var, gr, br, False, 0.0,
+                       1e-5).reshape(N, C, -1)
+    if with_res:
+        ref = ref + rr
+    if relu:
+        ref = F.relu(ref)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    xd, gd, bd = (t.to(dev).requires_grad_(True) for t in (x, gamma, beta))
+    rd = res.to(dev).requires_grad_(True) if with_res else None
+    y = Y.bn_act(xd, gd, bd, mean.to(dev), var.to(dev), 1e-5, rd, relu)
+    _close(y, ref, what='bn fwd')
+    y.backward(go.to(dev))
+    _close(xd.grad, xr.grad, what='bn dx')
+    _close(gd.grad, gr.grad, what='bn dgamma')
+    _close(bd.grad, br.grad, what='bn dbeta')
+    if with_res:
+        _close(rd.grad, rr.grad, what='bn dres')
+
+
+def test_gn_act_levels():
+    from ld_amd import layers as Y
+    dev = _dev()
+    g = torch.Generator().manual_seed(12)
+    levels = ((12, 20), (6, 10), (3, 5), (2, 3), (1, 2))
+    N, C, G = 2, 64, 32
+    P = sum(h * w for h, w in levels)
+    x = torch.randn(N, C, P, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(C, generator=g) + .5, torch.randn(C, generator=g)
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+    outs, off = [], 0
+    for h, w in levels:
+        xl = xr[:, :, off:off + h * w].reshape(N, C, h, w)
+        outs.append(F.relu(F.group_norm(xl, G, gr, br, 1e-5)).flatten(2))
+        off += h * w
+    ref = torch.cat(outs, 2)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    xd, gd, bd = (t.to(dev).requires_grad_(True) for t in (x, gamma, beta))
+    y = Y.gn_act(xd, gd, bd, G, 1e-5, levels, True)
+    _close(y, ref, what='gn fwd')
+    y.backward(go.to(dev))
+    _close(xd.grad, xr.grad, rtol=5e-4, what='gn dx')
+    _close(gd.grad, gr.grad, what='gn dgamma')
+    _close(bd.grad, br.grad, what='gn dbeta')
+
+
+@pytest.mark.parametrize('fine,coarse', [((50, 84), (25, 42)),
+                                         ((25, 25), (13, 13)),
+                                         ((13, 21), (7, 11))])
+def test_upsample_add(fine, coarse):
+    from ld_amd import layers as Y
+    dev = _dev()
+    g = torch.Generator().manual_seed(13)
+    a = torch.randn(2, 8, *fine, generator=g)
+    b = torch.randn(2, 8, *coarse, generator=g)
+    ar, brr = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = ar + F.interpolate(brr, size=fine, mode='nearest')
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    ad, bd = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = Y.upsample_add(ad, bd)
+    _close(y, ref, what='upsample_add fwd')
+    y.backward(go.to(dev))
+    _close(ad.grad, ar.grad, what='d fine')
+    _close(bd.grad, brr.grad, what='d coarse')
+
+
+def test_scale_levels_and_sgd():
+    from ld_amd import layers as Y
+    dev = _dev()
+    g = torch.Generator().manual_seed(14)
+    levels = ((6, 10), (3, 5), (2, 3))
+    P = sum(h * w for h, w in levels)
+    x = torch.randn(2, 68, P, generator=g)
+    s = torch.rand(3, generator=g) + .5
+    xr, sr = x.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    sc = torch.cat([sr[i].expand(h * w) for i, (h, w) in enumerate(levels)])
+    ref = xr * sc
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    xd, sd = x.to(dev).requires_grad_(True), s.to(dev).requires_grad_(True)
+    y = Y.scale_levels(xd, sd, levels)
+    _close(y, ref, what='scale fwd')
+    y.backward(go.to(dev))
+    _close(xd.grad, xr.grad, what='scale dx')
+    _close(sd.grad, sr.grad, what='dscale')
+    # SGD vs torch.optim.SGD, two steps, odd length (tail path)
+    n = 4099
+    p = torch.randn(n, generator=g)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    pd = p.to(dev)
+    buf = torch.zeros(n, device=dev)
+    for _ in range(2):
+        gr = torch.randn(n, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        Y.sgd_step(pd, gr.to(dev), buf, 0.01, 0.9, 1e-4)
+    _close(pd, pr, rtol=1e-5, atol_rel=1e-6, what='sgd')

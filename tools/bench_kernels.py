@@ -1,0 +1,159 @@
+"""Kernel micro-benchmarks on the MI355X (run through gpurun).  Writes
+gpurun_out/kernels_<tag>.json.
+
+  * the north-star fused LD-KL + Integral kernel at a saturating size
+    (2^22 anchors = 2^24 anchor-side rows) for vector widths 1/2/4, fwd-only
+    and fused fwd+grad, vs the HBM roofline;
+  * the fp32 MFMA implicit-GEMM conv (fwd / dgrad / wgrad) on the layer shapes
+    of the C2 config, next to MIOpen (torch F.conv2d) on the same shapes.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+from ld_amd import layers as Y  # noqa: E402
+from ld_amd import lossblock as LB  # noqa: E402
+
+
+def timeit(fn, warm=3, iters=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True),
+            torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2] * 1e-3  # median seconds
+
+
+def bench_kl(out):
+    dev = torch.device('cuda:0')
+    res = []
+    for rows in (1 << 22, 179200 // 4 * 1):  # saturating, and the C2 batch size
+        s = torch.randn(68, rows, device=dev) * 3
+        t = torch.randn(68, rows, device=dev) * 3
+        w = torch.rand(rows, device=dev)
+        for vec in (1, 2, 4):
+            os.environ['LD_KL_VEC'] = str(vec)
+            for grad in (False, True):
+                dt = timeit(lambda: LB.kl_integral_dense(s, t, w, 10.0, 1.0,
+                                                         grad))
+                # algorithmic bytes per anchor: 2*68*4 in, 4 weight, 16
+                # integral, 4 loss, (+ 68*4 grad)
+                b = rows * (544 + 4 + 16 + 4 + (272 if grad else 0))
+                res.append(dict(rows_anchor=rows, rows_side=rows * 4, vec=vec,
+                                grad=grad, us=dt * 1e6, GBps=b / dt / 1e9,
+                                frac_of_8TBps=b / dt / 8e12))
+                print(res[-1], flush=True)
+    os.environ.pop('LD_KL_VEC', None)
+    out['kl_integral_dense'] = res
+
+
+CONV_SHAPES = [
+    # name, N, Cin, Cout, k, stride, pad, levels   (C2: 2 x 800 x 1344)
+    ('r50.l1.conv2 3x3 64', 2, 64, 64, 3, 1, 1, ((200, 336), )),
+    ('r50.l1.conv3 1x1 64-256', 2, 64, 256, 1, 1, 0, ((200, 336), )),
+    ('r50.l2.conv2 3x3 128', 2, 128, 128, 3, 1, 1, ((100, 168), )),
+    ('r50.l2.conv3 1x1 128-512', 2, 128, 512, 1, 1, 0, ((100, 168), )),
+    ('r50.l3.conv2 3x3 256', 2, 256, 256, 3, 1, 1, ((50, 84), )),
+    ('r50.l3.conv1 1x1 1024-256', 2, 1024, 256, 1, 1, 0, ((50, 84), )),
+    ('r50.l4.conv2 3x3 512', 2, 512, 512, 3, 1, 1, ((25, 42), )),
+    ('r50.l3.0.conv2 3x3 s2 256', 2, 256, 256, 3, 2, 1, ((100, 168), )),
+    ('fpn.out 3x3 256 P3', 2, 256, 256, 3, 1, 1, ((100, 168), )),
+    ('head tower 3x3 256 all levels', 2, 256, 256, 3, 1, 1,
+     ((100, 168), (50, 84), (25, 42), (13, 21), (7, 11))),
+    ('head gfl_cls 3x3 256-80', 2, 256, 80, 3, 1, 1,
+     ((100, 168), (50, 84), (25, 42), (13, 21), (7, 11))),
+]
+
+
+def bench_conv(out, with_miopen=True):
+    dev = torch.device('cuda:0')
+    res = []
+    for name, N, cin, cout, k, stride, pad, levels in CONV_SHAPES:
+        P = sum(h * w for h, w in levels)
+        x = torch.randn(N, cin, P, device=dev)
+        w = torch.randn(cout, cin, k, k, device=dev) * 0.05
+        xg = x.clone().requires_grad_(True)
+        wg = w.clone().requires_grad_(True)
+        y, ol = Y.conv2d(xg, wg, None, stride, pad, levels)
+        Pout = y.shape[2]
+        go = torch.randn_like(y)
+        flops = 2.0 * N * Pout * cout * cin * k * k
+        r = dict(name=name, gflop=flops / 1e9)
+
+        t_f = timeit(lambda: Y.conv_forward_raw(x, w, stride, pad, levels))
+        import ctypes as C
+        from ld_amd import lib as L
+        lib = L.get_lib()
+        d, _ = Y.conv_desc(N, cin, cout, k, k, stride, pad, levels)
+        _, wt_bwd = Y.weight_images(wg, True)
+        dx = torch.empty_like(x)
+        st = L.stream_ptr(dev)
+        t_d = timeit(lambda: lib.ld_conv_dgrad(C.byref(d), L.ptr(go),
+                                               L.ptr(wt_bwd), L.ptr(dx), st))
+        dw = torch.empty_like(w)
+        need = lib.ld_conv_wgrad_workspace_bytes(C.byref(d))
+        ws = LB.workspace(dev, need, 'wgrad')
+        t_w = timeit(lambda: lib.ld_conv_wgrad(C.byref(d), L.ptr(x), L.ptr(go),
+                                               L.ptr(dw), 0, L.ptr(ws),
+                                               ws.numel(), st))
+        r.update(hip_fwd_ms=t_f * 1e3, hip_fwd_tflops=flops / t_f / 1e12,
+                 hip_dgrad_ms=t_d * 1e3, hip_dgrad_tflops=flops / t_d / 1e12,
+                 hip_wgrad_ms=t_w * 1e3, hip_wgrad_tflops=flops / t_w / 1e12)
+        if with_miopen and len(levels) == 1:
+            h, wd = levels[0]
+            x4 = x.reshape(N, cin, h, wd).clone().requires_grad_(True)
+            w4 = w.clone().requires_grad_(True)
+            torch.backends.cudnn.benchmark = True
+            t_mf = timeit(lambda: F.conv2d(x4.detach(), w4.detach(), None,
+                                           stride, pad))
+            y4 = F.conv2d(x4, w4, None, stride, pad)
+            go4 = torch.randn_like(y4)
+
+            def bwd():
+                torch.autograd.grad(y4, (x4, w4), go4, retain_graph=True)
+
+            t_mb = timeit(bwd)
+            r.update(miopen_fwd_ms=t_mf * 1e3,
+                     miopen_fwd_tflops=flops / t_mf / 1e12,
+                     miopen_bwd_ms=t_mb * 1e3,
+                     miopen_bwd_tflops=2 * flops / t_mb / 1e12)
+        res.append(r)
+        print({k: (round(v, 3) if isinstance(v, float) else v)
+               for k, v in r.items()}, flush=True)
+    out['conv'] = res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--tag', default='r01')
+    ap.add_argument('--only', default='kl,conv')
+    ap.add_argument('--no-miopen', action='store_true')
+    args = ap.parse_args()
+    out = dict(device=torch.cuda.get_device_name(0), time=time.time())
+    if 'kl' in args.only:
+        bench_kl(out)
+    if 'conv' in args.only:
+        bench_conv(out, not args.no_miopen)
+    os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
+    path = os.path.join(REPO, 'gpurun_out', f'kernels_{args.tag}.json')
+    with open(path, 'w') as f:
+        json.dump(out, f, indent=1)
+    print('wrote', path)
+
+
+if __name__ == '__main__':
+    main()
