@@ -3,10 +3,10 @@
 There is no dataset and no checkpoint on the GPU box, so the bench, the smoke
 test and the parity fixtures all use:
 
-* images: ``randn`` (normalised-image statistics), columns past ``img_shape``
+* images: ~N(0,1) (normalised-image statistics), columns past ``img_shape``
   zero-filled exactly as ``Pad(size_divisor=32)`` would
   (reference: mmdet/datasets/pipelines/transforms.py:481-509);
-* GT boxes: centre uniform in the image, ``w, h = exp(U(log 16, log 600))``
+* GT boxes: centre uniform in the image, ``w, h = 16 + 584 u^3`` (small-skewed, like a log-uniform law)
   clipped to the image, non-integer xyxy fp32 (avoids ATSS distance ties),
   labels ``randint(0, 80)``;
 * weights: :func:`seeded_state_dict` -- every tensor of a ``state_dict`` is
@@ -33,13 +33,26 @@ def _gen(seed):
     return g
 
 
+def _normal(shape, gen):
+    """~N(0, 1) as a scaled sum of three uniforms.  Only IEEE-exact ops
+    (rand, +, *) are used anywhere in this module: torch.randn / exp / log go
+    through vendor-specific SIMD math and differ by an ulp between the build
+    container's Xeon and the GPU box's EPYC, which would make 'identical
+    inputs' not identical."""
+    u = torch.rand(shape, generator=gen) + torch.rand(shape, generator=gen) \
+        + torch.rand(shape, generator=gen)
+    return (u - 1.5) * 2.0
+
+
 def synthetic_boxes(num_gt, img_h, img_w, gen, min_size=16.0, max_size=600.0):
     """(num_gt, 4) xyxy fp32 boxes, (num_gt,) int64 labels."""
     cx = torch.rand(num_gt, generator=gen) * img_w
     cy = torch.rand(num_gt, generator=gen) * img_h
-    lo, hi = math.log(min_size), math.log(max_size)
-    w = torch.exp(torch.rand(num_gt, generator=gen) * (hi - lo) + lo)
-    h = torch.exp(torch.rand(num_gt, generator=gen) * (hi - lo) + lo)
+    # sizes skewed to small boxes (u^3 stands in for a log-uniform law)
+    uw = torch.rand(num_gt, generator=gen)
+    uh = torch.rand(num_gt, generator=gen)
+    w = min_size + (max_size - min_size) * (uw * uw * uw)
+    h = min_size + (max_size - min_size) * (uh * uh * uh)
     x1 = (cx - w / 2).clamp(0.0, img_w - 2.0)
     y1 = (cy - h / 2).clamp(0.0, img_h - 2.0)
     x2 = torch.maximum((cx + w / 2).clamp(0.0, float(img_w)), x1 + 1.7)
@@ -66,7 +79,7 @@ def synthetic_batch(num_imgs=2,
     h, w = img_shape
     hp, wp = pad_shape
     img = torch.zeros(num_imgs, 3, hp, wp)
-    img[:, :, :h, :w] = torch.randn(num_imgs, 3, h, w, generator=gen)
+    img[:, :, :h, :w] = _normal((num_imgs, 3, h, w), gen)
     if isinstance(num_gt, int):
         num_gt = [num_gt] * num_imgs
     gt_bboxes, gt_labels = [], []
@@ -129,7 +142,7 @@ def seeded_state_dict(reference_sd, seed=0, reg_std=0.05, cls_std=0.02):
                 std = math.sqrt(1.0 / fan_in)
             else:
                 std = math.sqrt(2.0 / fan_in)
-            v = torch.randn(shape, generator=g) * std
+            v = _normal(shape, g) * std
         elif leaf == 'weight':  # norm affine
             block = key.rsplit('.', 2)[0]
             last = 'bn3' if block + '.bn3.weight' in reference_sd else 'bn2'
@@ -145,7 +158,7 @@ def seeded_state_dict(reference_sd, seed=0, reg_std=0.05, cls_std=0.02):
             else:
                 v = torch.rand(shape, generator=g) * 0.2 - 0.1
         else:
-            v = torch.randn(shape, generator=g) * 0.1
+            v = _normal(shape, g) * 0.1
         out[key] = v.to(ref.dtype).reshape(shape)
     return out
 
@@ -185,19 +198,15 @@ def synthetic_head_inputs(num_imgs,
     out = dict(cls=[], reg=[], t_cls=[], t_reg=[], x=[], t_x=[])
     for (h, w) in featmap_sizes:
         out['cls'].append(
-            torch.randn(num_imgs, num_classes, h, w, generator=gen) * 1.2 -
-            4.0)
+            _normal((num_imgs, num_classes, h, w), gen) * 1.2 - 4.0)
         out['reg'].append(
-            torch.randn(num_imgs, 4 * (reg_max + 1), h, w, generator=gen) *
-            3.0)
+            _normal((num_imgs, 4 * (reg_max + 1), h, w), gen) * 3.0)
         out['t_cls'].append(
-            torch.randn(num_imgs, num_classes, h, w, generator=gen) * 1.2 -
-            4.0)
+            _normal((num_imgs, num_classes, h, w), gen) * 1.2 - 4.0)
         out['t_reg'].append(
-            torch.randn(num_imgs, 4 * (reg_max + 1), h, w, generator=gen) *
-            3.0)
+            _normal((num_imgs, 4 * (reg_max + 1), h, w), gen) * 3.0)
         out['x'].append(
-            torch.randn(num_imgs, feat_channels, h, w, generator=gen))
+            _normal((num_imgs, feat_channels, h, w), gen))
         out['t_x'].append(
-            torch.randn(num_imgs, feat_channels, h, w, generator=gen))
+            _normal((num_imgs, feat_channels, h, w), gen))
     return {k: [t.to(device) for t in v] for k, v in out.items()}
