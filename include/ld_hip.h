@@ -117,6 +117,21 @@ int ld_atss_targets(const ld_geom_t* geom, const ld_loss_hp_t* hp,
                     float* vlr, float* im, int32_t* counts, void* workspace,
                     size_t workspace_bytes, ld_stream_t stream);
 
+/* Same, with (a) optional EXPLICIT anchors (A, 4) -- the reference-style
+ * ATSSAssigner.assign(bboxes, num_level_bboxes, ...) entry, where a level is
+ * just an index range: pass geometry levels with H = count, W = 1 -- and
+ * (b) optional per-anchor assign results: gt_inds (N, A) int64 1-based / 0,
+ * max_overlaps (N, A) (-1e8 where unassigned) as AssignResult carries them
+ * (atss_assigner.py:163-181).  anchors / gt_inds / max_overlaps may be NULL. */
+int ld_atss_targets_ex(const ld_geom_t* geom, const ld_loss_hp_t* hp,
+                       const float* anchors, const float* gt_bboxes,
+                       const int64_t* gt_labels, const int32_t* num_gt,
+                       int max_gt, const int32_t* valid_hw, int64_t* labels,
+                       float* label_weights, float* bbox_targets, float* vlr,
+                       float* im, int32_t* counts, int64_t* gt_inds,
+                       float* max_overlaps, void* workspace,
+                       size_t workspace_bytes, ld_stream_t stream);
+
 /* Materialise the anchors (A, 4) -- only for API compatibility
  * (AnchorGenerator.grid_anchors, anchor_generator.py:207-270); the kernels
  * never read them. */

@@ -1,0 +1,265 @@
+"""Building blocks with mmcv.cnn's names and state_dict keys (ConvModule,
+Scale, build_conv_layer, build_norm_layer, init helpers), implemented over the
+HIP layer functions in ld_amd.layers.  Parameter shapes and key names match
+mmdet/mmcv so released checkpoints map 1:1 (SURVEY.md section 5 "checkpoint").
+
+Modules take and return ordinary (N, C, H, W) tensors; the level-concatenated
+fast path of the head lives in ld_amd.heads.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import layers as Y
+
+
+# ------------------------------------------------------------------ inits --
+def constant_init(module, val, bias=0):
+    if getattr(module, 'weight', None) is not None:
+        nn.init.constant_(module.weight, val)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def normal_init(module, mean=0, std=1, bias=0):
+    if getattr(module, 'weight', None) is not None:
+        nn.init.normal_(module.weight, mean, std)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def xavier_init(module, gain=1, bias=0, distribution='normal'):
+    assert distribution in ['uniform', 'normal']
+    if getattr(module, 'weight', None) is not None:
+        if distribution == 'uniform':
+            nn.init.xavier_uniform_(module.weight, gain=gain)
+        else:
+            nn.init.xavier_normal_(module.weight, gain=gain)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def kaiming_init(module, a=0, mode='fan_out', nonlinearity='relu', bias=0,
+                 distribution='normal'):
+    assert distribution in ['uniform', 'normal']
+    if getattr(module, 'weight', None) is not None:
+        if distribution == 'uniform':
+            nn.init.kaiming_uniform_(module.weight, a=a, mode=mode,
+                                     nonlinearity=nonlinearity)
+        else:
+            nn.init.kaiming_normal_(module.weight, a=a, mode=mode,
+                                    nonlinearity=nonlinearity)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def bias_init_with_prob(prior_prob):
+    return float(-np.log((1 - prior_prob) / prior_prob))
+
+
+# ---------------------------------------------------------------- layers ---
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+class Conv2d(nn.Module):
+    """nn.Conv2d's parameters and keys; forward = MFMA implicit GEMM."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1,
+                 padding=0, dilation=1, groups=1, bias=True):
+        super().__init__()
+        k, s, p, d = (_pair(kernel_size), _pair(stride), _pair(padding),
+                      _pair(dilation))
+        if k[0] != k[1] or s[0] != s[1] or p[0] != p[1]:
+            raise NotImplementedError('only square kernels/strides/pads')
+        if d != (1, 1) or groups != 1:
+            raise NotImplementedError(
+                'dilated / grouped convs are not on the LD hot path')
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = k, s, p
+        self.weight = nn.Parameter(
+            torch.empty(out_channels, in_channels, k[0], k[1]))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+            bound = 1 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward3(self, x3, levels):
+        """(N, C, P) level-concatenated in/out."""
+        return Y.conv2d(x3, self.weight, self.bias, self.stride[0],
+                        self.padding[0], levels)
+
+    def forward(self, x):
+        n, c, h, w = x.shape
+        y3, lv = self.forward3(x.reshape(n, c, h * w), ((h, w), ))
+        return y3.view(n, self.out_channels, lv[0][0], lv[0][1])
+
+    def extra_repr(self):
+        return (f'{self.in_channels}, {self.out_channels}, '
+                f'kernel_size={self.kernel_size}, stride={self.stride}, '
+                f'padding={self.padding}, bias={self.bias is not None}')
+
+
+class BatchNorm2d(nn.Module):
+    """BatchNorm2d evaluated with its running statistics (the LD configs run
+    every BN with norm_eval=True, resnet.py:639-648); affine stays trainable.
+    Training-mode batch statistics are not on this path and raise."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+        self.register_buffer('num_batches_tracked',
+                             torch.tensor(0, dtype=torch.long))
+
+    def forward3(self, x3, residual=None, relu=False):
+        if self.training:
+            raise NotImplementedError(
+                'BatchNorm2d in training mode (batch statistics) is outside '
+                'the LD hot path: use norm_eval=True')
+        return Y.bn_act(x3, self.weight, self.bias, self.running_mean,
+                        self.running_var, self.eps, residual, relu)
+
+    def forward(self, x):
+        n, c, h, w = x.shape
+        return self.forward3(x.reshape(n, c, h * w)).view(n, c, h, w)
+
+
+class GroupNorm(nn.Module):
+
+    def __init__(self, num_groups, num_channels, eps=1e-5):
+        super().__init__()
+        self.num_groups, self.num_channels, self.eps = (num_groups,
+                                                        num_channels, eps)
+        self.weight = nn.Parameter(torch.ones(num_channels))
+        self.bias = nn.Parameter(torch.zeros(num_channels))
+
+    def forward3(self, x3, levels, relu=False):
+        return Y.gn_act(x3, self.weight, self.bias, self.num_groups, self.eps,
+                        levels, relu)
+
+    def forward(self, x):
+        n, c, h, w = x.shape
+        return self.forward3(x.reshape(n, c, h * w), ((h, w), )).view(
+            n, c, h, w)
+
+
+class ReLU(nn.Module):
+    """Marker module (mmcv ConvModule.activate); the ReLU itself is fused
+    into the preceding norm / conv epilogue kernel."""
+
+    def __init__(self, inplace=True):
+        super().__init__()
+        self.inplace = inplace
+
+
+def build_conv_layer(cfg, *args, **kwargs):
+    if cfg is None:
+        cfg = dict(type='Conv2d')
+    layer_type = cfg['type'] if isinstance(cfg, dict) else cfg
+    if layer_type in ('Conv2d', 'Conv'):
+        return Conv2d(*args, **kwargs)
+    raise NotImplementedError(
+        f'conv layer type {layer_type} is not implemented on the MI355X path '
+        '(DCN is the config-4 teacher, a later row of SURVEY.md section 8)')
+
+
+def build_norm_layer(cfg, num_features, postfix=''):
+    """-> (name, layer); mmcv: 'BN' -> bn{postfix}, 'GN' -> gn{postfix}."""
+    cfg_ = dict(cfg)
+    layer_type = cfg_.pop('type')
+    requires_grad = cfg_.pop('requires_grad', True)
+    cfg_.setdefault('eps', 1e-5)
+    if layer_type == 'BN':
+        layer, abbr = BatchNorm2d(num_features, **cfg_), 'bn'
+    elif layer_type == 'GN':
+        assert 'num_groups' in cfg_
+        layer, abbr = GroupNorm(num_channels=num_features, **cfg_), 'gn'
+    else:
+        raise NotImplementedError(f'norm type {layer_type}')
+    for p in layer.parameters():
+        p.requires_grad = requires_grad
+    return abbr + str(postfix), layer
+
+
+class Scale(nn.Module):
+    """mmcv.cnn.Scale: a learnable scalar."""
+
+    def __init__(self, scale=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.tensor(scale, dtype=torch.float))
+
+    def forward(self, x):
+        n, c, h, w = x.shape
+        return Y.scale_levels(x.reshape(n, c, h * w), self.scale.reshape(1),
+                              ((h, w), )).view(n, c, h, w)
+
+
+class ConvModule(nn.Module):
+    """conv -> norm -> activation, mmcv semantics: bias='auto' means bias iff
+    there is no norm; the norm layer is registered as ``gn`` / ``bn``."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1,
+                 padding=0, dilation=1, groups=1, bias='auto', conv_cfg=None,
+                 norm_cfg=None, act_cfg=dict(type='ReLU'), inplace=True,
+                 with_spectral_norm=False, padding_mode='zeros',
+                 order=('conv', 'norm', 'act')):
+        super().__init__()
+        assert order == ('conv', 'norm', 'act') and padding_mode == 'zeros'
+        assert not with_spectral_norm
+        self.with_norm = norm_cfg is not None
+        self.with_activation = act_cfg is not None
+        if bias == 'auto':
+            bias = not self.with_norm
+        self.with_bias = bias
+        self.conv = build_conv_layer(conv_cfg, in_channels, out_channels,
+                                     kernel_size, stride=stride,
+                                     padding=padding, dilation=dilation,
+                                     groups=groups, bias=bias)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        if self.with_norm:
+            self.norm_name, norm = build_norm_layer(norm_cfg, out_channels)
+            self.add_module(self.norm_name, norm)
+        if self.with_activation:
+            if act_cfg['type'] != 'ReLU':
+                raise NotImplementedError(act_cfg['type'])
+            self.activate = ReLU(inplace=inplace)
+        self.init_weights()
+
+    @property
+    def norm(self):
+        return getattr(self, self.norm_name)
+
+    def init_weights(self):
+        kaiming_init(self.conv, a=0, nonlinearity='relu')
+        if self.with_norm:
+            constant_init(self.norm, 1, bias=0)
+
+    def forward3(self, x3, levels, activate=True, norm=True):
+        y3, lv = self.conv.forward3(x3, levels)
+        act = activate and self.with_activation
+        if norm and self.with_norm:
+            n = self.norm
+            if isinstance(n, GroupNorm):
+                y3 = n.forward3(y3, lv, relu=act)
+            else:
+                y3 = n.forward3(y3, None, relu=act)
+        elif act:
+            raise NotImplementedError('conv -> ReLU without a norm layer')
+        return y3, lv
+
+    def forward(self, x, activate=True, norm=True):
+        n, c, h, w = x.shape
+        y3, lv = self.forward3(x.reshape(n, c, h * w), ((h, w), ), activate,
+                               norm)
+        return y3.view(n, self.out_channels, lv[0][0], lv[0][1])

@@ -1,0 +1,401 @@
+"""mmdet.core pieces on the LD path with their reference names and call
+signatures: AnchorGenerator, BboxOverlaps2D,
+ATSSAssigner (+ get_vlr_region), PseudoSampler, AssignResult, SamplingResult,
+DeltaXYWHBBoxCoder (constructed by AnchorHead's default, never called here),
+multi_apply / unmap / images_to_levels / reduce_mean, distance2bbox /
+bbox2distance.  Arithmetic goes through libldhip.so.
+"""
+import ctypes as C
+import math
+from functools import partial
+
+import torch
+import torch.distributed as dist
+
+from . import lib as L
+from . import lossblock as LB
+from .registry import (ANCHOR_GENERATORS, BBOX_ASSIGNERS, BBOX_CODERS,
+                       BBOX_SAMPLERS, IOU_CALCULATORS, build_iou_calculator)
+
+INF = 100000000
+
+
+# --------------------------------------------------------------- utilities --
+def multi_apply(func, *args, **kwargs):
+    """mmdet/core/utils/misc.py:10-29."""
+    pfunc = partial(func, **kwargs) if kwargs else func
+    map_results = map(pfunc, *args)
+    return tuple(map(list, zip(*map_results)))
+
+
+def unmap(data, count, inds, fill=0):
+    """mmdet/core/utils/misc.py:32-42 (device-side index plumbing)."""
+    if data.dim() == 1:
+        ret = data.new_full((count, ), fill)
+        ret[inds.type(torch.bool)] = data
+    else:
+        new_size = (count, ) + data.size()[1:]
+        ret = data.new_full(new_size, fill)
+        ret[inds.type(torch.bool), :] = data
+    return ret
+
+
+def images_to_levels(target, num_levels):
+    """mmdet/core/anchor/utils.py:4-17."""
+    target = torch.stack(target, 0)
+    level_targets = []
+    start = 0
+    for n in num_levels:
+        end = start + n
+        level_targets.append(target[:, start:end])
+        start = end
+    return level_targets
+
+
+def anchor_inside_flags(flat_anchors, valid_flags, img_shape,
+                        allowed_border=0):
+    """mmdet/core/anchor/utils.py:20-46."""
+    img_h, img_w = img_shape[:2]
+    if allowed_border >= 0:
+        inside_flags = valid_flags & \
+            (flat_anchors[:, 0] >= -allowed_border) & \
+            (flat_anchors[:, 1] >= -allowed_border) & \
+            (flat_anchors[:, 2] < img_w + allowed_border) & \
+            (flat_anchors[:, 3] < img_h + allowed_border)
+    else:
+        inside_flags = valid_flags
+    return inside_flags
+
+
+def reduce_mean(tensor):
+    """mmdet/core/utils/dist_utils.py:63-69."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return tensor
+    tensor = tensor.clone()
+    dist.all_reduce(tensor.div_(dist.get_world_size()), op=dist.ReduceOp.SUM)
+    return tensor
+
+
+def distance2bbox(points, distance, max_shape=None):
+    """mmdet/core/bbox/transforms.py:119-156 (glue on tiny tensors)."""
+    x1 = points[:, 0] - distance[:, 0]
+    y1 = points[:, 1] - distance[:, 1]
+    x2 = points[:, 0] + distance[:, 2]
+    y2 = points[:, 1] + distance[:, 3]
+    if max_shape is not None:
+        x1 = x1.clamp(min=0, max=max_shape[1])
+        y1 = y1.clamp(min=0, max=max_shape[0])
+        x2 = x2.clamp(min=0, max=max_shape[1])
+        y2 = y2.clamp(min=0, max=max_shape[0])
+    return torch.stack([x1, y1, x2, y2], -1)
+
+
+def bbox2distance(points, bbox, max_dis=None, eps=0.1):
+    """mmdet/core/bbox/transforms.py:159-180."""
+    left = points[:, 0] - bbox[:, 0]
+    top = points[:, 1] - bbox[:, 1]
+    right = bbox[:, 2] - points[:, 0]
+    bottom = bbox[:, 3] - points[:, 1]
+    if max_dis is not None:
+        left = left.clamp(min=0, max=max_dis - eps)
+        top = top.clamp(min=0, max=max_dis - eps)
+        right = right.clamp(min=0, max=max_dis - eps)
+        bottom = bottom.clamp(min=0, max=max_dis - eps)
+    return torch.stack([left, top, right, bottom], -1)
+
+
+# ---------------------------------------------------------- IoU calculator --
+_MODES = {'iou': 0, 'iof': 1, 'giou': 2, 'diou': 3}
+
+
+def bbox_overlaps(bboxes1, bboxes2, mode='iou', is_aligned=False, eps=1e-6):
+    """mmdet/core/bbox/iou_calculators/iou2d_calculator.py:43-188 incl. the
+    fork's IoF-based 'diou' mode; one HIP launch."""
+    assert mode in _MODES, f'Unsupported mode {mode}'
+    assert bboxes1.size(-1) == 4 or bboxes1.size(0) == 0
+    assert bboxes2.size(-1) == 4 or bboxes2.size(0) == 0
+    if bboxes1.dim() != 2 or bboxes2.dim() != 2:
+        raise NotImplementedError('batched bbox_overlaps')
+    rows, cols = bboxes1.size(0), bboxes2.size(0)
+    if is_aligned:
+        assert rows == cols
+    L.require_device(bboxes1, torch.float32, 'bboxes1')
+    L.require_device(bboxes2, torch.float32, 'bboxes2')
+    shape = (rows, ) if is_aligned else (rows, cols)
+    out = bboxes1.new_empty(shape)
+    if rows * cols == 0:
+        return out
+    lib = L.get_lib()
+    L.check(lib.ld_bbox_overlaps(L.ptr(bboxes1.contiguous()),
+                                 L.ptr(bboxes2.contiguous()), rows, cols,
+                                 _MODES[mode], 1 if is_aligned else 0, eps,
+                                 L.ptr(out), L.stream_ptr(out.device)),
+            'ld_bbox_overlaps')
+    return out
+
+
+@IOU_CALCULATORS.register_module()
+class BboxOverlaps2D:
+    """iou2d_calculator.py:10-35."""
+
+    def __call__(self, bboxes1, bboxes2, mode='iou', is_aligned=False):
+        assert bboxes1.size(-1) in [0, 4, 5]
+        assert bboxes2.size(-1) in [0, 4, 5]
+        if bboxes2.size(-1) == 5:
+            bboxes2 = bboxes2[..., :4]
+        if bboxes1.size(-1) == 5:
+            bboxes1 = bboxes1[..., :4]
+        return bbox_overlaps(bboxes1, bboxes2, mode, is_aligned)
+
+    def __repr__(self):
+        return self.__class__.__name__ + '()'
+
+
+# --------------------------------------------------------- anchor generator --
+@ANCHOR_GENERATORS.register_module()
+class AnchorGenerator:
+    """mmdet/core/anchor/anchor_generator.py:9-346 for the configuration every
+    LD/GFL config uses: one square anchor per cell (ratios=[1.0],
+    scales_per_octave=1), side = octave_base_scale * stride, centred on the
+    cell origin (center_offset=0)."""
+
+    def __init__(self, strides, ratios, scales=None, base_sizes=None,
+                 scale_major=True, octave_base_scale=None,
+                 scales_per_octave=None, centers=None, center_offset=0.):
+        if center_offset != 0 or centers is not None:
+            raise NotImplementedError('center_offset / centers')
+        if list(ratios) != [1.0]:
+            raise NotImplementedError('only ratios=[1.0] (one square anchor)')
+        if (octave_base_scale is not None and scales_per_octave is not None):
+            if scales_per_octave != 1 or scales is not None:
+                raise NotImplementedError('scales_per_octave != 1')
+            scale = float(octave_base_scale)
+        elif scales is not None and len(scales) == 1:
+            scale = float(scales[0])
+        else:
+            raise ValueError('Either scales or octave_base_scale with '
+                             'scales_per_octave should be set')
+        if scale != int(scale):
+            raise NotImplementedError('non-integer anchor scale')
+        self.anchor_scale = int(scale)
+        self.strides = [(s, s) if isinstance(s, int) else tuple(s)
+                        for s in strides]
+        for s in self.strides:
+            if s[0] != s[1]:
+                raise NotImplementedError('h stride != w stride')
+        self.base_sizes = [min(s) for s in self.strides] \
+            if base_sizes is None else list(base_sizes)
+        if self.base_sizes != [min(s) for s in self.strides]:
+            raise NotImplementedError('base_sizes != strides')
+        self.ratios = torch.Tensor(ratios)
+        self.scales = torch.Tensor([scale])
+        self.octave_base_scale = octave_base_scale
+        self.scales_per_octave = scales_per_octave
+        self.scale_major, self.centers = scale_major, centers
+        self.center_offset = center_offset
+
+    @property
+    def num_base_anchors(self):
+        return [1 for _ in self.strides]
+
+    @property
+    def num_levels(self):
+        return len(self.strides)
+
+    @property
+    def base_anchors(self):
+        """CPU tensors, as in the reference (gen_base_anchors)."""
+        out = []
+        for s in self.strides:
+            half = 0.5 * s[0] * self.anchor_scale
+            out.append(torch.tensor([[-half, -half, half, half]]))
+        return out
+
+    def grid_anchors(self, featmap_sizes, device='cuda'):
+        assert self.num_levels == len(featmap_sizes)
+        flat = LB.grid_anchors([tuple(int(v) for v in s)
+                                for s in featmap_sizes],
+                               [s[0] for s in self.strides],
+                               torch.device(device), self.anchor_scale)
+        out, off = [], 0
+        for h, w in featmap_sizes:
+            out.append(flat[off:off + int(h) * int(w)])
+            off += int(h) * int(w)
+        return out
+
+    def valid_flags(self, featmap_sizes, pad_shape, device='cuda'):
+        """anchor_generator.py:272-328."""
+        assert self.num_levels == len(featmap_sizes)
+        flags = []
+        for (fh, fw), s in zip(featmap_sizes, self.strides):
+            h, w = pad_shape[:2]
+            vh = min(int(math.ceil(h / s[1])), int(fh))
+            vw = min(int(math.ceil(w / s[0])), int(fw))
+            f = torch.zeros((int(fh), int(fw)), dtype=torch.bool,
+                            device=device)
+            f[:vh, :vw] = True
+            flags.append(f.reshape(-1))
+        return flags
+
+    def __repr__(self):
+        return (f'{self.__class__.__name__}(strides={self.strides}, '
+                f'anchor_scale={self.anchor_scale})')
+
+
+# --------------------------------------------------- assign / sample results --
+class AssignResult:
+    """mmdet/core/bbox/assigners/assign_result.py."""
+
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+        self.num_gts = num_gts
+        self.gt_inds = gt_inds
+        self.max_overlaps = max_overlaps
+        self.labels = labels
+        self._extra_properties = {}
+
+    @property
+    def num_preds(self):
+        return len(self.gt_inds)
+
+
+class SamplingResult:
+    """mmdet/core/bbox/samplers/sampling_result.py:25-49."""
+
+    def __init__(self, pos_inds, neg_inds, bboxes, gt_bboxes, assign_result,
+                 gt_flags):
+        self.pos_inds = pos_inds
+        self.neg_inds = neg_inds
+        self.pos_bboxes = bboxes[pos_inds]
+        self.neg_bboxes = bboxes[neg_inds]
+        self.pos_is_gt = gt_flags[pos_inds]
+        self.num_gts = gt_bboxes.shape[0]
+        self.pos_assigned_gt_inds = assign_result.gt_inds[pos_inds] - 1
+        if gt_bboxes.numel() == 0:
+            assert self.pos_assigned_gt_inds.numel() == 0
+            self.pos_gt_bboxes = torch.empty_like(gt_bboxes).view(-1, 4)
+        else:
+            if len(gt_bboxes.shape) < 2:
+                gt_bboxes = gt_bboxes.view(-1, 4)
+            self.pos_gt_bboxes = gt_bboxes[self.pos_assigned_gt_inds, :]
+        self.pos_gt_labels = assign_result.labels[pos_inds] \
+            if assign_result.labels is not None else None
+
+    @property
+    def bboxes(self):
+        return torch.cat([self.pos_bboxes, self.neg_bboxes])
+
+
+@BBOX_SAMPLERS.register_module()
+class PseudoSampler:
+    """mmdet/core/bbox/samplers/pseudo_sampler.py:8-41."""
+
+    def __init__(self, **kwargs):
+        pass
+
+    def sample(self, assign_result, bboxes, gt_bboxes, **kwargs):
+        pos_inds = torch.nonzero(assign_result.gt_inds > 0,
+                                 as_tuple=False).squeeze(-1).unique()
+        neg_inds = torch.nonzero(assign_result.gt_inds == 0,
+                                 as_tuple=False).squeeze(-1).unique()
+        gt_flags = bboxes.new_zeros(bboxes.shape[0], dtype=torch.uint8)
+        return SamplingResult(pos_inds, neg_inds, bboxes, gt_bboxes,
+                              assign_result, gt_flags)
+
+
+@BBOX_CODERS.register_module()
+class DeltaXYWHBBoxCoder:
+    """Constructed by AnchorHead's default bbox_coder (anchor_head.py:45-49)
+    but never called on the GFL/LD path: registrable stub."""
+
+    def __init__(self, target_means=(0., 0., 0., 0.),
+                 target_stds=(1., 1., 1., 1.), clip_border=True):
+        self.means, self.stds = target_means, target_stds
+        self.clip_border = clip_border
+
+    def encode(self, bboxes, gt_bboxes):
+        raise NotImplementedError('DeltaXYWHBBoxCoder is not on the LD path')
+
+    decode = encode
+
+
+# ------------------------------------------------------------ ATSS assigner --
+@BBOX_ASSIGNERS.register_module()
+class ATSSAssigner:
+    """mmdet/core/bbox/assigners/atss_assigner.py:9-298, reference call
+    signatures, on the batched HIP target kernels (explicit-anchor form)."""
+
+    def __init__(self, topk, iou_calculator=dict(type='BboxOverlaps2D'),
+                 ignore_iof_thr=-1):
+        self.topk = topk
+        self.iou_calculator = build_iou_calculator(iou_calculator)
+        self.ignore_iof_thr = ignore_iof_thr
+
+    def _run(self, bboxes, num_level_bboxes, gt_bboxes, gt_labels):
+        if self.ignore_iof_thr > 0:
+            raise NotImplementedError('ignore regions (ignore_iof_thr > 0)')
+        lib = L.get_lib()
+        bboxes = L.require_device(bboxes[:, :4].contiguous(), torch.float32,
+                                  'bboxes')
+        dev = bboxes.device
+        A, G = bboxes.shape[0], gt_bboxes.shape[0]
+        assert sum(num_level_bboxes) == A
+        geom = L.make_geom([(int(n), 1) for n in num_level_bboxes],
+                           [1] * len(num_level_bboxes), 1)
+        hp = LB.make_hp(topk=self.topk)
+        gtb = gt_bboxes.reshape(1, G, 4).contiguous() if G else \
+            torch.zeros((1, 1, 4), device=dev)
+        gtl = (gt_labels if gt_labels is not None else
+               torch.zeros(G, dtype=torch.int64, device=dev))
+        gtl = gtl.reshape(1, G).contiguous() if G else torch.zeros(
+            (1, 1), dtype=torch.int64, device=dev)
+        ng = torch.tensor([G], dtype=torch.int32).to(dev)
+        vhw = torch.tensor([[int(n), 1] for n in num_level_bboxes],
+                           dtype=torch.int32).to(dev)
+        out = dict(
+            labels=torch.empty((1, A), dtype=torch.int64, device=dev),
+            lw=torch.empty((1, A), device=dev),
+            bt=torch.empty((1, A, 4), device=dev),
+            vlr=torch.empty((1, A), device=dev),
+            im=torch.empty((1, A), device=dev),
+            counts=torch.empty(1 + 2 * geom.num_levels + 1,
+                               dtype=torch.int32, device=dev),
+            gt_inds=torch.empty((1, A), dtype=torch.int64, device=dev),
+            max_overlaps=torch.empty((1, A), device=dev))
+        need = lib.ld_atss_targets_workspace_bytes(C.byref(geom), G)
+        ws = LB.workspace(dev, need, 'targets')
+        L.check(lib.ld_atss_targets_ex(
+            C.byref(geom), C.byref(hp), L.ptr(bboxes), L.ptr(gtb), L.ptr(gtl),
+            L.ptr(ng), G, L.ptr(vhw), L.ptr(out['labels']), L.ptr(out['lw']),
+            L.ptr(out['bt']), L.ptr(out['vlr']), L.ptr(out['im']),
+            L.ptr(out['counts']), L.ptr(out['gt_inds']),
+            L.ptr(out['max_overlaps']), L.ptr(ws), ws.numel(),
+            L.stream_ptr(dev)), 'ld_atss_targets_ex')
+        return out
+
+    def assign(self, bboxes, num_level_bboxes, gt_bboxes,
+               gt_bboxes_ignore=None, gt_labels=None):
+        num_gt, num_bboxes = gt_bboxes.size(0), bboxes.size(0)
+        if num_gt == 0 or num_bboxes == 0:
+            gt_inds = bboxes.new_full((num_bboxes, ), 0, dtype=torch.long)
+            max_overlaps = bboxes.new_zeros((num_bboxes, ))
+            labels = None if gt_labels is None else bboxes.new_full(
+                (num_bboxes, ), -1, dtype=torch.long)
+            return AssignResult(num_gt, gt_inds, max_overlaps, labels=labels)
+        out = self._run(bboxes, num_level_bboxes, gt_bboxes, gt_labels)
+        gt_inds = out['gt_inds'][0]
+        labels = None
+        if gt_labels is not None:
+            # -1 for unassigned, as the reference (atss_assigner.py:170-177)
+            labels = torch.where(gt_inds > 0, out['labels'][0],
+                                 torch.full_like(gt_inds, -1))
+        return AssignResult(num_gt, gt_inds, out['max_overlaps'][0],
+                            labels=labels)
+
+    def get_vlr_region(self, bboxes, num_level_bboxes, gt_bboxes,
+                       gt_bboxes_ignore=None, gt_labels=None):
+        """atss_assigner.py:183-298.  With no GT the reference returns an
+        AssignResult by mistake (quirk Q2); this returns zeros."""
+        if gt_bboxes.size(0) == 0 or bboxes.size(0) == 0:
+            return bboxes.new_zeros((bboxes.size(0), ))
+        return self._run(bboxes, num_level_bboxes, gt_bboxes,
+                         gt_labels)['vlr'][0]

@@ -66,6 +66,17 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// explicit anchors (reference-style API: any (A,4) box list split into levels by
+// count) or implicit ones generated from the pyramid geometry
+__device__ __forceinline__ Box get_anchor(const float* __restrict__ anchors, int a,
+                                          int x, int y, int stride, float half) {
+  if (anchors) {
+    const float4 q = reinterpret_cast<const float4*>(anchors)[a];
+    return Box{q.x, q.y, q.z, q.w};
+  }
+  return ld::anchor_box(x, y, stride, half);
+}
+
 __device__ __forceinline__ int level_of(const ld_geom_t& g, int a) {
   int l = 0;
 #pragma unroll
@@ -78,10 +89,11 @@ __device__ __forceinline__ int level_of(const ld_geom_t& g, int a) {
 // workspace: keys (N*A u64), thr (N*max_gt f32), colmax (N*max_gt f32)
 template <int KMAX>
 __global__ __launch_bounds__(kBlock) void atss_select_kernel(
-    ld_geom_t geom, int topk, const float* __restrict__ gt_bboxes,
-    const int32_t* __restrict__ num_gt, int max_gt,
-    const int32_t* __restrict__ valid_hw, unsigned long long* __restrict__ keys,
-    float* __restrict__ thr_out, float* __restrict__ colmax_out) {
+    ld_geom_t geom, int topk, const float* __restrict__ anchors,
+    const float* __restrict__ gt_bboxes, const int32_t* __restrict__ num_gt,
+    int max_gt, const int32_t* __restrict__ valid_hw,
+    unsigned long long* __restrict__ keys, float* __restrict__ thr_out,
+    float* __restrict__ colmax_out) {
   const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   if (g >= num_gt[n]) return;
   const float* gp = gt_bboxes + ((size_t)n * max_gt + g) * 4;
@@ -113,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void atss_select_kernel(
     for (int v = tid; v < nvalid; v += kBlock) {
       const int y = v / vw, x = v - y * vw;
       const int a = lv.offset + y * lv.W + x;
-      const Box ab = ld::anchor_box(x, y, lv.stride, half);
+      const Box ab = get_anchor(anchors, a, x, y, lv.stride, half);
       const float acx = (ab.x1 + ab.x2) / 2.0f, acy = (ab.y1 + ab.y2) / 2.0f;
       float d = ld::centre_dist(acx, acy, gcx, gcy);
       my_colmax = fmaxf(my_colmax, ld::iou_pair(ab, gt));
@@ -170,8 +182,8 @@ __global__ __launch_bounds__(kBlock) void atss_select_kernel(
     const ld_level_t lv = geom.lv[l];
     const int r = a - lv.offset;
     const int y = r / lv.W, x = r - y * lv.W;
-    cab = ld::anchor_box(x, y, lv.stride,
-                         0.5f * (float)(geom.anchor_scale * lv.stride));
+    cab = get_anchor(anchors, a, x, y, lv.stride,
+                     0.5f * (float)(geom.anchor_scale * lv.stride));
     ciou = ld::iou_pair(cab, gt);
     s_ciou[tid] = ciou;
   }
@@ -217,14 +229,15 @@ __global__ __launch_bounds__(kBlock) void atss_select_kernel(
 constexpr int kGtChunk = 128;
 
 __global__ __launch_bounds__(kBlock) void atss_dense_kernel(
-    ld_geom_t geom, int num_classes, const float* __restrict__ gt_bboxes,
-    const int64_t* __restrict__ gt_labels, const int32_t* __restrict__ num_gt,
-    int max_gt, const int32_t* __restrict__ valid_hw,
+    ld_geom_t geom, int num_classes, const float* __restrict__ anchors,
+    const float* __restrict__ gt_bboxes, const int64_t* __restrict__ gt_labels,
+    const int32_t* __restrict__ num_gt, int max_gt,
+    const int32_t* __restrict__ valid_hw,
     const unsigned long long* __restrict__ keys, const float* __restrict__ thr,
     const float* __restrict__ colmax, int64_t* __restrict__ labels,
     float* __restrict__ label_weights, float* __restrict__ bbox_targets,
-    float* __restrict__ vlr, float* __restrict__ im,
-    int32_t* __restrict__ counts) {
+    float* __restrict__ vlr, float* __restrict__ im, int32_t* __restrict__ counts,
+    int64_t* __restrict__ gt_inds_out, float* __restrict__ max_overlaps_out) {
   const int n = blockIdx.y, tid = threadIdx.x;
   const int a = blockIdx.x * kBlock + tid;
   const int A = geom.num_anchors, L = geom.num_levels, N = geom.num_imgs;
@@ -244,8 +257,8 @@ __global__ __launch_bounds__(kBlock) void atss_dense_kernel(
     const int vh = valid_hw[((size_t)n * L + l) * 2 + 0];
     const int vw = valid_hw[((size_t)n * L + l) * 2 + 1];
     valid = (y < vh) && (x < vw);
-    ab = ld::anchor_box(x, y, lv.stride,
-                        0.5f * (float)(geom.anchor_scale * lv.stride));
+    ab = get_anchor(anchors, a, x, y, lv.stride,
+                    0.5f * (float)(geom.anchor_scale * lv.stride));
   }
   float vmax = ld::kNegInf;
   bool is_im = false;
@@ -275,13 +288,16 @@ __global__ __launch_bounds__(kBlock) void atss_dense_kernel(
   }
   if (a >= A) return;
   const size_t o = (size_t)n * A + a;
-  int64_t lab = num_classes;
+  int64_t lab = num_classes, gind = 0;
   float lw = 0.0f, bt[4] = {0, 0, 0, 0}, vl = 0.0f, imv = 0.0f;
+  float mov = ld::kNegInf;
   if (valid) {
     lw = 1.0f;  // pos_weight <= 0 -> 1.0 for positives, negatives 1.0
     const unsigned long long key = keys[o];
     if (key != 0ull) {
       const int g = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+      gind = g + 1;
+      mov = __uint_as_float((unsigned)(key >> 32));
       const float* gp = gt_bboxes + ((size_t)n * max_gt + g) * 4;
       bt[0] = gp[0];
       bt[1] = gp[1];
@@ -301,6 +317,8 @@ __global__ __launch_bounds__(kBlock) void atss_dense_kernel(
       make_float4(bt[0], bt[1], bt[2], bt[3]);
   vlr[o] = vl;
   im[o] = imv;
+  if (gt_inds_out) gt_inds_out[o] = gind;
+  if (max_overlaps_out) max_overlaps_out[o] = mov;
 }
 
 __global__ void atss_counts_finalize(int N, int L, int32_t* counts) {
@@ -356,6 +374,21 @@ extern "C" int ld_atss_targets(const ld_geom_t* geom, const ld_loss_hp_t* hp,
                                float* vlr, float* im, int32_t* counts,
                                void* workspace, size_t workspace_bytes,
                                ld_stream_t stream_) {
+  return ld_atss_targets_ex(geom, hp, nullptr, gt_bboxes, gt_labels, num_gt, max_gt,
+                            valid_hw, labels, label_weights, bbox_targets, vlr, im,
+                            counts, nullptr, nullptr, workspace, workspace_bytes,
+                            stream_);
+}
+
+extern "C" int ld_atss_targets_ex(const ld_geom_t* geom, const ld_loss_hp_t* hp,
+                                  const float* anchors, const float* gt_bboxes,
+                                  const int64_t* gt_labels, const int32_t* num_gt,
+                                  int max_gt, const int32_t* valid_hw,
+                                  int64_t* labels, float* label_weights,
+                                  float* bbox_targets, float* vlr, float* im,
+                                  int32_t* counts, int64_t* gt_inds,
+                                  float* max_overlaps, void* workspace,
+                                  size_t workspace_bytes, ld_stream_t stream_) {
   if (int e = check_geom(geom)) return e;
   if (!hp || !labels || !label_weights || !bbox_targets || !vlr || !im ||
       !counts || !num_gt || !valid_hw || max_gt < 0)
@@ -380,18 +413,19 @@ extern "C" int ld_atss_targets(const ld_geom_t* geom, const ld_loss_hp_t* hp,
     dim3 grid(max_gt, N);
     if (hp->topk <= 9)
       hipLaunchKernelGGL(atss_select_kernel<9>, grid, dim3(kBlock), 0, stream,
-                         *geom, hp->topk, gt_bboxes, num_gt, max_gt, valid_hw,
-                         keys, thr, colmax);
+                         *geom, hp->topk, anchors, gt_bboxes, num_gt, max_gt,
+                         valid_hw, keys, thr, colmax);
     else
       hipLaunchKernelGGL(atss_select_kernel<16>, grid, dim3(kBlock), 0, stream,
-                         *geom, hp->topk, gt_bboxes, num_gt, max_gt, valid_hw,
-                         keys, thr, colmax);
+                         *geom, hp->topk, anchors, gt_bboxes, num_gt, max_gt,
+                         valid_hw, keys, thr, colmax);
   }
   dim3 gridb((A + kBlock - 1) / kBlock, N);
   hipLaunchKernelGGL(atss_dense_kernel, gridb, dim3(kBlock), 0, stream, *geom,
-                     hp->num_classes, gt_bboxes, gt_labels, num_gt,
+                     hp->num_classes, anchors, gt_bboxes, gt_labels, num_gt,
                      max_gt > 0 ? max_gt : 1, valid_hw, keys, thr, colmax,
-                     labels, label_weights, bbox_targets, vlr, im, counts);
+                     labels, label_weights, bbox_targets, vlr, im, counts, gt_inds,
+                     max_overlaps);
   hipLaunchKernelGGL(atss_counts_finalize, dim3(1), dim3(64), 0, stream, N, L,
                      counts);
   return (int)hipGetLastError();

@@ -1,0 +1,200 @@
+"""Detector wrappers with mmdet's registry names and methods (reference:
+mmdet/models/detectors/{base,single_stage,gfl,kd_one_stage}.py)."""
+import os
+import warnings
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .config import Config, ConfigDict
+from .heads import LazyScalars
+from .registry import (DETECTORS, build_backbone, build_detector, build_head,
+                       build_neck)
+
+
+@DETECTORS.register_module()
+class SingleStageDetector(nn.Module):
+    """single_stage.py:10-57 + base.py:16-268 (train path)."""
+
+    def __init__(self, backbone, neck=None, bbox_head=None, train_cfg=None,
+                 test_cfg=None, pretrained=None):
+        super().__init__()
+        self.fp16_enabled = False
+        self.backbone = build_backbone(backbone)
+        if neck is not None:
+            self.neck = build_neck(neck)
+        bbox_head = dict(bbox_head)
+        bbox_head.update(train_cfg=ConfigDict.wrap(train_cfg) if train_cfg
+                         else train_cfg)
+        bbox_head.update(test_cfg=ConfigDict.wrap(test_cfg) if test_cfg
+                         else test_cfg)
+        self.bbox_head = build_head(bbox_head)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.init_weights(pretrained=pretrained)
+
+    @property
+    def with_neck(self):
+        return hasattr(self, 'neck') and self.neck is not None
+
+    def init_weights(self, pretrained=None):
+        """single_stage.py:35-50."""
+        if isinstance(pretrained, str) and ('://' in pretrained or
+                                            not os.path.isfile(pretrained)):
+            warnings.warn(
+                f'pretrained={pretrained!r} cannot be fetched offline; '
+                'initialising the backbone randomly instead')
+            pretrained = None
+        self.backbone.init_weights(pretrained=pretrained)
+        if self.with_neck:
+            self.neck.init_weights()
+        self.bbox_head.init_weights()
+
+    def extract_feat(self, img):
+        x = self.backbone(img)
+        if self.with_neck:
+            x = self.neck(x)
+        return x
+
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels,
+                      gt_bboxes_ignore=None):
+        x = self.extract_feat(img)
+        return self.bbox_head.forward_train(x, img_metas, gt_bboxes, gt_labels,
+                                            gt_bboxes_ignore)
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        """base.py:169-183."""
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        raise NotImplementedError('forward_test / simple_test is a "next" row '
+                                  'of SURVEY.md section 8f (inference)')
+
+    def _parse_losses(self, losses):
+        """base.py:185-218.  Same keys and values; computed on the device in
+        O(1) launches, with ONE all-reduce for all log values and a lazy D2H
+        copy (the reference does one all-reduce + .item() per key)."""
+        table = getattr(losses, 'table', None)
+        if table is not None:
+            key_sums = table[losses.rows].sum(1)
+            names = list(losses.keys())
+        else:
+            names, vals = [], []
+            for name, value in losses.items():
+                if isinstance(value, torch.Tensor):
+                    vals.append(value.mean())
+                elif isinstance(value, list):
+                    vals.append(sum(v.mean() for v in value))
+                else:
+                    raise TypeError(f'{name} is not a tensor or list of tensors')
+                names.append(name)
+            key_sums = torch.stack(vals)
+        sel = [i for i, k in enumerate(names) if 'loss' in k]
+        loss = key_sums[sel].sum()
+        logged = torch.cat([key_sums.detach(), loss.detach().reshape(1)])
+        if dist.is_available() and dist.is_initialized() and \
+                dist.get_world_size() > 1:
+            logged = logged.clone()
+            dist.all_reduce(logged.div_(dist.get_world_size()))
+        log_vars = LazyScalars(names + ['loss'], logged)
+        return loss, log_vars
+
+    def train_step(self, data, optimizer):
+        """base.py:220-253."""
+        losses = self(**data)
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars,
+                    num_samples=len(data['img_metas']))
+
+
+@DETECTORS.register_module()
+class GFL(SingleStageDetector):
+    """gfl.py:6-16."""
+
+
+@DETECTORS.register_module()
+class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
+    """kd_one_stage.py:12-108: student + frozen teacher (hidden from
+    ``parameters()`` / ``state_dict()``), dual forward, LD loss."""
+
+    def __init__(self, backbone, neck, bbox_head, teacher_config,
+                 output_feature=False, teacher_ckpt=None, eval_teacher=True,
+                 train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__(backbone, neck, bbox_head, train_cfg, test_cfg,
+                         pretrained)
+        self.eval_teacher = eval_teacher
+        self.output_feature = output_feature
+        if isinstance(teacher_config, str):
+            teacher_config = Config.fromfile(teacher_config)
+        tcfg = dict(teacher_config['model'])
+        self.teacher_model = build_detector(tcfg)
+        if teacher_ckpt is not None:
+            from .checkpoint import load_checkpoint
+            try:
+                load_checkpoint(self.teacher_model, teacher_ckpt,
+                                map_location='cpu')
+            except FileNotFoundError as e:
+                warnings.warn(f'teacher_ckpt not loaded: {e}')
+        # run the (independent) teacher forward on its own HIP stream so it
+        # overlaps the student's: under-filled launches of one net are
+        # back-filled by the other
+        self.teacher_stream = None
+        self.use_teacher_stream = os.environ.get('LD_TEACHER_STREAM',
+                                                 '1') == '1'
+
+    def _teacher_forward(self, img):
+        with torch.no_grad():
+            teacher_x = self.teacher_model.extract_feat(img)
+            out_teacher = self.teacher_model.bbox_head(teacher_x)
+        return teacher_x, out_teacher
+
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels,
+                      gt_bboxes_ignore=None):
+        """kd_one_stage.py:46-81."""
+        if not self.output_feature:
+            raise NotImplementedError(
+                'output_feature=False: the reference passes one argument too '
+                'few to LDHead.forward_train on that branch '
+                '(kd_one_stage.py:74-76 vs ld_head.py:73-82)')
+        side = None
+        if self.use_teacher_stream and img.is_cuda:
+            if self.teacher_stream is None:
+                self.teacher_stream = torch.cuda.Stream(device=img.device)
+            main = torch.cuda.current_stream(img.device)
+            side = self.teacher_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                teacher_x, out_teacher = self._teacher_forward(img)
+        x = self.extract_feat(img)
+        if side is not None:
+            main.wait_stream(side)
+            for t in list(teacher_x) + list(out_teacher[0]) + \
+                    list(out_teacher[1]):
+                t.record_stream(main)
+        else:
+            teacher_x, out_teacher = self._teacher_forward(img)
+        return self.bbox_head.forward_train(x, out_teacher, teacher_x,
+                                            img_metas, gt_bboxes, gt_labels,
+                                            gt_bboxes_ignore)
+
+    def cuda(self, device=None):
+        self.teacher_model.cuda(device=device)
+        return super().cuda(device=device)
+
+    def to(self, *args, **kwargs):
+        self.teacher_model.to(*args, **kwargs)
+        return super().to(*args, **kwargs)
+
+    def train(self, mode=True):
+        if self.eval_teacher:
+            self.teacher_model.train(False)
+        else:
+            self.teacher_model.train(mode)
+        return super().train(mode)
+
+    def __setattr__(self, name, value):
+        """kd_one_stage.py:97-108: keep the teacher a plain attribute."""
+        if name == 'teacher_model':
+            object.__setattr__(self, name, value)
+        else:
+            super().__setattr__(name, value)

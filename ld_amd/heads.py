@@ -1,0 +1,409 @@
+"""GFLHead / LDHead with mmdet's constructor arguments, state_dict keys and
+method signatures (reference: mmdet/models/dense_heads/gfl_head.py:15-625,
+ld_head.py:43-637, anchor_head.py:14-173, base_dense_head.py:6-59).
+
+MI355X-native execution:
+  * forward: the five FPN levels are concatenated into one (N, C, P) tensor
+    and every weight-shared tower conv / GroupNorm / predictor runs as ONE
+    launch over all levels (the reference runs 5 x 10 small convs);
+  * loss: anchors are never materialised, targets come from two batched
+    launches (targets.hip) and the whole loss_single x 5 levels, forward AND
+    gradient, is the fused block of loss.hip, reading the NCHW head outputs in
+    place.  No host synchronisation: the two normalisers stay on the device
+    (the reference does ~90 .item()/nonzero syncs per step).
+"""
+import torch
+import torch.nn as nn
+
+from . import layers as Y
+from . import lib as L
+from . import lossblock as LB
+from .cnn import ConvModule, Conv2d, Scale, bias_init_with_prob, normal_init
+from .core import multi_apply, reduce_mean
+from .registry import (HEADS, build_anchor_generator, build_assigner,
+                       build_bbox_coder, build_iou_calculator, build_loss,
+                       build_sampler)
+
+LOSS_KEYS = L.LOSS_KEYS
+
+
+class Integral(nn.Module):
+    """gfl_head.py:15-44: expectation of the softmax over {0..reg_max}."""
+
+    def __init__(self, reg_max=16):
+        super().__init__()
+        self.reg_max = reg_max
+        self.register_buffer('project',
+                             torch.linspace(0, self.reg_max, self.reg_max + 1))
+
+    def forward(self, x):
+        return _IntegralFn.apply(x.reshape(-1, 4 * (self.reg_max + 1)))
+
+
+class _IntegralFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x):
+        x = L.require_device(x.contiguous(), torch.float32, 'integral input')
+        if x.shape[1] != 68:
+            raise NotImplementedError('reg_max != 16')
+        out = x.new_empty((x.shape[0], 4))
+        if x.shape[0]:
+            L.check(L.get_lib().ld_integral_rows(L.ptr(x), x.shape[0],
+                                                 L.ptr(out),
+                                                 L.stream_ptr(x.device)),
+                    'ld_integral_rows')
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        if x.shape[0]:
+            L.check(L.get_lib().ld_integral_rows_bwd(L.ptr(x),
+                                                     L.ptr(g.contiguous()),
+                                                     x.shape[0], L.ptr(gx),
+                                                     L.stream_ptr(x.device)),
+                    'ld_integral_rows_bwd')
+        return gx
+
+
+class LossDict(dict):
+    """dict[str, list[Tensor]] as the reference returns, plus the (8, L) device
+    table it is a view of, so _parse_losses can reduce it in two launches."""
+    table = None
+    rows = None
+
+
+class LazyScalars(dict):
+    """dict of python floats backed by one device tensor; the single D2H copy
+    happens on first access (the reference syncs 9 times per step)."""
+
+    def __init__(self, keys, tensor):
+        super().__init__()
+        self._keys, self._tensor, self._done = list(keys), tensor, False
+        for k in keys:
+            dict.__setitem__(self, k, None)
+
+    def _sync(self):
+        if not self._done:
+            vals = self._tensor.detach().cpu().tolist()
+            for k, v in zip(self._keys, vals):
+                dict.__setitem__(self, k, v)
+            self._done = True
+
+    def __getitem__(self, k):
+        self._sync()
+        return dict.__getitem__(self, k)
+
+    def items(self):
+        self._sync()
+        return dict.items(self)
+
+    def values(self):
+        self._sync()
+        return dict.values(self)
+
+
+@HEADS.register_module()
+class GFLHead(nn.Module):
+    """Constructor = AnchorHead.__init__ (anchor_head.py:31-96) +
+    GFLHead.__init__ (gfl_head.py:76-100)."""
+
+    def __init__(self, num_classes, in_channels, stacked_convs=4,
+                 conv_cfg=None,
+                 norm_cfg=dict(type='GN', num_groups=32, requires_grad=True),
+                 loss_dfl=dict(type='DistributionFocalLoss', loss_weight=0.25),
+                 reg_max=16, feat_channels=256,
+                 anchor_generator=dict(type='AnchorGenerator', ratios=[1.0],
+                                       octave_base_scale=8,
+                                       scales_per_octave=1,
+                                       strides=[8, 16, 32, 64, 128]),
+                 bbox_coder=dict(type='DeltaXYWHBBoxCoder',
+                                 target_means=(.0, .0, .0, .0),
+                                 target_stds=(1.0, 1.0, 1.0, 1.0)),
+                 reg_decoded_bbox=False,
+                 loss_cls=dict(type='QualityFocalLoss', use_sigmoid=True,
+                               beta=2.0, loss_weight=1.0),
+                 loss_bbox=dict(type='GIoULoss', loss_weight=2.0),
+                 train_cfg=None, test_cfg=None):
+        super().__init__()
+        self.stacked_convs, self.conv_cfg, self.norm_cfg = (stacked_convs,
+                                                            conv_cfg, norm_cfg)
+        self.reg_max = reg_max
+        self.in_channels, self.num_classes = in_channels, num_classes
+        self.feat_channels = feat_channels
+        self.use_sigmoid_cls = loss_cls.get('use_sigmoid', False)
+        self.sampling = loss_cls['type'] not in [
+            'FocalLoss', 'GHMC', 'QualityFocalLoss'
+        ]
+        self.cls_out_channels = num_classes if self.use_sigmoid_cls \
+            else num_classes + 1
+        if self.cls_out_channels <= 0:
+            raise ValueError(f'num_classes={num_classes} is too small')
+        self.reg_decoded_bbox = reg_decoded_bbox
+        self.bbox_coder = build_bbox_coder(bbox_coder)
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_bbox = build_loss(loss_bbox)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        if self.train_cfg:
+            self.assigner = build_assigner(self.train_cfg.assigner)
+            self.sampler = build_sampler(dict(type='PseudoSampler'),
+                                         context=self)
+        self.sampling = False
+        self.fp16_enabled = False
+        self.anchor_generator = build_anchor_generator(anchor_generator)
+        self.num_anchors = self.anchor_generator.num_base_anchors[0]
+        self._init_layers()
+        self.integral = Integral(self.reg_max)
+        self.loss_dfl = build_loss(loss_dfl)
+
+    def _init_layers(self):
+        """gfl_head.py:102-133."""
+        self.relu = nn.ReLU(inplace=True)
+        self.cls_convs = nn.ModuleList()
+        self.reg_convs = nn.ModuleList()
+        for i in range(self.stacked_convs):
+            chn = self.in_channels if i == 0 else self.feat_channels
+            self.cls_convs.append(
+                ConvModule(chn, self.feat_channels, 3, stride=1, padding=1,
+                           conv_cfg=self.conv_cfg, norm_cfg=self.norm_cfg))
+            self.reg_convs.append(
+                ConvModule(chn, self.feat_channels, 3, stride=1, padding=1,
+                           conv_cfg=self.conv_cfg, norm_cfg=self.norm_cfg))
+        assert self.num_anchors == 1, 'anchor free version'
+        self.gfl_cls = Conv2d(self.feat_channels, self.cls_out_channels, 3,
+                              padding=1)
+        self.gfl_reg = Conv2d(self.feat_channels, 4 * (self.reg_max + 1), 3,
+                              padding=1)
+        self.scales = nn.ModuleList(
+            [Scale(1.0) for _ in self.anchor_generator.strides])
+
+    def init_weights(self):
+        """gfl_head.py:135-143."""
+        for m in self.cls_convs:
+            normal_init(m.conv, std=0.01)
+        for m in self.reg_convs:
+            normal_init(m.conv, std=0.01)
+        bias_cls = bias_init_with_prob(0.01)
+        normal_init(self.gfl_cls, std=0.01, bias=bias_cls)
+        normal_init(self.gfl_reg, std=0.01)
+
+    # ------------------------------------------------------------ forward --
+    def forward(self, feats):
+        """feats: tuple of per-level (N, C, H, W) -> (cls_scores, bbox_preds)
+        lists (gfl_head.py:145-183), all levels in one launch per layer."""
+        assert len(feats) == len(self.scales)
+        x3, levels = Y.pack_levels(feats)
+        cls_feat = reg_feat = x3
+        for m in self.cls_convs:
+            cls_feat, _ = m.forward3(cls_feat, levels)
+        for m in self.reg_convs:
+            reg_feat, _ = m.forward3(reg_feat, levels)
+        cls3, _ = self.gfl_cls.forward3(cls_feat, levels)
+        reg3, _ = self.gfl_reg.forward3(reg_feat, levels)
+        scales = torch.stack([s.scale for s in self.scales])
+        reg3 = Y.scale_levels(reg3, scales, levels)
+        return Y.split_levels(cls3, levels), Y.split_levels(reg3, levels)
+
+    def forward_single(self, x, scale):
+        raise NotImplementedError(
+            'use forward(feats): all levels run in one launch per layer')
+
+    def anchor_center(self, anchors):
+        """gfl_head.py:185-194."""
+        cx = (anchors[..., 2] + anchors[..., 0]) / 2
+        cy = (anchors[..., 3] + anchors[..., 1]) / 2
+        return torch.stack([cx, cy], dim=-1)
+
+    def get_anchors(self, featmap_sizes, img_metas, device='cuda'):
+        """anchor_head.py:145-173 (API compatibility; the loss never calls
+        it)."""
+        num_imgs = len(img_metas)
+        multi_level_anchors = self.anchor_generator.grid_anchors(
+            featmap_sizes, device)
+        anchor_list = [multi_level_anchors for _ in range(num_imgs)]
+        valid_flag_list = []
+        for meta in img_metas:
+            valid_flag_list.append(
+                self.anchor_generator.valid_flags(featmap_sizes,
+                                                  meta['pad_shape'], device))
+        return anchor_list, valid_flag_list
+
+    # --------------------------------------------------------------- loss --
+    def _hp(self, **over):
+        kw = dict(
+            num_classes=self.num_classes, reg_max=self.reg_max,
+            topk=self.assigner.topk, feat_channels=self.feat_channels,
+            lw_cls=self.loss_cls.loss_weight,
+            qfl_beta=getattr(self.loss_cls, 'beta', 2.0),
+            lw_bbox=self.loss_bbox.loss_weight,
+            giou_eps=getattr(self.loss_bbox, 'eps', 1e-6),
+            lw_dfl=self.loss_dfl.loss_weight, lw_ld=0.0, T_ld=1.0,
+            lw_ld_vlr=0.0, T_ld_vlr=1.0, lw_kd=0.0, T_kd=1.0, lw_im=0.0)
+        kw.update(over)
+        return LB.make_hp(**kw)
+
+    def _check_loss_cfg(self):
+        from .losses import GIoULoss, QualityFocalLoss
+        if not isinstance(self.loss_cls, QualityFocalLoss) or \
+                not isinstance(self.loss_bbox, GIoULoss):
+            raise NotImplementedError(
+                'the fused loss block implements QualityFocalLoss + GIoULoss '
+                f'(got {type(self.loss_cls).__name__}, '
+                f'{type(self.loss_bbox).__name__})')
+        if self.train_cfg.get('allowed_border', -1) >= 0:
+            raise NotImplementedError('allowed_border >= 0')
+        if self.train_cfg.get('pos_weight', -1) > 0:
+            raise NotImplementedError('pos_weight > 0')
+
+    def get_targets_batched(self, featmap_sizes, img_metas, gt_bboxes,
+                            gt_labels, hp, device):
+        """AnchorHead.get_anchors + LDHead.get_targets for the whole batch in
+        two launches (ld_head.py:377-577)."""
+        strides = [s[0] for s in self.anchor_generator.strides]
+        if gt_labels is None:
+            gt_labels = [b.new_zeros(b.shape[0], dtype=torch.long)
+                         for b in gt_bboxes]
+        return LB.atss_targets(featmap_sizes, strides, img_metas, gt_bboxes,
+                               gt_labels, hp, device,
+                               self.anchor_generator.anchor_scale)
+
+    @staticmethod
+    def _norm_reducer():
+        """Cross-rank mean of (num_total_pos, sum weight_targets): ONE device
+        side all-reduce instead of the reference's two reduce_mean(...).item()
+        host syncs (ld_head.py:338-341,362-363)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or \
+                dist.get_world_size() == 1:
+            return None
+        ws = float(dist.get_world_size())
+
+        def _r(norm):
+            dist.all_reduce(norm)
+            norm.div_(ws)
+
+        return _r
+
+    def _loss_dict(self, table, keys=LOSS_KEYS):
+        d = LossDict((k, [table[i, l] for l in range(table.shape[1])])
+                     for i, k in enumerate(LOSS_KEYS) if k in keys)
+        d.table, d.rows = table, [i for i, k in enumerate(LOSS_KEYS)
+                                  if k in keys]
+        return d
+
+    def loss(self, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas,
+             gt_bboxes_ignore=None):
+        """gfl_head.py:269-352 (plain GFL: QFL + GIoU + DFL)."""
+        self._check_loss_cfg()
+        sizes = [tuple(int(v) for v in f.shape[-2:]) for f in cls_scores]
+        device = cls_scores[0].device
+        hp = self._hp()
+        targets = self.get_targets_batched(sizes, img_metas, gt_bboxes,
+                                           gt_labels, hp, device)
+        # no teacher, no features: feed the student's own (detached) outputs;
+        # every distillation weight is zero
+        dummy_x = [c.detach() for c in cls_scores]
+        hp.feat_channels = cls_scores[0].shape[1]
+        teacher = ([c.detach() for c in cls_scores],
+                   [b.detach() for b in bbox_preds], dummy_x)
+        table, _ = LB.LDLossBlock.apply(hp, targets, teacher,
+                                        self._norm_reducer(),
+                                        getattr(self, 'unit_upstream', False),
+                                        *cls_scores, *bbox_preds, *dummy_x)
+        return self._loss_dict(table, ('loss_cls', 'loss_bbox', 'loss_dfl'))
+
+    def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None,
+                      gt_bboxes_ignore=None, proposal_cfg=None, **kwargs):
+        """base_dense_head.py:20-59."""
+        outs = self(x)
+        losses = self.loss(*outs, gt_bboxes, gt_labels, img_metas,
+                           gt_bboxes_ignore=gt_bboxes_ignore)
+        if proposal_cfg is not None:
+            raise NotImplementedError('get_bboxes (inference) is a "next" row '
+                                      'of SURVEY.md section 8f')
+        return losses
+
+    def get_bboxes(self, *args, **kwargs):
+        raise NotImplementedError('inference post-processing is a "next" row '
+                                  'of SURVEY.md section 8f')
+
+
+@HEADS.register_module()
+class LDHead(GFLHead):
+    """ld_head.py:43-637."""
+
+    def __init__(self, num_classes, in_channels,
+                 loss_ld=dict(type='KnowledgeDistillationKLDivLoss',
+                              loss_weight=0.25, T=10),
+                 loss_ld_vlr=dict(type='KnowledgeDistillationKLDivLoss',
+                                  loss_weight=0.25, T=10),
+                 loss_kd=dict(type='KnowledgeDistillationKLDivLoss',
+                              loss_weight=10, T=2),
+                 loss_im=dict(type='IMLoss', loss_weight=0),
+                 imitation_method='gibox', **kwargs):
+        super().__init__(num_classes, in_channels, **kwargs)
+        assert imitation_method in ['gibox', 'finegrained', 'fitnet',
+                                    'decouple']
+        self.imitation_method = imitation_method
+        self.loss_im = build_loss(loss_im)
+        self.loss_ld = build_loss(loss_ld)
+        self.loss_ld_vlr = build_loss(loss_ld_vlr)
+        self.loss_kd = build_loss(loss_kd)
+        self.iou_calculator = build_iou_calculator(dict(type='BboxOverlaps2D'))
+        # d(total)/d(loss_k) == 1 is promised by BaseDetector._parse_losses;
+        # the train engine sets this so the backward reuses the gradient the
+        # fused forward launch already produced
+        self.unit_upstream = False
+
+    def forward_train(self, x, out_teacher, teacher_x, img_metas, gt_bboxes,
+                      gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None,
+                      **kwargs):
+        """ld_head.py:73-114."""
+        outs = self(x)
+        if gt_labels is None:
+            raise NotImplementedError('LDHead needs gt_labels')
+        losses = self.loss(*outs, gt_bboxes, gt_labels, out_teacher, x,
+                           teacher_x, img_metas,
+                           gt_bboxes_ignore=gt_bboxes_ignore)
+        if proposal_cfg is not None:
+            raise NotImplementedError('get_bboxes (inference) is a "next" row '
+                                      'of SURVEY.md section 8f')
+        return losses
+
+    def loss(self, cls_scores, bbox_preds, gt_bboxes, gt_labels, soft_teacher,
+             x, teacher_x, img_metas, gt_bboxes_ignore=None):
+        """ld_head.py:284-375 -> dict of 8 lists of per-level scalars."""
+        self._check_loss_cfg()
+        lw_im = float(self.loss_im.loss_weight)
+        if self.imitation_method != 'finegrained' and lw_im != 0.0:
+            raise NotImplementedError(
+                f"imitation_method='{self.imitation_method}' with a non-zero "
+                'loss_im weight (gibox needs torchvision NMS and is CUDA-only '
+                'in the reference, SURVEY.md quirk Q3); with weight 0 the '
+                'term is exactly 0 and is evaluated as such')
+        if x[0].shape[1] != 256:
+            raise ValueError('LDHead hard-codes 256 feature channels '
+                             '(ld_head.py:153-154)')
+        soft_label, soft_target = soft_teacher
+        sizes = [tuple(int(v) for v in f.shape[-2:]) for f in cls_scores]
+        assert len(sizes) == self.anchor_generator.num_levels
+        device = cls_scores[0].device
+        hp = self._hp(lw_ld=self.loss_ld.loss_weight, T_ld=self.loss_ld.T,
+                      lw_ld_vlr=self.loss_ld_vlr.loss_weight,
+                      T_ld_vlr=self.loss_ld_vlr.T,
+                      lw_kd=self.loss_kd.loss_weight, T_kd=self.loss_kd.T,
+                      lw_im=lw_im)
+        targets = self.get_targets_batched(sizes, img_metas, gt_bboxes,
+                                           gt_labels, hp, device)
+        teacher = ([t.detach() for t in soft_label],
+                   [t.detach() for t in soft_target],
+                   [t.detach() for t in teacher_x])
+        table, _ = LB.LDLossBlock.apply(hp, targets, teacher,
+                                        self._norm_reducer(),
+                                        self.unit_upstream, *cls_scores,
+                                        *bbox_preds, *x)
+        self.last_targets = targets
+        return self._loss_dict(table)

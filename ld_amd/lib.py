@@ -111,6 +111,9 @@ SIGNATURES = {
     'ld_atss_targets_workspace_bytes': (_sz, [_G, _i32]),
     'ld_atss_targets': (C.c_int, [_G, _H, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'ld_atss_targets_ex': (C.c_int, [_G, _H, _vp, _vp, _vp, _vp, _i32, _vp,
+                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _vp, _sz, _vp]),
     'ld_grid_anchors': (C.c_int, [_G, _vp, _vp]),
     'ld_loss_workspace_bytes': (_sz, [_G]),
     'ld_loss_prepass': (C.c_int, [_G, _H, _M, _M, _vp, _vp, _vp, _vp, _vp,

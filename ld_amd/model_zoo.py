@@ -1,0 +1,107 @@
+"""Model config dicts for the LD benchmark configurations, built in code.
+
+The reference's own config files (configs/ld/*.py, configs/gfl/*.py) resolve
+through ld_amd's registry unchanged (tests/test_configs_resolve.py checks this
+wherever a reference checkout is present); they are not shipped with this
+repository, so the bench / smoke / GPU tests construct the same settings here.
+Values follow configs/ld/ld_r18_gflv1_r101_fpn_coco_1x.py:6-58,
+configs/ld/ld_r50_gflv1_r101_fpn_coco_1x.py:2-52 and
+configs/gfl/gfl_r50_fpn_1x_coco.py:5-56.
+"""
+import copy
+
+_RESNET_CH = {18: [64, 128, 256, 512], 34: [64, 128, 256, 512],
+              50: [256, 512, 1024, 2048], 101: [256, 512, 1024, 2048]}
+
+_TRAIN_CFG = dict(assigner=dict(type='ATSSAssigner', topk=9),
+                  allowed_border=-1, pos_weight=-1, debug=False)
+_TEST_CFG = dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05,
+                 nms=dict(type='nms', iou_threshold=0.6), max_per_img=100)
+
+
+def _backbone(depth):
+    return dict(type='ResNet', depth=depth, num_stages=4,
+                out_indices=(0, 1, 2, 3), frozen_stages=1,
+                norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True,
+                style='pytorch')
+
+
+def _neck(depth):
+    return dict(type='FPN', in_channels=list(_RESNET_CH[depth]),
+                out_channels=256, start_level=1, add_extra_convs='on_output',
+                num_outs=5)
+
+
+def _gfl_head_common():
+    return dict(
+        num_classes=80, in_channels=256, stacked_convs=4, feat_channels=256,
+        anchor_generator=dict(type='AnchorGenerator', ratios=[1.0],
+                              octave_base_scale=8, scales_per_octave=1,
+                              strides=[8, 16, 32, 64, 128]),
+        loss_cls=dict(type='QualityFocalLoss', use_sigmoid=True, beta=2.0,
+                      loss_weight=1.0),
+        loss_dfl=dict(type='DistributionFocalLoss', loss_weight=0.25),
+        reg_max=16)
+
+
+def gfl_detector(depth=101):
+    """A GFL teacher (configs/gfl/gfl_r{50,101}_fpn_*_coco.py)."""
+    head = dict(type='GFLHead', loss_bbox=dict(type='CIoULoss',
+                                               loss_weight=2.0),
+                **_gfl_head_common())
+    return dict(type='GFL', pretrained=None, backbone=_backbone(depth),
+                neck=_neck(depth), bbox_head=head,
+                train_cfg=copy.deepcopy(_TRAIN_CFG),
+                test_cfg=copy.deepcopy(_TEST_CFG))
+
+
+def ld_detector(student_depth=50, teacher_depth=101,
+                imitation_method='finegrained', loss_im_weight=2.0,
+                with_vlr_kd=True):
+    """KnowledgeDistillationSingleStageDetector as in
+    configs/ld/ld_r50_gflv1_r101_fpn_coco_1x.py (Main KD + Main LD + VLR LD +
+    fine-grained feature imitation).  ``with_vlr_kd=False`` gives the r18/r34
+    style config that only sets loss_ld."""
+    head = dict(type='LDHead', loss_bbox=dict(type='GIoULoss',
+                                              loss_weight=2.0),
+                loss_ld=dict(type='KnowledgeDistillationKLDivLoss',
+                             loss_weight=0.25, T=10),
+                **_gfl_head_common())
+    if with_vlr_kd:
+        head.update(
+            loss_ld_vlr=dict(type='KnowledgeDistillationKLDivLoss',
+                             loss_weight=0.25, T=10),
+            loss_kd=dict(type='KnowledgeDistillationKLDivLoss',
+                         loss_weight=10, T=2))
+    head.update(loss_im=dict(type='IMLoss', loss_weight=loss_im_weight),
+                imitation_method=imitation_method)
+    return dict(type='KnowledgeDistillationSingleStageDetector',
+                pretrained=None,
+                teacher_config=dict(model=gfl_detector(teacher_depth)),
+                teacher_ckpt=None, output_feature=True,
+                backbone=_backbone(student_depth), neck=_neck(student_depth),
+                bbox_head=head, train_cfg=copy.deepcopy(_TRAIN_CFG),
+                test_cfg=copy.deepcopy(_TEST_CFG))
+
+
+OPTIMIZER = dict(type='SGD', lr=0.0025, momentum=0.9, weight_decay=0.0001)
+
+
+def build_seeded_ld_detector(student_depth=50, teacher_depth=101, device=None,
+                             loss_im_weight=2.0, student_seed=1,
+                             teacher_seed=2):
+    """Detector with the deterministic synthetic weights the golden fixtures
+    were generated with (ld_amd.synthetic.seeded_state_dict)."""
+    from . import synthetic
+    from .registry import build_detector
+    det = build_detector(ld_detector(student_depth, teacher_depth,
+                                     loss_im_weight=loss_im_weight))
+    det.load_state_dict(synthetic.seeded_state_dict(det.state_dict(),
+                                                    seed=student_seed))
+    det.teacher_model.load_state_dict(
+        synthetic.seeded_state_dict(det.teacher_model.state_dict(),
+                                    seed=teacher_seed))
+    if device is not None:
+        det.to(device)
+    det.train()
+    return det

@@ -1,0 +1,278 @@
+"""ResNet-18/34/50/101 backbone with mmdet's constructor, state_dict keys and
+freezing semantics (reference: mmdet/models/backbones/resnet.py:13-648,
+mmdet/models/utils/res_layer.py:5-102), running on the HIP kernels.
+
+Execution plan per block:
+  * no gradient needed (teacher under no_grad, frozen stem / stages whose
+    input carries no grad): conv -> BN(eval) -> (+identity) -> ReLU is ONE
+    implicit-GEMM launch with the BN folded into its epilogue;
+  * trainable: conv (MFMA fwd/dgrad/wgrad) + one fused BN-affine/add/ReLU
+    elementwise kernel, keeping the conv output for the gamma/beta gradients.
+"""
+import torch
+import torch.nn as nn
+
+from . import layers as Y
+from . import lib as L
+from .cnn import (BatchNorm2d, Conv2d, build_conv_layer, build_norm_layer,
+                  constant_init, kaiming_init)
+from .registry import BACKBONES
+
+
+def _conv_bn(x3, levels, conv, bn, residual=None, relu=True):
+    """conv -> bn -> (+residual) -> relu with the right fusion level."""
+    w = conv.weight
+    need_grad = torch.is_grad_enabled() and (
+        x3.requires_grad or w.requires_grad or bn.weight.requires_grad or
+        (residual is not None and residual.requires_grad))
+    if bn.training:
+        raise NotImplementedError('BatchNorm in training mode (use '
+                                  'norm_eval=True; resnet.py:639-648)')
+    if not need_grad:
+        return Y.conv_bn_act_infer(x3, w, bn.weight, bn.bias, bn.running_mean,
+                                   bn.running_var, bn.eps, conv.stride[0],
+                                   conv.padding[0], levels, residual, relu)
+    y3, lv = conv.forward3(x3, levels)
+    return bn.forward3(y3, residual, relu), lv
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None,
+                 style='pytorch', with_cp=False, conv_cfg=None,
+                 norm_cfg=dict(type='BN'), dcn=None, plugins=None):
+        super().__init__()
+        assert dcn is None and plugins is None and dilation == 1
+        self.norm1_name, norm1 = build_norm_layer(norm_cfg, planes, postfix=1)
+        self.norm2_name, norm2 = build_norm_layer(norm_cfg, planes, postfix=2)
+        self.conv1 = build_conv_layer(conv_cfg, inplanes, planes, 3,
+                                      stride=stride, padding=1, bias=False)
+        self.add_module(self.norm1_name, norm1)
+        self.conv2 = build_conv_layer(conv_cfg, planes, planes, 3, padding=1,
+                                      bias=False)
+        self.add_module(self.norm2_name, norm2)
+        self.downsample = downsample
+        self.stride = stride
+
+    @property
+    def norm1(self):
+        return getattr(self, self.norm1_name)
+
+    @property
+    def norm2(self):
+        return getattr(self, self.norm2_name)
+
+    def forward3(self, x3, levels):
+        out, lv = _conv_bn(x3, levels, self.conv1, self.norm1)
+        identity = x3
+        if self.downsample is not None:
+            identity, _ = _conv_bn(x3, levels, self.downsample[0],
+                                   self.downsample[1], relu=False)
+        return _conv_bn(out, lv, self.conv2, self.norm2, residual=identity)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None,
+                 style='pytorch', with_cp=False, conv_cfg=None,
+                 norm_cfg=dict(type='BN'), dcn=None, plugins=None):
+        super().__init__()
+        assert style in ['pytorch', 'caffe']
+        if dcn is not None:
+            raise NotImplementedError(
+                'DCN (config 4 teacher) is a later row of SURVEY.md section 8')
+        assert plugins is None and dilation == 1
+        self.conv1_stride, self.conv2_stride = (1, stride) \
+            if style == 'pytorch' else (stride, 1)
+        self.norm1_name, norm1 = build_norm_layer(norm_cfg, planes, postfix=1)
+        self.norm2_name, norm2 = build_norm_layer(norm_cfg, planes, postfix=2)
+        self.norm3_name, norm3 = build_norm_layer(
+            norm_cfg, planes * self.expansion, postfix=3)
+        self.conv1 = build_conv_layer(conv_cfg, inplanes, planes, 1,
+                                      stride=self.conv1_stride, bias=False)
+        self.add_module(self.norm1_name, norm1)
+        self.conv2 = build_conv_layer(conv_cfg, planes, planes, 3,
+                                      stride=self.conv2_stride, padding=1,
+                                      bias=False)
+        self.add_module(self.norm2_name, norm2)
+        self.conv3 = build_conv_layer(conv_cfg, planes,
+                                      planes * self.expansion, 1, bias=False)
+        self.add_module(self.norm3_name, norm3)
+        self.downsample = downsample
+        self.stride = stride
+
+    @property
+    def norm1(self):
+        return getattr(self, self.norm1_name)
+
+    @property
+    def norm2(self):
+        return getattr(self, self.norm2_name)
+
+    @property
+    def norm3(self):
+        return getattr(self, self.norm3_name)
+
+    def forward3(self, x3, levels):
+        out, lv = _conv_bn(x3, levels, self.conv1, self.norm1)
+        out, lv = _conv_bn(out, lv, self.conv2, self.norm2)
+        identity = x3
+        if self.downsample is not None:
+            identity, _ = _conv_bn(x3, levels, self.downsample[0],
+                                   self.downsample[1], relu=False)
+        return _conv_bn(out, lv, self.conv3, self.norm3, residual=identity)
+
+
+class ResLayer(nn.Sequential):
+    """mmdet/models/utils/res_layer.py:5-102 (downsample_first=True,
+    avg_down=False)."""
+
+    def __init__(self, block, inplanes, planes, num_blocks, stride=1,
+                 avg_down=False, conv_cfg=None, norm_cfg=dict(type='BN'),
+                 downsample_first=True, **kwargs):
+        assert not avg_down and downsample_first
+        downsample = None
+        if stride != 1 or inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                build_conv_layer(conv_cfg, inplanes, planes * block.expansion,
+                                 1, stride=stride, bias=False),
+                build_norm_layer(norm_cfg, planes * block.expansion)[1])
+        layers = [block(inplanes=inplanes, planes=planes, stride=stride,
+                        downsample=downsample, conv_cfg=conv_cfg,
+                        norm_cfg=norm_cfg, **kwargs)]
+        inplanes = planes * block.expansion
+        for _ in range(1, num_blocks):
+            layers.append(block(inplanes=inplanes, planes=planes, stride=1,
+                                conv_cfg=conv_cfg, norm_cfg=norm_cfg, **kwargs))
+        super().__init__(*layers)
+
+
+@BACKBONES.register_module()
+class ResNet(nn.Module):
+    arch_settings = {
+        18: (BasicBlock, (2, 2, 2, 2)),
+        34: (BasicBlock, (3, 4, 6, 3)),
+        50: (Bottleneck, (3, 4, 6, 3)),
+        101: (Bottleneck, (3, 4, 23, 3)),
+        152: (Bottleneck, (3, 8, 36, 3))
+    }
+
+    def __init__(self, depth, in_channels=3, stem_channels=64, base_channels=64,
+                 num_stages=4, strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1),
+                 out_indices=(0, 1, 2, 3), style='pytorch', deep_stem=False,
+                 avg_down=False, frozen_stages=-1, conv_cfg=None,
+                 norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True,
+                 dcn=None, stage_with_dcn=(False, False, False, False),
+                 plugins=None, with_cp=False, zero_init_residual=True):
+        super().__init__()
+        if depth not in self.arch_settings:
+            raise KeyError(f'invalid depth {depth} for resnet')
+        if deep_stem or avg_down or plugins is not None or \
+                tuple(dilations) != (1, 1, 1, 1):
+            raise NotImplementedError('ResNet variant outside the LD configs')
+        if dcn is not None:
+            raise NotImplementedError(
+                'DCN (config 4 teacher) is a later row of SURVEY.md section 8')
+        self.depth, self.stem_channels = depth, stem_channels
+        self.base_channels, self.num_stages = base_channels, num_stages
+        assert 1 <= num_stages <= 4
+        self.strides, self.out_indices = strides, out_indices
+        assert max(out_indices) < num_stages
+        self.style, self.frozen_stages = style, frozen_stages
+        self.conv_cfg, self.norm_cfg = conv_cfg, norm_cfg
+        self.norm_eval = norm_eval
+        self.zero_init_residual = zero_init_residual
+        self.block, stage_blocks = self.arch_settings[depth]
+        self.stage_blocks = stage_blocks[:num_stages]
+        self.inplanes = stem_channels
+
+        self.conv1 = build_conv_layer(conv_cfg, in_channels, stem_channels, 7,
+                                      stride=2, padding=3, bias=False)
+        self.norm1_name, norm1 = build_norm_layer(norm_cfg, stem_channels,
+                                                  postfix=1)
+        self.add_module(self.norm1_name, norm1)
+
+        self.res_layers = []
+        for i, num_blocks in enumerate(self.stage_blocks):
+            planes = base_channels * 2**i
+            res_layer = ResLayer(self.block, self.inplanes, planes, num_blocks,
+                                 stride=strides[i], style=self.style,
+                                 conv_cfg=conv_cfg, norm_cfg=norm_cfg)
+            self.inplanes = planes * self.block.expansion
+            layer_name = f'layer{i + 1}'
+            self.add_module(layer_name, res_layer)
+            self.res_layers.append(layer_name)
+        self._freeze_stages()
+        self.feat_dim = self.block.expansion * base_channels * 2**(
+            len(self.stage_blocks) - 1)
+
+    @property
+    def norm1(self):
+        return getattr(self, self.norm1_name)
+
+    def _freeze_stages(self):
+        """resnet.py:572-588."""
+        if self.frozen_stages >= 0:
+            self.norm1.eval()
+            for m in [self.conv1, self.norm1]:
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, f'layer{i}')
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def init_weights(self, pretrained=None):
+        """resnet.py:590-620 (pretrained checkpoints need the checkpoint wire
+        format, SURVEY.md section 8f-2: not available offline)."""
+        if isinstance(pretrained, str):
+            from .checkpoint import load_checkpoint
+            load_checkpoint(self, pretrained, strict=False)
+        elif pretrained is None:
+            for m in self.modules():
+                if isinstance(m, Conv2d):
+                    kaiming_init(m)
+                elif isinstance(m, BatchNorm2d):
+                    constant_init(m, 1)
+            if self.zero_init_residual:
+                for m in self.modules():
+                    if isinstance(m, Bottleneck):
+                        constant_init(m.norm3, 0)
+                    elif isinstance(m, BasicBlock):
+                        constant_init(m.norm2, 0)
+        else:
+            raise TypeError('pretrained must be a str or None')
+
+    def forward(self, x):
+        """(N, 3, H, W) -> tuple of stage outputs (resnet.py:622-637)."""
+        L.require_device(x, torch.float32, 'backbone input')
+        n, c, h, w = x.shape
+        if self.frozen_stages < 0 and torch.is_grad_enabled():
+            raise NotImplementedError(
+                'a trainable stem needs a max-pool backward; the LD configs '
+                'freeze it (frozen_stages=1)')
+        x3 = x.reshape(n, c, h * w)
+        x3, lv = _conv_bn(x3, ((h, w), ), self.conv1, self.norm1)
+        x4 = Y.maxpool3x3s2(x3.view(n, -1, lv[0][0], lv[0][1]))
+        lv = ((x4.shape[2], x4.shape[3]), )
+        x3 = x4.reshape(n, x4.shape[1], -1)
+        outs = []
+        for i, layer_name in enumerate(self.res_layers):
+            for blk in getattr(self, layer_name):
+                x3, lv = blk.forward3(x3, lv)
+            if i in self.out_indices:
+                outs.append(x3.view(n, x3.shape[1], lv[0][0], lv[0][1]))
+        return tuple(outs)
+
+    def train(self, mode=True):
+        """resnet.py:639-648: keep frozen stages and (norm_eval) all BN in
+        eval mode."""
+        super().train(mode)
+        self._freeze_stages()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, BatchNorm2d):
+                    m.eval()

@@ -472,6 +472,14 @@ def gen_e2e(cases=None):
         d[name + '_grad_norms'] = np.array(norms)
         d[name + '_num_trainable'] = np.array(
             sum(p.numel() for p in det.parameters() if p.requires_grad))
+        # state_dict contract: key names + shapes, student and teacher
+        for tag, mod in (('student', det), ('teacher', det.teacher_model)):
+            sd = mod.state_dict()
+            d[f'{name}_{tag}_keys'] = np.array(list(sd.keys()))
+            d[f'{name}_{tag}_shapes'] = np.array(
+                ['x'.join(str(v) for v in t.shape) for t in sd.values()])
+            d[f'{name}_{tag}_trainable'] = np.array(
+                [k for k, p in mod.named_parameters() if p.requires_grad])
         # feature fingerprints
         with torch.no_grad():
             x = det.extract_feat(batch['img'])

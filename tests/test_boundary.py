@@ -1,0 +1,126 @@
+"""The drop-in boundary on the CPU: registry names resolve, the reference's
+own config files build through ld_amd (when a reference checkout is present),
+state_dict keys / shapes / trainable sets equal the reference's (golden)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ld_amd
+from ld_amd import Config, build_detector, model_zoo, registry
+
+REFERENCE = os.environ.get('LD_REFERENCE_ROOT', '/root/reference')
+
+
+def test_registry_names():
+    need = {
+        registry.DETECTORS: ['KnowledgeDistillationSingleStageDetector', 'GFL',
+                             'SingleStageDetector'],
+        registry.BACKBONES: ['ResNet'], registry.NECKS: ['FPN'],
+        registry.HEADS: ['LDHead', 'GFLHead'],
+        registry.LOSSES: ['QualityFocalLoss', 'DistributionFocalLoss',
+                          'GIoULoss', 'CIoULoss',
+                          'KnowledgeDistillationKLDivLoss', 'IMLoss',
+                          'LocalizationDistillationLoss'],
+        registry.BBOX_ASSIGNERS: ['ATSSAssigner'],
+        registry.BBOX_SAMPLERS: ['PseudoSampler'],
+        registry.BBOX_CODERS: ['DeltaXYWHBBoxCoder'],
+        registry.ANCHOR_GENERATORS: ['AnchorGenerator'],
+        registry.IOU_CALCULATORS: ['BboxOverlaps2D'],
+    }
+    for reg, names in need.items():
+        for n in names:
+            assert n in reg, f'{n} missing from {reg.name}'
+    with pytest.raises(KeyError):
+        registry.build_loss(dict(type='NoSuchLoss'))
+
+
+def test_build_from_cfg_semantics():
+    loss = registry.build_loss(dict(type='KnowledgeDistillationKLDivLoss',
+                                    loss_weight=0.25, T=10))
+    assert loss.T == 10 and loss.loss_weight == 0.25
+    with pytest.raises(AssertionError):  # kd_loss.py:51
+        registry.build_loss(dict(type='KnowledgeDistillationKLDivLoss', T=0.5))
+    with pytest.raises(KeyError):
+        registry.build_from_cfg(dict(loss_weight=1.0), registry.LOSSES)
+    ag = registry.build_anchor_generator(
+        dict(type='AnchorGenerator', ratios=[1.0], octave_base_scale=8,
+             scales_per_octave=1, strides=[8, 16, 32, 64, 128]))
+    assert ag.num_levels == 5 and ag.num_base_anchors == [1] * 5
+    # reference tests/test_anchor.py-style base-anchor check
+    np.testing.assert_array_equal(ag.base_anchors[1].numpy(),
+                                  [[-64, -64, 64, 64]])
+
+
+def test_config_base_inheritance(tmp_path):
+    (tmp_path / 'base.py').write_text(
+        "model = dict(type='A', backbone=dict(depth=18, frozen=1), "
+        "neck=dict(k=1))\nlr = 0.1\n")
+    (tmp_path / 'child.py').write_text(
+        "_base_ = ['./base.py']\nmodel = dict(backbone=dict(depth=50), "
+        "neck=dict(_delete_=True, j=2))\n")
+    cfg = Config.fromfile(str(tmp_path / 'child.py'))
+    assert cfg.model.type == 'A' and cfg.model.backbone.depth == 50
+    assert cfg.model.backbone.frozen == 1 and cfg.lr == 0.1
+    assert dict(cfg.model.neck) == dict(j=2)
+    cfg.merge_from_dict({'model.backbone.depth': 101})
+    assert cfg.model.backbone.depth == 101
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, 'configs')),
+                    reason='needs the reference checkout (build container)')
+@pytest.mark.parametrize('path', [
+    'configs/ld/ld_r18_gflv1_r101_fpn_coco_1x.py',
+    'configs/ld/ld_r34_gflv1_r101_fpn_coco_1x.py',
+    'configs/ld/ld_r50_gflv1_r101_fpn_coco_1x.py',
+])
+def test_reference_configs_resolve(path, monkeypatch):
+    """configs/ld/*.py (and the configs/gfl teacher configs they name) build
+    through ld_amd's registry unchanged."""
+    monkeypatch.chdir(REFERENCE)  # teacher_config is a relative path
+    cfg = Config.fromfile(path)
+    m = dict(cfg.model)
+    m['teacher_ckpt'] = None  # URLs cannot be fetched offline
+    with pytest.warns(UserWarning):  # torchvision:// pretrained -> random init
+        det = build_detector(m, train_cfg=cfg.get('train_cfg'),
+                             test_cfg=cfg.get('test_cfg'))
+    assert type(det).__name__ == 'KnowledgeDistillationSingleStageDetector'
+    assert type(det.bbox_head).__name__ == 'LDHead'
+    assert type(det.teacher_model).__name__ == 'GFL'
+    assert det.teacher_model.backbone.depth == 101
+    assert 'teacher_model' not in dict(det.named_modules())
+    assert not any(k.startswith('teacher') for k in det.state_dict())
+    opt = cfg.optimizer
+    assert opt['type'] == 'SGD' and opt['momentum'] == 0.9
+
+
+@pytest.mark.parametrize('name,sd,td', [('tiny_r18', 18, 101),
+                                        ('c2_r50', 50, 101)])
+def test_state_dict_contract(golden, name, sd, td):
+    g = golden['e2e']
+    det = build_detector(model_zoo.ld_detector(sd, td))
+    for tag, mod in (('student', det), ('teacher', det.teacher_model)):
+        state = mod.state_dict()
+        assert list(state.keys()) == [str(k) for k in g[f'{name}_{tag}_keys']]
+        shapes = ['x'.join(str(v) for v in t.shape) for t in state.values()]
+        assert shapes == [str(s) for s in g[f'{name}_{tag}_shapes']]
+        trainable = [k for k, p in mod.named_parameters() if p.requires_grad]
+        assert trainable == [str(k) for k in g[f'{name}_{tag}_trainable']]
+    assert sum(p.numel() for p in det.parameters() if p.requires_grad) == \
+        int(g[name + '_num_trainable'])
+    # train(): frozen stages + every BN stay in eval mode (resnet.py:639-648)
+    det.train()
+    from ld_amd.cnn import BatchNorm2d
+    assert all(not m.training for m in det.modules()
+               if isinstance(m, BatchNorm2d))
+    assert not det.teacher_model.training
+
+
+def test_no_cpu_path():
+    det = build_detector(model_zoo.ld_detector(18, 50))
+    from ld_amd import synthetic
+    b = synthetic.synthetic_batch(1, (64, 64), (64, 64), 1)
+    with pytest.raises(ld_amd.LdError):
+        det.forward_train(b['img'], b['img_metas'], b['gt_bboxes'],
+                          b['gt_labels'])
