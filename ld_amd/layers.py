@@ -16,6 +16,52 @@ from .lossblock import workspace
 _PARAM_GEN = [0]
 
 
+class KernelProfile:
+    """Opt-in HIP-event timing of the conv launches (bench.py's roofline
+    leg).  Events are recorded on the stream each kernel is launched on."""
+    active = None
+
+    def __init__(self):
+        self.records = []  # (tag, flops, start_event, end_event)
+
+    def __enter__(self):
+        KernelProfile.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelProfile.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for tag, flops, a, b in self.records:
+            t, f, n = agg.get(tag, (0.0, 0.0, 0))
+            agg[tag] = (t + a.elapsed_time(b) * 1e-3, f + flops, n + 1)
+        return agg
+
+
+class _timed:
+
+    def __init__(self, tag, flops):
+        self.tag, self.flops = tag, flops
+        self.prof = KernelProfile.active
+
+    def __enter__(self):
+        if self.prof is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if self.prof is not None:
+            self.b.record()
+            self.prof.records.append((self.tag, self.flops, self.a, self.b))
+
+
+def _conv_flops(d):
+    return 2.0 * d.N * d.Pout * d.Cout * d.Cin * d.KH * d.KW
+
+
 def bump_param_generation():
     """Called by the optimizer after it rewrites parameters in place (outside
     torch's version counters) so cached GEMM weight images are refreshed."""
@@ -131,8 +177,9 @@ def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
         assert residual.shape == y3.shape
     ep = _epilogue(bias, scale, shift, residual, relu)
     fn = lib.ld_conv_forward_smallc if smallc else lib.ld_conv_forward
-    L.check(fn(C.byref(d), L.ptr(x3), L.ptr(wt_fwd), C.byref(ep), L.ptr(y3),
-               L.stream_ptr(x3.device)), 'ld_conv_forward')
+    with _timed('conv_fwd', _conv_flops(d)):
+        L.check(fn(C.byref(d), L.ptr(x3), L.ptr(wt_fwd), C.byref(ep),
+                   L.ptr(y3), L.stream_ptr(x3.device)), 'ld_conv_forward')
     return y3, out_levels
 
 
@@ -161,15 +208,18 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             _, wt_bwd = weight_images(w, True)
             dx = torch.empty_like(x3)
-            L.check(lib.ld_conv_dgrad(C.byref(d), L.ptr(dy), L.ptr(wt_bwd),
-                                      L.ptr(dx), st), 'ld_conv_dgrad')
+            with _timed('conv_dgrad', _conv_flops(d)):
+                L.check(lib.ld_conv_dgrad(C.byref(d), L.ptr(dy),
+                                          L.ptr(wt_bwd), L.ptr(dx), st),
+                        'ld_conv_dgrad')
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             need = lib.ld_conv_wgrad_workspace_bytes(C.byref(d))
             ws = workspace(x3.device, need, 'wgrad')
-            L.check(lib.ld_conv_wgrad(C.byref(d), L.ptr(x3), L.ptr(dy),
-                                      L.ptr(dw), 0, L.ptr(ws), ws.numel(),
-                                      st), 'ld_conv_wgrad')
+            with _timed('conv_wgrad', _conv_flops(d)):
+                L.check(lib.ld_conv_wgrad(C.byref(d), L.ptr(x3), L.ptr(dy),
+                                          L.ptr(dw), 0, L.ptr(ws),
+                                          ws.numel(), st), 'ld_conv_wgrad')
         if has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(cout, dtype=torch.float32, device=x3.device)
             L.check(lib.ld_bias_grad(L.ptr(dy), N, cout, dy.shape[2],

@@ -1,0 +1,161 @@
+"""TEST INFRASTRUCTURE ONLY -- plain PyTorch (CPU, fp32) restatement of the
+networks on the LD path, driven by an mmdet-keyed state_dict.  It is the
+"plain PyTorch fp32 reference" the HIP conv/norm stack is checked against and
+the `cpu_baseline` ("port") leg of bench.py.  Never imported by `ld_amd`.
+
+Parity status: pinned through tests/golden/e2e.npz (loss tables, feature and
+gradient fingerprints produced by the reference itself with the same seeded
+state_dicts) -- tests/test_oracle_golden.py::test_net_oracle_vs_golden.
+
+Follows (reference file:line):
+  ResNet            mmdet/models/backbones/resnet.py:13-299,558-637
+  ResLayer          mmdet/models/utils/res_layer.py:24-102
+  FPN               mmdet/models/necks/fpn.py:170-221
+  GFLHead.forward   mmdet/models/dense_heads/gfl_head.py:145-183
+  forward_train     mmdet/models/detectors/kd_one_stage.py:46-81
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import ld_oracle as O
+
+STAGE_BLOCKS = {18: (2, 2, 2, 2), 34: (3, 4, 6, 3), 50: (3, 4, 6, 3),
+                101: (3, 4, 23, 3)}
+
+
+def _bn(x, sd, p, eps=1e-5):
+    return F.batch_norm(x, sd[p + '.running_mean'], sd[p + '.running_var'],
+                        sd[p + '.weight'], sd[p + '.bias'], False, 0.0, eps)
+
+
+def resnet_forward(sd, x, depth, prefix='backbone.'):
+    """-> (C2, C3, C4, C5); BN always with running stats (norm_eval)."""
+    bottleneck = depth >= 50
+    x = F.relu(_bn(F.conv2d(x, sd[prefix + 'conv1.weight'], stride=2,
+                            padding=3), sd, prefix + 'bn1'))
+    x = F.max_pool2d(x, 3, 2, 1)
+    outs = []
+    for li, nblocks in enumerate(STAGE_BLOCKS[depth]):
+        for b in range(nblocks):
+            p = f'{prefix}layer{li + 1}.{b}.'
+            stride = 2 if (b == 0 and li > 0) else 1
+            identity = x
+            if bottleneck:
+                out = F.relu(_bn(F.conv2d(x, sd[p + 'conv1.weight']), sd,
+                                 p + 'bn1'))
+                out = F.relu(_bn(F.conv2d(out, sd[p + 'conv2.weight'],
+                                          stride=stride, padding=1), sd,
+                                 p + 'bn2'))
+                out = _bn(F.conv2d(out, sd[p + 'conv3.weight']), sd,
+                          p + 'bn3')
+            else:
+                out = F.relu(_bn(F.conv2d(x, sd[p + 'conv1.weight'],
+                                          stride=stride, padding=1), sd,
+                                 p + 'bn1'))
+                out = _bn(F.conv2d(out, sd[p + 'conv2.weight'], padding=1),
+                          sd, p + 'bn2')
+            if p + 'downsample.0.weight' in sd:
+                identity = _bn(F.conv2d(x, sd[p + 'downsample.0.weight'],
+                                        stride=stride), sd,
+                               p + 'downsample.1')
+            x = F.relu(out + identity)
+        outs.append(x)
+    return tuple(outs)
+
+
+def fpn_forward(sd, feats, prefix='neck.', start_level=1, num_outs=5):
+    ins = feats[start_level:]
+    lats = [F.conv2d(f, sd[f'{prefix}lateral_convs.{i}.conv.weight'],
+                     sd[f'{prefix}lateral_convs.{i}.conv.bias'])
+            for i, f in enumerate(ins)]
+    for i in range(len(lats) - 1, 0, -1):
+        lats[i - 1] = lats[i - 1] + F.interpolate(
+            lats[i], size=lats[i - 1].shape[2:], mode='nearest')
+    outs = [F.conv2d(l, sd[f'{prefix}fpn_convs.{i}.conv.weight'],
+                     sd[f'{prefix}fpn_convs.{i}.conv.bias'], padding=1)
+            for i, l in enumerate(lats)]
+    for i in range(len(lats), num_outs):  # extra convs 'on_output'
+        outs.append(F.conv2d(outs[-1], sd[f'{prefix}fpn_convs.{i}.conv.weight'],
+                             sd[f'{prefix}fpn_convs.{i}.conv.bias'], stride=2,
+                             padding=1))
+    return tuple(outs)
+
+
+def gfl_head_forward(sd, feats, prefix='bbox_head.', stacked=4, groups=32):
+    cls_scores, bbox_preds = [], []
+    for l, x in enumerate(feats):
+        c = r = x
+        for i in range(stacked):
+            c = F.relu(F.group_norm(
+                F.conv2d(c, sd[f'{prefix}cls_convs.{i}.conv.weight'],
+                         padding=1), groups,
+                sd[f'{prefix}cls_convs.{i}.gn.weight'],
+                sd[f'{prefix}cls_convs.{i}.gn.bias'], 1e-5))
+            r = F.relu(F.group_norm(
+                F.conv2d(r, sd[f'{prefix}reg_convs.{i}.conv.weight'],
+                         padding=1), groups,
+                sd[f'{prefix}reg_convs.{i}.gn.weight'],
+                sd[f'{prefix}reg_convs.{i}.gn.bias'], 1e-5))
+        cls_scores.append(F.conv2d(c, sd[prefix + 'gfl_cls.weight'],
+                                   sd[prefix + 'gfl_cls.bias'], padding=1))
+        bbox_preds.append(F.conv2d(r, sd[prefix + 'gfl_reg.weight'],
+                                   sd[prefix + 'gfl_reg.bias'], padding=1) *
+                          sd[f'{prefix}scales.{l}.scale'])
+    return cls_scores, bbox_preds
+
+
+def detector_forward(sd, img, depth):
+    feats = fpn_forward(sd, resnet_forward(sd, img, depth))
+    cls, reg = gfl_head_forward(sd, feats)
+    return feats, cls, reg
+
+
+def trainable_keys(sd, frozen_stages=1):
+    """Parameters that receive gradients (resnet.py:572-588: stem + layer1
+    frozen; buffers excluded)."""
+    out = []
+    for k in sd:
+        if k.endswith(('running_mean', 'running_var', 'num_batches_tracked',
+                       'integral.project')):
+            continue
+        if k.startswith(('backbone.conv1.', 'backbone.bn1.')):
+            continue
+        if any(k.startswith(f'backbone.layer{i}.')
+               for i in range(1, frozen_stages + 1)):
+            continue
+        out.append(k)
+    return out
+
+
+def ld_train_step(student_sd, teacher_sd, batch, student_depth, teacher_depth,
+                  hp=None, with_backward=True):
+    """One LD forward (+backward) on the CPU: torch autograd for the nets,
+    the numpy oracle for targets + loss block.  Returns dict(losses (8,5),
+    grads {key: tensor}, feats, cls, reg)."""
+    keys = trainable_keys(student_sd)
+    sd = dict(student_sd)
+    for k in keys:
+        sd[k] = student_sd[k].detach().clone().requires_grad_(with_backward)
+    img = batch['img']
+    feats, cls, reg = detector_forward(sd, img, student_depth)
+    with torch.no_grad():
+        t_feats, t_cls, t_reg = detector_forward(teacher_sd, img,
+                                                 teacher_depth)
+    sizes = [tuple(f.shape[2:]) for f in cls]
+    targets = O.get_targets(sizes, batch['img_metas'],
+                            [b.numpy() for b in batch['gt_bboxes']],
+                            [l.numpy() for l in batch['gt_labels']])
+    npy = lambda ts: [t.detach().numpy() for t in ts]  # noqa: E731
+    out = O.ld_loss_block(npy(cls), npy(reg), npy(t_cls), npy(t_reg),
+                          npy(feats), npy(t_feats), targets, hp,
+                          with_grad=with_backward)
+    res = dict(losses=out['losses'], feats=feats, cls=cls, reg=reg,
+               targets=targets)
+    if with_backward:
+        heads = list(cls) + list(reg) + list(feats)
+        gs = [torch.from_numpy(g) for g in out['grads']['cls'] +
+              out['grads']['reg'] + out['grads']['x']]
+        torch.autograd.backward(heads, gs)
+        res['grads'] = {k: sd[k].grad for k in keys}
+    return res

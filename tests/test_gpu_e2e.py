@@ -1,0 +1,130 @@
+"""GPU end-to-end parity (-m gpu): the whole LD train step through the mmdet
+API mirror on the MI355X -- student+teacher dual forward on the HIP conv/norm
+stack, batched targets, fused loss block, backward -- against
+ (1) golden loss tables / gradient norms produced by the reference itself with
+     the same seeded state_dicts and synthetic batch, and
+ (2) the CPU oracle (torch-CPU nets + numpy loss block) on the same inputs.
+Tolerance: fp32 losses within 1e-4 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # name, student depth, loss_im weight
+    ('tiny_r18', 18, 0.0),
+    ('small_r50', 50, 2.0),
+    ('c1_r18', 18, 0.0),
+    ('c2_r50', 50, 2.0),
+]
+LOSS_KEYS = ['loss_cls', 'loss_bbox', 'loss_dfl', 'loss_ld', 'loss_ld_vlr',
+             'loss_kd', 'loss_kd_neg', 'loss_im']
+
+
+def _setup(golden, name, sdepth, lw_im):
+    from ld_amd import model_zoo, synthetic
+    dev = torch.device('cuda:0')
+    g = golden['e2e']
+    cfg = g[name + '_cfg']
+    pad, img_shape, bseed = tuple(cfg[:2]), tuple(cfg[2:4]), int(cfg[4])
+    num_gt = [int(x) for x in g[name + '_num_gt']]
+    batch = synthetic.synthetic_batch(len(num_gt), img_shape, pad, num_gt,
+                                      bseed)
+    det = model_zoo.build_seeded_ld_detector(sdepth, 101, dev,
+                                             loss_im_weight=lw_im)
+    dbatch = dict(img=batch['img'].to(dev), img_metas=batch['img_metas'],
+                  gt_bboxes=[b.to(dev) for b in batch['gt_bboxes']],
+                  gt_labels=[l.to(dev) for l in batch['gt_labels']])
+    return g, det, batch, dbatch
+
+
+@pytest.mark.parametrize('name,sdepth,lw_im', CASES,
+                         ids=[c[0] for c in CASES])
+def test_train_step_vs_reference_golden(golden, name, sdepth, lw_im):
+    g, det, batch, dbatch = _setup(golden, name, sdepth, lw_im)
+    losses = det(**dbatch)
+    assert list(losses.keys()) == LOSS_KEYS
+    table = torch.stack([torch.stack(losses[k]) for k in LOSS_KEYS])
+    loss, log_vars = det._parse_losses(losses)
+    loss.backward()
+    torch.cuda.synchronize()
+    got = table.detach().cpu().numpy().astype(np.float64)
+    ref = g[name + '_losses']
+    err = np.abs(got - ref)
+    print(name, 'max abs loss err', err.max(), '\n', got, '\n', ref)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+    ref_log = g[name + '_log_vars']
+    for k, r in zip(LOSS_KEYS + ['loss'], ref_log):
+        np.testing.assert_allclose(log_vars[k], r, rtol=1e-4, atol=1e-4,
+                                   err_msg=k)
+    # gradient fingerprints of every trainable parameter
+    names = [str(k) for k in g[name + '_grad_names']]
+    norms = g[name + '_grad_norms']
+    params = dict(det.named_parameters())
+    bad = []
+    for k, r in zip(names, norms):
+        assert params[k].grad is not None, k
+        got_n = float(params[k].grad.double().norm())
+        if not np.isclose(got_n, r, rtol=5e-3, atol=1e-6):
+            bad.append((k, got_n, r))
+    assert not bad, f'{len(bad)} grad norms off, first: {bad[:5]}'
+    # frozen parameters received nothing
+    for k, p in params.items():
+        if not p.requires_grad:
+            assert p.grad is None, k
+
+
+def test_features_vs_cpu_oracle(golden):
+    """Intermediate tensors (FPN features, head outputs) and parameter
+    gradients element-wise against the torch-CPU oracle at a small size."""
+    import net_oracle as NO
+    from ld_amd import synthetic
+    g, det, batch, dbatch = _setup(golden, 'small_r50', 50, 2.0)
+    ssd = {k: v.detach().cpu() for k, v in det.state_dict().items()}
+    tsd = {k: v.detach().cpu()
+           for k, v in det.teacher_model.state_dict().items()}
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    ref = NO.ld_train_step(ssd, tsd, batch, 50, 101)
+    x = det.extract_feat(dbatch['img'])
+    cls, reg = det.bbox_head(x)
+    for l in range(5):
+        for nm, a, b in (('feat', x[l], ref['feats'][l]),
+                         ('cls', cls[l], ref['cls'][l]),
+                         ('reg', reg[l], ref['reg'][l])):
+            a, b = a.detach().cpu().double(), b.detach().double()
+            scale = float(b.abs().max()) + 1e-12
+            err = float((a - b).abs().max())
+            assert err <= 2e-4 * scale + 1e-6, f'{nm}[{l}] err {err} scale {scale}'
+    losses = det(**dbatch)
+    loss, _ = det._parse_losses(losses)
+    loss.backward()
+    params = dict(det.named_parameters())
+    worst = 0.0
+    for k, gref in ref['grads'].items():
+        a = params[k].grad.detach().cpu().double()
+        b = gref.double()
+        rel = float((a - b).norm() / (b.norm() + 1e-12))
+        worst = max(worst, rel)
+        assert rel < 5e-3, f'{k}: relative grad error {rel}'
+    print('worst relative grad error', worst)
+
+
+def test_trainer_two_steps_reduce_loss(golden):
+    """SGDTrainer (flat arenas, hooks, fused SGD): two steps on the same batch
+    run, keep gradients in the arena, and change the weights."""
+    from ld_amd.train import SGDTrainer
+    g, det, batch, dbatch = _setup(golden, 'tiny_r18', 18, 0.0)
+    tr = SGDTrainer(det, lr=0.0025, momentum=0.9, weight_decay=1e-4)
+    p0 = tr.arena.flat_param.clone()
+    out1 = tr.step(dbatch)
+    out2 = tr.step(dbatch)
+    torch.cuda.synchronize()
+    l1, l2 = float(out1['loss']), float(out2['loss'])
+    assert np.isfinite(l1) and np.isfinite(l2)
+    np.testing.assert_allclose(l1, g['tiny_r18_log_vars'][-1], rtol=1e-4)
+    assert not torch.equal(p0, tr.arena.flat_param)
+    assert float(tr.flat_momentum.abs().sum()) > 0
+    for p in det.parameters():
+        if p.requires_grad:
+            assert p.grad.data_ptr() >= tr.arena.flat_grad.data_ptr()
+    assert out2['log_vars']['loss'] == pytest.approx(l2, rel=1e-6)

@@ -201,3 +201,33 @@ def test_lossblock_vs_golden(golden, name):
                 np.testing.assert_allclose(flat[idx],
                                            g[f'{name}_g{k}_{l}_sample'],
                                            rtol=2e-4, atol=2e-8)
+
+
+@pytest.mark.parametrize('name,sdepth', [('tiny_r18', 18), ('small_r50', 50)])
+def test_net_oracle_vs_golden(golden, name, sdepth):
+    """The torch-CPU restatement of the nets + the numpy loss block reproduce
+    the reference's end-to-end loss table and gradient norms."""
+    import net_oracle as NO
+    import torch
+    from ld_amd import build_detector, model_zoo
+    g = golden['e2e']
+    cfg = g[name + '_cfg']
+    pad, img_shape, bseed = tuple(cfg[:2]), tuple(cfg[2:4]), int(cfg[4])
+    num_gt = [int(x) for x in g[name + '_num_gt']]
+    batch = synthetic.synthetic_batch(len(num_gt), img_shape, pad, num_gt,
+                                      bseed)
+    det = build_detector(model_zoo.ld_detector(sdepth, 101))
+    ssd = synthetic.seeded_state_dict(det.state_dict(), seed=1)
+    tsd = synthetic.seeded_state_dict(det.teacher_model.state_dict(), seed=2)
+    hp = dict(lw_im=0.0) if sdepth == 18 else None
+    torch.set_num_threads(8)
+    res = NO.ld_train_step(ssd, tsd, batch, sdepth, 101, hp)
+    np.testing.assert_allclose(res['losses'], g[name + '_losses'], rtol=1e-4,
+                               atol=1e-5)
+    names = [str(k) for k in g[name + '_grad_names']]
+    norms = g[name + '_grad_norms']
+    assert sorted(names) == sorted(res['grads'])
+    for k, ref in zip(names, norms):
+        got = float(res['grads'][k].double().norm())
+        np.testing.assert_allclose(got, ref, rtol=2e-3, atol=1e-7,
+                                   err_msg=k)
