@@ -267,8 +267,12 @@ typedef struct {
   int32_t relu;
 } ld_conv_epilogue_t;
 
-/* (Cout,Cin,KH,KW) parameter -> GEMM images: wt_fwd [tap][Cin][Cout] and/or
- * wt_bwd [KH*KW-1-tap][Cout][Cin] (either may be NULL). */
+/* (Cout,Cin,KH,KW) parameter -> GEMM images: wt_fwd [tap][Cin_pad][Cout]
+ * and/or wt_bwd [KH*KW-1-tap][Cout_pad][Cin] (either may be NULL); *_pad = the
+ * reduction extent rounded up to 32 rows, zero filled.  Image sizes in floats
+ * come from ld_conv_weight_image_floats(..., backward = 0 | 1). */
+size_t ld_conv_weight_image_floats(int Cout, int Cin, int KH, int KW,
+                                   int backward);
 int ld_conv_weight_transform(const float* w, int Cout, int Cin, int KH, int KW,
                              float* wt_fwd, float* wt_bwd, ld_stream_t stream);
 int ld_conv_forward(const ld_conv_t* c, const float* x, const float* wt_fwd,
@@ -283,7 +287,7 @@ int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy, float* dw
                   ld_stream_t stream);
 
 /* Small-Cin variant (the 7x7 stride-2 stem, resnet.py:558-570): flat
- * (ci,kh,kw) reduction; wt = [Cin*KH*KW][Cout] image obtained with
+ * (ci,kh,kw) reduction; wt = [pad32(Cin*KH*KW)][Cout] image obtained with
  * ld_conv_weight_transform(w, Cout, Cin*KH*KW, 1, 1, wt, NULL). */
 int ld_conv_forward_smallc(const ld_conv_t* c, const float* x, const float* wt,
                            const ld_conv_epilogue_t* ep, float* y,

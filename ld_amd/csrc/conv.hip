@@ -29,6 +29,8 @@
 //                coalesced and summed in fixed order (deterministic, no float
 //                atomics) by conv_wgrad_reduce.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/ld_hip.h"
 
@@ -37,10 +39,34 @@ namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
-constexpr int BN = 128;   // GEMM columns (spatial) per block
-constexpr int BK = 16;    // k-slice (input channels of one tap) per step
 constexpr int WBK = 32;   // wgrad k-slice (spatial positions) per step
 constexpr int WLD = WBK + 1;  // odd LDS row stride -> conflict-free columns
+
+// Weight-image rows per tap are padded with zero rows to a multiple of this,
+// so the k-tail of the GEMM needs no masking on the A side.
+constexpr int kKPad = 32;
+inline int kpad_rows(int k) { return (k + kKPad - 1) / kKPad * kKPad; }
+
+// A voffset at/above this is out of range for every descriptor we build
+// (extents are checked < 2 GiB on the host): buffer loads return 0 there.
+constexpr unsigned kOOB = 0x80000000u;
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  // descriptor inputs pinned wave-uniform (cdna_hip_programming.md T20)
+  const uintptr_t u = (uintptr_t)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  void* q = (void*)(((uintptr_t)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes),
+                                           0x00020000);
+}
+
+__device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float,
+                            __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
 
 struct Geo {  // pyramid geometry as the gather sees it
   int stride, pad, num_levels;
@@ -59,6 +85,8 @@ struct ConvK {  // kernel-side view of ld_conv_t + pointers
   int N, Cin, Cout, KH, KW;
   int Pin, Pout;
   int J;  // N * Pout
+  int Kpad;               // rows per tap of the weight image (Cin rounded up)
+  unsigned x_bytes, wt_bytes;  // buffer-descriptor extents
   Geo g;
 };
 
@@ -104,145 +132,241 @@ __device__ __forceinline__ bool tap_offset(const Geo& a, int l, int ho, int wo,
 }
 
 // ------------------------------------------------------------ forward/dgrad
-template <int BM, int MODE>
+// Tile shape is a template parameter: BM x BNT block tile, BKT k-slice.  Four
+// wavefronts as 2 x 2, each owning a (BM/2) x (BNT/2) sub-tile = TM x TN MFMA
+// 32x32 tiles.  Large tiles (128x128) for big spatial extents; small ones
+// (64x64) keep >= 2 workgroups per CU on the 50x84 / 25x42 stages where a
+// 128x128 tiling would leave half the 256 CUs idle.
+template <int BM, int BNT, int BKT, int MODE>
 __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvK a) {
-  constexpr int WM = BM / 2;       // wave tile rows
-  constexpr int TM = WM / 32;      // MFMA tiles per wave along M
-  constexpr int A_PER = BK * BM / kThreads;  // A floats per thread per step
-  constexpr int B_PER = BK * BN / kThreads;  // = 8
-  __shared__ float lds[2 * BK * (BM + BN)];
-  float* As = lds;                  // [2][BK][BM]
-  float* Bs = lds + 2 * BK * BM;    // [2][BK][BN]
+  constexpr int WM = BM / 2, WN = BNT / 2;   // wave tile
+  constexpr int TM = WM / 32, TN = WN / 32;  // MFMA tiles per wave
+  constexpr int A_PER = BKT * BM / kThreads;   // A floats per thread per step
+  constexpr int B_PER = BKT * BNT / kThreads;  // B floats per thread per step
+  static_assert(A_PER >= 1 && B_PER >= 1, "tile too small");
+  __shared__ float lds[2 * BKT * (BM + BNT)];
+  float* As = lds;                    // [2][BKT][BM]
+  float* Bs = lds + 2 * BKT * BM;     // [2][BKT][BNT]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int mtiles = (a.Cout + BM - 1) / BM;
   const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
   const int m0 = (tile % mtiles) * BM;
-  const int n0 = (tile / mtiles) * BN;
+  const int n0 = (tile / mtiles) * BNT;
 
   // ---- this thread's B column (spatial position) -----------------------
-  const int jb = n0 + (t & (BN - 1));
+  // Everything about the column is resolved ONCE into registers (level
+  // geometry included): the k-loop's gather is then pure register arithmetic
+  // (a per-step lookup of a.g.lv[level] is a dependent vector load + wait).
+  const int jb = n0 + (t % BNT);
   const bool jvalid = jb < a.J;
-  int bl = 0, bho = 0, bwo = 0;
-  const float* xin = a.x;
+  int bHin = 0, bWin = 0, boff = 0, bh0 = 0, bw0 = 0;
   if (jvalid) {
     const int n = jb / a.Pout, p = jb - n * a.Pout;
+    int bl, bho, bwo;
     locate_out(a.g, p, bl, bho, bwo);
-    xin = a.x + (size_t)n * a.Cin * a.Pin;
+    bHin = a.g.lv[bl].Hin;
+    bWin = a.g.lv[bl].Win;
+    boff = n * a.Cin * a.Pin + a.g.lv[bl].off_in;  // element index of (n, 0, level)
+    if (MODE == 1) {
+      bh0 = bho - a.g.pad;
+      bw0 = bwo - a.g.pad;
+    } else {
+      bh0 = bho * a.g.stride - a.g.pad;
+      bw0 = bwo * a.g.stride - a.g.pad;
+    }
   }
-  const int bk0 = (t / BN) * B_PER;  // first k row this thread loads for B
+  // input offset of tap (kh, kw) for this column, or false when it falls in
+  // the padding (MODE 1: or between the dilated samples of a stride-2 dgrad)
+  auto tap_off = [&](int kh, int kw, int& off) -> bool {
+    int hi = bh0 + kh, wi = bw0 + kw;
+    if (MODE == 1) {
+      if ((hi | wi) < 0 || ((hi | wi) & 1)) return false;
+      hi >>= 1;
+      wi >>= 1;
+    }
+    if (hi < 0 || hi >= bHin || wi < 0 || wi >= bWin) return false;
+    off = boff + hi * bWin + wi;
+    return true;
+  };
+  // first k row this thread loads for B / A: wave-uniform (a wave never spans
+  // two row groups), pinned to SGPRs so the row offsets go in `soffset`
+  const int bk0 = __builtin_amdgcn_readfirstlane((t / BNT) * B_PER);
   // ---- this thread's A column (output channel) ------------------------
-  const int am = t & (BM - 1);
+  const int am = t % BM;
   const bool avalid = (m0 + am) < a.Cout;
-  const int ak0 = (t / BM) * A_PER;
+  const int ak0 = __builtin_amdgcn_readfirstlane((t / BM) * A_PER);
 
-  floatx16 acc[TM][2];
+  floatx16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int ntaps = a.KH * a.KW;
-  const int csteps = (a.Cin + BK - 1) / BK;
-  const int ktot = a.Cin * ntaps;  // MODE 2: flat (ci, kh, kw) reduction index
-  const int nsteps = (MODE == 2) ? (ktot + BK - 1) / BK : ntaps * csteps;
+  // wave-uniform scalars pinned to SGPRs
+  const int Cin = __builtin_amdgcn_readfirstlane(a.Cin);
+  const int Cout = __builtin_amdgcn_readfirstlane(a.Cout);
+  const int KW = __builtin_amdgcn_readfirstlane(a.KW);
+  const int Pin = __builtin_amdgcn_readfirstlane(a.Pin);
+  const int ntaps = __builtin_amdgcn_readfirstlane(a.KH * a.KW);
+  const int csteps = (Cin + BKT - 1) / BKT;
+  const int ktot = Cin * ntaps;  // MODE 2: flat (ci, kh, kw) reduction index
+  const int nsteps = (MODE == 2) ? (ktot + BKT - 1) / BKT : ntaps * csteps;
   float a_st[A_PER], b_st[B_PER];
 
+  // Tile loads are raw buffer loads: one 32-bit per-lane voffset (kOOB when the
+  // element is padding / outside the tile -> the hardware returns 0), the row
+  // (k) offsets wave-uniform in soffset.  No branches, no selects on loaded
+  // values, 2 address VGPRs per tile side: nothing forces a vmcnt wait before
+  // the MFMAs, so the loads of step s+1 fly under the MFMAs of step s.
+  const rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  const rsrc_t rw = make_rsrc(a.wt, a.wt_bytes);
+  const int Kpad = __builtin_amdgcn_readfirstlane(a.Kpad);
+  const unsigned va = avalid ? (unsigned)(m0 + am) * 4u : kOOB;
   auto load_tile = [&](int step) {
     if (MODE == 2) {
       // small-Cin (stem) im2col: every k row has its own (ci, kh, kw)
-      const int k0 = step * BK;
-      const float* wp = a.wt + (size_t)(k0 + ak0) * a.Cout + m0 + am;
+      const int k0 = step * BKT;
 #pragma unroll
       for (int i = 0; i < A_PER; ++i)
-        a_st[i] = (avalid && k0 + ak0 + i < ktot) ? wp[(size_t)i * a.Cout] : 0.0f;
+        a_st[i] = buf_load(rw, va, (unsigned)(k0 + ak0 + i) * Cout * 4u);
 #pragma unroll
       for (int i = 0; i < B_PER; ++i) {
-        const int k = k0 + bk0 + i;
-        float v = 0.0f;
-        if (jvalid && k < ktot) {
-          const int ci = k / ntaps, r = k - ci * ntaps;
-          const int kh = r / a.KW, kw = r - kh * a.KW;
-          int off = 0;
-          if (tap_offset<0>(a.g, bl, bho, bwo, kh, kw, off))
-            v = xin[(size_t)ci * a.Pin + off];
-        }
-        b_st[i] = v;
+        const int k = k0 + bk0 + i;          // scalar
+        const int ci = min(k / ntaps, Cin - 1);
+        const int r = k % ntaps;
+        const int kh = r / KW, kw = r - kh * KW;
+        int off = 0;
+        const bool kb = jvalid && tap_off(kh, kw, off);
+        b_st[i] = buf_load(rx, kb ? (unsigned)off * 4u : kOOB,
+                           (unsigned)ci * Pin * 4u);
       }
       return;
     }
-    const int tap = step / csteps, ci0 = (step - tap * csteps) * BK;
-    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int tap = step / csteps, ci0 = (step - tap * csteps) * BKT;
+    const int kh = tap / KW, kw = tap - kh * KW;
     int off = 0;
-    const bool ok = jvalid && tap_offset<MODE>(a.g, bl, bho, bwo, kh, kw, off);
-    const float* wp = a.wt + ((size_t)tap * a.Cin + ci0 + ak0) * a.Cout + m0 + am;
+    const bool ok = jvalid && tap_off(kh, kw, off);
+    const unsigned vb = ok ? (unsigned)off * 4u : kOOB;
+    const unsigned sa = (unsigned)(tap * Kpad + ci0 + ak0) * Cout * 4u;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i)
-      a_st[i] = (avalid && ci0 + ak0 + i < a.Cin) ? wp[(size_t)i * a.Cout] : 0.0f;
-    const float* xp = xin + (size_t)(ci0 + bk0) * a.Pin + off;
+      a_st[i] = buf_load(rw, va, sa + (unsigned)i * Cout * 4u);
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i)
-      b_st[i] = (ok && ci0 + bk0 + i < a.Cin) ? xp[(size_t)i * a.Pin] : 0.0f;
+    for (int i = 0; i < B_PER; ++i) {
+      // k-tail rows re-read the last valid channel (finite); their A rows are
+      // the zero padding of the weight image
+      const int row = min(ci0 + bk0 + i, Cin - 1);
+      b_st[i] = buf_load(rx, vb, (unsigned)row * Pin * 4u);
+    }
   };
   auto store_tile = [&](int buf) {
-    float* ap = As + buf * BK * BM + ak0 * BM + am;
+    float* ap = As + buf * BKT * BM + ak0 * BM + am;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) ap[i * BM] = a_st[i];
-    float* bp = Bs + buf * BK * BN + bk0 * BN + (t & (BN - 1));
+    float* bp = Bs + buf * BKT * BNT + bk0 * BNT + (t % BNT);
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i) bp[i * BN] = b_st[i];
+    for (int i = 0; i < B_PER; ++i) bp[i * BNT] = b_st[i];
   };
 
   load_tile(0);
   store_tile(0);
   __syncthreads();
   const int l31 = lane & 31, lk = lane >> 5;
+  constexpr int KP = BKT / 2;
   for (int step = 0; step < nsteps; ++step) {
     const int cur = step & 1;
     if (step + 1 < nsteps) load_tile(step + 1);
-    const float* ap = As + cur * BK * BM + wm * WM + l31;
-    const float* bp = Bs + cur * BK * BN + wn * 64 + l31;
+    const float* ap = As + cur * BKT * BM + wm * WM + l31;
+    const float* bp = Bs + cur * BKT * BNT + wn * WN + l31;
+    // register double-buffered fragments: the LDS reads of k-pair kp+1 are in
+    // flight while the MFMAs of k-pair kp issue
+    float af[2][TM], bf[2][TN];
 #pragma unroll
-    for (int kp = 0; kp < BK / 2; ++kp) {
-      const int kr = 2 * kp + lk;
-      float af[TM], bf[2];
+    for (int i = 0; i < TM; ++i) af[0][i] = ap[lk * BM + i * 32];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = ap[kr * BM + i * 32];
+    for (int j = 0; j < TN; ++j) bf[0][j] = bp[lk * BNT + j * 32];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = bp[kr * BN + j * 32];
+    for (int kp = 0; kp < KP; ++kp) {
+      const int c = kp & 1;
+      if (kp + 1 < KP) {
+        const int kr = 2 * (kp + 1) + lk;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[c ^ 1][i] = ap[kr * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[c ^ 1][j] = bp[kr * BNT + j * 32];
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j],
-                                                           0, 0, 0);
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i], bf[c][j],
+                                                           acc[i][j], 0, 0, 0);
+    }
+    // pin the interleave: fragment reads run one k-pair ahead of the MFMAs
+    // (mask 0x100 = DS read, 0x008 = MFMA; LLVM SchedGroupMask)
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+      if (kp + 1 < KP) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
     }
     if (step + 1 < nsteps) store_tile(cur ^ 1);
     __syncthreads();
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // Per-channel affine / bias are staged through LDS once per block (the
+  // k-loop's LDS is free now), so the store loop has no dependent global
+  // loads; without an affine the defaults (1, 0) make it branch-free.
+  float* s_scale = lds;        // [BM]
+  float* s_shift = lds + BM;   // [BM]  shift (+ bias)
+  if (t < BM) {
+    const int co = m0 + t;
+    float sc = 1.0f, sh = 0.0f;
+    if (co < a.Cout) {
+      if (a.scale) {
+        sc = a.scale[co];
+        sh = a.shift[co];
+      }
+      if (a.bias) sh += a.bias[co];
+    }
+    s_scale[t] = sc;
+    s_shift[t] = sh;
+  }
+  __syncthreads();
+  const bool has_res = a.residual != nullptr;
+  const bool relu = a.relu != 0;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int jc = n0 + wn * 64 + j * 32 + l31;
+  for (int j = 0; j < TN; ++j) {
+    const int jc = n0 + wn * WN + j * 32 + l31;
     if (jc >= a.J) continue;
     const int n = jc / a.Pout, p = jc - n * a.Pout;
+    const size_t colbase = (size_t)n * a.Cout * a.Pout + p;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      const int rbase = wm * WM + i * 32 + 4 * lk;
+      float res[16];
+      if (has_res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          res[r] = (m0 + row < a.Cout)
+                       ? a.residual[colbase + (size_t)(m0 + row) * a.Pout]
+                       : 0.0f;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (co >= a.Cout) continue;
-        const size_t idx = ((size_t)n * a.Cout + co) * a.Pout + p;
-        float v = acc[i][j][r];
-        if (a.scale) v = v * a.scale[co] + a.shift[co];
-        if (a.bias) v += a.bias[co];
-        if (a.residual) v += a.residual[idx];
-        if (a.relu) v = fmaxf(v, 0.0f);
-        a.y[idx] = v;
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        if (m0 + row >= a.Cout) continue;
+        float v = acc[i][j][r] * s_scale[row] + s_shift[row];
+        if (has_res) v += res[r];
+        if (relu) v = fmaxf(v, 0.0f);
+        a.y[colbase + (size_t)(m0 + row) * a.Pout] = v;
       }
     }
   }
@@ -256,6 +380,7 @@ struct WgradK {
   int N, Cin, Cout, KH, KW;
   int Pin, Pout;
   int J, splits, jchunk;  // jchunk: columns per split (multiple of WBK)
+  unsigned x_bytes, dy_bytes;
   Geo g;
 };
 
@@ -263,12 +388,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(WgradK a) {
   constexpr int BM = 128, BNc = 128;  // co x ci tile
   constexpr int ROWS_PER = BM / 8;    // rows per thread (8 row-groups of 32 lanes)
   __shared__ float lds[2 * (BM + BNc) * WLD];
+  __shared__ int s_geo[LD_MAX_LEVELS * 6];  // level table (LDS: cheap per-step lookups)
   float* As = lds;                       // [2][BM][WLD]   dY rows (co), k = j
   float* Bs = lds + 2 * BM * WLD;        // [2][BNc][WLD]  X rows (ci), k = j
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int mt = (a.Cout + BM - 1) / BM, nt = (a.Cin + BNc - 1) / BNc;
+  const int Cin = __builtin_amdgcn_readfirstlane(a.Cin);
+  const int Cout = __builtin_amdgcn_readfirstlane(a.Cout);
+  const int Pin = __builtin_amdgcn_readfirstlane(a.Pin);
+  const int Pout = __builtin_amdgcn_readfirstlane(a.Pout);
+  const int nlev = __builtin_amdgcn_readfirstlane(a.g.num_levels);
+  const int stride = __builtin_amdgcn_readfirstlane(a.g.stride);
+  const int pad = __builtin_amdgcn_readfirstlane(a.g.pad);
+  const int mt = (Cout + BM - 1) / BM, nt = (Cin + BNc - 1) / BNc;
   const int ntaps = a.KH * a.KW;
   int b = xcd_swizzle(blockIdx.x, gridDim.x);
   const int ntile = b % nt;
@@ -282,6 +415,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(WgradK a) {
   const int jbeg = split * a.jchunk;
   const int jend = min(a.J, jbeg + a.jchunk);
 
+  if (t < LD_MAX_LEVELS) {
+    const ld_conv_level_t lv = a.g.lv[t];
+    s_geo[t * 6 + 0] = lv.Hin;
+    s_geo[t * 6 + 1] = lv.Win;
+    s_geo[t * 6 + 2] = lv.Hout;
+    s_geo[t * 6 + 3] = lv.Wout;
+    s_geo[t * 6 + 4] = lv.off_in;
+    s_geo[t * 6 + 5] = lv.off_out;
+  }
+  __syncthreads();
+
   const int kq = t & (WBK - 1);  // this thread's k (column j offset) in a step
   const int r0 = t >> 5;         // 0..7: first row; rows r0 + 8*i
 
@@ -293,27 +437,36 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(WgradK a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+  const rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  const rsrc_t ry = make_rsrc(a.dy, a.dy_bytes);
   float a_st[ROWS_PER], b_st[ROWS_PER];
+
+  // buffer loads: per-lane voffset (kOOB -> 0), row offsets 8*i*P in soffset
   auto load_tile = [&](int j0) {
     const int j = j0 + kq;
-    bool jok = j < jend;
-    int off = 0;
-    size_t ybase = 0, xbase = 0;
-    bool xok = false;
+    const bool jok = j < jend;
+    unsigned vy = kOOB, vx = kOOB;
     if (jok) {
-      const int n = j / a.Pout, p = j - n * a.Pout;
-      int l, ho, wo;
-      locate_out(a.g, p, l, ho, wo);
-      ybase = (size_t)n * a.Cout * a.Pout + p;
-      xbase = (size_t)n * a.Cin * a.Pin;
-      xok = tap_offset<0>(a.g, l, ho, wo, kh, kw, off);
+      const int n = j / Pout, p = j - n * Pout;
+      int l = 0;
+      for (int i = 1; i < nlev; ++i)
+        if (p >= s_geo[i * 6 + 5]) l = i;
+      const int Hin = s_geo[l * 6 + 0], Win = s_geo[l * 6 + 1];
+      const int Wout = s_geo[l * 6 + 3];
+      const int r = p - s_geo[l * 6 + 5];
+      const int ho = r / Wout, wo = r - ho * Wout;
+      const int hi = ho * stride - pad + kh, wi = wo * stride - pad + kw;
+      vy = (unsigned)(n * Cout * Pout + (m0 + r0) * Pout + p) * 4u;
+      if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win)
+        vx = (unsigned)(n * Cin * Pin + (c0 + r0) * Pin + s_geo[l * 6 + 4] +
+                        hi * Win + wi) * 4u;
     }
 #pragma unroll
     for (int i = 0; i < ROWS_PER; ++i) {
-      const int co = m0 + r0 + 8 * i;
-      a_st[i] = (jok && co < a.Cout) ? a.dy[ybase + (size_t)co * a.Pout] : 0.0f;
-      const int ci = c0 + r0 + 8 * i;
-      b_st[i] = (xok && ci < a.Cin) ? a.x[xbase + (size_t)ci * a.Pin + off] : 0.0f;
+      a_st[i] = buf_load(ry, (m0 + r0 + 8 * i < Cout) ? vy : kOOB,
+                         (unsigned)(8 * i) * Pout * 4u);
+      b_st[i] = buf_load(rx, (c0 + r0 + 8 * i < Cin) ? vx : kOOB,
+                         (unsigned)(8 * i) * Pin * 4u);
     }
   };
   auto store_tile = [&](int buf) {
@@ -333,41 +486,55 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(WgradK a) {
     store_tile(0);
   }
   __syncthreads();
+  constexpr int KP = WBK / 2;
   for (int step = 0; step < nsteps; ++step) {
     const int cur = step & 1;
     if (step + 1 < nsteps) load_tile(jbeg + (step + 1) * WBK);
     const float* ap = As + cur * BM * WLD + (wm * 64 + l31) * WLD;
     const float* bp = Bs + cur * BNc * WLD + (wn * 64 + l31) * WLD;
+    float af[2][2], bf[2][2];
 #pragma unroll
-    for (int kp = 0; kp < WBK / 2; ++kp) {
-      const int kc = 2 * kp + lk;
-      float af[2], bf[2];
+    for (int i = 0; i < 2; ++i) af[0][i] = ap[i * 32 * WLD + lk];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = ap[i * 32 * WLD + kc];
+    for (int j = 0; j < 2; ++j) bf[0][j] = bp[j * 32 * WLD + lk];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = bp[j * 32 * WLD + kc];
+    for (int kp = 0; kp < KP; ++kp) {
+      const int c = kp & 1;
+      if (kp + 1 < KP) {
+        const int kc = 2 * (kp + 1) + lk;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[c ^ 1][i] = ap[i * 32 * WLD + kc];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[c ^ 1][j] = bp[j * 32 * WLD + kc];
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j],
-                                                           0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i], bf[c][j],
+                                                           acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+      if (kp + 1 < KP) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     }
     if (step + 1 < nsteps) store_tile(cur ^ 1);
     __syncthreads();
   }
   // slab store: [split][tap][co][ci], ci fastest (= lane & 31)
-  float* slab = a.slabs + ((size_t)split * ntaps + tap) * a.Cout * a.Cin;
+  float* slab = a.slabs + ((size_t)split * ntaps + tap) * Cout * Cin;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int ci = c0 + wn * 64 + j * 32 + l31;
-    if (ci >= a.Cin) continue;
+    if (ci >= Cin) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (co < a.Cout) slab[(size_t)co * a.Cin + ci] = acc[i][j][r];
+        if (co < Cout) slab[(size_t)co * Cin + ci] = acc[i][j][r];
       }
   }
 }
@@ -389,26 +556,29 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, int sp
   dw[o] = accumulate ? dw[o] + s : s;
 }
 
-// (Cout, Cin, KH, KW) -> fwd image [tap][Cin][Cout] and dgrad image
-// [KH*KW-1-tap][Cout][Cin]
+// (Cout, Cin, KH, KW) -> fwd image [tap][Cin_pad][Cout] and dgrad image
+// [KH*KW-1-tap][Cout_pad][Cin]; the pad rows (k >= Cin resp. Cout) are zero.
 __global__ void conv_weight_transform_kernel(const float* __restrict__ w, int Cout,
-                                             int Cin, int ntaps,
+                                             int Cin, int ntaps, int CinPad,
+                                             int CoutPad,
                                              float* __restrict__ wt_fwd,
                                              float* __restrict__ wt_bwd) {
-  const size_t total = (size_t)Cout * Cin * ntaps;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  if (wt_fwd) {  // i enumerates the fwd image [tap][ci][co] (coalesced writes)
+  if (wt_fwd && i < (size_t)ntaps * CinPad * Cout) {
+    // i enumerates the fwd image [tap][ci][co] (coalesced writes)
     const int co = (int)(i % Cout);
     const size_t q = i / Cout;
-    const int ci = (int)(q % Cin), tap = (int)(q / Cin);
-    wt_fwd[i] = w[((size_t)co * Cin + ci) * ntaps + tap];
+    const int ci = (int)(q % CinPad), tap = (int)(q / CinPad);
+    wt_fwd[i] = ci < Cin ? w[((size_t)co * Cin + ci) * ntaps + tap] : 0.0f;
   }
-  if (wt_bwd) {  // i enumerates the bwd image [tapf][co][ci]
+  if (wt_bwd && i < (size_t)ntaps * CoutPad * Cin) {
+    // i enumerates the bwd image [tapf][co][ci]
     const int ci = (int)(i % Cin);
     const size_t q = i / Cin;
-    const int co = (int)(q % Cout), tapf = (int)(q / Cout);
-    wt_bwd[i] = w[((size_t)co * Cin + ci) * ntaps + (ntaps - 1 - tapf)];
+    const int co = (int)(q % CoutPad), tapf = (int)(q / CoutPad);
+    wt_bwd[i] = co < Cout
+                    ? w[((size_t)co * Cin + ci) * ntaps + (ntaps - 1 - tapf)]
+                    : 0.0f;
   }
 }
 
@@ -431,33 +601,89 @@ int check_conv(const ld_conv_t* c) {
   return 0;
 }
 
+// Tile selection.  Candidates in decreasing MFMA efficiency; take the first
+// that yields >= kWantBlocks workgroups (2 per CU), else the one with the most.
+// LD_CONV_TILE=BMxBNxBK overrides (benchmarking).
+struct TileCfg { int bm, bn, bk; };
+constexpr int kWantBlocks = 512;
+
+inline int tile_blocks(const ConvK& k, const TileCfg& c) {
+  return ((k.Cout + c.bm - 1) / c.bm) * ((k.J + c.bn - 1) / c.bn);
+}
+
+inline TileCfg pick_tile(const ConvK& k) {
+  static const TileCfg cands[] = {{128, 128, 16}, {128, 64, 16}, {64, 128, 16},
+                                  {64, 64, 32}};
+  if (const char* env = getenv("LD_CONV_TILE")) {
+    TileCfg c{0, 0, 0};
+    if (sscanf(env, "%dx%dx%d", &c.bm, &c.bn, &c.bk) == 3) return c;
+  }
+  TileCfg best = cands[0];
+  int best_blocks = -1;
+  for (const TileCfg& c : cands) {
+    if (k.Cout <= 64 && c.bm == 128) continue;
+    const int nb = tile_blocks(k, c);
+    if (nb >= kWantBlocks) return c;
+    if (nb > best_blocks) {
+      best_blocks = nb;
+      best = c;
+    }
+  }
+  return best;
+}
+
+inline int set_extents(ConvK& k, size_t x_floats, size_t wt_floats) {
+  if (x_floats * 4 >= (size_t)kOOB || wt_floats * 4 >= (size_t)kOOB)
+    return LD_EUNSUPPORTED;  // 32-bit buffer offsets: tensors must be < 2 GiB
+  k.x_bytes = (unsigned)(x_floats * 4);
+  k.wt_bytes = (unsigned)(wt_floats * 4);
+  return 0;
+}
+
 template <int MODE>
 int launch_igemm(const ConvK& k, hipStream_t stream) {
-  const int J = k.J;
-  const int ntile = (J + BN - 1) / BN;
-  if (k.Cout <= 64) {
-    const int mt = (k.Cout + 63) / 64;
-    hipLaunchKernelGGL((conv_igemm_kernel<64, MODE>), dim3(mt * ntile),
-                       dim3(kThreads), 0, stream, k);
-  } else {
-    const int mt = (k.Cout + 127) / 128;
-    hipLaunchKernelGGL((conv_igemm_kernel<128, MODE>), dim3(mt * ntile),
-                       dim3(kThreads), 0, stream, k);
+  const TileCfg c = pick_tile(k);
+  const int nb = tile_blocks(k, c);
+#define LD_CONV_CASE(BM_, BN_, BK_)                                               \
+  if (c.bm == BM_ && c.bn == BN_ && c.bk == BK_) {                                \
+    hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, BK_, MODE>), dim3(nb),        \
+                       dim3(kThreads), 0, stream, k);                             \
+    return (int)hipGetLastError();                                                \
   }
-  return (int)hipGetLastError();
+  LD_CONV_CASE(128, 128, 16)
+  LD_CONV_CASE(128, 128, 32)
+  LD_CONV_CASE(128, 64, 16)
+  LD_CONV_CASE(128, 64, 32)
+  LD_CONV_CASE(64, 128, 16)
+  LD_CONV_CASE(64, 128, 32)
+  LD_CONV_CASE(64, 64, 16)
+  LD_CONV_CASE(64, 64, 32)
+#undef LD_CONV_CASE
+  return LD_EUNSUPPORTED;
 }
 
 }  // namespace
+
+extern "C" size_t ld_conv_weight_image_floats(int Cout, int Cin, int KH, int KW,
+                                             int backward) {
+  if (Cout < 1 || Cin < 1 || KH < 1 || KW < 1) return 0;
+  return backward ? (size_t)KH * KW * kpad_rows(Cout) * Cin
+                  : (size_t)KH * KW * kpad_rows(Cin) * Cout;
+}
 
 extern "C" int ld_conv_weight_transform(const float* w, int Cout, int Cin, int KH,
                                         int KW, float* wt_fwd, float* wt_bwd,
                                         ld_stream_t stream) {
   if (!w || Cout < 1 || Cin < 1 || KH < 1 || KW < 1 || (!wt_fwd && !wt_bwd))
     return LD_EINVAL;
-  const size_t total = (size_t)Cout * Cin * KH * KW;
+  const int cip = kpad_rows(Cin), cop = kpad_rows(Cout);
+  size_t total = 0;
+  if (wt_fwd) total = (size_t)KH * KW * cip * Cout;
+  if (wt_bwd) total = max(total, (size_t)KH * KW * cop * Cin);
   hipLaunchKernelGGL(conv_weight_transform_kernel,
                      dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, w, Cout, Cin, KH * KW, wt_fwd, wt_bwd);
+                     (hipStream_t)stream, w, Cout, Cin, KH * KW, cip, cop, wt_fwd,
+                     wt_bwd);
   return (int)hipGetLastError();
 }
 
@@ -481,6 +707,10 @@ extern "C" int ld_conv_forward(const ld_conv_t* c, const float* x,
   k.g.num_levels = c->num_levels;
   k.J = c->N * c->Pout;
   for (int l = 0; l < LD_MAX_LEVELS; ++l) k.g.lv[l] = c->lv[l];
+  k.Kpad = kpad_rows(c->Cin);
+  if (int e = set_extents(k, (size_t)c->N * c->Cin * c->Pin,
+                          (size_t)c->KH * c->KW * k.Kpad * c->Cout))
+    return e;
   return launch_igemm<0>(k, (hipStream_t)stream);
 }
 
@@ -507,6 +737,10 @@ extern "C" int ld_conv_forward_smallc(const ld_conv_t* c, const float* x,
   k.g.num_levels = c->num_levels;
   k.J = c->N * c->Pout;
   for (int l = 0; l < LD_MAX_LEVELS; ++l) k.g.lv[l] = c->lv[l];
+  k.Kpad = kpad_rows(c->Cin * c->KH * c->KW);
+  if (int e = set_extents(k, (size_t)c->N * c->Cin * c->Pin,
+                          (size_t)k.Kpad * c->Cout))
+    return e;
   return launch_igemm<2>(k, (hipStream_t)stream);
 }
 
@@ -534,6 +768,10 @@ extern "C" int ld_conv_dgrad(const ld_conv_t* c, const float* dy,
     k.g.lv[l].Hout = c->lv[l].Hin; k.g.lv[l].Wout = c->lv[l].Win;
     k.g.lv[l].off_in = c->lv[l].off_out; k.g.lv[l].off_out = c->lv[l].off_in;
   }
+  k.Kpad = kpad_rows(c->Cout);
+  if (int e = set_extents(k, (size_t)c->N * c->Cout * c->Pout,
+                          (size_t)c->KH * c->KW * k.Kpad * c->Cin))
+    return e;
   if (c->stride == 1) return launch_igemm<0>(k, (hipStream_t)stream);
   return launch_igemm<1>(k, (hipStream_t)stream);
 }
@@ -573,6 +811,13 @@ extern "C" int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy
   jchunk = (jchunk + WBK - 1) / WBK * WBK;
   k.jchunk = jchunk;
   for (int l = 0; l < LD_MAX_LEVELS; ++l) k.g.lv[l] = c->lv[l];
+  {
+    const size_t xf = (size_t)c->N * c->Cin * c->Pin;
+    const size_t yf = (size_t)c->N * c->Cout * c->Pout;
+    if (xf * 4 >= (size_t)kOOB || yf * 4 >= (size_t)kOOB) return LD_EUNSUPPORTED;
+    k.x_bytes = (unsigned)(xf * 4);
+    k.dy_bytes = (unsigned)(yf * 4);
+  }
   const int ntaps = c->KH * c->KW;
   const int blocks = ((c->Cout + 127) / 128) * ((c->Cin + 127) / 128) * ntaps * k.splits;
   hipLaunchKernelGGL(conv_wgrad_kernel, dim3(blocks), dim3(kThreads), 0, stream, k);

@@ -123,7 +123,10 @@ def weight_images(w, need_bwd, smallc=False):
     st = L.stream_ptr(w.device)
     if cache['stamp'] != stamp:
         if cache['fwd'] is None:
-            cache['fwd'] = torch.empty(w.numel(), dtype=torch.float32,
+            n = lib.ld_conv_weight_image_floats(
+                cout, cin * kh * kw if smallc else cin, 1 if smallc else kh,
+                1 if smallc else kw, 0)
+            cache['fwd'] = torch.empty(n, dtype=torch.float32,
                                        device=w.device)
         if smallc:
             rc = lib.ld_conv_weight_transform(L.ptr(w), cout, cin * kh * kw,
@@ -138,7 +141,8 @@ def weight_images(w, need_bwd, smallc=False):
         if smallc:
             raise L.LdError('small-Cin (stem) conv has no data gradient')
         if cache['bwd'] is None:
-            cache['bwd'] = torch.empty(w.numel(), dtype=torch.float32,
+            n = lib.ld_conv_weight_image_floats(cout, cin, kh, kw, 1)
+            cache['bwd'] = torch.empty(n, dtype=torch.float32,
                                        device=w.device)
         L.check(lib.ld_conv_weight_transform(L.ptr(w), cout, cin, kh, kw, None,
                                              L.ptr(cache['bwd']), st),

@@ -137,6 +137,7 @@ SIGNATURES = {
     'ld_bbox_overlaps': (C.c_int, [_vp, _vp, _i64, _i64, _i32, _i32, _f32,
                                    _vp, _vp]),
     'ld_sum': (C.c_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    'ld_conv_weight_image_floats': (_sz, [_i32, _i32, _i32, _i32, _i32]),
     'ld_conv_weight_transform': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp,
                                            _vp, _vp]),
     'ld_conv_forward': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),

@@ -76,7 +76,40 @@ CONV_SHAPES = [
      ((100, 168), (50, 84), (25, 42), (13, 21), (7, 11))),
     ('head gfl_cls 3x3 256-80', 2, 256, 80, 3, 1, 1,
      ((100, 168), (50, 84), (25, 42), (13, 21), (7, 11))),
+    ('r101.l3.conv3 1x1 256-1024', 2, 256, 1024, 1, 1, 0, ((50, 84), )),
+    ('r50.l4.conv1 1x1 2048-512', 2, 2048, 512, 1, 1, 0, ((25, 42), )),
+    ('r50.l4.conv3 1x1 512-2048', 2, 512, 2048, 1, 1, 0, ((25, 42), )),
 ]
+
+TILES = ['128x128x16', '128x64x16', '64x128x16', '64x64x32', '64x64x16',
+         '128x128x32', '128x64x32', '64x128x32']
+
+
+def bench_conv_tiles(out):
+    """Forward implicit-GEMM under every tile shape (LD_CONV_TILE)."""
+    dev = torch.device('cuda:0')
+    res = []
+    for name, N, cin, cout, k, stride, pad, levels in CONV_SHAPES:
+        P = sum(h * w for h, w in levels)
+        x = torch.randn(N, cin, P, device=dev)
+        w = torch.randn(cout, cin, k, k, device=dev) * 0.05
+        y, _ = Y.conv_forward_raw(x, w, stride, pad, levels)
+        flops = 2.0 * N * y.shape[2] * cout * cin * k * k
+        r = dict(name=name, J=N * y.shape[2], cout=cout, K=cin * k * k)
+        os.environ.pop('LD_CONV_TILE', None)
+        t = timeit(lambda: Y.conv_forward_raw(x, w, stride, pad, levels))
+        r['auto'] = round(flops / t / 1e12, 1)
+        for tile in TILES:
+            if cout <= 64 and tile.startswith('128'):
+                continue
+            os.environ['LD_CONV_TILE'] = tile
+            t = timeit(lambda: Y.conv_forward_raw(x, w, stride, pad, levels))
+            r[tile] = round(flops / t / 1e12, 1)
+        os.environ.pop('LD_CONV_TILE', None)
+        res.append(r)
+        print(r, flush=True)
+    out['conv_tiles'] = res
+
 
 
 def bench_conv(out, with_miopen=True):
@@ -144,10 +177,12 @@ def main():
     ap.add_argument('--no-miopen', action='store_true')
     args = ap.parse_args()
     out = dict(device=torch.cuda.get_device_name(0), time=time.time())
-    if 'kl' in args.only:
+    if 'kl' in args.only.split(','):
         bench_kl(out)
-    if 'conv' in args.only:
+    if 'conv' in args.only.split(','):
         bench_conv(out, not args.no_miopen)
+    if 'tiles' in args.only.split(','):
+        bench_conv_tiles(out)
     os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
     path = os.path.join(REPO, 'gpurun_out', f'kernels_{args.tag}.json')
     with open(path, 'w') as f:
