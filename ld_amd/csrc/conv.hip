@@ -601,35 +601,24 @@ int check_conv(const ld_conv_t* c) {
   return 0;
 }
 
-// Tile selection.  Candidates in decreasing MFMA efficiency; take the first
-// that yields >= kWantBlocks workgroups (2 per CU), else the one with the most.
+// Tile selection (measured on MI355X, profiles/r01_kernels_s4.json): the 64x64
+// tile wins or ties on every layer shape of the LD step -- finer granularity
+// over the 256 CUs beats the larger tile's operand reuse at fp32-MFMA rates --
+// with a 32-deep k-slice once the reduction is long enough to amortise it.
 // LD_CONV_TILE=BMxBNxBK overrides (benchmarking).
 struct TileCfg { int bm, bn, bk; };
-constexpr int kWantBlocks = 512;
 
 inline int tile_blocks(const ConvK& k, const TileCfg& c) {
   return ((k.Cout + c.bm - 1) / c.bm) * ((k.J + c.bn - 1) / c.bn);
 }
 
 inline TileCfg pick_tile(const ConvK& k) {
-  static const TileCfg cands[] = {{128, 128, 16}, {128, 64, 16}, {64, 128, 16},
-                                  {64, 64, 32}};
   if (const char* env = getenv("LD_CONV_TILE")) {
     TileCfg c{0, 0, 0};
     if (sscanf(env, "%dx%dx%d", &c.bm, &c.bn, &c.bk) == 3) return c;
   }
-  TileCfg best = cands[0];
-  int best_blocks = -1;
-  for (const TileCfg& c : cands) {
-    if (k.Cout <= 64 && c.bm == 128) continue;
-    const int nb = tile_blocks(k, c);
-    if (nb >= kWantBlocks) return c;
-    if (nb > best_blocks) {
-      best_blocks = nb;
-      best = c;
-    }
-  }
-  return best;
+  const int ktot = k.Cin * k.KH * k.KW;
+  return TileCfg{64, 64, ktot >= 512 ? 32 : 16};
 }
 
 inline int set_extents(ConvK& k, size_t x_floats, size_t wt_floats) {
