@@ -97,7 +97,6 @@ def ldkl_roofline(dev):
     s = torch.randn(68, rows, device=dev) * 3
     t = torch.randn(68, rows, device=dev) * 3
     w = torch.rand(rows, device=dev)
-    os.environ.setdefault('LD_KL_VEC', '1')
     for _ in range(3):
         LB.kl_integral_dense(s, t, w, 10.0, 1.0, True)
     torch.cuda.synchronize()
@@ -110,14 +109,14 @@ def ldkl_roofline(dev):
     b.record()
     torch.cuda.synchronize()
     dt = a.elapsed_time(b) * 1e-3 / iters
-    # algorithmic bytes per anchor-side row: 136 logits in + 1 weight + 4
-    # integral out + 1 loss out + 68 grad out = 210 B
-    nbytes = rows * 4 * 210.0
+    # algorithmic bytes per anchor-side row: 136 logits in + 4 weight + 4
+    # integral out + 4 loss out + 68 grad out = 216 B
+    nbytes = rows * 4 * 216.0
     ach = nbytes / dt / 1e9
     return dict(kernel='kl_integral_dense (fused LD-KL + Integral fwd+grad)',
                 bound='hbm', achieved=ach, peak=PEAK_HBM_GBPS, unit='GB/s',
                 frac=ach / PEAK_HBM_GBPS, traffic=None, rows=rows * 4,
-                bytes_per_row=210, us=dt * 1e6)
+                bytes_per_row=216, us=dt * 1e6)
 
 
 def cpu_baseline(batch, sdepth=50, tdepth=101):

@@ -188,8 +188,10 @@ int ld_loss_finalize(const ld_geom_t* geom, const ld_loss_hp_t* hp,
 /* The north-star kernel on its own, at any size: LD KL (T) + Integral
  * (+ fused gradient) over `rows`-many anchors x 4 sides, channel-major
  * (68, rows) student and teacher logits, weight (rows).
- *   integral (4, rows) out, loss_rows (rows) out = weight * sum_sides KL,
+ *   integral (4, rows) out, loss_rows (4, rows) out = weight * KL per side,
  *   grad (68, rows) out or NULL (forward only).
+ * Algorithmic bytes per anchor-side row: 136 logits in + 4 weight + 4 integral
+ * + 4 loss (+ 68 gradient) = 148 forward / 216 fused forward+gradient.
  * Replaces Integral.forward (gfl_head.py:32-44) +
  * knowledge_distillation_kl_div_loss (kd_loss.py:10-36) on the dense map. */
 int ld_kl_integral_dense(const float* s_reg, const float* t_reg,
@@ -327,9 +329,11 @@ int ld_bias_grad(const float* dy, int N, int C, int P, float* db, int accumulate
 /* GroupNorm(G) (+ReLU) applied per FPN level of a level-concatenated tensor
  * (gfl_head.py:102-126: each level is normalised on its own).  mean/rstd:
  * (N, G, num_levels) outputs kept for the backward. */
+size_t ld_gn_forward_workspace_bytes(const ld_levels_t* lv, int N, int G);
 int ld_gn_forward(const ld_levels_t* lv, const float* x, const float* gamma,
                   const float* beta, int N, int C, int G, float eps, int relu,
-                  float* y, float* mean, float* rstd, ld_stream_t stream);
+                  float* y, float* mean, float* rstd, void* workspace,
+                  size_t workspace_bytes, ld_stream_t stream);
 size_t ld_gn_backward_workspace_bytes(const ld_levels_t* lv, int N, int C);
 int ld_gn_backward(const ld_levels_t* lv, const float* dy, const float* y,
                    const float* x, const float* gamma, const float* mean,
@@ -352,9 +356,11 @@ int ld_upsample_add_backward(const float* dout, int rows, int Hf, int Wf, int Hc
 int ld_scale_levels_forward(const ld_levels_t* lv, const float* x,
                             const float* scales, int rows, float* y,
                             ld_stream_t stream);
+size_t ld_scale_levels_backward_workspace_bytes(const ld_levels_t* lv);
 int ld_scale_levels_backward(const ld_levels_t* lv, const float* dy, const float* x,
                              const float* scales, int rows, float* dx,
-                             float* dscales, int accumulate, ld_stream_t stream);
+                             float* dscales, int accumulate, void* workspace,
+                             size_t workspace_bytes, ld_stream_t stream);
 /* torch.optim.SGD(momentum, weight_decay) over a flat parameter arena
  * (apis/train.py:88): d = g*grad_scale + wd*p; buf = mu*buf + d; p -= lr*buf. */
 int ld_sgd_step(float* params, const float* grads, float* momentum_buf, size_t n,

@@ -438,89 +438,89 @@ __global__ __launch_bounds__(kWave) void loss_finalize_kernel(
 
 // ------------------------------------ the north-star kernel, stand-alone ----
 // LD KL + Integral (+ gradient) over a dense channel-major (68, rows) map.
-// R consecutive rows per thread, loaded as float / float2 / float4.
+// One thread owns R consecutive anchors of ONE side (grid.y = side): 34 input
+// streams per thread, ~60 VGPRs, 8 waves/SIMD -- the kernel is pure HBM
+// streaming, so occupancy (bytes in flight) is what sets the rate.  R floats
+// are moved per access (float / float2 / float4); NT selects non-temporal
+// (streaming) loads and stores.
 template <int R>
 struct VecT;
 template <>
-struct VecT<1> { using T = float; };
+struct VecT<1> { typedef float T; };
 template <>
-struct VecT<2> { using T = float2; };
+struct VecT<2> { typedef float T __attribute__((ext_vector_type(2))); };
 template <>
-struct VecT<4> { using T = float4; };
+struct VecT<4> { typedef float T __attribute__((ext_vector_type(4))); };
 
-template <int R, bool GRAD>
+template <int R, bool NT>
+__device__ __forceinline__ void vload(const float* p, float* out) {
+  typedef typename VecT<R>::T V;
+  V v = NT ? __builtin_nontemporal_load(reinterpret_cast<const V*>(p))
+           : *reinterpret_cast<const V*>(p);
+  const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+  for (int j = 0; j < R; ++j) out[j] = f[j];
+}
+template <int R, bool NT>
+__device__ __forceinline__ void vstore(float* p, const float* in) {
+  typedef typename VecT<R>::T V;
+  V v;
+  float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+  for (int j = 0; j < R; ++j) f[j] = in[j];
+  if (NT)
+    __builtin_nontemporal_store(v, reinterpret_cast<V*>(p));
+  else
+    *reinterpret_cast<V*>(p) = v;
+}
+
+template <int R, bool GRAD, bool NT>
 __global__ __launch_bounds__(256) void kl_integral_dense_kernel(
     const float* __restrict__ s_reg, const float* __restrict__ t_reg,
     const float* __restrict__ weight, int64_t rows, float T, float scale,
     float* __restrict__ integral, float* __restrict__ loss_rows,
     float* __restrict__ grad) {
-  using V = typename VecT<R>::T;
+  const int side = blockIdx.y;
   const int64_t r0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * R;
   if (r0 >= rows) return;
   const float invT = 1.0f / T;
-  float w[R], lsum[R];
-  {
-    V wv = *reinterpret_cast<const V*>(weight + r0);
-    const float* wp = reinterpret_cast<const float*>(&wv);
+  float w[R];
+  vload<R, false>(weight + r0, w);
+  float sv[R][K17], tv[R][K17];
+#pragma unroll
+  for (int k = 0; k < K17; ++k) {
+    float a[R], b[R];
+    vload<R, NT>(s_reg + (int64_t)(side * K17 + k) * rows + r0, a);
+    vload<R, NT>(t_reg + (int64_t)(side * K17 + k) * rows + r0, b);
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-      w[j] = wp[j];
-      lsum[j] = 0.0f;
+      sv[j][k] = a[j];
+      tv[j][k] = b[j];
     }
   }
-#pragma unroll 1
-  for (int s = 0; s < 4; ++s) {
-    float sv[R][K17], tv[R][K17];
+  float e[R], l[R], gr[R][K17];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    float d[K17], p[K17];
+    const float kl = ld::kl_rows<K17>(sv[j], tv[j], invT, T, d);
+    e[j] = ld::softmax_expect<K17>(sv[j], p);
+    l[j] = w[j] * kl;
+    if (GRAD) {
+      const float cg = scale * w[j] * (T / (float)K17);
+#pragma unroll
+      for (int k = 0; k < K17; ++k) gr[j][k] = cg * d[k];
+    }
+  }
+  vstore<R, NT>(integral + (int64_t)side * rows + r0, e);
+  vstore<R, NT>(loss_rows + (int64_t)side * rows + r0, l);
+  if (GRAD) {
 #pragma unroll
     for (int k = 0; k < K17; ++k) {
-      V a = *reinterpret_cast<const V*>(s_reg + (int64_t)(s * K17 + k) * rows + r0);
-      V b = *reinterpret_cast<const V*>(t_reg + (int64_t)(s * K17 + k) * rows + r0);
-      const float* ap = reinterpret_cast<const float*>(&a);
-      const float* bp = reinterpret_cast<const float*>(&b);
+      float g[R];
 #pragma unroll
-      for (int j = 0; j < R; ++j) {
-        sv[j][k] = ap[j];
-        tv[j][k] = bp[j];
-      }
+      for (int j = 0; j < R; ++j) g[j] = gr[j][k];
+      vstore<R, NT>(grad + (int64_t)(side * K17 + k) * rows + r0, g);
     }
-    float e[R];
-    float gr[R][K17];
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-      float d[K17], p[K17];
-      const float kl = ld::kl_rows<K17>(sv[j], tv[j], invT, T, d);
-      e[j] = ld::softmax_expect<K17>(sv[j], p);
-      lsum[j] += kl;
-      if (GRAD) {
-        const float cg = scale * w[j] * (T / (float)K17);
-#pragma unroll
-        for (int k = 0; k < K17; ++k) gr[j][k] = cg * d[k];
-      }
-    }
-    {
-      V ev;
-      float* ep = reinterpret_cast<float*>(&ev);
-#pragma unroll
-      for (int j = 0; j < R; ++j) ep[j] = e[j];
-      *reinterpret_cast<V*>(integral + (int64_t)s * rows + r0) = ev;
-    }
-    if (GRAD) {
-#pragma unroll
-      for (int k = 0; k < K17; ++k) {
-        V gv;
-        float* gp = reinterpret_cast<float*>(&gv);
-#pragma unroll
-        for (int j = 0; j < R; ++j) gp[j] = gr[j][k];
-        *reinterpret_cast<V*>(grad + (int64_t)(s * K17 + k) * rows + r0) = gv;
-      }
-    }
-  }
-  {
-    V lv;
-    float* lp = reinterpret_cast<float*>(&lv);
-#pragma unroll
-    for (int j = 0; j < R; ++j) lp[j] = w[j] * lsum[j];
-    *reinterpret_cast<V*>(loss_rows + r0) = lv;
   }
 }
 
@@ -647,26 +647,36 @@ extern "C" int ld_kl_integral_dense(const float* s_reg, const float* t_reg,
            aligned(weight, 8) && aligned(integral, 8) && aligned(loss_rows, 8) &&
            (!grad || aligned(grad, 8)))
     R = 2;
-  // LD_KL_VEC overrides the vector width (1/2/4) for benchmarking
+  // LD_KL_VEC / LD_KL_NT override the vector width (1/2/4) and the
+  // non-temporal access mode for benchmarking
+  bool nt = true;
   if (const char* env = getenv("LD_KL_VEC")) {
     int v = atoi(env);
     if ((v == 1 || v == 2 || v == 4) && v <= R) R = v;
+  } else if (R > 2) {
+    R = 2;
   }
+  if (const char* env = getenv("LD_KL_NT")) nt = atoi(env) != 0;
   const int64_t threads = (rows + R - 1) / R;
-  const dim3 block(256), grid((unsigned)((threads + 255) / 256));
-#define LD_LAUNCH_KL(RR, GG)                                                      \
-  hipLaunchKernelGGL((kl_integral_dense_kernel<RR, GG>), grid, block, 0, stream,  \
-                     s_reg, t_reg, weight, rows, T, scale, integral, loss_rows,   \
-                     grad)
-  if (grad) {
-    if (R == 4) LD_LAUNCH_KL(4, true);
-    else if (R == 2) LD_LAUNCH_KL(2, true);
-    else LD_LAUNCH_KL(1, true);
-  } else {
-    if (R == 4) LD_LAUNCH_KL(4, false);
-    else if (R == 2) LD_LAUNCH_KL(2, false);
-    else LD_LAUNCH_KL(1, false);
-  }
+  const dim3 block(256), grid((unsigned)((threads + 255) / 256), 4);
+#define LD_LAUNCH_KL(RR, GG, NN)                                                  \
+  hipLaunchKernelGGL((kl_integral_dense_kernel<RR, GG, NN>), grid, block, 0,      \
+                     stream, s_reg, t_reg, weight, rows, T, scale, integral,      \
+                     loss_rows, grad)
+#define LD_LAUNCH_KL_R(RR)                                                        \
+  do {                                                                            \
+    if (grad) {                                                                   \
+      if (nt) LD_LAUNCH_KL(RR, true, true);                                       \
+      else LD_LAUNCH_KL(RR, true, false);                                         \
+    } else {                                                                      \
+      if (nt) LD_LAUNCH_KL(RR, false, true);                                      \
+      else LD_LAUNCH_KL(RR, false, false);                                        \
+    }                                                                             \
+  } while (0)
+  if (R == 4) LD_LAUNCH_KL_R(4);
+  else if (R == 2) LD_LAUNCH_KL_R(2);
+  else LD_LAUNCH_KL_R(1);
+#undef LD_LAUNCH_KL_R
 #undef LD_LAUNCH_KL
   return (int)hipGetLastError();
 }

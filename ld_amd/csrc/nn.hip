@@ -178,17 +178,26 @@ __device__ __forceinline__ int level_of_pos(const Levels& lv, int p) {
   return l;
 }
 
-// one block per (n, group, level): mean / rstd over (C/G channels) x A_l
-__global__ __launch_bounds__(256) void gn_stats_kernel(
-    const float* __restrict__ x, Levels lv, int C, int G, float eps,
-    float* __restrict__ mean, float* __restrict__ rstd) {
+// mean / rstd over (C/G channels) x A_l per (n, group, level), two stages so
+// the 16800-cell level does not serialise on one workgroup:
+//   stage 1  kGnSplit blocks per (n, g, l) -> partial (sum, sumsq) in fp64
+//   stage 2  one thread per (n, g, l) adds the partials in fixed order
+constexpr int kGnSplit = 32;
+
+__global__ __launch_bounds__(256) void gn_stats_partial_kernel(
+    const float* __restrict__ x, Levels lv, int C, int G,
+    double* __restrict__ partial) {
   const int L = lv.num_levels;
-  const int l = blockIdx.x % L, g = (blockIdx.x / L) % G, n = blockIdx.x / (L * G);
+  const int sp = blockIdx.x % kGnSplit;
+  const int ngl = blockIdx.x / kGnSplit;
+  const int l = ngl % L, g = (ngl / L) % G, n = ngl / (L * G);
   const int cpg = C / G, A = lv.off[l + 1] - lv.off[l];
   const float* base = x + ((size_t)n * C + (size_t)g * cpg) * lv.P + lv.off[l];
-  double s = 0.0, q = 0.0;
   const int total = cpg * A;
-  for (int e = threadIdx.x; e < total; e += 256) {
+  const int per = (total + kGnSplit - 1) / kGnSplit;
+  const int beg = sp * per, end = min(total, beg + per);
+  double s = 0.0, q = 0.0;
+  for (int e = beg + threadIdx.x; e < end; e += 256) {
     const int ch = e / A, p = e - ch * A;
     const double v = (double)base[(size_t)ch * lv.P + p];
     s += v;
@@ -196,13 +205,30 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(
   }
   block_sum2(s, q);
   if (threadIdx.x == 0) {
-    const double m = s / total;
-    double var = q / total - m * m;
-    if (var < 0.0) var = 0.0;
-    const size_t o = ((size_t)n * G + g) * L + l;
-    mean[o] = (float)m;
-    rstd[o] = (float)(1.0 / sqrt(var + (double)eps));
+    partial[(size_t)blockIdx.x * 2 + 0] = s;
+    partial[(size_t)blockIdx.x * 2 + 1] = q;
   }
+}
+
+__global__ void gn_stats_final_kernel(const double* __restrict__ partial, Levels lv,
+                                      int N, int C, int G, float eps,
+                                      float* __restrict__ mean,
+                                      float* __restrict__ rstd) {
+  const int L = lv.num_levels;
+  const int ngl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ngl >= N * G * L) return;
+  const int l = ngl % L;
+  const double total = (double)(C / G) * (lv.off[l + 1] - lv.off[l]);
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < kGnSplit; ++k) {
+    s += partial[((size_t)ngl * kGnSplit + k) * 2 + 0];
+    q += partial[((size_t)ngl * kGnSplit + k) * 2 + 1];
+  }
+  const double m = s / total;
+  double var = q / total - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[ngl] = (float)m;
+  rstd[ngl] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 // y = relu?( (x - mean) * rstd * gamma[c] + beta[c] )
@@ -384,21 +410,36 @@ __global__ __launch_bounds__(256) void scale_levels_kernel(
   y[idx] = x[idx] * scales[l];
 }
 
-// dscale[l] = sum dy * x over level l (all rows); one block per level
-__global__ __launch_bounds__(256) void scale_levels_bwd_kernel(
+// dscale[l] = sum dy * x over level l (all rows): kScaleSplit blocks per level
+// write fp64 partials, a second tiny kernel adds them in fixed order
+constexpr int kScaleSplit = 64;
+
+__global__ __launch_bounds__(256) void scale_levels_bwd_partial_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, Levels lv, int rows,
-    float* __restrict__ dscale, int accumulate) {
-  const int l = blockIdx.x;
+    double* __restrict__ partial) {
+  const int l = blockIdx.x / kScaleSplit, sp = blockIdx.x % kScaleSplit;
   const int A = lv.off[l + 1] - lv.off[l];
-  double s = 0.0, z = 0.0;
   const long long total = (long long)rows * A;
-  for (long long e = threadIdx.x; e < total; e += 256) {
+  const long long per = (total + kScaleSplit - 1) / kScaleSplit;
+  const long long beg = sp * per, end = min(total, beg + per);
+  double s = 0.0, z = 0.0;
+  for (long long e = beg + threadIdx.x; e < end; e += 256) {
     const int r = (int)(e / A), p = (int)(e - (long long)r * A);
     const size_t idx = (size_t)r * lv.P + lv.off[l] + p;
     s += (double)(dy[idx] * x[idx]);
   }
   block_sum2(s, z);
-  if (threadIdx.x == 0) dscale[l] = accumulate ? dscale[l] + (float)s : (float)s;
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ void scale_levels_bwd_final_kernel(const double* __restrict__ partial,
+                                              int L, float* __restrict__ dscale,
+                                              int accumulate) {
+  const int l = threadIdx.x;
+  if (l >= L) return;
+  double s = 0.0;
+  for (int k = 0; k < kScaleSplit; ++k) s += partial[l * kScaleSplit + k];
+  dscale[l] = accumulate ? dscale[l] + (float)s : (float)s;
 }
 
 // --------------------------------------------------------------------- SGD --
@@ -533,17 +574,30 @@ extern "C" int ld_bias_grad(const float* dy, int N, int C, int P, float* db,
   return (int)hipGetLastError();
 }
 
+extern "C" size_t ld_gn_forward_workspace_bytes(const ld_levels_t* lv, int N,
+                                                int G) {
+  if (check_levels(lv) != 0 || N < 1 || G < 1) return 0;
+  return (size_t)N * G * lv->num_levels * kGnSplit * 2 * sizeof(double);
+}
+
 extern "C" int ld_gn_forward(const ld_levels_t* lv, const float* x,
                              const float* gamma, const float* beta, int N, int C,
                              int G, float eps, int relu, float* y, float* mean,
-                             float* rstd, ld_stream_t stream) {
+                             float* rstd, void* workspace, size_t workspace_bytes,
+                             ld_stream_t stream) {
   if (int e = check_levels(lv)) return e;
   if (!x || !gamma || !beta || !y || !mean || !rstd || N < 1 || C < 1 || G < 1 ||
       C % G)
     return LD_EINVAL;
+  if (!workspace || workspace_bytes < ld_gn_forward_workspace_bytes(lv, N, G))
+    return LD_ENOSPACE;
   const Levels k = make_levels(lv);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(N * G * k.num_levels), dim3(256), 0,
-                     LD_STREAM, x, k, C, G, eps, mean, rstd);
+  const int ngl = N * G * k.num_levels;
+  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(ngl * kGnSplit), dim3(256), 0,
+                     LD_STREAM, x, k, C, G, (double*)workspace);
+  hipLaunchKernelGGL(gn_stats_final_kernel, dim3((ngl + 255) / 256), dim3(256), 0,
+                     LD_STREAM, (const double*)workspace, k, N, C, G, eps, mean,
+                     rstd);
   hipLaunchKernelGGL(gn_apply_kernel, dim3((k.P + 255) / 256, N * C), dim3(256), 0,
                      LD_STREAM, x, k, C, G, mean, rstd, gamma, beta, relu, y);
   return (int)hipGetLastError();
@@ -623,18 +677,32 @@ extern "C" int ld_scale_levels_forward(const ld_levels_t* lv, const float* x,
   return (int)hipGetLastError();
 }
 
+extern "C" size_t ld_scale_levels_backward_workspace_bytes(const ld_levels_t* lv) {
+  if (check_levels(lv) != 0) return 0;
+  return (size_t)lv->num_levels * kScaleSplit * sizeof(double);
+}
+
 extern "C" int ld_scale_levels_backward(const ld_levels_t* lv, const float* dy,
                                         const float* x, const float* scales,
                                         int rows, float* dx, float* dscales,
-                                        int accumulate, ld_stream_t stream) {
+                                        int accumulate, void* workspace,
+                                        size_t workspace_bytes, ld_stream_t stream) {
   if (int e = check_levels(lv)) return e;
   if (!dy || !x || !scales || !dx || rows < 1) return LD_EINVAL;
+  if (dscales && (!workspace ||
+                  workspace_bytes < ld_scale_levels_backward_workspace_bytes(lv)))
+    return LD_ENOSPACE;
   const Levels k = make_levels(lv);
   hipLaunchKernelGGL(scale_levels_kernel, dim3((k.P + 255) / 256, rows), dim3(256),
                      0, LD_STREAM, dy, k, scales, dx);
-  if (dscales)
-    hipLaunchKernelGGL(scale_levels_bwd_kernel, dim3(k.num_levels), dim3(256), 0,
-                       LD_STREAM, dy, x, k, rows, dscales, accumulate);
+  if (dscales) {
+    hipLaunchKernelGGL(scale_levels_bwd_partial_kernel,
+                       dim3(k.num_levels * kScaleSplit), dim3(256), 0, LD_STREAM, dy,
+                       x, k, rows, (double*)workspace);
+    hipLaunchKernelGGL(scale_levels_bwd_final_kernel, dim3(1), dim3(64), 0,
+                       LD_STREAM, (const double*)workspace, k.num_levels, dscales,
+                       accumulate);
+  }
   return (int)hipGetLastError();
 }
 

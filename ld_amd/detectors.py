@@ -128,6 +128,14 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
             teacher_config = Config.fromfile(teacher_config)
         tcfg = dict(teacher_config['model'])
         self.teacher_model = build_detector(tcfg)
+        if eval_teacher:
+            # the teacher only ever runs under no_grad (kd_one_stage.py:70-72)
+            # and no optimizer owns it: tag its parameters static so the conv
+            # weight images and folded-BN coefficients are computed once
+            # instead of every step (requires_grad is left as the reference
+            # has it)
+            for p in self.teacher_model.parameters():
+                p._ld_static = True
         if teacher_ckpt is not None:
             from .checkpoint import load_checkpoint
             try:

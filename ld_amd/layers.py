@@ -112,7 +112,8 @@ def weight_images(w, need_bwd, smallc=False):
     conv parameter; rebuilt when the parameter changed."""
     lib = L.get_lib()
     _dev_f32(w, 'conv weight')
-    stamp = (w._version, _PARAM_GEN[0] if w.requires_grad else -1,
+    dynamic = w.requires_grad and not getattr(w, '_ld_static', False)
+    stamp = (w._version, _PARAM_GEN[0] if dynamic else -1,
              w.data_ptr(), smallc)
     cache = getattr(w, '_ld_images', None)
     if cache is None or cache['ident'] != stamp[2:]:
@@ -246,7 +247,30 @@ def conv2d(x3, w, bias, stride, pad, levels):
 # ---------------------------------------------------------------------------
 # BatchNorm (eval statistics) + residual + ReLU
 # ---------------------------------------------------------------------------
+_BN_CACHE = {}
+
+
 def bn_prepare(gamma, beta, mean, var, eps):
+    """scale/shift/rstd of an eval-mode BN.  For a frozen BN (no trainable
+    affine: the teacher, the student's frozen stages) the result is cached
+    until any of the four tensors changes."""
+    frozen = not (gamma.requires_grad or beta.requires_grad) or \
+        getattr(gamma, '_ld_static', False)
+    if frozen:
+        key = (gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+               var.data_ptr())
+        stamp = (gamma._version, beta._version, mean._version, var._version,
+                 eps)
+        hit = _BN_CACHE.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+    out = _bn_prepare(gamma, beta, mean, var, eps)
+    if frozen:
+        _BN_CACHE[key] = (stamp, out)
+    return out
+
+
+def _bn_prepare(gamma, beta, mean, var, eps):
     lib = L.get_lib()
     c = gamma.numel()
     buf = torch.empty((3, c), dtype=torch.float32, device=gamma.device)
@@ -331,6 +355,17 @@ def conv_bn_act_infer(x3, w, gamma, beta, mean, var, eps, stride, pad, levels,
 # ---------------------------------------------------------------------------
 # GroupNorm + ReLU on level-concatenated tensors
 # ---------------------------------------------------------------------------
+def _gn_forward_launch(lv, x3, gamma, beta, N, c, groups, eps, relu, y, stats):
+    lib = L.get_lib()
+    need = lib.ld_gn_forward_workspace_bytes(C.byref(lv), N, groups)
+    ws = workspace(x3.device, need, 'gn_fwd')
+    L.check(lib.ld_gn_forward(C.byref(lv), L.ptr(x3), L.ptr(gamma),
+                              L.ptr(beta), N, c, groups, eps,
+                              1 if relu else 0, L.ptr(y), L.ptr(stats[0]),
+                              L.ptr(stats[1]), L.ptr(ws), ws.numel(),
+                              L.stream_ptr(x3.device)), 'ld_gn_forward')
+
+
 class GnActFn(torch.autograd.Function):
 
     @staticmethod
@@ -342,11 +377,8 @@ class GnActFn(torch.autograd.Function):
         y = torch.empty_like(x3)
         stats = torch.empty((2, N, groups, len(levels)), dtype=torch.float32,
                             device=x3.device)
-        L.check(lib.ld_gn_forward(C.byref(lv), L.ptr(x3), L.ptr(gamma),
-                                  L.ptr(beta), N, c, groups, eps,
-                                  1 if relu else 0, L.ptr(y), L.ptr(stats[0]),
-                                  L.ptr(stats[1]), L.stream_ptr(x3.device)),
-                'ld_gn_forward')
+        _gn_forward_launch(lv, x3, gamma, beta, N, c, groups, eps, relu, y,
+                           stats)
         ctx.save_for_backward(x3, y, gamma, stats)
         ctx.meta = (groups, levels, relu)
         return y
@@ -381,11 +413,7 @@ def gn_act(x3, gamma, beta, groups, eps, levels, relu=True):
     y = torch.empty_like(x3)
     stats = torch.empty((2, N, groups, len(levels)), dtype=torch.float32,
                         device=x3.device)
-    L.check(lib.ld_gn_forward(C.byref(lv), L.ptr(x3), L.ptr(gamma),
-                              L.ptr(beta), N, c, groups, eps,
-                              1 if relu else 0, L.ptr(y), L.ptr(stats[0]),
-                              L.ptr(stats[1]), L.stream_ptr(x3.device)),
-            'ld_gn_forward')
+    _gn_forward_launch(lv, x3, gamma, beta, N, c, groups, eps, relu, y, stats)
     return y
 
 
@@ -472,9 +500,12 @@ class ScaleLevelsFn(torch.autograd.Function):
         lv = levels_desc(ctx.levels)
         dx = torch.empty_like(x3)
         ds = torch.empty_like(scales) if ctx.needs_input_grad[1] else None
+        need = lib.ld_scale_levels_backward_workspace_bytes(C.byref(lv))
+        ws = workspace(x3.device, need, 'scale_bwd')
         L.check(lib.ld_scale_levels_backward(
             C.byref(lv), L.ptr(dy), L.ptr(x3), L.ptr(scales), N * c, L.ptr(dx),
-            L.ptr(ds), 0, L.stream_ptr(x3.device)), 'ld_scale_levels_backward')
+            L.ptr(ds), 0, L.ptr(ws), ws.numel(), L.stream_ptr(x3.device)),
+            'ld_scale_levels_backward')
         return dx, ds, None
 
 

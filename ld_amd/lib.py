@@ -154,8 +154,9 @@ SIGNATURES = {
                                      _i32, _i32, _vp, _vp, _vp, _vp, _i32,
                                      _vp, _sz, _vp]),
     'ld_bias_grad': (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
+    'ld_gn_forward_workspace_bytes': (_sz, [_LV, _i32, _i32]),
     'ld_gn_forward': (C.c_int, [_LV, _vp, _vp, _vp, _i32, _i32, _i32, _f32,
-                                _i32, _vp, _vp, _vp, _vp]),
+                                _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     'ld_gn_backward_workspace_bytes': (_sz, [_LV, _i32, _i32]),
     'ld_gn_backward': (C.c_int, [_LV, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
                                  _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp,
@@ -166,8 +167,9 @@ SIGNATURES = {
     'ld_upsample_add_backward': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32,
                                            _vp, _vp]),
     'ld_scale_levels_forward': (C.c_int, [_LV, _vp, _vp, _i32, _vp, _vp]),
+    'ld_scale_levels_backward_workspace_bytes': (_sz, [_LV]),
     'ld_scale_levels_backward': (C.c_int, [_LV, _vp, _vp, _vp, _i32, _vp, _vp,
-                                           _i32, _vp]),
+                                           _i32, _vp, _sz, _vp]),
     'ld_sgd_step': (C.c_int, [_vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32,
                               _vp]),
 }

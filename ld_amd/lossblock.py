@@ -14,8 +14,10 @@ _WS = {}
 
 
 def workspace(device, nbytes, tag='ws'):
-    """A cached per-device scratch buffer (never shrinks)."""
-    key = (str(device), tag)
+    """A cached scratch buffer (never shrinks), private to (device, current
+    stream, tag): the teacher runs on its own stream concurrently with the
+    student, so scratch must not be shared across streams."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8,
@@ -222,7 +224,8 @@ def _rerun_with_upstream(hp, targets, teacher, norm, cls, reg, x, upstream):
 # ---------------------------------------------------------------------------
 def kl_integral_dense(s_reg, t_reg, weight, T=10.0, scale=1.0, with_grad=True):
     """(68, rows) student/teacher logits, (rows,) weight ->
-    integral (4, rows), loss_rows (rows,), grad (68, rows) | None."""
+    integral (4, rows), loss_rows (4, rows) = weight * KL per side,
+    grad (68, rows) | None."""
     lib = L.get_lib()
     for t in (s_reg, t_reg, weight):
         L.require_device(t, torch.float32)
@@ -230,7 +233,8 @@ def kl_integral_dense(s_reg, t_reg, weight, T=10.0, scale=1.0, with_grad=True):
     assert s_reg.shape[0] == 68 and s_reg.is_contiguous()
     integral = torch.empty((4, rows), dtype=torch.float32,
                            device=s_reg.device)
-    loss_rows = torch.empty(rows, dtype=torch.float32, device=s_reg.device)
+    loss_rows = torch.empty((4, rows), dtype=torch.float32,
+                            device=s_reg.device)
     grad = torch.empty_like(s_reg) if with_grad else None
     L.check(lib.ld_kl_integral_dense(
         L.ptr(s_reg), L.ptr(t_reg), L.ptr(weight), rows, T, scale,

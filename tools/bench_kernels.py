@@ -41,23 +41,25 @@ def timeit(fn, warm=3, iters=10):
 def bench_kl(out):
     dev = torch.device('cuda:0')
     res = []
-    for rows in (1 << 22, 179200 // 4 * 1):  # saturating, and the C2 batch size
+    for rows in (1 << 22, 44800):  # saturating, and the C2 batch size
         s = torch.randn(68, rows, device=dev) * 3
         t = torch.randn(68, rows, device=dev) * 3
         w = torch.rand(rows, device=dev)
         for vec in (1, 2, 4):
-            os.environ['LD_KL_VEC'] = str(vec)
-            for grad in (False, True):
-                dt = timeit(lambda: LB.kl_integral_dense(s, t, w, 10.0, 1.0,
-                                                         grad))
-                # algorithmic bytes per anchor: 2*68*4 in, 4 weight, 16
-                # integral, 4 loss, (+ 68*4 grad)
-                b = rows * (544 + 4 + 16 + 4 + (272 if grad else 0))
-                res.append(dict(rows_anchor=rows, rows_side=rows * 4, vec=vec,
-                                grad=grad, us=dt * 1e6, GBps=b / dt / 1e9,
-                                frac_of_8TBps=b / dt / 8e12))
-                print(res[-1], flush=True)
+            for nt in (0, 1):
+                os.environ['LD_KL_VEC'] = str(vec)
+                os.environ['LD_KL_NT'] = str(nt)
+                for grad in (False, True):
+                    dt = timeit(lambda: LB.kl_integral_dense(s, t, w, 10.0,
+                                                             1.0, grad))
+                    b = rows * 4 * (148 + (68 if grad else 0))
+                    res.append(dict(rows_side=rows * 4, vec=vec, nt=nt,
+                                    grad=grad, us=round(dt * 1e6, 1),
+                                    GBps=round(b / dt / 1e9),
+                                    frac_of_8TBps=round(b / dt / 8e12, 3)))
+                    print(res[-1], flush=True)
     os.environ.pop('LD_KL_VEC', None)
+    os.environ.pop('LD_KL_NT', None)
     out['kl_integral_dense'] = res
 
 
