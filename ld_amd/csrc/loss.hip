@@ -653,8 +653,9 @@ extern "C" int ld_kl_integral_dense(const float* s_reg, const float* t_reg,
   if (const char* env = getenv("LD_KL_VEC")) {
     int v = atoi(env);
     if ((v == 1 || v == 2 || v == 4) && v <= R) R = v;
-  } else if (R > 2) {
-    R = 2;
+  } else {
+    R = 1;  // measured best on MI355X (profiles/r01_kernels_s6.json): one float
+            // per lane per stream + non-temporal access, 8 waves/SIMD
   }
   if (const char* env = getenv("LD_KL_NT")) nt = atoi(env) != 0;
   const int64_t threads = (rows + R - 1) / R;
