@@ -137,16 +137,20 @@ __device__ __forceinline__ bool tap_offset(const Geo& a, int l, int ho, int wo,
 // 32x32 tiles.  Large tiles (128x128) for big spatial extents; small ones
 // (64x64) keep >= 2 workgroups per CU on the 50x84 / 25x42 stages where a
 // 128x128 tiling would leave half the 256 CUs idle.
-template <int BM, int BNT, int BKT, int MODE>
+template <int BM, int BNT, int BKT, int MODE, bool DEEP>
 __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvK a) {
   constexpr int WM = BM / 2, WN = BNT / 2;   // wave tile
   constexpr int TM = WM / 32, TN = WN / 32;  // MFMA tiles per wave
   constexpr int A_PER = BKT * BM / kThreads;   // A floats per thread per step
   constexpr int B_PER = BKT * BNT / kThreads;  // B floats per thread per step
   static_assert(A_PER >= 1 && B_PER >= 1, "tile too small");
-  __shared__ float lds[2 * BKT * (BM + BNT)];
-  float* As = lds;                    // [2][BKT][BM]
-  float* Bs = lds + 2 * BKT * BM;     // [2][BKT][BNT]
+  // DEEP: 3 LDS buffers + two register stages = global loads run TWO k-steps
+  // ahead of the MFMAs (small-spatial layers have only ~2 waves per SIMD, one
+  // step of MFMAs does not cover the L2/HBM latency there)
+  constexpr int NBUF = DEEP ? 3 : 2;
+  __shared__ float lds[NBUF * BKT * (BM + BNT)];
+  float* As = lds;                       // [NBUF][BKT][BM]
+  float* Bs = lds + NBUF * BKT * BM;     // [NBUF][BKT][BNT]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -216,6 +220,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvK a) {
   const int ktot = Cin * ntaps;  // MODE 2: flat (ci, kh, kw) reduction index
   const int nsteps = (MODE == 2) ? (ktot + BKT - 1) / BKT : ntaps * csteps;
   float a_st[A_PER], b_st[B_PER];
+  float a_s2[DEEP ? A_PER : 1], b_s2[DEEP ? B_PER : 1];  // second stage
 
   // Tile loads are raw buffer loads: one 32-bit per-lane voffset (kOOB when the
   // element is padding / outside the tile -> the hardware returns 0), the row
@@ -226,13 +231,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvK a) {
   const rsrc_t rw = make_rsrc(a.wt, a.wt_bytes);
   const int Kpad = __builtin_amdgcn_readfirstlane(a.Kpad);
   const unsigned va = avalid ? (unsigned)(m0 + am) * 4u : kOOB;
-  auto load_tile = [&](int step) {
+  auto load_tile = [&](int step, float* ra, float* rb) {
     if (MODE == 2) {
       // small-Cin (stem) im2col: every k row has its own (ci, kh, kw)
       const int k0 = step * BKT;
 #pragma unroll
       for (int i = 0; i < A_PER; ++i)
-        a_st[i] = buf_load(rw, va, (unsigned)(k0 + ak0 + i) * Cout * 4u);
+        ra[i] = buf_load(rw, va, (unsigned)(k0 + ak0 + i) * Cout * 4u);
 #pragma unroll
       for (int i = 0; i < B_PER; ++i) {
         const int k = k0 + bk0 + i;          // scalar
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvK a) {
         const int kh = r / KW, kw = r - kh * KW;
         int off = 0;
         const bool kb = jvalid && tap_off(kh, kw, off);
-        b_st[i] = buf_load(rx, kb ? (unsigned)off * 4u : kOOB,
+        rb[i] = buf_load(rx, kb ? (unsigned)off * 4u : kOOB,
                            (unsigned)ci * Pin * 4u);
       }
       return;
@@ -254,36 +259,30 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvK a) {
     const unsigned sa = (unsigned)(tap * Kpad + ci0 + ak0) * Cout * 4u;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i)
-      a_st[i] = buf_load(rw, va, sa + (unsigned)i * Cout * 4u);
+      ra[i] = buf_load(rw, va, sa + (unsigned)i * Cout * 4u);
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       // k-tail rows re-read the last valid channel (finite); their A rows are
       // the zero padding of the weight image
       const int row = min(ci0 + bk0 + i, Cin - 1);
-      b_st[i] = buf_load(rx, vb, (unsigned)row * Pin * 4u);
+      rb[i] = buf_load(rx, vb, (unsigned)row * Pin * 4u);
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const float* ra, const float* rb) {
     float* ap = As + buf * BKT * BM + ak0 * BM + am;
 #pragma unroll
-    for (int i = 0; i < A_PER; ++i) ap[i * BM] = a_st[i];
+    for (int i = 0; i < A_PER; ++i) ap[i * BM] = ra[i];
     float* bp = Bs + buf * BKT * BNT + bk0 * BNT + (t % BNT);
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i) bp[i * BNT] = b_st[i];
+    for (int i = 0; i < B_PER; ++i) bp[i * BNT] = rb[i];
   };
 
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
   const int l31 = lane & 31, lk = lane >> 5;
   constexpr int KP = BKT / 2;
-  for (int step = 0; step < nsteps; ++step) {
-    const int cur = step & 1;
-    if (step + 1 < nsteps) load_tile(step + 1);
-    const float* ap = As + cur * BKT * BM + wm * WM + l31;
-    const float* bp = Bs + cur * BKT * BNT + wn * WN + l31;
-    // register double-buffered fragments: the LDS reads of k-pair kp+1 are in
-    // flight while the MFMAs of k-pair kp issue
+  // one k-step of MFMAs on LDS buffer `buf`, fragment reads one k-pair ahead
+  auto compute = [&](int buf) {
+    const float* ap = As + buf * BKT * BM + wm * WM + l31;
+    const float* bp = Bs + buf * BKT * BNT + wn * WN + l31;
     float af[2][TM], bf[2][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) af[0][i] = ap[lk * BM + i * 32];
@@ -306,16 +305,51 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvK a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i], bf[c][j],
                                                            acc[i][j], 0, 0, 0);
     }
-    // pin the interleave: fragment reads run one k-pair ahead of the MFMAs
-    // (mask 0x100 = DS read, 0x008 = MFMA; LLVM SchedGroupMask)
+    // pin the interleave (0x100 = DS read, 0x008 = MFMA; LLVM SchedGroupMask)
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
     for (int kp = 0; kp < KP; ++kp) {
       if (kp + 1 < KP) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
     }
-    if (step + 1 < nsteps) store_tile(cur ^ 1);
+  };
+
+  if (!DEEP) {
+    load_tile(0, a_st, b_st);
+    store_tile(0, a_st, b_st);
     __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+      const int cur = step & 1;
+      if (step + 1 < nsteps) load_tile(step + 1, a_st, b_st);
+      compute(cur);
+      if (step + 1 < nsteps) store_tile(cur ^ 1, a_st, b_st);
+      __syncthreads();
+    }
+  } else {
+    // tile s lives in LDS buffer s % 3; register stage (s & 1): st for even
+    // tiles, s2 for odd ones.  At step s: issue loads of tile s+2, compute
+    // tile s, park tile s+1 (loaded during step s-1) in LDS.
+    load_tile(0, a_st, b_st);
+    store_tile(0, a_st, b_st);
+    if (nsteps > 1) load_tile(1, a_s2, b_s2);
+    __syncthreads();
+    int buf = 0;  // s % 3
+    for (int step = 0; step < nsteps; step += 2) {
+      int nxt = buf == 2 ? 0 : buf + 1;
+      if (step + 2 < nsteps) load_tile(step + 2, a_st, b_st);
+      compute(buf);
+      if (step + 1 < nsteps) store_tile(nxt, a_s2, b_s2);
+      __syncthreads();
+      if (step + 1 < nsteps) {
+        buf = nxt;
+        nxt = buf == 2 ? 0 : buf + 1;
+        if (step + 3 < nsteps) load_tile(step + 3, a_s2, b_s2);
+        compute(buf);
+        if (step + 2 < nsteps) store_tile(nxt, a_st, b_st);
+        __syncthreads();
+        buf = nxt;
+      }
+    }
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -633,17 +667,23 @@ template <int MODE>
 int launch_igemm(const ConvK& k, hipStream_t stream) {
   const TileCfg c = pick_tile(k);
   const int nb = tile_blocks(k, c);
+  // depth-2 prefetch measured neutral-to-negative on every LD layer shape
+  // (profiles/r01_kernels_s7.json): the kernel is MFMA-pipe / wave-count
+  // bound, not latency bound.  Kept selectable for re-measurement.
+  bool deep = false;
+  if (const char* env = getenv("LD_CONV_DEEP")) deep = atoi(env) != 0;
 #define LD_CONV_CASE(BM_, BN_, BK_)                                               \
   if (c.bm == BM_ && c.bn == BN_ && c.bk == BK_) {                                \
-    hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, BK_, MODE>), dim3(nb),        \
-                       dim3(kThreads), 0, stream, k);                             \
+    if (deep)                                                                     \
+      hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, BK_, MODE, true>), dim3(nb),\
+                         dim3(kThreads), 0, stream, k);                           \
+    else                                                                          \
+      hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, BK_, MODE, false>),         \
+                         dim3(nb), dim3(kThreads), 0, stream, k);                 \
     return (int)hipGetLastError();                                                \
   }
   LD_CONV_CASE(128, 128, 16)
-  LD_CONV_CASE(128, 128, 32)
-  LD_CONV_CASE(128, 64, 16)
   LD_CONV_CASE(128, 64, 32)
-  LD_CONV_CASE(64, 128, 16)
   LD_CONV_CASE(64, 128, 32)
   LD_CONV_CASE(64, 64, 16)
   LD_CONV_CASE(64, 64, 32)
