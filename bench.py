@@ -151,7 +151,7 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world,
                                 device_id=dev)
@@ -225,7 +225,7 @@ def main():
         res['cpu_baseline'] = cpu_baseline(cpu_batch)
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -137,22 +137,31 @@ __device__ __forceinline__ bool tap_offset(const Geo& a, int l, int ho, int wo,
 // 32x32 tiles.  Large tiles (128x128) for big spatial extents; small ones
 // (64x64) keep >= 2 workgroups per CU on the 50x84 / 25x42 stages where a
 // 128x128 tiling would leave half the 256 CUs idle.
-template <int BM, int BNT, int BKT, int MODE, bool DEEP>
-__global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvK a) {
+//
+// KG > 1 = intra-block split-K: the block has KG groups of 4 wavefronts, group g
+// owns k-steps g, g+KG, ... with its own LDS double buffer; the partial
+// accumulators are summed through LDS before the (single) epilogue.  Used when
+// the layer yields too few 64x64 tiles to give every SIMD several waves (the
+// 50x84 / 25x42 stages: PMC shows the MFMA pipe only ~45 % busy at 2
+// waves/SIMD); the tile count, and with it the fused epilogue, is unchanged.
+template <int BM, int BNT, int BKT, int MODE, int KG>
+__global__ __launch_bounds__(kThreads * KG) void conv_igemm_kernel(ConvK a) {
   constexpr int WM = BM / 2, WN = BNT / 2;   // wave tile
   constexpr int TM = WM / 32, TN = WN / 32;  // MFMA tiles per wave
   constexpr int A_PER = BKT * BM / kThreads;   // A floats per thread per step
   constexpr int B_PER = BKT * BNT / kThreads;  // B floats per thread per step
   static_assert(A_PER >= 1 && B_PER >= 1, "tile too small");
-  // DEEP: 3 LDS buffers + two register stages = global loads run TWO k-steps
-  // ahead of the MFMAs (small-spatial layers have only ~2 waves per SIMD, one
-  // step of MFMAs does not cover the L2/HBM latency there)
-  constexpr int NBUF = DEEP ? 3 : 2;
-  __shared__ float lds[NBUF * BKT * (BM + BNT)];
-  float* As = lds;                       // [NBUF][BKT][BM]
-  float* Bs = lds + NBUF * BKT * BM;     // [NBUF][BKT][BNT]
+  constexpr int NBUF = 2;
+  constexpr int GROUP_LDS = NBUF * BKT * (BM + BNT);  // floats per k-group
+  constexpr int NACC = TM * TN * 16;                  // accumulators per thread
+  static_assert(KG == 1 || (KG - 1) * NACC * kThreads <= KG * GROUP_LDS,
+                "split-K reduction does not fit the tile LDS");
+  __shared__ float lds[KG * GROUP_LDS + 2 * BM];
+  const int kg = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kThreads);
+  float* As = lds + kg * GROUP_LDS;      // [NBUF][BKT][BM]
+  float* Bs = As + NBUF * BKT * BM;      // [NBUF][BKT][BNT]
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x % kThreads, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int mtiles = (a.Cout + BM - 1) / BM;
   const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -220,7 +229,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvK a) {
   const int ktot = Cin * ntaps;  // MODE 2: flat (ci, kh, kw) reduction index
   const int nsteps = (MODE == 2) ? (ktot + BKT - 1) / BKT : ntaps * csteps;
   float a_st[A_PER], b_st[B_PER];
-  float a_s2[DEEP ? A_PER : 1], b_s2[DEEP ? B_PER : 1];  // second stage
 
   // Tile loads are raw buffer loads: one 32-bit per-lane voffset (kOOB when the
   // element is padding / outside the tile -> the hardware returns 0), the row
@@ -314,51 +322,42 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvK a) {
     }
   };
 
-  if (!DEEP) {
-    load_tile(0, a_st, b_st);
+  // group kg runs k-steps kg, kg+KG, ...; every group executes the same number
+  // of barriers
+  const int iters = (nsteps + KG - 1) / KG;
+  if (kg < nsteps) {
+    load_tile(kg, a_st, b_st);
     store_tile(0, a_st, b_st);
+  }
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    const int cur = it & 1;
+    const int step = kg + it * KG;
+    const bool more = step + KG < nsteps;
+    if (more) load_tile(step + KG, a_st, b_st);
+    if (step < nsteps) compute(cur);
+    if (more) store_tile(cur ^ 1, a_st, b_st);
     __syncthreads();
-    for (int step = 0; step < nsteps; ++step) {
-      const int cur = step & 1;
-      if (step + 1 < nsteps) load_tile(step + 1, a_st, b_st);
-      compute(cur);
-      if (step + 1 < nsteps) store_tile(cur ^ 1, a_st, b_st);
-      __syncthreads();
-    }
-  } else {
-    // tile s lives in LDS buffer s % 3; register stage (s & 1): st for even
-    // tiles, s2 for odd ones.  At step s: issue loads of tile s+2, compute
-    // tile s, park tile s+1 (loaded during step s-1) in LDS.
-    load_tile(0, a_st, b_st);
-    store_tile(0, a_st, b_st);
-    if (nsteps > 1) load_tile(1, a_s2, b_s2);
-    __syncthreads();
-    int buf = 0;  // s % 3
-    for (int step = 0; step < nsteps; step += 2) {
-      int nxt = buf == 2 ? 0 : buf + 1;
-      if (step + 2 < nsteps) load_tile(step + 2, a_st, b_st);
-      compute(buf);
-      if (step + 1 < nsteps) store_tile(nxt, a_s2, b_s2);
-      __syncthreads();
-      if (step + 1 < nsteps) {
-        buf = nxt;
-        nxt = buf == 2 ? 0 : buf + 1;
-        if (step + 3 < nsteps) load_tile(step + 3, a_s2, b_s2);
-        compute(buf);
-        if (step + 2 < nsteps) store_tile(nxt, a_st, b_st);
-        __syncthreads();
-        buf = nxt;
-      }
-    }
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   // Per-channel affine / bias are staged through LDS once per block (the
   // k-loop's LDS is free now), so the store loop has no dependent global
   // loads; without an affine the defaults (1, 0) make it branch-free.
-  float* s_scale = lds;        // [BM]
-  float* s_shift = lds + BM;   // [BM]  shift (+ bias)
-  if (t < BM) {
+  float* s_scale = lds + KG * GROUP_LDS;  // [BM]
+  float* s_shift = s_scale + BM;          // [BM]  shift (+ bias)
+  if (KG > 1 && kg > 0) {
+    // partial accumulators -> LDS, [group-1][reg][thread] (conflict-free)
+    float* red = lds + (size_t)(kg - 1) * NACC * kThreads + t;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          red[((i * TN + j) * 16 + r) * kThreads] = acc[i][j][r];
+  }
+  if (kg == 0 && t < BM) {
     const int co = m0 + t;
     float sc = 1.0f, sh = 0.0f;
     if (co < a.Cout) {
@@ -372,6 +371,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvK a) {
     s_shift[t] = sh;
   }
   __syncthreads();
+  if (KG > 1) {
+    if (kg > 0) return;
+#pragma unroll
+    for (int g = 1; g < KG; ++g) {
+      const float* red = lds + (size_t)(g - 1) * NACC * kThreads + t;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            acc[i][j][r] += red[((i * TN + j) * 16 + r) * kThreads];
+    }
+  }
   const bool has_res = a.residual != nullptr;
   const bool relu = a.relu != 0;
 #pragma unroll
@@ -667,26 +680,43 @@ template <int MODE>
 int launch_igemm(const ConvK& k, hipStream_t stream) {
   const TileCfg c = pick_tile(k);
   const int nb = tile_blocks(k, c);
-  // depth-2 prefetch measured neutral-to-negative on every LD layer shape
-  // (profiles/r01_kernels_s7.json): the kernel is MFMA-pipe / wave-count
-  // bound, not latency bound.  Kept selectable for re-measurement.
-  bool deep = false;
-  if (const char* env = getenv("LD_CONV_DEEP")) deep = atoi(env) != 0;
+  // intra-block split-K when the grid would leave SIMDs with < ~4 waves
+  int kgroups = 1;
+  if (c.bm == 64 && c.bn == 64 && MODE != 2) {
+    const int ksteps = ((k.Cin + c.bk - 1) / c.bk) * k.KH * k.KW;
+    // measured (profiles/r01_kernels_s9.json): 2 groups pay off only on the
+    // 25x42 stages (~1 workgroup per CU); neutral or negative elsewhere
+    if (nb < 400 && ksteps >= 8) kgroups = 2;
+  }
+  if (const char* env = getenv("LD_CONV_KG")) {
+    const int v = atoi(env);
+    if (v == 1 || ((v == 2 || v == 4) && c.bm == 64 && c.bn == 64 && MODE != 2))
+      kgroups = v;
+  }
+#define LD_CONV_LAUNCH(BM_, BN_, BK_, KG_)                                        \
+  hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, BK_, MODE, KG_>), dim3(nb),     \
+                     dim3(kThreads * KG_), 0, stream, k)
 #define LD_CONV_CASE(BM_, BN_, BK_)                                               \
   if (c.bm == BM_ && c.bn == BN_ && c.bk == BK_) {                                \
-    if (deep)                                                                     \
-      hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, BK_, MODE, true>), dim3(nb),\
-                         dim3(kThreads), 0, stream, k);                           \
-    else                                                                          \
-      hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, BK_, MODE, false>),         \
-                         dim3(nb), dim3(kThreads), 0, stream, k);                 \
+    LD_CONV_LAUNCH(BM_, BN_, BK_, 1);                                             \
     return (int)hipGetLastError();                                                \
+  }
+  if (c.bm == 64 && c.bn == 64 && kgroups > 1) {
+    if (c.bk == 32) {
+      if (kgroups == 2) LD_CONV_LAUNCH(64, 64, 32, 2);
+      else LD_CONV_LAUNCH(64, 64, 16, 4);  // 4 groups: 16-deep slices (LDS)
+    } else {
+      if (kgroups == 2) LD_CONV_LAUNCH(64, 64, 16, 2);
+      else LD_CONV_LAUNCH(64, 64, 16, 4);
+    }
+    return (int)hipGetLastError();
   }
   LD_CONV_CASE(128, 128, 16)
   LD_CONV_CASE(128, 64, 32)
   LD_CONV_CASE(64, 128, 32)
   LD_CONV_CASE(64, 64, 16)
   LD_CONV_CASE(64, 64, 32)
+#undef LD_CONV_LAUNCH
 #undef LD_CONV_CASE
   return LD_EUNSUPPORTED;
 }

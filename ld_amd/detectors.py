@@ -92,8 +92,8 @@ class SingleStageDetector(nn.Module):
         sel = [i for i, k in enumerate(names) if 'loss' in k]
         loss = key_sums[sel].sum()
         logged = torch.cat([key_sums.detach(), loss.detach().reshape(1)])
-        if dist.is_available() and dist.is_initialized() and \
-                dist.get_world_size() > 1:
+        from .train import collectives_on
+        if collectives_on():
             logged = logged.clone()
             dist.all_reduce(logged.div_(dist.get_world_size()))
         log_vars = LazyScalars(names + ['loss'], logged)

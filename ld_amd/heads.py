@@ -276,8 +276,8 @@ class GFLHead(nn.Module):
         side all-reduce instead of the reference's two reduce_mean(...).item()
         host syncs (ld_head.py:338-341,362-363)."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or \
-                dist.get_world_size() == 1:
+        from .train import collectives_on
+        if not collectives_on():
             return None
         ws = float(dist.get_world_size())
 

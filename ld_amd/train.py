@@ -21,6 +21,8 @@ torch's per-tensor allocations:
 The reducer itself is device-agnostic torch.distributed code (tested on gloo
 with 2 CPU processes); the optimizer launch is the HIP kernel.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -31,6 +33,16 @@ def _world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_world_size()
     return 1
+
+
+def collectives_on():
+    """True when gradient / scalar collectives must be issued.  With
+    LD_FORCE_COLLECTIVES=1 they are issued even in a 1-rank group, which lets
+    the RCCL code path be exercised on a single-GPU box."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or \
+        os.environ.get('LD_FORCE_COLLECTIVES', '0') == '1'
 
 
 class GradArena:
@@ -88,7 +100,7 @@ class GradArena:
             return
         b = self.bucket_of[id(p)]
         self._ready[b] += 1
-        if self._ready[b] == self.buckets[b]['n'] and _world() > 1:
+        if self._ready[b] == self.buckets[b]['n'] and collectives_on():
             bk = self.buckets[b]
             self._works.append(
                 dist.all_reduce(self.flat_grad[bk['start']:bk['end']],
@@ -98,7 +110,7 @@ class GradArena:
         """Wait for the in-flight bucket reductions (sums, not yet averaged).
         Buckets whose parameters received no gradient this step are reduced
         here so every rank issues the same collectives."""
-        if _world() > 1:
+        if collectives_on():
             for b, bk in enumerate(self.buckets):
                 if self._ready[b] != bk['n']:
                     self._works.append(

@@ -99,11 +99,13 @@ def bench_conv_tiles(out):
         flops = 2.0 * N * y.shape[2] * cout * cin * k * k
         r = dict(name=name, J=N * y.shape[2], cout=cout, K=cin * k * k)
         os.environ.pop('LD_CONV_TILE', None)
-        for deep in ('0', '1'):
-            os.environ['LD_CONV_DEEP'] = deep
+        t = timeit(lambda: Y.conv_forward_raw(x, w, stride, pad, levels))
+        r['auto'] = round(flops / t / 1e12, 1)
+        for kg in ('1', '2', '4'):
+            os.environ['LD_CONV_KG'] = kg
             t = timeit(lambda: Y.conv_forward_raw(x, w, stride, pad, levels))
-            r['auto_deep' + deep] = round(flops / t / 1e12, 1)
-        os.environ.pop('LD_CONV_DEEP', None)
+            r['kg' + kg] = round(flops / t / 1e12, 1)
+        os.environ.pop('LD_CONV_KG', None)
         for tile in TILES if os.environ.get('LD_SWEEP_TILES') else []:
             if cout <= 64 and tile.startswith('128'):
                 continue
