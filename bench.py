@@ -180,6 +180,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = trainer.step(dbatch)
+    t_enq = time.perf_counter() - t0  # host time to enqueue K steps
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -209,6 +210,7 @@ def main():
                 'parallelism': f'dp{world}',
                 'optimizer': 'SGD(momentum 0.9, wd 1e-4), step included',
                 'last_loss': loss_val,
+                'host_enqueue_ms_per_step': t_enq / args.steps * 1e3,
             },
         }
     # kernel-level legs (rank 0 / single GPU only: they are per-device figures)

@@ -348,9 +348,9 @@ class ATSSAssigner:
                torch.zeros(G, dtype=torch.int64, device=dev))
         gtl = gtl.reshape(1, G).contiguous() if G else torch.zeros(
             (1, 1), dtype=torch.int64, device=dev)
-        ng = torch.tensor([G], dtype=torch.int32).to(dev)
-        vhw = torch.tensor([[int(n), 1] for n in num_level_bboxes],
-                           dtype=torch.int32).to(dev)
+        ng = LB._small_int_tensor((G, ), dev)
+        vhw = LB._small_int_tensor(
+            tuple((int(n), 1) for n in num_level_bboxes), dev)
         out = dict(
             labels=torch.empty((1, A), dtype=torch.int64, device=dev),
             lw=torch.empty((1, A), device=dev),

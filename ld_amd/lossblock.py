@@ -54,6 +54,26 @@ def valid_hw_from_metas(featmap_sizes, strides, img_metas):
     return rows
 
 
+_INT_CACHE = {}
+
+
+def _small_int_tensor(values, device):
+    """Host integers -> device int32 tensor WITHOUT a synchronising pageable
+    H2D copy (which would stall the host until the whole forward has drained):
+    values seen before are served from a cache, new ones go through pinned
+    memory with a non-blocking copy."""
+    key = (str(device), values)
+    t = _INT_CACHE.get(key)
+    if t is None:
+        if len(_INT_CACHE) > 4096:
+            _INT_CACHE.clear()
+        host = torch.tensor(values, dtype=torch.int32).pin_memory()
+        t = host.to(device, non_blocking=True)
+        _INT_CACHE[key] = (t, host)  # keep the pinned source alive
+        return t
+    return t[0]
+
+
 def atss_targets(featmap_sizes, strides, img_metas, gt_bboxes, gt_labels, hp,
                  device, anchor_scale=8):
     """Dense ATSS / VLR / IM targets for a batch (see ld_atss_targets in
@@ -72,9 +92,10 @@ def atss_targets(featmap_sizes, strides, img_metas, gt_bboxes, gt_labels, hp,
             L.require_device(b, torch.float32, 'gt_bboxes')
             gtb[i, :num_gt[i]] = b
             gtl[i, :num_gt[i]] = l
-    ng = torch.tensor(num_gt, dtype=torch.int32).to(device)
-    vhw = torch.tensor(valid_hw_from_metas(featmap_sizes, strides, img_metas),
-                       dtype=torch.int32).to(device)
+    ng = _small_int_tensor(tuple(num_gt), device)
+    vhw = _small_int_tensor(
+        tuple(tuple(r) for r in valid_hw_from_metas(featmap_sizes, strides,
+                                                    img_metas)), device)
     out = dict(
         labels=torch.empty((N, A), dtype=torch.int64, device=device),
         label_weights=torch.empty((N, A), dtype=torch.float32, device=device),
