@@ -100,23 +100,32 @@ def ldkl_roofline(dev):
     for _ in range(3):
         LB.kl_integral_dense(s, t, w, 10.0, 1.0, True)
     torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(
-        enable_timing=True)
-    iters = 10
-    a.record()
-    for _ in range(iters):
+    iters = 11
+    evs = [(torch.cuda.Event(enable_timing=True),
+            torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
         LB.kl_integral_dense(s, t, w, 10.0, 1.0, True)
-    b.record()
+        b.record()
     torch.cuda.synchronize()
-    dt = a.elapsed_time(b) * 1e-3 / iters
+    ts = sorted(a.elapsed_time(b) * 1e-3 for a, b in evs)
+    dt = ts[len(ts) // 2]  # median launch duration
     # algorithmic bytes per anchor-side row: 136 logits in + 4 weight + 4
     # integral out + 4 loss out + 68 grad out = 216 B
     nbytes = rows * 4 * 216.0
     ach = nbytes / dt / 1e9
     return dict(kernel='kl_integral_dense (fused LD-KL + Integral fwd+grad)',
                 bound='hbm', achieved=ach, peak=PEAK_HBM_GBPS, unit='GB/s',
-                frac=ach / PEAK_HBM_GBPS, traffic=None, rows=rows * 4,
-                bytes_per_row=216, us=dt * 1e6)
+                frac=ach / PEAK_HBM_GBPS,
+                # PMC pass (profiles/r01_pmc_traffic/kl_*.csv): WRITE_SIZE
+                # 1 245 184 KB + 2 x FETCH_SIZE 1 122 379 KB (gfx950 FETCH_SIZE
+                # counts half the bytes of a coalesced stream,
+                # MI355X_MICROARCH.md "HBM") = 3.57 GB per launch vs 3.62 GB
+                # algorithmic: no wasted re-reads
+                traffic=(1245184 + 2 * 1122379) * 1024.0,
+                traffic_source='profiles/r01_pmc_traffic (separate --pmc '
+                               'passes, same kernel and size)',
+                rows=rows * 4, bytes_per_row=216, us=dt * 1e6)
 
 
 def cpu_baseline(batch, sdepth=50, tdepth=101):
