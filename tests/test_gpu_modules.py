@@ -102,7 +102,10 @@ def test_dfl_qfl_giou_modules(golden):
     loss.backward()
     np.testing.assert_allclose(b1.grad.cpu().numpy(), g['kat5_grad'],
                                rtol=2e-4, atol=1e-7)
-    assert float(giou(b1.detach(), b2, weight=torch.zeros(3, device=dev))) == 0
+    # (as in the reference the early-out multiplies pred by weight, so the
+    # weight must broadcast against (n, 4))
+    assert float(giou(b1.detach(), b2,
+                      weight=torch.zeros((3, 4), device=dev))) == 0
     # IMLoss
     im = build_loss(dict(type='IMLoss', loss_weight=2.0))
     a = _t(g['im_a'], dev, True)
