@@ -87,6 +87,13 @@ struct ConvK {  // kernel-side view of ld_conv_t + pointers
   int J;  // N * Pout
   int Kpad;               // rows per tap of the weight image (Cin rounded up)
   unsigned x_bytes, wt_bytes;  // buffer-descriptor extents
+  // MODE 1 (data-gradient of a stride-2 conv, one output-parity class per
+  // launch): g.lv[].Hout/Wout/off_out describe the COMPACT grid of the class;
+  // the class is (ph, pw); only taps kh = kh0 + 2*i (i < nth), kw = kw0 + 2*j
+  // (j < ntw) reach it; input row = hc + ch0 + i, col = wc + cw0 + j.
+  int ph, pw, kh0, kw0, nth, ntw, ch0, cw0;
+  int Pfull;                       // positions per (n, c) row of the output
+  int fW[LD_MAX_LEVELS], foff[LD_MAX_LEVELS];  // full output row length/offset
   Geo g;
 };
 
@@ -183,22 +190,17 @@ __global__ __launch_bounds__(kThreads * KG) void conv_igemm_kernel(ConvK a) {
     bWin = a.g.lv[bl].Win;
     boff = n * a.Cin * a.Pin + a.g.lv[bl].off_in;  // element index of (n, 0, level)
     if (MODE == 1) {
-      bh0 = bho - a.g.pad;
-      bw0 = bwo - a.g.pad;
+      bh0 = bho + a.ch0;
+      bw0 = bwo + a.cw0;
     } else {
       bh0 = bho * a.g.stride - a.g.pad;
       bw0 = bwo * a.g.stride - a.g.pad;
     }
   }
-  // input offset of tap (kh, kw) for this column, or false when it falls in
-  // the padding (MODE 1: or between the dilated samples of a stride-2 dgrad)
+  // input offset of tap (kh, kw) for this column (MODE 1: of the class's tap
+  // (i, j)), or false when it falls in the padding
   auto tap_off = [&](int kh, int kw, int& off) -> bool {
-    int hi = bh0 + kh, wi = bw0 + kw;
-    if (MODE == 1) {
-      if ((hi | wi) < 0 || ((hi | wi) & 1)) return false;
-      hi >>= 1;
-      wi >>= 1;
-    }
+    const int hi = bh0 + kh, wi = bw0 + kw;
     if (hi < 0 || hi >= bHin || wi < 0 || wi >= bWin) return false;
     off = boff + hi * bWin + wi;
     return true;
@@ -224,7 +226,8 @@ __global__ __launch_bounds__(kThreads * KG) void conv_igemm_kernel(ConvK a) {
   const int Cout = __builtin_amdgcn_readfirstlane(a.Cout);
   const int KW = __builtin_amdgcn_readfirstlane(a.KW);
   const int Pin = __builtin_amdgcn_readfirstlane(a.Pin);
-  const int ntaps = __builtin_amdgcn_readfirstlane(a.KH * a.KW);
+  const int ntaps = __builtin_amdgcn_readfirstlane(
+      MODE == 1 ? a.nth * a.ntw : a.KH * a.KW);
   const int csteps = (Cin + BKT - 1) / BKT;
   const int ktot = Cin * ntaps;  // MODE 2: flat (ci, kh, kw) reduction index
   const int nsteps = (MODE == 2) ? (ktot + BKT - 1) / BKT : ntaps * csteps;
@@ -259,8 +262,18 @@ __global__ __launch_bounds__(kThreads * KG) void conv_igemm_kernel(ConvK a) {
       }
       return;
     }
-    const int tap = step / csteps, ci0 = (step - tap * csteps) * BKT;
-    const int kh = tap / KW, kw = tap - kh * KW;
+    int tap = step / csteps;
+    const int ci0 = (step - tap * csteps) * BKT;
+    int kh, kw;
+    if (MODE == 1) {  // class-local tap (i, j) -> weight-image tap
+      const int ntw = __builtin_amdgcn_readfirstlane(a.ntw);
+      kh = tap / ntw;
+      kw = tap - kh * ntw;
+      tap = (a.kh0 + 2 * kh) * KW + a.kw0 + 2 * kw;
+    } else {
+      kh = tap / KW;
+      kw = tap - kh * KW;
+    }
     int off = 0;
     const bool ok = jvalid && tap_off(kh, kw, off);
     const unsigned vb = ok ? (unsigned)off * 4u : kOOB;
@@ -391,8 +404,16 @@ __global__ __launch_bounds__(kThreads * KG) void conv_igemm_kernel(ConvK a) {
   for (int j = 0; j < TN; ++j) {
     const int jc = n0 + wn * WN + j * 32 + l31;
     if (jc >= a.J) continue;
-    const int n = jc / a.Pout, p = jc - n * a.Pout;
-    const size_t colbase = (size_t)n * a.Cout * a.Pout + p;
+    const int n = jc / a.Pout;
+    int p = jc - n * a.Pout;
+    int prow = a.Pout;  // positions per (n, c) row of y
+    if (MODE == 1) {    // compact class position -> full output position
+      int l, hc, wc;
+      locate_out(a.g, p, l, hc, wc);
+      p = a.foff[l] + (2 * hc + a.ph) * a.fW[l] + 2 * wc + a.pw;
+      prow = a.Pfull;
+    }
+    const size_t colbase = (size_t)n * a.Cout * prow + p;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int rbase = wm * WM + i * 32 + 4 * lk;
@@ -402,7 +423,7 @@ __global__ __launch_bounds__(kThreads * KG) void conv_igemm_kernel(ConvK a) {
         for (int r = 0; r < 16; ++r) {
           const int row = rbase + (r & 3) + 8 * (r >> 2);
           res[r] = (m0 + row < a.Cout)
-                       ? a.residual[colbase + (size_t)(m0 + row) * a.Pout]
+                       ? a.residual[colbase + (size_t)(m0 + row) * prow]
                        : 0.0f;
         }
       }
@@ -413,7 +434,7 @@ __global__ __launch_bounds__(kThreads * KG) void conv_igemm_kernel(ConvK a) {
         float v = acc[i][j][r] * s_scale[row] + s_shift[row];
         if (has_res) v += res[r];
         if (relu) v = fmaxf(v, 0.0f);
-        a.y[colbase + (size_t)(m0 + row) * a.Pout] = v;
+        a.y[colbase + (size_t)(m0 + row) * prow] = v;
       }
     }
   }
@@ -805,11 +826,15 @@ extern "C" int ld_conv_forward_smallc(const ld_conv_t* c, const float* x,
 
 // dx = conv_transpose(dy): runs the same implicit GEMM with the roles of the
 // channel dims swapped, the flipped-tap weight image and pad' = K - 1 - pad.
+// Stride 2: the output positions are split into their four (row, col) parity
+// classes; each class sees only the taps of matching parity (1, 2, 2 or 4 of
+// the 9 for a 3x3), so no MFMA work is spent on the dilation zeros.
 extern "C" int ld_conv_dgrad(const ld_conv_t* c, const float* dy,
-                             const float* wt_bwd, float* dx, ld_stream_t stream) {
+                             const float* wt_bwd, float* dx, ld_stream_t stream_) {
   if (int e = check_conv(c)) return e;
   if (!dy || !wt_bwd || !dx) return LD_EINVAL;
   if (c->KH != c->KW) return LD_EUNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
   ConvK k;
   k.x = dy;
   k.wt = wt_bwd;
@@ -827,12 +852,61 @@ extern "C" int ld_conv_dgrad(const ld_conv_t* c, const float* dy,
     k.g.lv[l].Hout = c->lv[l].Hin; k.g.lv[l].Wout = c->lv[l].Win;
     k.g.lv[l].off_in = c->lv[l].off_out; k.g.lv[l].off_out = c->lv[l].off_in;
   }
+  k.ph = k.pw = k.kh0 = k.kw0 = k.nth = k.ntw = k.ch0 = k.cw0 = 0;
+  k.Pfull = c->Pin;
+  for (int l = 0; l < LD_MAX_LEVELS; ++l) {
+    k.fW[l] = c->lv[l].Win;
+    k.foff[l] = c->lv[l].off_in;
+  }
   k.Kpad = kpad_rows(c->Cout);
   if (int e = set_extents(k, (size_t)c->N * c->Cout * c->Pout,
                           (size_t)c->KH * c->KW * k.Kpad * c->Cin))
     return e;
-  if (c->stride == 1) return launch_igemm<0>(k, (hipStream_t)stream);
-  return launch_igemm<1>(k, (hipStream_t)stream);
+  if (c->stride == 1) return launch_igemm<0>(k, stream);
+
+  const int padp = c->KH - 1 - c->pad;
+  // a class no tap reaches (1x1 stride 2: every odd row / column) is all
+  // zeros: clear dx up front, then launch only the classes that have taps
+  bool any_empty = false;
+  for (int ph = 0; ph < 2; ++ph) {
+    const int k0 = ((ph - padp) % 2 + 2) % 2;
+    if (k0 >= c->KH) any_empty = true;
+  }
+  if (any_empty) {
+    hipError_t err = hipMemsetAsync(
+        dx, 0, (size_t)c->N * c->Cin * c->Pin * sizeof(float), stream);
+    if (err) return (int)err;
+  }
+  for (int ph = 0; ph < 2; ++ph)
+    for (int pw = 0; pw < 2; ++pw) {
+      ConvK q = k;
+      q.ph = ph;
+      q.pw = pw;
+      // taps with (ph - pad' + kh) even
+      q.kh0 = ((ph - padp) % 2 + 2) % 2;
+      q.kw0 = ((pw - padp) % 2 + 2) % 2;
+      q.nth = q.kh0 < c->KH ? (c->KH - q.kh0 + 1) / 2 : 0;
+      q.ntw = q.kw0 < c->KW ? (c->KW - q.kw0 + 1) / 2 : 0;
+      q.ch0 = (ph - padp + q.kh0) / 2;  // exact: the numerator is even
+      q.cw0 = (pw - padp + q.kw0) / 2;
+      int pc = 0;
+      bool empty = false;
+      for (int l = 0; l < c->num_levels; ++l) {
+        const int Hc = (c->lv[l].Hin - ph + 1) / 2, Wc = (c->lv[l].Win - pw + 1) / 2;
+        q.g.lv[l].Hout = Hc;
+        q.g.lv[l].Wout = Wc;
+        q.g.lv[l].off_out = pc;
+        if (Hc <= 0 || Wc <= 0) empty = true;
+        pc += max(Hc, 0) * max(Wc, 0);
+      }
+      if (empty && c->num_levels > 1) return LD_EUNSUPPORTED;
+      if (pc == 0) continue;
+      q.Pout = pc;
+      q.J = c->N * pc;
+      if (q.nth * q.ntw == 0) continue;  // zero class, cleared above
+      if (int e = launch_igemm<1>(q, stream)) return e;
+    }
+  return 0;
 }
 
 static int wgrad_splits(const ld_conv_t* c) {
