@@ -86,6 +86,7 @@ struct ConvK {  // kernel-side view of ld_conv_t + pointers
   int Pin, Pout;
   int J;  // N * Pout
   int Kpad;               // rows per tap of the weight image (Cin rounded up)
+  int pipe;               // use the software-pipelined main loop
   unsigned x_bytes, wt_bytes;  // buffer-descriptor extents
   // MODE 1 (data-gradient of a stride-2 conv, one output-parity class per
   // launch): g.lv[].Hout/Wout/off_out describe the COMPACT grid of the class;
@@ -151,25 +152,28 @@ __device__ __forceinline__ bool tap_offset(const Geo& a, int l, int ho, int wo,
 // the layer yields too few 64x64 tiles to give every SIMD several waves (the
 // 50x84 / 25x42 stages: PMC shows the MFMA pipe only ~45 % busy at 2
 // waves/SIMD); the tile count, and with it the fused epilogue, is unchanged.
-template <int BM, int BNT, int BKT, int MODE, int KG>
-__global__ __launch_bounds__(kThreads * KG) void conv_igemm_kernel(ConvK a) {
-  constexpr int WM = BM / 2, WN = BNT / 2;   // wave tile
+template <int BM, int BNT, int BKT, int MODE, int KG, int WVM, int WVN>
+__global__ __launch_bounds__(64 * WVM * WVN * KG) void conv_igemm_kernel(ConvK a) {
+  // WVM x WVN wavefronts per k-group (2 x 2, or 1 x 2 for the 32 x 64 tile that
+  // doubles the workgroup count on the small-spatial stages)
+  constexpr int NT = 64 * WVM * WVN;          // threads per k-group
+  constexpr int WM = BM / WVM, WN = BNT / WVN;  // wave tile
   constexpr int TM = WM / 32, TN = WN / 32;  // MFMA tiles per wave
-  constexpr int A_PER = BKT * BM / kThreads;   // A floats per thread per step
-  constexpr int B_PER = BKT * BNT / kThreads;  // B floats per thread per step
+  constexpr int A_PER = BKT * BM / NT;   // A floats per thread per step
+  constexpr int B_PER = BKT * BNT / NT;  // B floats per thread per step
   static_assert(A_PER >= 1 && B_PER >= 1, "tile too small");
   constexpr int NBUF = 2;
   constexpr int GROUP_LDS = NBUF * BKT * (BM + BNT);  // floats per k-group
   constexpr int NACC = TM * TN * 16;                  // accumulators per thread
-  static_assert(KG == 1 || (KG - 1) * NACC * kThreads <= KG * GROUP_LDS,
+  static_assert(KG == 1 || (KG - 1) * NACC * NT <= KG * GROUP_LDS,
                 "split-K reduction does not fit the tile LDS");
   __shared__ float lds[KG * GROUP_LDS + 2 * BM];
-  const int kg = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kThreads);
+  const int kg = __builtin_amdgcn_readfirstlane((int)threadIdx.x / NT);
   float* As = lds + kg * GROUP_LDS;      // [NBUF][BKT][BM]
   float* Bs = As + NBUF * BKT * BM;      // [NBUF][BKT][BNT]
 
-  const int t = threadIdx.x % kThreads, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int t = threadIdx.x % NT, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WVN, wn = wave % WVN;
   const int mtiles = (a.Cout + BM - 1) / BM;
   const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
   const int m0 = (tile % mtiles) * BM;
@@ -207,11 +211,17 @@ __global__ __launch_bounds__(kThreads * KG) void conv_igemm_kernel(ConvK a) {
   };
   // first k row this thread loads for B / A: wave-uniform (a wave never spans
   // two row groups), pinned to SGPRs so the row offsets go in `soffset`
+  static_assert(BNT >= 64, "B row groups must be wave-uniform");
   const int bk0 = __builtin_amdgcn_readfirstlane((t / BNT) * B_PER);
   // ---- this thread's A column (output channel) ------------------------
   const int am = t % BM;
   const bool avalid = (m0 + am) < a.Cout;
-  const int ak0 = __builtin_amdgcn_readfirstlane((t / BM) * A_PER);
+  // A row group = wave-uniform part (soffset) + lane part (only when BM < 64:
+  // the two half-waves own different row groups; goes into voffset -- safe on
+  // the A side because the weight image is zero-padded to 32 k-rows)
+  const int ak0s = __builtin_amdgcn_readfirstlane(((wave * 64) / BM) * A_PER);
+  const int ak0v = (BM < 64) ? (lane / BM) * A_PER : 0;
+  const int ak0 = ak0s + ak0v;
 
   floatx16 acc[TM][TN];
 #pragma unroll
@@ -241,14 +251,15 @@ __global__ __launch_bounds__(kThreads * KG) void conv_igemm_kernel(ConvK a) {
   const rsrc_t rx = make_rsrc(a.x, a.x_bytes);
   const rsrc_t rw = make_rsrc(a.wt, a.wt_bytes);
   const int Kpad = __builtin_amdgcn_readfirstlane(a.Kpad);
-  const unsigned va = avalid ? (unsigned)(m0 + am) * 4u : kOOB;
+  const unsigned va =
+      avalid ? (unsigned)(m0 + am + ak0v * Cout) * 4u : kOOB;
   auto load_tile = [&](int step, float* ra, float* rb) {
     if (MODE == 2) {
       // small-Cin (stem) im2col: every k row has its own (ci, kh, kw)
       const int k0 = step * BKT;
 #pragma unroll
       for (int i = 0; i < A_PER; ++i)
-        ra[i] = buf_load(rw, va, (unsigned)(k0 + ak0 + i) * Cout * 4u);
+        ra[i] = buf_load(rw, va, (unsigned)(k0 + ak0s + i) * Cout * 4u);
 #pragma unroll
       for (int i = 0; i < B_PER; ++i) {
         const int k = k0 + bk0 + i;          // scalar
@@ -277,7 +288,7 @@ __global__ __launch_bounds__(kThreads * KG) void conv_igemm_kernel(ConvK a) {
     int off = 0;
     const bool ok = jvalid && tap_off(kh, kw, off);
     const unsigned vb = ok ? (unsigned)off * 4u : kOOB;
-    const unsigned sa = (unsigned)(tap * Kpad + ci0 + ak0) * Cout * 4u;
+    const unsigned sa = (unsigned)(tap * Kpad + ci0 + ak0s) * Cout * 4u;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i)
       ra[i] = buf_load(rw, va, sa + (unsigned)i * Cout * 4u);
@@ -335,6 +346,82 @@ __global__ __launch_bounds__(kThreads * KG) void conv_igemm_kernel(ConvK a) {
     }
   };
 
+  // ---- software-pipelined main loop (KG == 1) ---------------------------
+  // Per k-step the plain loop pays, between the last MFMA of tile s and the
+  // first of tile s+1: ds_write + barrier + first ds_read latency -- a bubble
+  // that only other resident workgroups can fill (PMC: pipe 45 % busy at ~2
+  // waves/SIMD).  Here instead
+  //   * global loads run two tiles ahead (two register stages),
+  //   * tile s+1 is written to LDS in the MIDDLE of tile s's MFMAs,
+  //   * the barrier and the first fragment reads of tile s+1 are issued before
+  //     the last two k-pairs of tile s, whose MFMAs cover that latency.
+  constexpr bool PIPE = (KG == 1) && (MODE != 2) && (KP >= 8);
+  bool use_pipe = PIPE && a.pipe;
+  if (use_pipe) {
+    float a_s2[A_PER], b_s2[B_PER];
+    float f0a[TM], f0b[TN];  // fragments of k-pair 0 of the current tile
+    constexpr int WPOS = KP / 2;  // k-pair after which tile s+1 goes to LDS
+    auto frag0 = [&](int buf) {
+      const float* ap = As + buf * BKT * BM + wm * WM + l31;
+      const float* bp = Bs + buf * BKT * BNT + wn * WN + l31;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) f0a[i] = ap[lk * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) f0b[j] = bp[lk * BNT + j * 32];
+    };
+    // one pipelined k-step: tile in `buf`; `wa/wb` = register stage holding
+    // tile s+1 (written to buf^1 mid-step when has_next)
+    auto pstep = [&](int buf, bool has_next, const float* wa, const float* wb) {
+      const float* ap = As + buf * BKT * BM + wm * WM + l31;
+      const float* bp = Bs + buf * BKT * BNT + wn * WN + l31;
+      float af[2][TM], bf[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[0][i] = f0a[i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[0][j] = f0b[j];
+#pragma unroll
+      for (int kp = 0; kp < KP; ++kp) {
+        const int c = kp & 1;
+        if (kp + 1 < KP) {
+          const int kr = 2 * (kp + 1) + lk;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[c ^ 1][i] = ap[kr * BM + i * 32];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bf[c ^ 1][j] = bp[kr * BNT + j * 32];
+        }
+        if (kp == WPOS && has_next) store_tile(buf ^ 1, wa, wb);
+        if (kp == KP - 2) {
+          // every fragment of this tile has been requested; after the barrier
+          // nobody reads `buf` any more and tile s+1 is complete in buf^1
+          __syncthreads();
+          if (has_next) frag0(buf ^ 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i], bf[c][j],
+                                                             acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    load_tile(0, a_st, b_st);
+    store_tile(0, a_st, b_st);
+    if (nsteps > 1) load_tile(1, a_s2, b_s2);  // stage B <- tile 1
+    __syncthreads();
+    frag0(0);
+    for (int step = 0; step < nsteps; step += 2) {
+      // even step: tile `step` in buffer 0; tile step+1 waits in stage B
+      if (step + 2 < nsteps) load_tile(step + 2, a_st, b_st);
+      pstep(0, step + 1 < nsteps, a_s2, b_s2);
+      if (step + 1 < nsteps) {
+        // odd step: tile step+1 in buffer 1; tile step+2 waits in stage A
+        if (step + 3 < nsteps) load_tile(step + 3, a_s2, b_s2);
+        pstep(1, step + 2 < nsteps, a_st, b_st);
+      }
+    }
+  } else {
   // group kg runs k-steps kg, kg+KG, ...; every group executes the same number
   // of barriers
   const int iters = (nsteps + KG - 1) / KG;
@@ -352,6 +439,8 @@ __global__ __launch_bounds__(kThreads * KG) void conv_igemm_kernel(ConvK a) {
     if (more) store_tile(cur ^ 1, a_st, b_st);
     __syncthreads();
   }
+  }
+  __syncthreads();
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   // Per-channel affine / bias are staged through LDS once per block (the
@@ -361,14 +450,14 @@ __global__ __launch_bounds__(kThreads * KG) void conv_igemm_kernel(ConvK a) {
   float* s_shift = s_scale + BM;          // [BM]  shift (+ bias)
   if (KG > 1 && kg > 0) {
     // partial accumulators -> LDS, [group-1][reg][thread] (conflict-free)
-    float* red = lds + (size_t)(kg - 1) * NACC * kThreads + t;
+    float* red = lds + (size_t)(kg - 1) * NACC * NT + t;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          red[((i * TN + j) * 16 + r) * kThreads] = acc[i][j][r];
+          red[((i * TN + j) * 16 + r) * NT] = acc[i][j][r];
   }
   if (kg == 0 && t < BM) {
     const int co = m0 + t;
@@ -388,14 +477,14 @@ __global__ __launch_bounds__(kThreads * KG) void conv_igemm_kernel(ConvK a) {
     if (kg > 0) return;
 #pragma unroll
     for (int g = 1; g < KG; ++g) {
-      const float* red = lds + (size_t)(g - 1) * NACC * kThreads + t;
+      const float* red = lds + (size_t)(g - 1) * NACC * NT + t;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            acc[i][j][r] += red[((i * TN + j) * 16 + r) * kThreads];
+            acc[i][j][r] += red[((i * TN + j) * 16 + r) * NT];
     }
   }
   const bool has_res = a.residual != nullptr;
@@ -698,7 +787,10 @@ inline int set_extents(ConvK& k, size_t x_floats, size_t wt_floats) {
 }
 
 template <int MODE>
-int launch_igemm(const ConvK& k, hipStream_t stream) {
+int launch_igemm(const ConvK& k_in, hipStream_t stream) {
+  ConvK k = k_in;
+  k.pipe = 1;
+  if (const char* env = getenv("LD_CONV_PIPE")) k.pipe = atoi(env) != 0;
   const TileCfg c = pick_tile(k);
   const int nb = tile_blocks(k, c);
   // intra-block split-K when the grid would leave SIMDs with < ~4 waves
@@ -715,8 +807,8 @@ int launch_igemm(const ConvK& k, hipStream_t stream) {
       kgroups = v;
   }
 #define LD_CONV_LAUNCH(BM_, BN_, BK_, KG_)                                        \
-  hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, BK_, MODE, KG_>), dim3(nb),     \
-                     dim3(kThreads * KG_), 0, stream, k)
+  hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, BK_, MODE, KG_, 2, 2>),         \
+                     dim3(nb), dim3(kThreads * KG_), 0, stream, k)
 #define LD_CONV_CASE(BM_, BN_, BK_)                                               \
   if (c.bm == BM_ && c.bn == BN_ && c.bk == BK_) {                                \
     LD_CONV_LAUNCH(BM_, BN_, BK_, 1);                                             \
@@ -730,6 +822,15 @@ int launch_igemm(const ConvK& k, hipStream_t stream) {
       if (kgroups == 2) LD_CONV_LAUNCH(64, 64, 16, 2);
       else LD_CONV_LAUNCH(64, 64, 16, 4);
     }
+    return (int)hipGetLastError();
+  }
+  if (c.bm == 32 && c.bn == 64) {  // 2-wavefront workgroups
+    if (c.bk == 32)
+      hipLaunchKernelGGL((conv_igemm_kernel<32, 64, 32, MODE, 1, 1, 2>), dim3(nb),
+                         dim3(128), 0, stream, k);
+    else
+      hipLaunchKernelGGL((conv_igemm_kernel<32, 64, 16, MODE, 1, 1, 2>), dim3(nb),
+                         dim3(128), 0, stream, k);
     return (int)hipGetLastError();
   }
   LD_CONV_CASE(128, 128, 16)

@@ -101,11 +101,13 @@ def bench_conv_tiles(out):
         os.environ.pop('LD_CONV_TILE', None)
         t = timeit(lambda: Y.conv_forward_raw(x, w, stride, pad, levels))
         r['auto'] = round(flops / t / 1e12, 1)
-        for kg in ('1', '2', '4'):
-            os.environ['LD_CONV_KG'] = kg
+        for tile in ('64x64x32', '32x64x32', '32x64x16'):
+            os.environ['LD_CONV_TILE'] = tile
+            os.environ['LD_CONV_KG'] = '1'
             t = timeit(lambda: Y.conv_forward_raw(x, w, stride, pad, levels))
-            r['kg' + kg] = round(flops / t / 1e12, 1)
+            r[tile] = round(flops / t / 1e12, 1)
         os.environ.pop('LD_CONV_KG', None)
+        os.environ.pop('LD_CONV_TILE', None)
         for tile in TILES if os.environ.get('LD_SWEEP_TILES') else []:
             if cout <= 64 and tile.startswith('128'):
                 continue
