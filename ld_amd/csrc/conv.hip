@@ -32,6 +32,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "../../include/ld_hip.h"
 
 namespace {
@@ -529,6 +532,202 @@ __global__ __launch_bounds__(64 * WVM * WVN * KG) void conv_igemm_kernel(ConvK a
   }
 }
 
+// ------------------------------------------------- forward/dgrad, streaming
+// LDS-free variant.  The 32x32x2 MFMA operand layouts are directly loadable:
+//   A (weights) lane l <- Wt[tap][ci + (l>>5)][co0 + (l&31)]   2 x 128 B rows
+//   B (pixels)  lane l <- X[n][ci + (l>>5)][pos(j0 + (l&31))]  2 x 128 B rows
+// so LDS is not needed as a layout transformer, and fp32 MFMA is slow enough
+// (256 flop/clk/CU) that a wavefront owning a (TM*32) x (TN*32) register tile
+// needs only (TM+TN)*256 B per TM*TN*64 MFMA cycles from L1/L2 -- 16 B/clk/CU
+// at 2x2, a quarter of the L1 rate.  Every wavefront therefore streams its
+// own operands through a D-deep register ring (vmcnt-tracked, D k-pairs in
+// flight) and never meets another wavefront at a barrier: the MFMA pipe of a
+// SIMD stays busy as long as ANY resident wave has operands, instead of the
+// whole workgroup stalling on ds_write -> s_barrier -> ds_read every k-step.
+// The four waves of a workgroup sit on neighbouring tiles only so that their
+// shared A / B rows hit in the CU's L1.
+template <int TM, int TN, int WVM, int MODE, int D, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_stream_kernel(ConvK a) {
+  constexpr int WVN = 4 / WVM;
+  constexpr int WM = TM * 32, WN = TN * 32;
+  constexpr int BM = WVM * WM, BNT = WVN * WN;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wm = wave / WVN, wn = wave % WVN;
+  const int l31 = lane & 31, lk = lane >> 5;
+  const int mtiles = (a.Cout + BM - 1) / BM;
+  const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int m0 = (tile % mtiles) * BM + wm * WM;
+  const int n0 = (tile / mtiles) * BNT + wn * WN;
+  if (m0 >= a.Cout || n0 >= a.J) return;  // no barriers below: waves are independent
+
+  const int Cin = __builtin_amdgcn_readfirstlane(a.Cin);
+  const int Cout = __builtin_amdgcn_readfirstlane(a.Cout);
+  const int KW = __builtin_amdgcn_readfirstlane(a.KW);
+  const int Pin = __builtin_amdgcn_readfirstlane(a.Pin);
+  const int Kpad = __builtin_amdgcn_readfirstlane(a.Kpad);
+  const int ntw = __builtin_amdgcn_readfirstlane(MODE == 1 ? a.ntw : a.KW);
+  const int ntaps = __builtin_amdgcn_readfirstlane(
+      MODE == 1 ? a.nth * a.ntw : a.KH * a.KW);
+
+  // ---- per-lane column geometry, resolved once ----------------------------
+  int bHin[TN], bWin[TN], boff[TN], bh0[TN], bw0[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int jb = n0 + j * 32 + l31;
+    bHin[j] = 0;  // Hin = 0 -> every tap out of range -> kOOB -> zeros
+    bWin[j] = 0;
+    boff[j] = 0;
+    bh0[j] = 0;
+    bw0[j] = 0;
+    if (jb < a.J) {
+      const int n = jb / a.Pout, p = jb - n * a.Pout;
+      int bl, bho, bwo;
+      locate_out(a.g, p, bl, bho, bwo);
+      bHin[j] = a.g.lv[bl].Hin;
+      bWin[j] = a.g.lv[bl].Win;
+      boff[j] = n * Cin * Pin + a.g.lv[bl].off_in + lk * Pin;
+      if (MODE == 1) {
+        bh0[j] = bho + a.ch0;
+        bw0[j] = bwo + a.cw0;
+      } else {
+        bh0[j] = bho * a.g.stride - a.g.pad;
+        bw0[j] = bwo * a.g.stride - a.g.pad;
+      }
+    }
+  }
+  unsigned va[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int co = m0 + i * 32 + l31;
+    va[i] = co < Cout ? (unsigned)(lk * Cout + co) * 4u : kOOB;
+  }
+  const rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  const rsrc_t rw = make_rsrc(a.wt, a.wt_bytes);
+
+  // load cursor: (tap, ci) of the next chunk of D k-pairs
+  unsigned vb[TN];
+  int wtap = 0;  // weight-image tap of the cursor
+  auto set_tap = [&](int tap) {
+    int kh = tap / ntw, kw = tap - kh * ntw;
+    if (MODE == 1) {
+      wtap = (a.kh0 + 2 * kh) * KW + a.kw0 + 2 * kw;
+    } else {
+      wtap = tap;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int hi = bh0[j] + kh, wi = bw0[j] + kw;
+      const bool ok = hi >= 0 && hi < bHin[j] && wi >= 0 && wi < bWin[j];
+      vb[j] = ok ? (unsigned)(boff[j] + hi * bWin[j] + wi) * 4u : kOOB;
+    }
+  };
+  float ra[D][TM], rb[D][TN];
+  auto load_kp = [&](int d, unsigned sa, unsigned sb) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ra[d][i] = buf_load(rw, va[i], sa);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) rb[d][j] = buf_load(rx, vb[j], sb);
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  auto mfma_kp = [&](int d) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][i], rb[d][j],
+                                                         acc[i][j], 0, 0, 0);
+  };
+
+  const int cchunks = Cin / (2 * D);  // host guarantees Cin % (2*D) == 0
+  const int nchunks = ntaps * cchunks;
+  int ltap = 0, lci = 0;
+  set_tap(0);
+  auto advance = [&]() {
+    lci += 2 * D;
+    if (lci >= Cin) {
+      lci = 0;
+      ++ltap;
+      if (ltap < ntaps) set_tap(ltap);
+    }
+  };
+  {
+    const unsigned sa = (unsigned)(wtap * Kpad) * Cout * 4u;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      // same issue order as the steady state, so the loop-header vmcnt merge
+      // stays exact (4 * (D - 1) outstanding)
+      load_kp(d, sa + (unsigned)(2 * d) * Cout * 4u, (unsigned)(2 * d) * Pin * 4u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    advance();
+  }
+  for (int c = 0; c + 1 < nchunks; ++c) {
+    const unsigned sa = (unsigned)(wtap * Kpad + lci) * Cout * 4u;
+    const unsigned sb = (unsigned)lci * Pin * 4u;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      // pin the ring order: without the fences the scheduler sinks all D
+      // refills below the MFMAs and the prefetch distance collapses to zero
+      mfma_kp(d);
+      __builtin_amdgcn_sched_barrier(0);
+      load_kp(d, sa + (unsigned)(2 * d) * Cout * 4u, sb + (unsigned)(2 * d) * Pin * 4u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    advance();
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) mfma_kp(d);
+
+  // ---- epilogue: direct stores, 32 consecutive positions per accumulator row
+  const bool has_res = a.residual != nullptr;
+  const bool relu = a.relu != 0;
+  const bool has_aff = a.scale != nullptr, has_bias = a.bias != nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int rbase = m0 + i * 32 + 4 * lk;
+    float sc[16], sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = min(rbase + (r & 3) + 8 * (r >> 2), Cout - 1);
+      sc[r] = has_aff ? a.scale[row] : 1.0f;
+      sh[r] = has_aff ? a.shift[row] : 0.0f;
+      if (has_bias) sh[r] += a.bias[row];
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int jc = n0 + j * 32 + l31;
+      if (jc >= a.J) continue;
+      const int n = jc / a.Pout;
+      int p = jc - n * a.Pout;
+      int prow = a.Pout;
+      if (MODE == 1) {
+        int l, hc, wc;
+        locate_out(a.g, p, l, hc, wc);
+        p = a.foff[l] + (2 * hc + a.ph) * a.fW[l] + 2 * wc + a.pw;
+        prow = a.Pfull;
+      }
+      const size_t colbase = (size_t)n * Cout * prow + p;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        if (row >= Cout) continue;
+        float v = acc[i][j][r] * sc[r] + sh[r];
+        if (has_res) v += a.residual[colbase + (size_t)row * prow];
+        if (relu) v = fmaxf(v, 0.0f);
+        a.y[colbase + (size_t)row * prow] = v;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ wgrad --
 struct WgradK {
   const float* x;    // (N, Cin, Pin)
@@ -786,11 +985,178 @@ inline int set_extents(ConvK& k, size_t x_floats, size_t wt_floats) {
   return 0;
 }
 
+// ---- streaming kernel dispatch + per-shape autotune -----------------------
+// Shapes are "TM x TN x WVM x D" (wave tile in 32s, waves along Cout, ring
+// depth).  Which one wins is decided by how the tile count divides over the
+// 1024 SIMDs (profiles/r01_kernels_s20_stream.json: 2x2 reaches 0.83 of peak
+// on the head towers but 0.44 on the 50x84 stages where 1x1 reaches 0.57), so
+// the first launch of every distinct layer geometry times the candidates on
+// the caller's buffers (the launch is idempotent) and caches the winner -- the
+// same contract as cudnn.benchmark=True, which mmdet sets for these configs
+// (mmdet/apis/train.py).  All candidates accumulate each output element in the
+// same order (tap-major, channel ascending, one accumulator), so the choice
+// never changes a single bit of the result.
+//   LD_CONV_STREAM = "0"           LDS kernel only
+//   LD_CONV_STREAM = "2x2x2x8"     force a shape
+//   LD_CONV_AUTOTUNE = "0"         model-based pick, no timing
+//   LD_CONV_TUNE_LOG = "1"         print the picks to stderr
+struct StreamCfg {
+  int tm, tn, wvm, d;
+};
+#define LD_STREAM_SHAPES(X)                                                        \
+  X(2, 2, 2, 8) X(2, 2, 1, 8) X(2, 1, 2, 8) X(1, 2, 2, 8) X(1, 2, 4, 8)            \
+  X(1, 2, 1, 8) X(1, 1, 2, 8) X(1, 1, 1, 8) X(1, 1, 4, 8) X(3, 1, 1, 8)            \
+  X(3, 2, 1, 8) X(2, 2, 2, 4) X(2, 2, 1, 4) X(1, 2, 2, 4) X(1, 1, 2, 4)            \
+  X(1, 1, 1, 4) X(3, 1, 1, 4) X(3, 2, 1, 4)
+constexpr StreamCfg kStreamCfgs[] = {
+#define LD_STREAM_ROW(TM_, TN_, WVM_, D_) {TM_, TN_, WVM_, D_},
+    LD_STREAM_SHAPES(LD_STREAM_ROW)
+#undef LD_STREAM_ROW
+};
+constexpr int kNumStreamCfgs = sizeof(kStreamCfgs) / sizeof(kStreamCfgs[0]);
+
+template <int MODE>
+int launch_stream_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream) {
+  const int bm = c.wvm * c.tm * 32, bn = (4 / c.wvm) * c.tn * 32;
+  const int nb = ((k.Cout + bm - 1) / bm) * ((k.J + bn - 1) / bn);
+#define LD_STREAM_CASE(TM_, TN_, WVM_, D_)                                         \
+  if (c.tm == TM_ && c.tn == TN_ && c.wvm == WVM_ && c.d == D_) {                  \
+    hipLaunchKernelGGL((conv_stream_kernel<TM_, TN_, WVM_, MODE, D_, 2>),          \
+                       dim3(nb), dim3(256), 0, stream, k);                         \
+    return (int)hipGetLastError();                                                 \
+  }
+  LD_STREAM_SHAPES(LD_STREAM_CASE)
+#undef LD_STREAM_CASE
+  return LD_EUNSUPPORTED;
+}
+
+inline bool stream_cfg_fits(const ConvK& k, const StreamCfg& c) {
+  if (k.Cin % (2 * c.d) != 0) return false;
+  if (c.d == 4 && k.Cin % 16 == 0) return false;  // the 8-deep ring covers it
+  const int bm = c.wvm * c.tm * 32;
+  const int cout32 = (k.Cout + 31) / 32 * 32;
+  if (c.wvm > 1 && bm > cout32) return false;  // whole waves of padding rows
+  if (c.wvm == 1 && c.tm * 32 >= cout32 + 32) return false;
+  return true;
+}
+
+// model-based pick: workgroup rounds over 256 CUs x per-shape pipe efficiency
+inline int stream_cfg_model(const ConvK& k) {
+  int best = -1;
+  double best_t = 0;
+  for (int i = 0; i < kNumStreamCfgs; ++i) {
+    const StreamCfg& c = kStreamCfgs[i];
+    if (!stream_cfg_fits(k, c)) continue;
+    const int bm = c.wvm * c.tm * 32, bn = (4 / c.wvm) * c.tn * 32;
+    const long nb = (long)((k.Cout + bm - 1) / bm) * ((k.J + bn - 1) / bn);
+    const int area = c.tm * c.tn;
+    const double eff = area >= 4 ? 0.90 : area >= 2 ? 0.84 : 0.79;
+    const int occ = area >= 4 ? 4 : 5;  // resident workgroups per CU
+    const double rounds =
+        nb <= 256L * occ ? (double)((nb + 255) / 256) : (double)nb / 256.0;
+    const double t = rounds * 4 * area / eff;
+    if (best < 0 || t < best_t) {
+      best = i;
+      best_t = t;
+    }
+  }
+  return best;
+}
+
+struct TuneKey {
+  int v[16];
+  bool operator==(const TuneKey& o) const {
+    for (int i = 0; i < 16; ++i)
+      if (v[i] != o.v[i]) return false;
+    return true;
+  }
+};
+struct TuneKeyHash {
+  size_t operator()(const TuneKey& k) const {
+    size_t h = 1469598103934665603ull;
+    for (int i = 0; i < 16; ++i) h = (h ^ (size_t)(unsigned)k.v[i]) * 1099511628211ull;
+    return h;
+  }
+};
+std::mutex g_tune_mu;
+std::unordered_map<TuneKey, int, TuneKeyHash> g_tune;
+
+template <int MODE>
+int launch_stream(const ConvK& k, hipStream_t stream) {
+  if (k.Cin % 8 != 0) return LD_EUNSUPPORTED;
+  if (const char* env = getenv("LD_CONV_STREAM")) {
+    if (env[0] == '0' && env[1] == 0) return LD_EUNSUPPORTED;
+    StreamCfg c;
+    if (sscanf(env, "%dx%dx%dx%d", &c.tm, &c.tn, &c.wvm, &c.d) == 4) {
+      if (k.Cin % (2 * c.d) != 0) c.d = 4;
+      return launch_stream_cfg<MODE>(k, c, stream);
+    }
+  }
+  const TuneKey key = {{MODE, k.Cin, k.Cout, k.KH, k.KW, k.g.stride, k.g.pad, k.J,
+                        k.g.num_levels, k.g.lv[0].Hin, k.g.lv[0].Win, k.ph, k.pw,
+                        k.relu, k.residual != nullptr, k.scale != nullptr}};
+  int pick = -1;
+  {
+    std::lock_guard<std::mutex> lock(g_tune_mu);
+    auto it = g_tune.find(key);
+    if (it != g_tune.end()) pick = it->second;
+  }
+  if (pick < 0) {
+    pick = stream_cfg_model(k);
+    if (pick < 0) return LD_EUNSUPPORTED;
+    const char* at = getenv("LD_CONV_AUTOTUNE");
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cap);
+    float best_ms = -1.0f;
+    if (!(at && at[0] == '0') && cap == hipStreamCaptureStatusNone) {
+      hipEvent_t e0, e1;
+      (void)hipEventCreate(&e0);
+      (void)hipEventCreate(&e1);
+      for (int i = 0; i < kNumStreamCfgs; ++i) {
+        if (!stream_cfg_fits(k, kStreamCfgs[i])) continue;
+        if (launch_stream_cfg<MODE>(k, kStreamCfgs[i], stream) != 0) continue;
+        (void)hipEventRecord(e0, stream);
+        launch_stream_cfg<MODE>(k, kStreamCfgs[i], stream);
+        launch_stream_cfg<MODE>(k, kStreamCfgs[i], stream);
+        (void)hipEventRecord(e1, stream);
+        if (hipEventSynchronize(e1) != hipSuccess) continue;
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (best_ms < 0.0f || ms < best_ms) {
+          best_ms = ms;
+          pick = i;
+        }
+      }
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    }
+    if (const char* lg = getenv("LD_CONV_TUNE_LOG"))
+      if (lg[0] == '1') {
+        const StreamCfg& c = kStreamCfgs[pick];
+        const double fl = 2.0 * k.J * k.Cout * k.Cin *
+                          (MODE == 1 ? k.nth * k.ntw : k.KH * k.KW);
+        fprintf(stderr,
+                "[ld_conv] mode %d Cin %d Cout %d k %dx%d s%d J %d lv %d -> "
+                "%dx%dx%dx%d  %.1f TFLOP/s\n",
+                MODE, k.Cin, k.Cout, k.KH, k.KW, k.g.stride, k.J, k.g.num_levels,
+                c.tm, c.tn, c.wvm, c.d,
+                best_ms > 0 ? fl / (best_ms * 0.5e-3) / 1e12 : 0.0);
+      }
+    std::lock_guard<std::mutex> lock(g_tune_mu);
+    g_tune[key] = pick;
+  }
+  return launch_stream_cfg<MODE>(k, kStreamCfgs[pick], stream);
+}
+
 template <int MODE>
 int launch_igemm(const ConvK& k_in, hipStream_t stream) {
   ConvK k = k_in;
   k.pipe = 1;
   if (const char* env = getenv("LD_CONV_PIPE")) k.pipe = atoi(env) != 0;
+  if constexpr (MODE != 2) {
+    const int rc = launch_stream<MODE>(k, stream);
+    if (rc != LD_EUNSUPPORTED) return rc;
+  }
   const TileCfg c = pick_tile(k);
   const int nb = tile_blocks(k, c);
   // intra-block split-K when the grid would leave SIMDs with < ~4 waves

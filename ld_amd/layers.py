@@ -247,26 +247,24 @@ def conv2d(x3, w, bias, stride, pad, levels):
 # ---------------------------------------------------------------------------
 # BatchNorm (eval statistics) + residual + ReLU
 # ---------------------------------------------------------------------------
-_BN_CACHE = {}
-
-
 def bn_prepare(gamma, beta, mean, var, eps):
     """scale/shift/rstd of an eval-mode BN.  For a frozen BN (no trainable
-    affine: the teacher, the student's frozen stages) the result is cached
-    until any of the four tensors changes."""
+    affine: the teacher, the student's frozen stages) the result is cached ON
+    the gamma tensor until any of the four tensors changes (a process-wide
+    table keyed by address would hand a new model the coefficients of a freed
+    one whose storage it happens to reuse)."""
     frozen = not (gamma.requires_grad or beta.requires_grad) or \
         getattr(gamma, '_ld_static', False)
     if frozen:
-        key = (gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
-               var.data_ptr())
-        stamp = (gamma._version, beta._version, mean._version, var._version,
-                 eps)
-        hit = _BN_CACHE.get(key)
+        stamp = (gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                 var.data_ptr(), gamma._version, beta._version, mean._version,
+                 var._version, eps)
+        hit = getattr(gamma, '_ld_bn', None)
         if hit is not None and hit[0] == stamp:
             return hit[1]
     out = _bn_prepare(gamma, beta, mean, var, eps)
     if frozen:
-        _BN_CACHE[key] = (stamp, out)
+        gamma._ld_bn = (stamp, out)
     return out
 
 

@@ -99,14 +99,14 @@ def test_features_vs_cpu_oracle(golden):
     loss, _ = det._parse_losses(losses)
     loss.backward()
     params = dict(det.named_parameters())
-    worst = 0.0
+    rels = {}
     for k, gref in ref['grads'].items():
         a = params[k].grad.detach().cpu().double()
         b = gref.double()
-        rel = float((a - b).norm() / (b.norm() + 1e-12))
-        worst = max(worst, rel)
-        assert rel < 5e-3, f'{k}: relative grad error {rel}'
-    print('worst relative grad error', worst)
+        rels[k] = float((a - b).norm() / (b.norm() + 1e-12))
+    bad = sorted(((v, k) for k, v in rels.items() if not v < 5e-3), reverse=True)
+    print('worst relative grad error', max(rels.values()))
+    assert not bad, f'{len(bad)} of {len(rels)} gradients off: {bad[:8]}'
 
 
 def test_trainer_two_steps_reduce_loss(golden):

@@ -102,6 +102,35 @@ def test_conv_fwd_bwd(case):
     _close(bd.grad, br.grad, what=name + ' bias grad')
 
 
+STREAM_SHAPES = ['2x2x2x8', '2x2x1x8', '2x1x2x8', '1x2x2x8', '1x2x4x8', '1x2x1x8',
+                 '1x1x2x8', '1x1x1x8', '1x1x4x8', '3x1x1x8', '3x2x1x8', '0']
+
+
+@pytest.mark.parametrize('shape', STREAM_SHAPES)
+def test_conv_stream_shapes(shape, monkeypatch):
+    """Every register-tile shape of the streaming conv kernel (and the LDS
+    kernel, '0') on every case: forward and data-gradient against F.conv2d.
+    The autotuner may pick any of them, so each must be right on its own."""
+    from ld_amd import layers as Y
+    monkeypatch.setenv('LD_CONV_STREAM', shape)
+    dev = _dev()
+    for case in CONV_CASES:
+        name, N, cin, cout, k, stride, pad, levels = case
+        g = torch.Generator().manual_seed(len(name) * 7 + cin)
+        P = sum(h * w for h, w in levels)
+        x = torch.randn(N, cin, P, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k)**0.5
+        xr, wr = (t.clone().requires_grad_(True) for t in (x, w))
+        ref = _ref_conv_levels(xr, wr, None, stride, pad, levels)
+        go = torch.randn(ref.shape, generator=g)
+        ref.backward(go)
+        xd, wd = (t.to(dev).requires_grad_(True) for t in (x, w))
+        y, _ = Y.conv2d(xd, wd, None, stride, pad, levels)
+        _close(y, ref, what=f'{name} fwd [{shape}]')
+        y.backward(go.to(dev))
+        _close(xd.grad, xr.grad, what=f'{name} dgrad [{shape}]')
+
+
 def test_conv_fused_epilogue_and_stem():
     from ld_amd import layers as Y
     dev = _dev()

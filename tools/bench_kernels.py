@@ -121,6 +121,46 @@ def bench_conv_tiles(out):
 
 
 
+STREAM_CFGS = ['2x2x2x8x2', '2x2x1x8x3', '2x2x4x8x3', '2x1x2x8x4', '1x2x2x8x4',
+               '1x2x1x8x4', '1x2x4x8x4', '1x1x2x8x5', '1x1x1x8x5', '1x1x4x8x5',
+               '1x1x2x4x5', '1x2x2x4x4', '1x1x2x8x8', '3x1x1x8x4', '3x2x1x8x2',
+               '2x2x2x4x2']
+
+
+def bench_stream_sweep(out):
+    """Forward conv under every streaming-kernel shape (LD_CONV_STREAM) next to
+    the LDS kernel (LD_CONV_STREAM=0)."""
+    dev = torch.device('cuda:0')
+    res = []
+    for name, N, cin, cout, k, stride, pad, levels in CONV_SHAPES:
+        P = sum(h * w for h, w in levels)
+        x = torch.randn(N, cin, P, device=dev)
+        w = torch.randn(cout, cin, k, k, device=dev) * 0.05
+        y, _ = Y.conv_forward_raw(x, w, stride, pad, levels)
+        flops = 2.0 * N * y.shape[2] * cout * cin * k * k
+        r = dict(name=name, J=N * y.shape[2], cout=cout, K=cin * k * k)
+        os.environ['LD_CONV_STREAM'] = '0'
+        t = timeit(lambda: Y.conv_forward_raw(x, w, stride, pad, levels), 2, 5)
+        r['lds'] = round(flops / t / 1e12, 1)
+        for cfg in STREAM_CFGS:
+            tm, tn, wvm = (int(v) for v in cfg.split('x')[:3])
+            if wvm * tm * 32 >= 2 * cout and wvm > 1:
+                continue  # more than half the workgroup's rows would be padding
+            os.environ['LD_CONV_STREAM'] = cfg
+            t = timeit(lambda: Y.conv_forward_raw(x, w, stride, pad, levels), 2, 5)
+            r[cfg] = round(flops / t / 1e12, 1)
+        os.environ.pop('LD_CONV_STREAM', None)
+        t = timeit(lambda: Y.conv_forward_raw(x, w, stride, pad, levels), 2, 5)
+        r['auto'] = round(flops / t / 1e12, 1)
+        res.append(r)
+        best = max((v, k_) for k_, v in r.items()
+                   if isinstance(v, float) and k_ not in ('auto', ))
+        print(name, '| best', best, '|',
+              ' '.join(f'{k_}={v}' for k_, v in r.items()
+                       if isinstance(v, float)), flush=True)
+    out['conv_stream'] = res
+
+
 def bench_conv(out, with_miopen=True):
     dev = torch.device('cuda:0')
     res = []
@@ -192,6 +232,8 @@ def main():
         bench_conv(out, not args.no_miopen)
     if 'tiles' in args.only.split(','):
         bench_conv_tiles(out)
+    if 'stream' in args.only.split(','):
+        bench_stream_sweep(out)
     os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
     path = os.path.join(REPO, 'gpurun_out', f'kernels_{args.tag}.json')
     with open(path, 'w') as f:
