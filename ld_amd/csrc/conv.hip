@@ -895,6 +895,191 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(WgradK a) {
   }
 }
 
+// ---------------------------------------------------- wgrad, wave-private --
+// Same decoupling as the streaming forward kernel, for the GEMM whose operands
+// cannot be loaded in MFMA layout (both dY and X are contiguous along the
+// reduction index j, the MFMA wants a lane per ROW): every wavefront is its own
+// workgroup, owns a 64(co) x 64(ci) tile of one tap and one j-split, and
+// transposes its operand tiles through a PRIVATE LDS buffer -- global -> regs
+// (coalesced along j) -> LDS [row][j] -> fragment reads [row = lane][k].  LDS
+// traffic of one wave is ordered by the hardware, so no s_barrier exists
+// anywhere: a SIMD's MFMA pipe idles only when all of its resident waves are
+// between tiles at the same moment.  The next tile's global loads are in flight
+// under the 64 MFMAs of the current one.
+template <int BKJ>
+__global__ __launch_bounds__(64, BKJ == 32 ? 2 : 3) void conv_wgrad_wave_kernel(WgradK a) {
+  constexpr int TB = 64;         // tile edge (co and ci)
+  constexpr int LDW = BKJ + 1;   // odd row stride: conflict-free fragment reads
+  constexpr int RG = 64 / BKJ;   // rows covered by one load instruction
+  constexpr int RPER = TB / RG;  // rows per lane and operand
+  __shared__ float lds[2 * TB * LDW];
+  __shared__ int s_geo[LD_MAX_LEVELS * 6];
+  float* As = lds;             // [TB][LDW]  dY rows (co)
+  float* Bs = lds + TB * LDW;  // [TB][LDW]  X rows (ci)
+
+  const int lane = threadIdx.x;
+  const int Cin = __builtin_amdgcn_readfirstlane(a.Cin);
+  const int Cout = __builtin_amdgcn_readfirstlane(a.Cout);
+  const int Pin = __builtin_amdgcn_readfirstlane(a.Pin);
+  const int Pout = __builtin_amdgcn_readfirstlane(a.Pout);
+  const int nlev = __builtin_amdgcn_readfirstlane(a.g.num_levels);
+  const int stride = __builtin_amdgcn_readfirstlane(a.g.stride);
+  const int pad = __builtin_amdgcn_readfirstlane(a.g.pad);
+  const int mt = (Cout + TB - 1) / TB, nt = (Cin + TB - 1) / TB;
+  const int ntaps = a.KH * a.KW;
+  int b = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int ntile = b % nt;
+  b /= nt;
+  const int mtile = b % mt;
+  b /= mt;
+  const int tap = b % ntaps;
+  const int split = b / ntaps;
+  const int m0 = mtile * TB, c0 = ntile * TB;
+  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int jbeg = split * a.jchunk;
+  const int jend = min(a.J, jbeg + a.jchunk);
+
+  if (lane < LD_MAX_LEVELS) {
+    const ld_conv_level_t lv = a.g.lv[lane];
+    s_geo[lane * 6 + 0] = lv.Hin;
+    s_geo[lane * 6 + 1] = lv.Win;
+    s_geo[lane * 6 + 2] = lv.Hout;
+    s_geo[lane * 6 + 3] = lv.Wout;
+    s_geo[lane * 6 + 4] = lv.off_in;
+    s_geo[lane * 6 + 5] = lv.off_out;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  const int kq = lane % BKJ;  // this lane's j offset within a step
+  const int r0 = lane / BKJ;  // first row; rows r0 + RG*i
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  const rsrc_t ry = make_rsrc(a.dy, a.dy_bytes);
+  float a_st[RPER], b_st[RPER];
+  const bool rows_full = (m0 + TB <= Cout) && (c0 + TB <= Cin);
+
+  auto load_tile = [&](int j0) {
+    const int j = j0 + kq;
+    unsigned vy = kOOB, vx = kOOB;
+    if (j < jend) {
+      const int n = j / Pout, p = j - n * Pout;
+      int l = 0;
+      for (int i = 1; i < nlev; ++i)
+        if (p >= s_geo[i * 6 + 5]) l = i;
+      const int Hin = s_geo[l * 6 + 0], Win = s_geo[l * 6 + 1];
+      const int Wout = s_geo[l * 6 + 3];
+      const int r = p - s_geo[l * 6 + 5];
+      const int ho = r / Wout, wo = r - ho * Wout;
+      const int hi = ho * stride - pad + kh, wi = wo * stride - pad + kw;
+      vy = (unsigned)(n * Cout * Pout + (m0 + r0) * Pout + p) * 4u;
+      if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win)
+        vx = (unsigned)(n * Cin * Pin + (c0 + r0) * Pin + s_geo[l * 6 + 4] +
+                        hi * Win + wi) * 4u;
+    }
+    // row offsets advance in SGPRs inside the step: 2 * RPER loop-invariant
+    // soffsets would be hoisted, exhaust the SGPR file, get parked in VGPRs and
+    // come back as waterfall loops around every load (seen in the ISA)
+    unsigned da = (unsigned)RG * Pout * 4u, db = (unsigned)RG * Pin * 4u;
+    asm volatile("" : "+s"(da), "+s"(db));
+    unsigned sa = 0, sb = 0;
+    if (rows_full) {
+#pragma unroll
+      for (int i = 0; i < RPER; ++i) {
+        a_st[i] = buf_load(ry, vy, sa);
+        b_st[i] = buf_load(rx, vx, sb);
+        sa += da;
+        sb += db;
+      }
+    } else {
+      // rows past the channel count: per-lane row budgets compared inside the
+      // step (hoisted lane masks would again spill the SGPR file)
+      int na = (Cout - m0 - r0 + RG - 1) / RG, nb = (Cin - c0 - r0 + RG - 1) / RG;
+      asm volatile("" : "+v"(na), "+v"(nb));
+#pragma unroll
+      for (int i = 0; i < RPER; ++i) {
+        a_st[i] = buf_load(ry, i < na ? vy : kOOB, sa);
+        b_st[i] = buf_load(rx, i < nb ? vx : kOOB, sb);
+        sa += da;
+        sb += db;
+      }
+    }
+  };
+  auto store_tile = [&]() {
+    float* ap = As + r0 * LDW + kq;
+    float* bp = Bs + r0 * LDW + kq;
+#pragma unroll
+    for (int i = 0; i < RPER; ++i) {
+      ap[RG * i * LDW] = a_st[i];
+      bp[RG * i * LDW] = b_st[i];
+    }
+  };
+
+  const int nsteps = (jend - jbeg + BKJ - 1) / BKJ;
+  const int l31 = lane & 31, lk = lane >> 5;
+  constexpr int KP = BKJ / 2;
+  if (nsteps > 0) load_tile(jbeg);
+  for (int step = 0; step < nsteps; ++step) {
+    store_tile();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (step + 1 < nsteps) load_tile(jbeg + (step + 1) * BKJ);
+    const float* ap = As + l31 * LDW;
+    const float* bp = Bs + l31 * LDW;
+    float af[2][2], bf[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) af[0][i] = ap[i * 32 * LDW + lk];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bf[0][j] = bp[j * 32 * LDW + lk];
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+      const int c = kp & 1;
+      if (kp + 1 < KP) {
+        const int kc = 2 * (kp + 1) + lk;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[c ^ 1][i] = ap[i * 32 * LDW + kc];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[c ^ 1][j] = bp[j * 32 * LDW + kc];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i], bf[c][j],
+                                                           acc[i][j], 0, 0, 0);
+    }
+    // all fragment reads of this tile are issued before the next tile's
+    // ds_writes (LDS executes one wave's operations in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  // slab store: [split][tap][co][ci], ci fastest (= lane & 31)
+  float* slab = a.slabs + ((size_t)split * ntaps + tap) * Cout * Cin;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ci = c0 + j * 32 + l31;
+    if (ci >= Cin) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (co < Cout) slab[(size_t)co * Cin + ci] = acc[i][j][r];
+      }
+  }
+}
+
 // dW[co][ci][tap] (+)= sum_split slab[split][tap][co][ci]
 __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, int splits,
                                          int ntaps, int Cout, int Cin,
@@ -1078,6 +1263,7 @@ struct TuneKeyHash {
     return h;
   }
 };
+constexpr int kTuneReps = 3;
 std::mutex g_tune_mu;
 std::unordered_map<TuneKey, int, TuneKeyHash> g_tune;
 
@@ -1109,6 +1295,10 @@ int launch_stream(const ConvK& k, hipStream_t stream) {
     (void)hipStreamIsCapturing(stream, &cap);
     float best_ms = -1.0f;
     if (!(at && at[0] == '0') && cap == hipStreamCaptureStatusNone) {
+      // quiesce the device first: work queued on other streams (the teacher's
+      // forward) would otherwise share the CUs with some candidates and not
+      // others
+      (void)hipDeviceSynchronize();
       hipEvent_t e0, e1;
       (void)hipEventCreate(&e0);
       (void)hipEventCreate(&e1);
@@ -1116,8 +1306,8 @@ int launch_stream(const ConvK& k, hipStream_t stream) {
         if (!stream_cfg_fits(k, kStreamCfgs[i])) continue;
         if (launch_stream_cfg<MODE>(k, kStreamCfgs[i], stream) != 0) continue;
         (void)hipEventRecord(e0, stream);
-        launch_stream_cfg<MODE>(k, kStreamCfgs[i], stream);
-        launch_stream_cfg<MODE>(k, kStreamCfgs[i], stream);
+        for (int rep = 0; rep < kTuneReps; ++rep)
+          launch_stream_cfg<MODE>(k, kStreamCfgs[i], stream);
         (void)hipEventRecord(e1, stream);
         if (hipEventSynchronize(e1) != hipSuccess) continue;
         float ms = 0.0f;
@@ -1140,7 +1330,7 @@ int launch_stream(const ConvK& k, hipStream_t stream) {
                 "%dx%dx%dx%d  %.1f TFLOP/s\n",
                 MODE, k.Cin, k.Cout, k.KH, k.KW, k.g.stride, k.J, k.g.num_levels,
                 c.tm, c.tn, c.wvm, c.d,
-                best_ms > 0 ? fl / (best_ms * 0.5e-3) / 1e12 : 0.0);
+                best_ms > 0 ? fl / (best_ms * 1e-3 / kTuneReps) / 1e12 : 0.0);
       }
     std::lock_guard<std::mutex> lock(g_tune_mu);
     g_tune[key] = pick;
@@ -1376,15 +1566,61 @@ extern "C" int ld_conv_dgrad(const ld_conv_t* c, const float* dy,
   return 0;
 }
 
+// which wgrad kernel: 0 = 128x128 workgroup tiles (LDS shared by 4 waves),
+// 32 / 16 = wave-private 64x64 tiles with that many j per step
+static int wgrad_mode() {
+  if (const char* env = getenv("LD_CONV_WGRAD")) {
+    const int v = atoi(env);
+    if (v == 0 || v == 16 || v == 32) return v;
+  }
+  return 32;
+}
+
 static int wgrad_splits(const ld_conv_t* c) {
   const int J = c->N * c->Pout;
-  const int tiles = ((c->Cout + 127) / 128) * ((c->Cin + 127) / 128) * c->KH * c->KW;
-  int splits = (1024 + tiles - 1) / tiles;            // aim at ~1024 blocks
-  const int max_by_k = (J + 8 * WBK - 1) / (8 * WBK); // >= 8 steps per block
-  if (splits > max_by_k) splits = max_by_k;
-  if (splits < 1) splits = 1;
-  if (splits > 64) splits = 64;
-  return splits;
+  const int mode = wgrad_mode();
+  const int edge = mode ? 64 : 128, bk = mode ? mode : WBK;
+  const int tiles = ((c->Cout + edge - 1) / edge) * ((c->Cin + edge - 1) / edge) *
+                    c->KH * c->KW;
+  if (const char* env = getenv("LD_CONV_WGRAD_TARGET")) {
+    const int target = max(1, atoi(env));
+    int splits = (target + tiles - 1) / tiles;
+    const int max_by_k = (J + 8 * bk - 1) / (8 * bk);  // >= 8 steps per block
+    return max(1, min(min(splits, max_by_k), 64));
+  }
+  if (!mode) {
+    int splits = (1024 + tiles - 1) / tiles;            // aim at ~1024 workgroups
+    const int max_by_k = (J + 8 * bk - 1) / (8 * bk);
+    return max(1, min(min(splits, max_by_k), 64));
+  }
+  // Wave-private kernel: every wavefront is a workgroup and the device holds
+  // `slots` of them at once (VGPR-limited: 2 per SIMD at 32 j/step, 3 at 16).
+  // A launch runs in ceil(waves / slots) rounds of (steps + fixed) each, so the
+  // split count is chosen to fill whole rounds -- 2112 waves on 2048 slots cost
+  // two rounds, 2048 cost one (profiles/r01_kernels_s24_wgrad.txt).
+  const int slots = 1024 * (mode == 32 ? 2 : 3);
+  const double fixed = mode == 32 ? 5.0 : 8.0;  // prologue + 64x64 slab store, in steps
+  int best = 1;
+  double best_cost = 0;
+  const size_t wbytes = (size_t)c->KH * c->KW * c->Cout * c->Cin * sizeof(float);
+  for (int sp = 1; sp <= 256; ++sp) {
+    if (sp > 1 && sp * wbytes > ((size_t)256 << 20)) break;  // slab budget
+    int jchunk = (J + sp - 1) / sp;
+    jchunk = (jchunk + bk - 1) / bk * bk;
+    if (sp > 1 && (long)(sp - 1) * jchunk >= J) continue;  // empty last split
+    const int steps = jchunk / bk;
+    if (sp > 1 && steps < 4) break;
+    const long waves = (long)tiles * sp;
+    const double rounds = (double)((waves + slots - 1) / slots);
+    // slab traffic of the reduce pass, in step units (rough: 64x64 floats
+    // written + read per wave vs 16 KB of operand tile per step)
+    const double cost = rounds * (steps + fixed) + 1e-3 * sp;
+    if (sp == 1 || cost < best_cost) {
+      best = sp;
+      best_cost = cost;
+    }
+  }
+  return best;
 }
 
 extern "C" size_t ld_conv_wgrad_workspace_bytes(const ld_conv_t* c) {
@@ -1407,8 +1643,10 @@ extern "C" int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy
   k.g.num_levels = c->num_levels;
   k.J = c->N * c->Pout;
   k.splits = wgrad_splits(c);
+  const int wmode = wgrad_mode();
+  const int wbk = wmode ? wmode : WBK;
   int jchunk = (k.J + k.splits - 1) / k.splits;
-  jchunk = (jchunk + WBK - 1) / WBK * WBK;
+  jchunk = (jchunk + wbk - 1) / wbk * wbk;
   k.jchunk = jchunk;
   for (int l = 0; l < LD_MAX_LEVELS; ++l) k.g.lv[l] = c->lv[l];
   {
@@ -1419,8 +1657,19 @@ extern "C" int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy
     k.dy_bytes = (unsigned)(yf * 4);
   }
   const int ntaps = c->KH * c->KW;
-  const int blocks = ((c->Cout + 127) / 128) * ((c->Cin + 127) / 128) * ntaps * k.splits;
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(blocks), dim3(kThreads), 0, stream, k);
+  if (wmode) {
+    const int blocks = ((c->Cout + 63) / 64) * ((c->Cin + 63) / 64) * ntaps * k.splits;
+    if (wmode == 32)
+      hipLaunchKernelGGL(conv_wgrad_wave_kernel<32>, dim3(blocks), dim3(64), 0,
+                         stream, k);
+    else
+      hipLaunchKernelGGL(conv_wgrad_wave_kernel<16>, dim3(blocks), dim3(64), 0,
+                         stream, k);
+  } else {
+    const int blocks =
+        ((c->Cout + 127) / 128) * ((c->Cin + 127) / 128) * ntaps * k.splits;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(blocks), dim3(kThreads), 0, stream, k);
+  }
   const size_t per = (size_t)ntaps * c->Cout * c->Cin;
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)),
                      dim3(256), 0, stream, k.slabs, k.splits, ntaps, c->Cout, c->Cin,

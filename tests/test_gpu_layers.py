@@ -131,6 +131,29 @@ def test_conv_stream_shapes(shape, monkeypatch):
         _close(xd.grad, xr.grad, what=f'{name} dgrad [{shape}]')
 
 
+@pytest.mark.parametrize('mode', ['0', '16', '32'])
+def test_conv_wgrad_kernels(mode, monkeypatch):
+    """Weight gradient under each kernel (LD_CONV_WGRAD: 0 = workgroup tiles,
+    16/32 = wave-private tiles) against autograd of F.conv2d."""
+    from ld_amd import layers as Y
+    monkeypatch.setenv('LD_CONV_WGRAD', mode)
+    dev = _dev()
+    for case in CONV_CASES:
+        name, N, cin, cout, k, stride, pad, levels = case
+        g = torch.Generator().manual_seed(len(name) * 11 + cout)
+        P = sum(h * w for h, w in levels)
+        x = torch.randn(N, cin, P, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k)**0.5
+        xr, wr = (t.clone().requires_grad_(True) for t in (x, w))
+        ref = _ref_conv_levels(xr, wr, None, stride, pad, levels)
+        go = torch.randn(ref.shape, generator=g)
+        ref.backward(go)
+        xd, wd = (t.to(dev).requires_grad_(True) for t in (x, w))
+        y, _ = Y.conv2d(xd, wd, None, stride, pad, levels)
+        y.backward(go.to(dev))
+        _close(wd.grad, wr.grad, what=f'{name} wgrad [{mode}]')
+
+
 def test_conv_fused_epilogue_and_stem():
     from ld_amd import layers as Y
     dev = _dev()
