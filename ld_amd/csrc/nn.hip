@@ -193,15 +193,27 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(
   const int l = ngl % L, g = (ngl / L) % G, n = ngl / (L * G);
   const int cpg = C / G, A = lv.off[l + 1] - lv.off[l];
   const float* base = x + ((size_t)n * C + (size_t)g * cpg) * lv.P + lv.off[l];
-  const int total = cpg * A;
-  const int per = (total + kGnSplit - 1) / kGnSplit;
-  const int beg = sp * per, end = min(total, beg + per);
+  // split sp owns positions [beg, end) of the level in every channel of the
+  // group: coalesced rows, no per-element index arithmetic
+  // at least 1024 positions per slice: the small levels collapse onto one
+  // workgroup each and the other slices return at once
+  const int per = max((A + kGnSplit - 1) / kGnSplit, 1024);
+  const int beg = sp * per, end = min(A, beg + per);
+  if (beg >= end) {
+    if (threadIdx.x == 0) {
+      partial[(size_t)blockIdx.x * 2 + 0] = 0.0;
+      partial[(size_t)blockIdx.x * 2 + 1] = 0.0;
+    }
+    return;
+  }
   double s = 0.0, q = 0.0;
-  for (int e = beg + threadIdx.x; e < end; e += 256) {
-    const int ch = e / A, p = e - ch * A;
-    const double v = (double)base[(size_t)ch * lv.P + p];
-    s += v;
-    q += v * v;
+  for (int p = beg + threadIdx.x; p < end; p += 256) {
+#pragma unroll 8
+    for (int ch = 0; ch < cpg; ++ch) {
+      const double v = (double)base[(size_t)ch * lv.P + p];
+      s += v;
+      q += v * v;
+    }
   }
   block_sum2(s, q);
   if (threadIdx.x == 0) {
@@ -249,21 +261,70 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
   y[idx] = v;
 }
 
-// backward pass A: per (n, c, level): s1 = sum dz, s2 = sum dz * xhat
+// the same, four consecutive positions per thread (rows 16-byte aligned)
+__global__ __launch_bounds__(256) void gn_apply4_kernel(
+    const float* __restrict__ x, Levels lv, int C, int G,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+    float* __restrict__ y) {
+  const int row = blockIdx.y;  // n*C + c
+  const int c = row % C, n = row / C;
+  const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (p >= lv.P) return;
+  const size_t ob = ((size_t)n * G + c / (C / G)) * lv.num_levels;
+  const size_t idx = (size_t)row * lv.P + p;
+  const float4 v = *reinterpret_cast<const float4*>(x + idx);
+  const float ga = gamma[c], be = beta[c];
+  const int l0 = level_of_pos(lv, p), l3 = level_of_pos(lv, p + 3);
+  float in[4] = {v.x, v.y, v.z, v.w}, out[4];
+  if (l0 == l3) {
+    const float mu = mean[ob + l0], rs = rstd[ob + l0];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = (in[k] - mu) * rs * ga + be;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int l = level_of_pos(lv, p + k);
+      out[k] = (in[k] - mean[ob + l]) * rstd[ob + l] * ga + be;
+    }
+  }
+  if (relu) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = fmaxf(out[k], 0.f);
+  }
+  *reinterpret_cast<float4*>(y + idx) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
+// backward pass A: per (n, c, level): s1 = sum dz, s2 = sum dz * xhat, each
+// level cut into kGnBwdSplit slices (the 16800-cell level would otherwise sit
+// on two workgroups per CU)
+constexpr int kGnBwdSplit = 8;
+
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(
     const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ x, Levels lv, int C, int G,
     const float* __restrict__ mean, const float* __restrict__ rstd, int relu,
     double* __restrict__ sums) {
   const int L = lv.num_levels;
-  const int l = blockIdx.x % L, row = blockIdx.x / L;  // row = n*C + c
+  const int sp = blockIdx.x % kGnBwdSplit;
+  const int rl = blockIdx.x / kGnBwdSplit;
+  const int l = rl % L, row = rl / L;  // row = n*C + c
   const int c = row % C, n = row / C;
   const int A = lv.off[l + 1] - lv.off[l];
+  const int per = max((A + kGnBwdSplit - 1) / kGnBwdSplit, 1024);
+  const int beg = sp * per, end = min(A, beg + per);
+  if (beg >= end) {
+    if (threadIdx.x == 0) {
+      sums[(size_t)blockIdx.x * 2 + 0] = 0.0;
+      sums[(size_t)blockIdx.x * 2 + 1] = 0.0;
+    }
+    return;
+  }
   const size_t o = ((size_t)n * G + c / (C / G)) * L + l;
   const float mu = mean[o], rs = rstd[o];
   const size_t base = (size_t)row * lv.P + lv.off[l];
   double s1 = 0.0, s2 = 0.0;
-  for (int p = threadIdx.x; p < A; p += 256) {
+  for (int p = beg + threadIdx.x; p < end; p += 256) {
     float dz = dy[base + p];
     if (relu && !(y[base + p] > 0.f)) dz = 0.f;
     s1 += (double)dz;
@@ -271,42 +332,90 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(
   }
   block_sum2(s1, s2);
   if (threadIdx.x == 0) {
-    sums[((size_t)row * L + l) * 2 + 0] = s1;
-    sums[((size_t)row * L + l) * 2 + 1] = s2;
+    sums[(size_t)blockIdx.x * 2 + 0] = s1;
+    sums[(size_t)blockIdx.x * 2 + 1] = s2;
   }
 }
 
-// backward pass B: dx = rstd * (gamma*dz - m1 - xhat*m2),
-//   m1 = mean_group(gamma*dz), m2 = mean_group(gamma*dz*xhat)
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
-    const float* __restrict__ dy, const float* __restrict__ y,
-    const float* __restrict__ x, Levels lv, int C, int G,
-    const float* __restrict__ mean, const float* __restrict__ rstd,
-    const float* __restrict__ gamma, const double* __restrict__ sums, int relu,
-    float* __restrict__ dx) {
-  const int row = blockIdx.y;
-  const int c = row % C, n = row / C;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= lv.P) return;
-  const int L = lv.num_levels, cpg = C / G, g = c / cpg;
-  const int l = level_of_pos(lv, p);
-  const int A = lv.off[l + 1] - lv.off[l];
+// slices -> per (n, c, level) sums (in place at slice 0), fixed order
+__global__ void gn_bwd_fold_kernel(double* __restrict__ sums, int rows_levels) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows_levels) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < kGnBwdSplit; ++k) {
+    s1 += sums[((size_t)i * kGnBwdSplit + k) * 2 + 0];
+    s2 += sums[((size_t)i * kGnBwdSplit + k) * 2 + 1];
+  }
+  sums[(size_t)i * kGnBwdSplit * 2 + 0] = s1;
+  sums[(size_t)i * kGnBwdSplit * 2 + 1] = s2;
+}
+
+// per (n, group, level): m1 = mean_group(gamma*dz), m2 = mean_group(gamma*dz*xhat)
+__global__ void gn_bwd_group_kernel(const double* __restrict__ sums, Levels lv, int N,
+                                    int C, int G, const float* __restrict__ gamma,
+                                    float* __restrict__ gm) {
+  const int L = lv.num_levels;
+  const int ngl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ngl >= N * G * L) return;
+  const int l = ngl % L, g = (ngl / L) % G, n = ngl / (L * G);
+  const int cpg = C / G, A = lv.off[l + 1] - lv.off[l];
   double m1 = 0.0, m2 = 0.0;
   for (int k = 0; k < cpg; ++k) {
     const int cc = g * cpg + k;
-    const size_t r = ((size_t)(n * C + cc) * L + l) * 2;
+    const size_t r = ((size_t)(n * C + cc) * L + l) * kGnBwdSplit * 2;
     m1 += (double)gamma[cc] * sums[r + 0];
     m2 += (double)gamma[cc] * sums[r + 1];
   }
   const double cnt = (double)cpg * A;
-  const float fm1 = (float)(m1 / cnt), fm2 = (float)(m2 / cnt);
-  const size_t o = ((size_t)n * G + g) * L + l;
-  const float mu = mean[o], rs = rstd[o];
+  gm[(size_t)ngl * 2 + 0] = (float)(m1 / cnt);
+  gm[(size_t)ngl * 2 + 1] = (float)(m2 / cnt);
+}
+
+// backward pass B: dx = rstd * (gamma*dz - m1 - xhat*m2)
+template <int V>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y,
+    const float* __restrict__ x, Levels lv, int C, int G,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ gm, int relu,
+    float* __restrict__ dx) {
+  const int row = blockIdx.y;
+  const int c = row % C, n = row / C;
+  const int p = (blockIdx.x * 256 + threadIdx.x) * V;
+  if (p >= lv.P) return;
+  const int L = lv.num_levels, g = c / (C / G);
+  const size_t ob = ((size_t)n * G + g) * L;
   const size_t idx = (size_t)row * lv.P + p;
-  float dz = dy[idx];
-  if (relu && !(y[idx] > 0.f)) dz = 0.f;
-  const float xh = (x[idx] - mu) * rs;
-  dx[idx] = rs * (gamma[c] * dz - fm1 - xh * fm2);
+  const float ga = gamma[c];
+  float a_dy[V], a_y[V], a_x[V], out[V];
+  if (V == 4) {
+    const float4 t0 = *reinterpret_cast<const float4*>(dy + idx);
+    const float4 t2 = *reinterpret_cast<const float4*>(x + idx);
+    a_dy[0] = t0.x; a_dy[1] = t0.y; a_dy[2] = t0.z; a_dy[3] = t0.w;
+    a_x[0] = t2.x; a_x[1] = t2.y; a_x[2] = t2.z; a_x[3] = t2.w;
+    if (relu) {
+      const float4 t1 = *reinterpret_cast<const float4*>(y + idx);
+      a_y[0] = t1.x; a_y[1] = t1.y; a_y[2] = t1.z; a_y[3] = t1.w;
+    }
+  } else {
+    a_dy[0] = dy[idx];
+    a_x[0] = x[idx];
+    if (relu) a_y[0] = y[idx];
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const int l = level_of_pos(lv, p + k);
+    const float mu = mean[ob + l], rs = rstd[ob + l];
+    const float fm1 = gm[(ob + l) * 2 + 0], fm2 = gm[(ob + l) * 2 + 1];
+    float dz = a_dy[k];
+    if (relu && !(a_y[k] > 0.f)) dz = 0.f;
+    const float xh = (a_x[k] - mu) * rs;
+    out[k] = rs * (ga * dz - fm1 - xh * fm2);
+  }
+  if (V == 4)
+    *reinterpret_cast<float4*>(dx + idx) = make_float4(out[0], out[1], out[2], out[3]);
+  else
+    dx[idx] = out[0];
 }
 
 // dgamma[c] = sum_{n,l} s2, dbeta[c] = sum_{n,l} s1
@@ -318,7 +427,7 @@ __global__ void gn_bwd_param_kernel(const double* __restrict__ sums, int N, int 
   double s1 = 0.0, s2 = 0.0;
   for (int n = 0; n < N; ++n)
     for (int l = 0; l < L; ++l) {
-      const size_t r = ((size_t)(n * C + c) * L + l) * 2;
+      const size_t r = ((size_t)(n * C + c) * L + l) * kGnBwdSplit * 2;
       s1 += sums[r + 0];
       s2 += sums[r + 1];
     }
@@ -598,15 +707,26 @@ extern "C" int ld_gn_forward(const ld_levels_t* lv, const float* x,
   hipLaunchKernelGGL(gn_stats_final_kernel, dim3((ngl + 255) / 256), dim3(256), 0,
                      LD_STREAM, (const double*)workspace, k, N, C, G, eps, mean,
                      rstd);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((k.P + 255) / 256, N * C), dim3(256), 0,
-                     LD_STREAM, x, k, C, G, mean, rstd, gamma, beta, relu, y);
+  if (k.P % 4 == 0 && ((uintptr_t)x | (uintptr_t)y) % 16 == 0)
+    hipLaunchKernelGGL(gn_apply4_kernel, dim3((k.P / 4 + 255) / 256, N * C),
+                       dim3(256), 0, LD_STREAM, x, k, C, G, mean, rstd, gamma, beta,
+                       relu, y);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((k.P + 255) / 256, N * C), dim3(256), 0,
+                       LD_STREAM, x, k, C, G, mean, rstd, gamma, beta, relu, y);
   return (int)hipGetLastError();
+}
+
+static size_t gn_bwd_sums_bytes(int L, int N, int C) {
+  return (size_t)N * C * L * kGnBwdSplit * 2 * sizeof(double);
 }
 
 extern "C" size_t ld_gn_backward_workspace_bytes(const ld_levels_t* lv, int N,
                                                  int C) {
   if (check_levels(lv) != 0 || N < 1 || C < 1) return 0;
-  return (size_t)N * C * lv->num_levels * 2 * sizeof(double);
+  // slice sums (fp64) + per (n, group, level) means (fp32; G <= C)
+  return gn_bwd_sums_bytes(lv->num_levels, N, C) +
+         (size_t)N * C * lv->num_levels * 2 * sizeof(float);
 }
 
 extern "C" int ld_gn_backward(const ld_levels_t* lv, const float* dy, const float* y,
@@ -624,11 +744,25 @@ extern "C" int ld_gn_backward(const ld_levels_t* lv, const float* dy, const floa
     return LD_ENOSPACE;
   const Levels k = make_levels(lv);
   double* sums = (double*)workspace;
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(N * C * k.num_levels), dim3(256), 0,
+  float* gm = (float*)((char*)workspace + gn_bwd_sums_bytes(k.num_levels, N, C));
+  const int rl = N * C * k.num_levels, ngl = N * G * k.num_levels;
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(rl * kGnBwdSplit), dim3(256), 0,
                      LD_STREAM, dy, y, x, k, C, G, mean, rstd, relu, sums);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((k.P + 255) / 256, N * C), dim3(256),
-                     0, LD_STREAM, dy, y, x, k, C, G, mean, rstd, gamma, sums, relu,
-                     dx);
+  hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((rl + 255) / 256), dim3(256), 0,
+                     LD_STREAM, sums, rl);
+  hipLaunchKernelGGL(gn_bwd_group_kernel, dim3((ngl + 255) / 256), dim3(256), 0,
+                     LD_STREAM, sums, k, N, C, G, gamma, gm);
+  const bool vec = k.P % 4 == 0 &&
+                   ((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx |
+                    (uintptr_t)(relu ? y : x)) % 16 == 0;
+  if (vec)
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<4>, dim3((k.P / 4 + 255) / 256, N * C),
+                       dim3(256), 0, LD_STREAM, dy, y, x, k, C, G, mean, rstd, gamma,
+                       gm, relu, dx);
+  else
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, dim3((k.P + 255) / 256, N * C),
+                       dim3(256), 0, LD_STREAM, dy, y, x, k, C, G, mean, rstd, gamma,
+                       gm, relu, dx);
   if (dgamma && dbeta)
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0,
                        LD_STREAM, sums, N, C, k.num_levels, dgamma, dbeta,

@@ -67,6 +67,10 @@ class GradArena:
             view.copy_(p.data)
             p.data = view
             p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+            # direct sink for the backward kernels (layers._sink / _emit)
+            p._ld_grad = p.grad
+            p._ld_ready = self._on_grad
+            p._ld_pending = 0
         # buckets: contiguous [start, end) ranges of the arena
         self.buckets, start, count = [], 0, 0
         cap = max(bucket_bytes // 4, 1)
@@ -80,6 +84,7 @@ class GradArena:
                 start, count = end, 0
         self._ready = [0] * len(self.buckets)
         self._works = []
+        self._seen = set()
         self._hooks = [
             p.register_post_accumulate_grad_hook(self._on_grad)
             for p in self.params
@@ -92,12 +97,19 @@ class GradArena:
             if p.grad is None or p.grad.data_ptr() != \
                     self.flat_grad.data_ptr() + 4 * o:
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+                p._ld_grad = p.grad
+            p._ld_pending = 0
         self._ready = [0] * len(self.buckets)
         self._works = []
+        self._seen = set()
 
     def _on_grad(self, p):
-        if not self.enabled:
+        """A parameter's gradient is complete (called by autograd's
+        post-accumulate hook and/or by the direct-sink path of ld_amd.layers;
+        whichever comes first counts, once per step)."""
+        if not self.enabled or id(p) in self._seen:
             return
+        self._seen.add(id(p))
         b = self.bucket_of[id(p)]
         self._ready[b] += 1
         if self._ready[b] == self.buckets[b]['n'] and collectives_on():

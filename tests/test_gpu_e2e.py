@@ -109,6 +109,37 @@ def test_features_vs_cpu_oracle(golden):
     assert not bad, f'{len(bad)} of {len(rels)} gradients off: {bad[:8]}'
 
 
+def test_arena_direct_grads_match_autograd(golden):
+    """With a GradArena the backward kernels accumulate straight into the flat
+    gradient arena (no temporaries, no add kernels) and autograd sees None for
+    those inputs; the result must be the very same bits as plain autograd
+    accumulation, and every parameter must be reported ready exactly once."""
+    from ld_amd.train import GradArena
+    g, det, batch, dbatch = _setup(golden, 'tiny_r18', 18, 0.0)
+    losses = det(**dbatch)
+    loss, _ = det._parse_losses(losses)
+    loss.backward()
+    ref = {k: p.grad.detach().clone() for k, p in det.named_parameters()
+           if p.grad is not None}
+    for p in det.parameters():
+        p.grad = None
+    arena = GradArena(list(det.parameters()))
+    arena.zero_grad()
+    losses = det(**dbatch)
+    loss, _ = det._parse_losses(losses)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert len(ref) == len(arena.params)
+    for k, p in det.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad.data_ptr() == p._ld_grad.data_ptr(), k
+        assert torch.equal(p.grad, ref[k]), \
+            f'{k}: max diff {(p.grad - ref[k]).abs().max().item()}'
+    assert arena._seen == {id(p) for p in arena.params}
+    assert arena._ready == [bk['n'] for bk in arena.buckets]
+
+
 def test_trainer_two_steps_reduce_loss(golden):
     """SGDTrainer (flat arenas, hooks, fused SGD): two steps on the same batch
     run, keep gradients in the arena, and change the weights."""
