@@ -546,20 +546,32 @@ __global__ __launch_bounds__(64 * WVM * WVN * KG) void conv_igemm_kernel(ConvK a
 // whole workgroup stalling on ds_write -> s_barrier -> ds_read every k-step.
 // The four waves of a workgroup sit on neighbouring tiles only so that their
 // shared A / B rows hit in the CU's L1.
-template <int TM, int TN, int WVM, int MODE, int D, int OCC>
+//
+// KS = 4: the four waves of a workgroup share ONE wave tile and split its
+// reduction (chunk c goes to wave c % 4); the partial accumulators meet once, in
+// LDS, before the epilogue.  Layers whose tile count is only ~1-5 per SIMD
+// (J = 8400 / 2100 stages) lose up to half the machine to the rounding of
+// tiles-per-SIMD; quartering the work unit brings that back (8.2 -> 9 instead
+// of 2.05 -> 3).  The per-element summation order differs from KS = 1.
+template <int TM, int TN, int WVM, int MODE, int D, int OCC, int KS>
 __global__ __launch_bounds__(256, OCC) void conv_stream_kernel(ConvK a) {
+  static_assert(KS == 1 || (KS == 4 && WVM == 1), "KS is 1 or 4");
   constexpr int WVN = 4 / WVM;
   constexpr int WM = TM * 32, WN = TN * 32;
-  constexpr int BM = WVM * WM, BNT = WVN * WN;
+  constexpr int BM = KS == 4 ? WM : WVM * WM, BNT = KS == 4 ? WN : WVN * WN;
+  __shared__ float red[KS == 4 ? 3 * TM * TN * 16 * 64 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int wm = wave / WVN, wn = wave % WVN;
+  const int wm = KS == 4 ? 0 : wave / WVN, wn = KS == 4 ? 0 : wave % WVN;
+  const int kslice = KS == 4 ? wave : 0;
   const int l31 = lane & 31, lk = lane >> 5;
   const int mtiles = (a.Cout + BM - 1) / BM;
   const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
   const int m0 = (tile % mtiles) * BM + wm * WM;
   const int n0 = (tile / mtiles) * BNT + wn * WN;
-  if (m0 >= a.Cout || n0 >= a.J) return;  // no barriers below: waves are independent
+  // KS == 1: no barriers below, waves are independent.  KS == 4: the condition
+  // is uniform over the workgroup.
+  if (m0 >= a.Cout || n0 >= a.J) return;
 
   const int Cin = __builtin_amdgcn_readfirstlane(a.Cin);
   const int Cout = __builtin_amdgcn_readfirstlane(a.Cout);
@@ -648,43 +660,79 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_kernel(ConvK a) {
 
   const int cchunks = Cin / (2 * D);  // host guarantees Cin % (2*D) == 0
   const int nchunks = ntaps * cchunks;
+  // this wave's chunks: kslice, kslice + KS, ...
+  const int mychunks = nchunks > kslice ? (nchunks - kslice + KS - 1) / KS : 0;
   int ltap = 0, lci = 0;
-  set_tap(0);
-  auto advance = [&]() {
-    lci += 2 * D;
-    if (lci >= Cin) {
-      lci = 0;
+  auto advance = [&](int n) {
+    lci += 2 * D * n;
+    const int t0 = ltap;
+    while (lci >= Cin) {
+      lci -= Cin;
       ++ltap;
-      if (ltap < ntaps) set_tap(ltap);
     }
+    if (ltap != t0 && ltap < ntaps) set_tap(ltap);
   };
-  {
-    const unsigned sa = (unsigned)(wtap * Kpad) * Cout * 4u;
+  set_tap(0);
+  if (KS > 1) advance(kslice);
+  if (mychunks > 0) {
+    {
+      const unsigned sa = (unsigned)(wtap * Kpad + lci) * Cout * 4u;
+      const unsigned sb = (unsigned)lci * Pin * 4u;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      // same issue order as the steady state, so the loop-header vmcnt merge
-      // stays exact (4 * (D - 1) outstanding)
-      load_kp(d, sa + (unsigned)(2 * d) * Cout * 4u, (unsigned)(2 * d) * Pin * 4u);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int d = 0; d < D; ++d) {
+        // same issue order as the steady state, so the loop-header vmcnt merge
+        // stays exact (4 * (D - 1) outstanding)
+        load_kp(d, sa + (unsigned)(2 * d) * Cout * 4u,
+                sb + (unsigned)(2 * d) * Pin * 4u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      advance(KS);
     }
-    advance();
-  }
-  for (int c = 0; c + 1 < nchunks; ++c) {
-    const unsigned sa = (unsigned)(wtap * Kpad + lci) * Cout * 4u;
-    const unsigned sb = (unsigned)lci * Pin * 4u;
+    for (int c = 0; c + 1 < mychunks; ++c) {
+      const unsigned sa = (unsigned)(wtap * Kpad + lci) * Cout * 4u;
+      const unsigned sb = (unsigned)lci * Pin * 4u;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      // pin the ring order: without the fences the scheduler sinks all D
-      // refills below the MFMAs and the prefetch distance collapses to zero
-      mfma_kp(d);
-      __builtin_amdgcn_sched_barrier(0);
-      load_kp(d, sa + (unsigned)(2 * d) * Cout * 4u, sb + (unsigned)(2 * d) * Pin * 4u);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int d = 0; d < D; ++d) {
+        // pin the ring order: without the fences the scheduler sinks all D
+        // refills below the MFMAs and the prefetch distance collapses to zero
+        mfma_kp(d);
+        __builtin_amdgcn_sched_barrier(0);
+        load_kp(d, sa + (unsigned)(2 * d) * Cout * 4u,
+                sb + (unsigned)(2 * d) * Pin * 4u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      advance(KS);
     }
-    advance();
-  }
 #pragma unroll
-  for (int d = 0; d < D; ++d) mfma_kp(d);
+    for (int d = 0; d < D; ++d) mfma_kp(d);
+  }
+  if (KS == 4) {
+    // partial accumulators of waves 1..3 -> LDS [wave-1][reg][lane]; wave 0
+    // adds them in fixed order and runs the epilogue
+    if (wave > 0) {
+      float* dst = red + (size_t)(wave - 1) * TM * TN * 16 * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            dst[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      const float* src = red + (size_t)w * TM * TN * 16 * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            acc[i][j][r] += src[((i * TN + j) * 16 + r) * 64];
+    }
+  }
 
   // ---- epilogue: direct stores, 32 consecutive positions per accumulator row
   const bool has_res = a.residual != nullptr;
@@ -1186,15 +1234,17 @@ inline int set_extents(ConvK& k, size_t x_floats, size_t wt_floats) {
 //   LD_CONV_AUTOTUNE = "0"         model-based pick, no timing
 //   LD_CONV_TUNE_LOG = "1"         print the picks to stderr
 struct StreamCfg {
-  int tm, tn, wvm, d;
+  int tm, tn, wvm, d, ks;
 };
 #define LD_STREAM_SHAPES(X)                                                        \
-  X(2, 2, 2, 8) X(2, 2, 1, 8) X(2, 1, 2, 8) X(1, 2, 2, 8) X(1, 2, 4, 8)            \
-  X(1, 2, 1, 8) X(1, 1, 2, 8) X(1, 1, 1, 8) X(1, 1, 4, 8) X(3, 1, 1, 8)            \
-  X(3, 2, 1, 8) X(2, 2, 2, 4) X(2, 2, 1, 4) X(1, 2, 2, 4) X(1, 1, 2, 4)            \
-  X(1, 1, 1, 4) X(3, 1, 1, 4) X(3, 2, 1, 4)
+  X(2, 2, 2, 8, 1) X(2, 2, 1, 8, 1) X(2, 1, 2, 8, 1) X(1, 2, 2, 8, 1)              \
+  X(1, 2, 4, 8, 1) X(1, 2, 1, 8, 1) X(1, 1, 2, 8, 1) X(1, 1, 1, 8, 1)              \
+  X(1, 1, 4, 8, 1) X(3, 1, 1, 8, 1) X(3, 2, 1, 8, 1) X(2, 2, 2, 4, 1)              \
+  X(2, 2, 1, 4, 1) X(1, 2, 2, 4, 1) X(1, 1, 2, 4, 1) X(1, 1, 1, 4, 1)              \
+  X(3, 1, 1, 4, 1) X(3, 2, 1, 4, 1) X(1, 1, 1, 8, 4) X(1, 2, 1, 8, 4)              \
+  X(2, 1, 1, 8, 4) X(2, 2, 1, 8, 4)
 constexpr StreamCfg kStreamCfgs[] = {
-#define LD_STREAM_ROW(TM_, TN_, WVM_, D_) {TM_, TN_, WVM_, D_},
+#define LD_STREAM_ROW(TM_, TN_, WVM_, D_, KS_) {TM_, TN_, WVM_, D_, KS_},
     LD_STREAM_SHAPES(LD_STREAM_ROW)
 #undef LD_STREAM_ROW
 };
@@ -1202,11 +1252,12 @@ constexpr int kNumStreamCfgs = sizeof(kStreamCfgs) / sizeof(kStreamCfgs[0]);
 
 template <int MODE>
 int launch_stream_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream) {
-  const int bm = c.wvm * c.tm * 32, bn = (4 / c.wvm) * c.tn * 32;
+  const int bm = (c.ks == 4 ? 1 : c.wvm) * c.tm * 32;
+  const int bn = (c.ks == 4 ? 1 : 4 / c.wvm) * c.tn * 32;
   const int nb = ((k.Cout + bm - 1) / bm) * ((k.J + bn - 1) / bn);
-#define LD_STREAM_CASE(TM_, TN_, WVM_, D_)                                         \
-  if (c.tm == TM_ && c.tn == TN_ && c.wvm == WVM_ && c.d == D_) {                  \
-    hipLaunchKernelGGL((conv_stream_kernel<TM_, TN_, WVM_, MODE, D_, 2>),          \
+#define LD_STREAM_CASE(TM_, TN_, WVM_, D_, KS_)                                    \
+  if (c.tm == TM_ && c.tn == TN_ && c.wvm == WVM_ && c.d == D_ && c.ks == KS_) {   \
+    hipLaunchKernelGGL((conv_stream_kernel<TM_, TN_, WVM_, MODE, D_, 2, KS_>),     \
                        dim3(nb), dim3(256), 0, stream, k);                         \
     return (int)hipGetLastError();                                                 \
   }
@@ -1215,11 +1266,17 @@ int launch_stream_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream) {
   return LD_EUNSUPPORTED;
 }
 
+#define MODE1_TAPS(k) ((k).nth > 0 ? (k).nth * (k).ntw : (k).KH * (k).KW)
 inline bool stream_cfg_fits(const ConvK& k, const StreamCfg& c) {
   if (k.Cin % (2 * c.d) != 0) return false;
   if (c.d == 4 && k.Cin % 16 == 0) return false;  // the 8-deep ring covers it
   const int bm = c.wvm * c.tm * 32;
   const int cout32 = (k.Cout + 31) / 32 * 32;
+  if (c.ks == 4) {
+    // split-K only pays when the reduction is long enough to quarter
+    const int nchunks = (MODE1_TAPS(k)) * (k.Cin / (2 * c.d));
+    if (nchunks < 16) return false;
+  }
   if (c.wvm > 1 && bm > cout32) return false;  // whole waves of padding rows
   if (c.wvm == 1 && c.tm * 32 >= cout32 + 32) return false;
   return true;
@@ -1232,14 +1289,17 @@ inline int stream_cfg_model(const ConvK& k) {
   for (int i = 0; i < kNumStreamCfgs; ++i) {
     const StreamCfg& c = kStreamCfgs[i];
     if (!stream_cfg_fits(k, c)) continue;
-    const int bm = c.wvm * c.tm * 32, bn = (4 / c.wvm) * c.tn * 32;
+    const int bm = (c.ks == 4 ? 1 : c.wvm) * c.tm * 32;
+    const int bn = (c.ks == 4 ? 1 : 4 / c.wvm) * c.tn * 32;
     const long nb = (long)((k.Cout + bm - 1) / bm) * ((k.J + bn - 1) / bn);
     const int area = c.tm * c.tn;
-    const double eff = area >= 4 ? 0.90 : area >= 2 ? 0.84 : 0.79;
+    const double eff = (area >= 4 ? 0.90 : area >= 2 ? 0.84 : 0.79) *
+                       (c.ks == 4 ? 0.97 : 1.0);
     const int occ = area >= 4 ? 4 : 5;  // resident workgroups per CU
     const double rounds =
         nb <= 256L * occ ? (double)((nb + 255) / 256) : (double)nb / 256.0;
-    const double t = rounds * 4 * area / eff;
+    // work per workgroup: 4 wave tiles, or one when its K is split four ways
+    const double t = rounds * (c.ks == 4 ? 1 : 4) * area / eff;
     if (best < 0 || t < best_t) {
       best = i;
       best_t = t;
@@ -1268,7 +1328,7 @@ std::mutex g_tune_mu;
 std::unordered_map<TuneKey, int, TuneKeyHash> g_tune;
 bool g_tune_file_loaded = false;
 
-// LD_CONV_TUNE_FILE: text file of "16 key ints  tm tn wvm d" lines.  Loaded once
+// LD_CONV_TUNE_FILE: text file of "16 key ints  tm tn wvm d ks" lines.  Loaded once
 // per process, appended to whenever a new geometry is tuned -- lets a profiling
 // run (or every rank after the first) start from the picks of an earlier run
 // instead of re-timing the candidates.  Caller holds g_tune_mu.
@@ -1284,11 +1344,12 @@ void tune_file_load_locked() {
     StreamCfg c;
     int got = 0;
     for (int i = 0; i < 16; ++i) got += fscanf(f, "%d", &k.v[i]) == 1;
-    got += fscanf(f, "%d %d %d %d", &c.tm, &c.tn, &c.wvm, &c.d) == 4;
+    got += fscanf(f, "%d %d %d %d %d", &c.tm, &c.tn, &c.wvm, &c.d, &c.ks) == 5;
     if (got != 17) break;
     for (int i = 0; i < kNumStreamCfgs; ++i)
       if (kStreamCfgs[i].tm == c.tm && kStreamCfgs[i].tn == c.tn &&
-          kStreamCfgs[i].wvm == c.wvm && kStreamCfgs[i].d == c.d)
+          kStreamCfgs[i].wvm == c.wvm && kStreamCfgs[i].d == c.d &&
+          kStreamCfgs[i].ks == c.ks)
         g_tune[k] = i;
   }
   fclose(f);
@@ -1301,7 +1362,7 @@ void tune_file_append_locked(const TuneKey& k, int pick) {
   if (!f) return;
   for (int i = 0; i < 16; ++i) fprintf(f, "%d ", k.v[i]);
   const StreamCfg& c = kStreamCfgs[pick];
-  fprintf(f, " %d %d %d %d\n", c.tm, c.tn, c.wvm, c.d);
+  fprintf(f, " %d %d %d %d %d\n", c.tm, c.tn, c.wvm, c.d, c.ks);
   fclose(f);
 }
 
@@ -1311,8 +1372,12 @@ int launch_stream(const ConvK& k, hipStream_t stream) {
   if (const char* env = getenv("LD_CONV_STREAM")) {
     if (env[0] == '0' && env[1] == 0) return LD_EUNSUPPORTED;
     StreamCfg c;
-    if (sscanf(env, "%dx%dx%dx%d", &c.tm, &c.tn, &c.wvm, &c.d) == 4) {
+    c.ks = 1;
+    if (sscanf(env, "%dx%dx%dx%dx%d", &c.tm, &c.tn, &c.wvm, &c.d, &c.ks) >= 4) {
       if (k.Cin % (2 * c.d) != 0) c.d = 4;
+      const int rc = launch_stream_cfg<MODE>(k, c, stream);
+      if (rc != LD_EUNSUPPORTED) return rc;
+      c.ks = 1;  // no split-K instance at this ring depth
       return launch_stream_cfg<MODE>(k, c, stream);
     }
   }
@@ -1366,9 +1431,9 @@ int launch_stream(const ConvK& k, hipStream_t stream) {
                           (MODE == 1 ? k.nth * k.ntw : k.KH * k.KW);
         fprintf(stderr,
                 "[ld_conv] mode %d Cin %d Cout %d k %dx%d s%d J %d lv %d -> "
-                "%dx%dx%dx%d  %.1f TFLOP/s\n",
+                "%dx%dx%dx%dx%d  %.1f TFLOP/s\n",
                 MODE, k.Cin, k.Cout, k.KH, k.KW, k.g.stride, k.J, k.g.num_levels,
-                c.tm, c.tn, c.wvm, c.d,
+                c.tm, c.tn, c.wvm, c.d, c.ks,
                 best_ms > 0 ? fl / (best_ms * 1e-3 / kTuneReps) / 1e12 : 0.0);
       }
     std::lock_guard<std::mutex> lock(g_tune_mu);
@@ -1469,7 +1534,7 @@ extern "C" int ld_conv_forward(const ld_conv_t* c, const float* x,
                                float* y, ld_stream_t stream) {
   if (int e = check_conv(c)) return e;
   if (!x || !wt_fwd || !y) return LD_EINVAL;
-  ConvK k;
+  ConvK k{};
   k.x = x;
   k.wt = wt_fwd;
   k.y = y;
@@ -1499,7 +1564,7 @@ extern "C" int ld_conv_forward_smallc(const ld_conv_t* c, const float* x,
                                       float* y, ld_stream_t stream) {
   if (int e = check_conv(c)) return e;
   if (!x || !wt || !y) return LD_EINVAL;
-  ConvK k;
+  ConvK k{};
   k.x = x;
   k.wt = wt;
   k.y = y;
@@ -1532,7 +1597,7 @@ extern "C" int ld_conv_dgrad(const ld_conv_t* c, const float* dy,
   if (!dy || !wt_bwd || !dx) return LD_EINVAL;
   if (c->KH != c->KW) return LD_EUNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
-  ConvK k;
+  ConvK k{};
   k.x = dy;
   k.wt = wt_bwd;
   k.y = dx;
