@@ -277,6 +277,19 @@ size_t ld_conv_weight_image_floats(int Cout, int Cin, int KH, int KW,
                                    int backward);
 int ld_conv_weight_transform(const float* w, int Cout, int Cin, int KH, int KW,
                              float* wt_fwd, float* wt_bwd, ld_stream_t stream);
+/* Many weight images in ONE launch (after the optimizer step every trainable
+ * conv of the student needs new images: 137 launches of a few microseconds
+ * each otherwise).  `jobs` and `block_job` live in DEVICE memory; job j owns
+ * the 256-thread blocks [first_block, first_block of job j+1); block_job[b] is
+ * the job of block b.  wt_fwd / wt_bwd may be NULL per job. */
+typedef struct {
+  const float* w;
+  float* wt_fwd;
+  float* wt_bwd;
+  int32_t Cout, Cin, ntaps, first_block;
+} ld_wt_job_t;
+int ld_conv_weight_transform_batch(const ld_wt_job_t* jobs, const int32_t* block_job,
+                                   int nblocks, ld_stream_t stream);
 int ld_conv_forward(const ld_conv_t* c, const float* x, const float* wt_fwd,
                     const ld_conv_epilogue_t* ep, float* y, ld_stream_t stream);
 /* dx (N,Cin,Pin) fully overwritten. */
@@ -309,6 +322,21 @@ typedef struct {
 int ld_bn_prepare(const float* gamma, const float* beta, const float* mean,
                   const float* var, float eps, int C, float* scale, float* shift,
                   float* rstd, ld_stream_t stream);
+/* The same for many BatchNorms in one launch (device-resident job table, as
+ * ld_conv_weight_transform_batch). */
+typedef struct {
+  const float* gamma;
+  const float* beta;
+  const float* mean;
+  const float* var;
+  float* scale;
+  float* shift;
+  float* rstd;
+  float eps;
+  int32_t C, first_block, reserved;
+} ld_bn_job_t;
+int ld_bn_prepare_batch(const ld_bn_job_t* jobs, const int32_t* block_job,
+                        int nblocks, ld_stream_t stream);
 /* y = act(x*scale[c] + shift[c] (+ residual)) on (N, C, P)
  * (Bottleneck/BasicBlock tails, resnet.py:65-92,260-299). */
 int ld_bn_act_forward(const float* x, const float* residual, const float* scale,

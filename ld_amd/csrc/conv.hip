@@ -1147,12 +1147,12 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, int sp
 
 // (Cout, Cin, KH, KW) -> fwd image [tap][Cin_pad][Cout] and dgrad image
 // [KH*KW-1-tap][Cout_pad][Cin]; the pad rows (k >= Cin resp. Cout) are zero.
-__global__ void conv_weight_transform_kernel(const float* __restrict__ w, int Cout,
-                                             int Cin, int ntaps, int CinPad,
-                                             int CoutPad,
-                                             float* __restrict__ wt_fwd,
-                                             float* __restrict__ wt_bwd) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void weight_transform_at(const float* __restrict__ w,
+                                                    int Cout, int Cin, int ntaps,
+                                                    int CinPad, int CoutPad,
+                                                    float* __restrict__ wt_fwd,
+                                                    float* __restrict__ wt_bwd,
+                                                    size_t i) {
   if (wt_fwd && i < (size_t)ntaps * CinPad * Cout) {
     // i enumerates the fwd image [tap][ci][co] (coalesced writes)
     const int co = (int)(i % Cout);
@@ -1169,6 +1169,24 @@ __global__ void conv_weight_transform_kernel(const float* __restrict__ w, int Co
                     ? w[((size_t)co * Cin + ci) * ntaps + (ntaps - 1 - tapf)]
                     : 0.0f;
   }
+}
+
+__global__ void conv_weight_transform_kernel(const float* __restrict__ w, int Cout,
+                                             int Cin, int ntaps, int CinPad,
+                                             int CoutPad,
+                                             float* __restrict__ wt_fwd,
+                                             float* __restrict__ wt_bwd) {
+  weight_transform_at(w, Cout, Cin, ntaps, CinPad, CoutPad, wt_fwd, wt_bwd,
+                      (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void conv_weight_transform_batch_kernel(
+    const ld_wt_job_t* __restrict__ jobs, const int32_t* __restrict__ block_job) {
+  const ld_wt_job_t j = jobs[block_job[blockIdx.x]];
+  const int CinPad = (j.Cin + kKPad - 1) / kKPad * kKPad;
+  const int CoutPad = (j.Cout + kKPad - 1) / kKPad * kKPad;
+  weight_transform_at(j.w, j.Cout, j.Cin, j.ntaps, CinPad, CoutPad, j.wt_fwd, j.wt_bwd,
+                      (size_t)(blockIdx.x - j.first_block) * 256 + threadIdx.x);
 }
 
 int check_conv(const ld_conv_t* c) {
@@ -1531,6 +1549,15 @@ extern "C" int ld_conv_weight_transform(const float* w, int Cout, int Cin, int K
                      dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, w, Cout, Cin, KH * KW, cip, cop, wt_fwd,
                      wt_bwd);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_conv_weight_transform_batch(const ld_wt_job_t* jobs,
+                                              const int32_t* block_job, int nblocks,
+                                              ld_stream_t stream) {
+  if (!jobs || !block_job || nblocks < 1) return LD_EINVAL;
+  hipLaunchKernelGGL(conv_weight_transform_batch_kernel, dim3(nblocks), dim3(256), 0,
+                     (hipStream_t)stream, jobs, block_job);
   return (int)hipGetLastError();
 }
 

@@ -627,6 +627,26 @@ extern "C" int ld_bn_prepare(const float* gamma, const float* beta,
   return (int)hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void bn_prepare_batch_kernel(
+    const ld_bn_job_t* __restrict__ jobs, const int32_t* __restrict__ block_job) {
+  const ld_bn_job_t j = jobs[block_job[blockIdx.x]];
+  const int c = (blockIdx.x - j.first_block) * 256 + threadIdx.x;
+  if (c >= j.C) return;
+  const float r = 1.0f / sqrtf(j.var[c] + j.eps);
+  const float s = j.gamma[c] * r;
+  j.scale[c] = s;
+  j.shift[c] = j.beta[c] - j.mean[c] * s;
+  if (j.rstd) j.rstd[c] = r;
+}
+
+extern "C" int ld_bn_prepare_batch(const ld_bn_job_t* jobs, const int32_t* block_job,
+                                   int nblocks, ld_stream_t stream) {
+  if (!jobs || !block_job || nblocks < 1) return LD_EINVAL;
+  hipLaunchKernelGGL(bn_prepare_batch_kernel, dim3(nblocks), dim3(256), 0, LD_STREAM,
+                     jobs, block_job);
+  return (int)hipGetLastError();
+}
+
 extern "C" int ld_bn_act_forward(const float* x, const float* residual,
                                  const float* scale, const float* shift, int N,
                                  int C, int P, int relu, float* y,

@@ -105,6 +105,114 @@ def levels_desc(levels):
 
 
 # ---------------------------------------------------------------------------
+# per-step refresh of everything derived from trainable parameters
+# ---------------------------------------------------------------------------
+# After the optimizer step every trainable conv needs new GEMM weight images
+# and every trainable BN new scale/shift: 137 + 58 launches of a few
+# microseconds each on the C2 step.  Tensors that went through
+# weight_images() / bn_prepare() once are remembered (weakly) and refreshed by
+# ONE launch per kind from device-resident job tables.
+import weakref  # noqa: E402
+
+_WT_REG, _BN_REG = {}, {}
+_TABLES = {}
+
+
+def _register(reg, t):
+    if id(t) not in reg:
+        reg[id(t)] = weakref.ref(t)
+        _TABLES.clear()
+
+
+def _job_table(structs, blocks_of, device):
+    """ctypes job array + block->job map as device tensors."""
+    first, block_job = 0, []
+    for j, (st, nb) in enumerate(zip(structs, blocks_of)):
+        st.first_block = first
+        block_job.extend([j] * nb)
+        first += nb
+    arr = (type(structs[0]) * len(structs))(*structs)
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return (raw.to(device), torch.tensor(block_job, dtype=torch.int32,
+                                         device=device), first)
+
+
+def refresh_params(device):
+    """Recompute the images / coefficients of all registered trainable
+    parameters for the current parameter generation."""
+    lib = L.get_lib()
+    gen = _PARAM_GEN[0]
+    key = str(device)
+    tabs = _TABLES.get(key)
+    if tabs is None:
+        live_w, wjobs, wblocks = [], [], []
+        for ref in list(_WT_REG.values()):
+            w = ref()
+            cache = getattr(w, '_ld_images', None) if w is not None else None
+            if w is None or cache is None or w.device != device or \
+                    cache['ident'] != (w.data_ptr(), False) or \
+                    cache['fwd'] is None:
+                continue
+            cout, cin, kh, kw = w.shape
+            j = L.WtJobT()
+            j.w, j.wt_fwd = w.data_ptr(), cache['fwd'].data_ptr()
+            j.wt_bwd = cache['bwd'].data_ptr() if cache['bwd'] is not None \
+                else None
+            j.Cout, j.Cin, j.ntaps = cout, cin, kh * kw
+            n = cache['fwd'].numel()
+            if cache['bwd'] is not None:
+                n = max(n, cache['bwd'].numel())
+            live_w.append((w, cache, cache['bwd'] is not None))
+            wjobs.append(j)
+            wblocks.append((n + 255) // 256)
+        live_b, bjobs, bblocks = [], [], []
+        for ref in list(_BN_REG.values()):
+            g = ref()
+            hit = getattr(g, '_ld_bn', None) if g is not None else None
+            if g is None or hit is None or g.device != device:
+                continue
+            beta, mean, var, eps = g._ld_bn_src
+            scale, shift, rstd = hit[1]
+            j = L.BnJobT()
+            j.gamma, j.beta, j.mean, j.var = (g.data_ptr(), beta.data_ptr(),
+                                              mean.data_ptr(), var.data_ptr())
+            j.scale, j.shift, j.rstd = (scale.data_ptr(), shift.data_ptr(),
+                                        rstd.data_ptr())
+            j.eps, j.C = eps, g.numel()
+            live_b.append((g, beta, mean, var, eps))
+            bjobs.append(j)
+            bblocks.append((g.numel() + 255) // 256)
+        tabs = dict(
+            w=_job_table(wjobs, wblocks, device) if wjobs else None,
+            b=_job_table(bjobs, bblocks, device) if bjobs else None,
+            live_w=live_w, live_b=live_b)
+        _TABLES[key] = tabs
+    st = L.stream_ptr(device)
+    if tabs['w'] is not None:
+        jobs, bmap, nb = tabs['w']
+        L.check(lib.ld_conv_weight_transform_batch(L.ptr(jobs), L.ptr(bmap),
+                                                   nb, st),
+                'ld_conv_weight_transform_batch')
+        for w, cache, has_bwd in tabs['live_w']:
+            stamp = (w._version, gen, w.data_ptr(), False)
+            if cache['ident'] == stamp[2:]:
+                cache['stamp'] = stamp
+                if has_bwd and cache['bwd'] is not None:
+                    cache['bwd_stamp'] = stamp
+    if tabs['b'] is not None:
+        jobs, bmap, nb = tabs['b']
+        L.check(lib.ld_bn_prepare_batch(L.ptr(jobs), L.ptr(bmap), nb, st),
+                'ld_bn_prepare_batch')
+        for g, beta, mean, var, eps in tabs['live_b']:
+            hit = g._ld_bn
+            stamp = (g.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                     var.data_ptr(), g._version, beta._version,
+                     mean._version, var._version, eps, gen)
+            if hit[0][:4] == stamp[:4]:
+                g._ld_bn = (stamp, hit[1])
+
+
+# ---------------------------------------------------------------------------
 # GEMM weight images (cached on the parameter)
 # ---------------------------------------------------------------------------
 def weight_images(w, need_bwd, smallc=False):
@@ -138,6 +246,8 @@ def weight_images(w, need_bwd, smallc=False):
                                               L.ptr(cache['fwd']), None, st)
         L.check(rc, 'ld_conv_weight_transform')
         cache['stamp'] = stamp
+        if dynamic and not smallc:
+            _register(_WT_REG, w)
     if need_bwd and cache['bwd_stamp'] != stamp:
         if smallc:
             raise L.LdError('small-Cin (stem) conv has no data gradient')
@@ -145,10 +255,13 @@ def weight_images(w, need_bwd, smallc=False):
             n = lib.ld_conv_weight_image_floats(cout, cin, kh, kw, 1)
             cache['bwd'] = torch.empty(n, dtype=torch.float32,
                                        device=w.device)
+            _TABLES.clear()  # the refresh job of this weight gains an output
         L.check(lib.ld_conv_weight_transform(L.ptr(w), cout, cin, kh, kw, None,
                                              L.ptr(cache['bwd']), st),
                 'ld_conv_weight_transform')
         cache['bwd_stamp'] = stamp
+        if dynamic:
+            _register(_WT_REG, w)
     return cache['fwd'], cache['bwd']
 
 
@@ -298,23 +411,26 @@ def conv2d(x3, w, bias, stride, pad, levels):
 # BatchNorm (eval statistics) + residual + ReLU
 # ---------------------------------------------------------------------------
 def bn_prepare(gamma, beta, mean, var, eps):
-    """scale/shift/rstd of an eval-mode BN.  For a frozen BN (no trainable
-    affine: the teacher, the student's frozen stages) the result is cached ON
-    the gamma tensor until any of the four tensors changes (a process-wide
-    table keyed by address would hand a new model the coefficients of a freed
-    one whose storage it happens to reuse)."""
+    """scale/shift/rstd of an eval-mode BN, cached ON the gamma tensor (a
+    process-wide table keyed by address would hand a new model the
+    coefficients of a freed one whose storage it happens to reuse).  Frozen BN
+    (the teacher, the student's frozen stages): valid until one of the four
+    tensors changes.  Trainable affine: valid for one parameter generation;
+    `refresh_params` recomputes all of them in one launch after the optimizer
+    step."""
     frozen = not (gamma.requires_grad or beta.requires_grad) or \
         getattr(gamma, '_ld_static', False)
-    if frozen:
-        stamp = (gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
-                 var.data_ptr(), gamma._version, beta._version, mean._version,
-                 var._version, eps)
-        hit = getattr(gamma, '_ld_bn', None)
-        if hit is not None and hit[0] == stamp:
-            return hit[1]
+    stamp = (gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+             var.data_ptr(), gamma._version, beta._version, mean._version,
+             var._version, eps, -1 if frozen else _PARAM_GEN[0])
+    hit = getattr(gamma, '_ld_bn', None)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
     out = _bn_prepare(gamma, beta, mean, var, eps)
-    if frozen:
-        gamma._ld_bn = (stamp, out)
+    gamma._ld_bn = (stamp, out)
+    if not frozen:
+        gamma._ld_bn_src = (beta, mean, var, eps)
+        _register(_BN_REG, gamma)
     return out
 
 
@@ -607,6 +723,7 @@ def sgd_step(params_flat, grads_flat, momentum_flat, lr, momentum,
                             momentum, weight_decay, grad_scale,
                             L.stream_ptr(params_flat.device)), 'ld_sgd_step')
     bump_param_generation()
+    refresh_params(params_flat.device)
 
 
 # ---------------------------------------------------------------------------

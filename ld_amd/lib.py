@@ -63,6 +63,21 @@ class ConvT(C.Structure):
                 ('lv', ConvLevelT * LD_MAX_LEVELS)]
 
 
+class WtJobT(C.Structure):  # ld_wt_job_t
+    _fields_ = [('w', C.c_void_p), ('wt_fwd', C.c_void_p),
+                ('wt_bwd', C.c_void_p), ('Cout', C.c_int32),
+                ('Cin', C.c_int32), ('ntaps', C.c_int32),
+                ('first_block', C.c_int32)]
+
+
+class BnJobT(C.Structure):  # ld_bn_job_t
+    _fields_ = [('gamma', C.c_void_p), ('beta', C.c_void_p),
+                ('mean', C.c_void_p), ('var', C.c_void_p),
+                ('scale', C.c_void_p), ('shift', C.c_void_p),
+                ('rstd', C.c_void_p), ('eps', C.c_float), ('C', C.c_int32),
+                ('first_block', C.c_int32), ('reserved', C.c_int32)]
+
+
 class ConvEpilogueT(C.Structure):
     _fields_ = [('bias', C.c_void_p), ('scale', C.c_void_p),
                 ('shift', C.c_void_p), ('residual', C.c_void_p),
@@ -140,6 +155,8 @@ SIGNATURES = {
     'ld_conv_weight_image_floats': (_sz, [_i32, _i32, _i32, _i32, _i32]),
     'ld_conv_weight_transform': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp,
                                            _vp, _vp]),
+    'ld_conv_weight_transform_batch': (C.c_int, [_vp, _vp, _i32, _vp]),
+    'ld_bn_prepare_batch': (C.c_int, [_vp, _vp, _i32, _vp]),
     'ld_conv_forward': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
     'ld_conv_forward_smallc': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
     'ld_conv_dgrad': (C.c_int, [_CV, _vp, _vp, _vp, _vp]),

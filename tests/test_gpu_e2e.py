@@ -159,3 +159,37 @@ def test_trainer_two_steps_reduce_loss(golden):
         if p.requires_grad:
             assert p.grad.data_ptr() >= tr.arena.flat_grad.data_ptr()
     assert out2['log_vars']['loss'] == pytest.approx(l2, rel=1e-6)
+    # the one-launch refresh after the optimizer step left every cached GEMM
+    # weight image and BN coefficient equal to a fresh per-tensor computation
+    import ctypes as C
+    from ld_amd import layers as Y, lib as L
+    lib = L.get_lib()
+    st = L.stream_ptr(dbatch['img'].device)
+    n_w = n_b = 0
+    for ref in Y._WT_REG.values():
+        w = ref()
+        if w is None or getattr(w, '_ld_images', None) is None:
+            continue
+        cache = w._ld_images
+        if cache['stamp'] != (w._version, Y._PARAM_GEN[0], w.data_ptr(), False):
+            continue
+        cout, cin, kh, kw = w.shape
+        fwd = torch.empty_like(cache['fwd'])
+        bwd = torch.empty_like(cache['bwd']) if cache['bwd'] is not None \
+            else None
+        L.check(lib.ld_conv_weight_transform(L.ptr(w), cout, cin, kh, kw,
+                                             L.ptr(fwd), L.ptr(bwd), st), 'wt')
+        assert torch.equal(fwd, cache['fwd'])
+        if bwd is not None and cache['bwd_stamp'] == cache['stamp']:
+            assert torch.equal(bwd, cache['bwd'])
+        n_w += 1
+    for ref in Y._BN_REG.values():
+        gmm = ref()
+        if gmm is None or gmm._ld_bn[0][-1] != Y._PARAM_GEN[0]:
+            continue
+        beta, mean, var, eps = gmm._ld_bn_src
+        fresh = Y._bn_prepare(gmm, beta, mean, var, eps)
+        for a, b in zip(fresh, gmm._ld_bn[1]):
+            assert torch.equal(a, b)
+        n_b += 1
+    assert n_w >= 15 and n_b >= 15, (n_w, n_b)
