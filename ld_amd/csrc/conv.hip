@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_kernel(ConvK a) {
   constexpr int WVN = 4 / WVM;
   constexpr int WM = TM * 32, WN = TN * 32;
   constexpr int BM = KS == 4 ? WM : WVM * WM, BNT = KS == 4 ? WN : WVN * WN;
-  __shared__ float red[KS == 4 ? 3 * TM * TN * 16 * 64 : 1];
+  __shared__ float red[KS == 4 ? 2 * TM * TN * 16 * 64 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int wm = KS == 4 ? 0 : wave / WVN, wn = KS == 4 ? 0 : wave % WVN;
@@ -707,31 +707,35 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_kernel(ConvK a) {
     for (int d = 0; d < D; ++d) mfma_kp(d);
   }
   if (KS == 4) {
-    // partial accumulators of waves 1..3 -> LDS [wave-1][reg][lane]; wave 0
-    // adds them in fixed order and runs the epilogue
-    if (wave > 0) {
-      float* dst = red + (size_t)(wave - 1) * TM * TN * 16 * 64 + lane;
+    // pairwise tree through LDS, fixed order ((w0 + w2) + (w1 + w3)); two
+    // slots instead of three keep the 2x2 tile at 32 KB per workgroup
+    constexpr int NACC = TM * TN * 16;
+    auto put = [&](float* dst) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            dst[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
-    }
+            dst[((i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    };
+    auto add = [&](const float* src) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            acc[i][j][r] += src[((i * TN + j) * 16 + r) * 64 + lane];
+    };
+    if (wave >= 2) put(red + (size_t)(wave - 2) * NACC * 64);
     __syncthreads();
-    if (wave > 0) return;
-#pragma unroll
-    for (int w = 0; w < 3; ++w) {
-      const float* src = red + (size_t)w * TM * TN * 16 * 64 + lane;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            acc[i][j][r] += src[((i * TN + j) * 16 + r) * 64];
-    }
+    if (wave < 2) add(red + (size_t)wave * NACC * 64);
+    __syncthreads();
+    if (wave == 1) put(red);
+    __syncthreads();
+    if (wave != 0) return;
+    add(red);
   }
 
   // ---- epilogue: direct stores, 32 consecutive positions per accumulator row
@@ -1275,7 +1279,7 @@ int launch_stream_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream) {
   const int nb = ((k.Cout + bm - 1) / bm) * ((k.J + bn - 1) / bn);
 #define LD_STREAM_CASE(TM_, TN_, WVM_, D_, KS_)                                    \
   if (c.tm == TM_ && c.tn == TN_ && c.wvm == WVM_ && c.d == D_ && c.ks == KS_) {   \
-    hipLaunchKernelGGL((conv_stream_kernel<TM_, TN_, WVM_, MODE, D_, 2, KS_>),     \
+    hipLaunchKernelGGL((conv_stream_kernel<TM_, TN_, WVM_, MODE, D_, (KS_ == 4 ? 4 : 2), KS_>), \
                        dim3(nb), dim3(256), 0, stream, k);                         \
     return (int)hipGetLastError();                                                 \
   }
