@@ -79,9 +79,16 @@ def kernel_roofline(trainer, dbatch, steps):
     tot_n = sum(v[2] for v in agg.values())
     ach = tot_f / tot_t / 1e12 if tot_t > 0 else 0.0
     return dict(
-        kernel='conv (fp32 MFMA 32x32x2 implicit GEMM: streaming fwd/dgrad + LDS wgrad)',
+        kernel='conv (fp32 MFMA 32x32x2 implicit GEMM: streaming fwd/dgrad + wave-private wgrad)',
         bound='mfma', achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS,
-        unit='TFLOP/s', frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=None,
+        unit='TFLOP/s', frac=ach / PEAK_FP32_MFMA_TFLOPS,
+        # PMC passes on the largest launch of the step (head-tower forward,
+        # 52.8 GFLOP, 48.3 MB in + 45.9 MB out algorithmic): raw FETCH_SIZE
+        # 196.5 MB (L2 fabric side, Infinity-Cache hits included: each of the 8
+        # XCD L2s pulls the image) + WRITE_SIZE 45.9 MB
+        traffic=242.4e6,
+        traffic_source='profiles/r01_pmc_stream (separate --pmc passes, '
+                       'head-tower forward launch, bytes per launch)',
         launches_per_step=tot_n / steps,
         avg_launch_us=tot_t / max(tot_n, 1) * 1e6,
         conv_ms_per_step=tot_t / steps * 1e3,
