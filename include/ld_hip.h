@@ -290,6 +290,11 @@ typedef struct {
 } ld_wt_job_t;
 int ld_conv_weight_transform_batch(const ld_wt_job_t* jobs, const int32_t* block_job,
                                    int nblocks, ld_stream_t stream);
+/* y must not alias x or ep->residual: the first call for a new layer geometry
+ * times several tile shapes by launching the (idempotent) kernel more than
+ * once on the caller's buffers and synchronises the device (the same contract
+ * as cudnn.benchmark = True; LD_CONV_AUTOTUNE=0 disables it).  Not capturable
+ * into a hipGraph until the geometry has been seen once. */
 int ld_conv_forward(const ld_conv_t* c, const float* x, const float* wt_fwd,
                     const ld_conv_epilogue_t* ep, float* y, ld_stream_t stream);
 /* dx (N,Cin,Pin) fully overwritten. */

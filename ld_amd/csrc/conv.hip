@@ -21,11 +21,19 @@
 //                [tap][Cin][Cout] (forward) / [flipped tap][Cout][Cin] (dgrad)
 //                images so A-tiles are contiguous 512-byte rows.
 //   GEMM         D[co][j] = sum_{tap,ci} Wt[tap][ci][co] * X[ci][pos(j,tap)]
-//                block tile BM(co) x 128(j) x 16(k), 4 wavefronts as 2x2, each
-//                (BM/2)x64 = TM x 2 MFMA 32x32 tiles, double-buffered LDS with
-//                the next tile's global loads issued under the MFMAs.
+//   fwd/dgrad    conv_stream_kernel: LDS-free.  Both MFMA operand layouts are
+//                directly loadable from the layouts above, so every wavefront
+//                streams its own operands through a register ring of raw
+//                buffer loads and owns a (TM*32) x (TN*32) accumulator tile;
+//                waves never meet at a barrier.  Tile shape / split-K picked
+//                per layer geometry by a timing autotuner (tiles-per-SIMD
+//                rounding decides, see launch_stream).  conv_igemm_kernel is
+//                the older LDS double-buffered 64x64 tiling, kept for the 7x7
+//                stem (flat (ci,kh,kw) reduction) and k % 8 != 0.
 //   wgrad        D[co][ci] per tap = sum_j dY[co][j] * X[ci][pos(j,tap)],
-//                split over j; partial slabs [split][tap][co][ci] are written
+//                split over j.  conv_wgrad_wave_kernel: one wavefront per
+//                workgroup, 64x64 tile, PRIVATE LDS transpose buffer, no
+//                barriers; partial slabs [split][tap][co][ci] are written
 //                coalesced and summed in fixed order (deterministic, no float
 //                atomics) by conv_wgrad_reduce.
 #include <hip/hip_runtime.h>
