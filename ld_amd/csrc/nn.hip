@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(
 
 // backward of the above.  dz = relu ? dy*(y>0) : dy;  dx = dz*scale[c];
 // dres = dz (optional);  partial[c][split] = (sum dz, sum dz * xhat)
+template <bool VEC>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ x, const float* __restrict__ scale,
@@ -110,20 +111,57 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(
   const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
   const float s = scale[c], mu = mean ? mean[c] : 0.f, rs = rstd ? rstd[c] : 0.f;
   const long long total = (long long)N * P;
-  const long long per = (total + nsplit - 1) / nsplit;
+  long long per = (total + nsplit - 1) / nsplit;
+  if (VEC) per = (per + 3) / 4 * 4;  // P % 4 == 0: slices start on float4 bounds
   const long long beg = (long long)split * per, end = min(total, beg + per);
   double s1 = 0.0, s2 = 0.0;
-  for (long long e = beg + threadIdx.x; e < end; e += 256) {
-    const int n = (int)(e / P);
-    const int p = (int)(e - (long long)n * P);
-    const size_t idx = ((size_t)n * C + c) * P + p;
-    float dz = dy[idx];
-    if (relu && !(y[idx] > 0.f)) dz = 0.f;
-    if (dx) dx[idx] = dz * s;
-    if (dres) dres[idx] = dz;
-    if (partial) {
-      s1 += (double)dz;
-      s2 += (double)(dz * ((x[idx] - mu) * rs));
+  if (VEC) {
+    // walk the images the slice touches; inside an image the row is contiguous
+    for (int n = (int)(beg / P); beg < end && n <= (int)((end - 1) / P); ++n) {
+      const int p0 = (int)max(beg - (long long)n * P, 0LL);
+      const int p1 = (int)min(end - (long long)n * P, (long long)P);
+      const size_t base = ((size_t)n * C + c) * P;
+      for (int p = p0 + 4 * threadIdx.x; p < p1; p += 1024) {
+        const size_t idx = base + p;
+        const float4 g = *reinterpret_cast<const float4*>(dy + idx);
+        float dz[4] = {g.x, g.y, g.z, g.w};
+        if (relu) {
+          const float4 yy = *reinterpret_cast<const float4*>(y + idx);
+          if (!(yy.x > 0.f)) dz[0] = 0.f;
+          if (!(yy.y > 0.f)) dz[1] = 0.f;
+          if (!(yy.z > 0.f)) dz[2] = 0.f;
+          if (!(yy.w > 0.f)) dz[3] = 0.f;
+        }
+        if (dx)
+          *reinterpret_cast<float4*>(dx + idx) =
+              make_float4(dz[0] * s, dz[1] * s, dz[2] * s, dz[3] * s);
+        if (dres)
+          *reinterpret_cast<float4*>(dres + idx) =
+              make_float4(dz[0], dz[1], dz[2], dz[3]);
+        if (partial) {
+          const float4 xx = *reinterpret_cast<const float4*>(x + idx);
+          const float xv[4] = {xx.x, xx.y, xx.z, xx.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            s1 += (double)dz[k];
+            s2 += (double)(dz[k] * ((xv[k] - mu) * rs));
+          }
+        }
+      }
+    }
+  } else {
+    for (long long e = beg + threadIdx.x; e < end; e += 256) {
+      const int n = (int)(e / P);
+      const int p = (int)(e - (long long)n * P);
+      const size_t idx = ((size_t)n * C + c) * P + p;
+      float dz = dy[idx];
+      if (relu && !(y[idx] > 0.f)) dz = 0.f;
+      if (dx) dx[idx] = dz * s;
+      if (dres) dres[idx] = dz;
+      if (partial) {
+        s1 += (double)dz;
+        s2 += (double)(dz * ((x[idx] - mu) * rs));
+      }
     }
   }
   if (partial) {
@@ -685,9 +723,17 @@ extern "C" int ld_bn_act_backward(const float* dy, const float* y, const float* 
                  workspace_bytes < ld_bn_act_backward_workspace_bytes(N, C, P)))
     return LD_ENOSPACE;
   const int ns = bn_splits(N, C, P);
-  hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(C, ns), dim3(256), 0, LD_STREAM, dy, y,
-                     x, scale, mean, rstd, N, C, P, relu, dx, dres,
-                     params ? (double*)workspace : nullptr);
+  const bool vec = P % 4 == 0 &&
+                   ((uintptr_t)dy | (uintptr_t)(y ? y : dy) | (uintptr_t)(x ? x : dy) |
+                    (uintptr_t)(dx ? dx : dy) | (uintptr_t)(dres ? dres : dy)) % 16 == 0;
+  if (vec)
+    hipLaunchKernelGGL((bn_act_bwd_kernel<true>), dim3(C, ns), dim3(256), 0, LD_STREAM,
+                       dy, y, x, scale, mean, rstd, N, C, P, relu, dx, dres,
+                       params ? (double*)workspace : nullptr);
+  else
+    hipLaunchKernelGGL((bn_act_bwd_kernel<false>), dim3(C, ns), dim3(256), 0,
+                       LD_STREAM, dy, y, x, scale, mean, rstd, N, C, P, relu, dx, dres,
+                       params ? (double*)workspace : nullptr);
   if (params)
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0,
                        LD_STREAM, (const double*)workspace, C, ns, dgamma, dbeta,
