@@ -55,3 +55,15 @@ def test_no_cpu_fallback():
         L.require_device(torch.zeros(3), torch.float32, 'x')
     with pytest.raises(L.LdError):
         L.make_maps([torch.zeros(1, 2, 3, 4)])
+
+
+def test_job_table_struct_layout():
+    """ctypes mirrors of the device-resident job records match the C layout
+    (LP64: three / seven pointers followed by 32-bit fields, no tail padding
+    surprises): the tables are built as raw bytes on the host."""
+    import ctypes as C
+    from ld_amd import lib as L
+    assert C.sizeof(L.WtJobT) == 3 * 8 + 4 * 4 == 40
+    assert C.sizeof(L.BnJobT) == 7 * 8 + 4 + 3 * 4 == 72
+    assert L.WtJobT.first_block.offset == 36
+    assert L.BnJobT.eps.offset == 56 and L.BnJobT.first_block.offset == 64
