@@ -148,6 +148,60 @@ class SGDTrainer:
         if head is not None and hasattr(head, 'unit_upstream'):
             head.unit_upstream = True  # _parse_losses sums the keys
         self.iter = 0
+        self.epoch = 0
+
+    # -- optimizer state in torch.optim.SGD's wire format (checkpoints) -------
+    def _all_params(self):
+        return list(self.model.parameters())
+
+    def state_dict(self):
+        """What ``torch.optim.SGD(model.parameters(), lr, momentum,
+        weight_decay).state_dict()`` would hold: one param group over ALL
+        student parameters in ``model.parameters()`` order (frozen ones too, as
+        mmcv's DefaultOptimizerConstructor passes them), and a
+        ``momentum_buffer`` per parameter that has taken a step."""
+        allp = self._all_params()
+        index = {id(p): i for i, p in enumerate(allp)}
+        state = {}
+        if self.iter > 0 or bool(self.flat_momentum.any()):
+            for p, o in zip(self.arena.order, self.arena.offsets):
+                buf = self.flat_momentum[o:o + p.numel()].view_as(p)
+                state[index[id(p)]] = dict(momentum_buffer=buf.detach().clone())
+        group = dict(lr=self.lr, momentum=self.momentum, dampening=0,
+                     weight_decay=self.weight_decay, nesterov=False,
+                     params=list(range(len(allp))))
+        return dict(state=state, param_groups=[group])
+
+    def load_state_dict(self, sd):
+        groups = sd['param_groups']
+        if len(groups) != 1:
+            raise ValueError('expected the single param group of the LD '
+                             f'configs, got {len(groups)}')
+        g = groups[0]
+        allp = self._all_params()
+        if len(g['params']) != len(allp):
+            raise ValueError(f"optimizer state is for {len(g['params'])} "
+                             f'parameters, the model has {len(allp)}')
+        if g.get('nesterov') or g.get('dampening', 0) != 0:
+            raise NotImplementedError('nesterov / dampening are not on the LD '
+                                      'recipe (configs/ld/*.py: plain SGD)')
+        self.lr = float(g['lr'])
+        self.momentum = float(g['momentum'])
+        self.weight_decay = float(g['weight_decay'])
+        offset_of = {id(p): o for p, o in zip(self.arena.order,
+                                              self.arena.offsets)}
+        self.flat_momentum.zero_()
+        for idx, st in sd['state'].items():
+            p = allp[int(idx)]
+            buf = st.get('momentum_buffer')
+            if buf is None:
+                continue
+            if id(p) not in offset_of:
+                raise ValueError(f'momentum for parameter {idx}, which is '
+                                 'frozen in this model')
+            o = offset_of[id(p)]
+            self.flat_momentum[o:o + p.numel()].copy_(
+                buf.reshape(-1).to(self.flat_momentum.device))
 
     def step(self, data):
         self.arena.zero_grad()
