@@ -1388,11 +1388,16 @@ void tune_file_load_locked() {
 void tune_file_append_locked(const TuneKey& k, int pick) {
   const char* path = getenv("LD_CONV_TUNE_FILE");
   if (!path || !*path) return;
+  // one write() per record: several ranks may append to the same file
+  char line[512];
+  int n = 0;
+  for (int i = 0; i < 16; ++i) n += snprintf(line + n, sizeof(line) - n, "%d ", k.v[i]);
+  const StreamCfg& c = kStreamCfgs[pick];
+  n += snprintf(line + n, sizeof(line) - n, " %d %d %d %d %d\n", c.tm, c.tn, c.wvm, c.d,
+                c.ks);
   FILE* f = fopen(path, "a");
   if (!f) return;
-  for (int i = 0; i < 16; ++i) fprintf(f, "%d ", k.v[i]);
-  const StreamCfg& c = kStreamCfgs[pick];
-  fprintf(f, " %d %d %d %d %d\n", c.tm, c.tn, c.wvm, c.d, c.ks);
+  fwrite(line, 1, (size_t)n, f);
   fclose(f);
 }
 
