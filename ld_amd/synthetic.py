@@ -210,3 +210,38 @@ def synthetic_head_inputs(num_imgs,
         out['t_x'].append(
             _normal((num_imgs, feat_channels, h, w), gen))
     return {k: [t.to(device) for t in v] for k, v in out.items()}
+
+
+# ---------------------------------------------------------------------------
+# inference cases (GFLHead.get_bboxes parity, tests/golden/infer.npz)
+# ---------------------------------------------------------------------------
+# name, pad, img_shapes, scale_factors, seed, nms_pre, cls_scale, cls_shift,
+# store_all.  The class logits of synthetic_head_inputs are re-scaled to
+# cls * cls_scale + cls_shift so the number of (anchor, class) pairs above
+# score_thr = 0.05 lands on either side of batched_nms' split_thr = 10000.
+INFER_CASES = [
+    ('small', (128, 160), [(128, 160, 3), (120, 150, 3)],
+     [[1.0, 1.0, 1.0, 1.0], [1.25, 1.25, 1.25, 1.25]], 51, 1000, 1.25, -1.0,
+     True),
+    ('small_topk', (128, 160), [(128, 160, 3), (100, 140, 3)],
+     [[0.5, 0.5, 0.5, 0.5], [2.0, 2.0, 2.0, 2.0]], 52, 50, 1.25, -1.0, True),
+    ('c2', (800, 1344), [(800, 1333, 3), (750, 1344, 3)],
+     [[1.6675, 1.6675, 1.6675, 1.6675], [1.0, 1.0, 1.0, 1.0]], 53, 1000, 1.25,
+     -1.0, False),
+    ('c2_dense', (800, 1344), [(800, 1333, 3), (800, 1344, 3)],
+     [[1.0, 1.0, 1.0, 1.0], [1.0, 1.0, 1.0, 1.0]], 54, 1000, 1.0, 0.0, False),
+]
+
+
+def infer_inputs(case, device='cpu'):
+    """(cls_scores, bbox_preds, img_metas) of an INFER_CASES row."""
+    import numpy as np
+    name, pad, img_shapes, sfs, seed, nms_pre, cs, sh, store = case
+    sizes = level_shapes(pad)
+    hi = synthetic_head_inputs(len(img_shapes), sizes, seed=seed)
+    cls = [(c * cs + sh).to(device) for c in hi['cls']]
+    reg = [r.to(device) for r in hi['reg']]
+    metas = [dict(img_shape=s_, pad_shape=tuple(pad) + (3, ),
+                  scale_factor=np.array(f, dtype=np.float32))
+             for s_, f in zip(img_shapes, sfs)]
+    return cls, reg, metas

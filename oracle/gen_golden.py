@@ -3,7 +3,7 @@ REFERENCE CODE at /root/reference (unmodified, imported through
 oracle/ref_shim.py) on CPU in fp32.  Run from the repo root in the build
 container:
 
-    python oracle/gen_golden.py [--only kat,anchors,targets,lossblock,e2e]
+    python oracle/gen_golden.py [--only kat,anchors,targets,lossblock,e2e,infer]
 
 The fixtures it writes are committed; the GPU box has no /root/reference and
 only ever reads the .npz files.  Inputs that can be regenerated from a seed
@@ -20,6 +20,7 @@ Reference entry points exercised (file:line under /root/reference):
   mmdet/models/dense_heads/ld_head.py:116-611   LDHead.loss / get_targets
   mmdet/models/detectors/kd_one_stage.py:46-81  forward_train
   mmdet/models/detectors/base.py:185-218        _parse_losses
+  mmdet/models/dense_heads/gfl_head.py:354-451  GFLHead._get_bboxes (+ multiclass_nms)
 """
 import argparse
 import os
@@ -496,9 +497,64 @@ def gen_e2e(cases=None):
     print('e2e.npz')
 
 
+# ------------------------------------------------------------ inference ----
+# GFLHead.get_bboxes (anchor_head.py:497-589 -> gfl_head.py:354-451 ->
+# post_processing/bbox_nms.py:70-195 multiclass_nms -> mmcv.ops.batched_nms,
+# the latter restated in ref_shim).  Head outputs come from
+# synthetic.synthetic_head_inputs; the class logits are re-scaled to
+# cls * cls_scale + cls_shift so the candidate count lands on either side of
+# batched_nms' split_thr = 10000.
+# the cases and their seeded inputs live in ld_amd.synthetic (INFER_CASES,
+# infer_inputs) so the tests regenerate exactly the same tensors
+
+
+def gen_infer():
+    import mmcv
+    head = _ld_head()
+    d = {}
+    for case in synthetic.INFER_CASES:
+        name, pad, img_shapes, sfs, seed, nms_pre, cs, sh, store = case
+        cls, reg, metas = synthetic.infer_inputs(case)
+        cfg = mmcv.ConfigDict(dict(nms_pre=nms_pre, min_bbox_size=0,
+                                   score_thr=0.05,
+                                   nms=dict(type='nms', iou_threshold=0.6),
+                                   max_per_img=100))
+        t0 = time.time()
+        for rescale in (False, True):
+            res = head.get_bboxes(cls, reg, metas, cfg=cfg, rescale=rescale)
+            tag = f'{name}_r{int(rescale)}'
+            for i, (db, dl) in enumerate(res):
+                d[f'{tag}_bboxes_{i}'] = _np(db).astype(np.float32)
+                d[f'{tag}_labels_{i}'] = _np(dl).astype(np.int64)
+        # pre-NMS stage (top-k selection + decode), rescale=False
+        pre = head.get_bboxes(cls, reg, metas, cfg=cfg, rescale=False,
+                              with_nms=False)
+        for i, (bb, sc) in enumerate(pre):
+            sc = sc[:, :-1]  # drop the padded background column
+            d[f'{name}_pre_count_{i}'] = np.array(bb.shape[0])
+            cand = int((sc > 0.05).sum())
+            d[f'{name}_candidates_{i}'] = np.array(cand)
+            if store:
+                d[f'{name}_pre_bboxes_{i}'] = _np(bb).astype(np.float32)
+                d[f'{name}_pre_scores_{i}'] = _np(sc).astype(np.float32)
+            else:  # fingerprints of the full-size stage
+                d[f'{name}_pre_bboxes_sum_{i}'] = np.array(
+                    float(bb.double().sum()))
+                d[f'{name}_pre_scores_sum_{i}'] = np.array(
+                    float(sc.double().sum()))
+                d[f'{name}_pre_maxscore_{i}'] = _np(sc.max(1)[0]).astype(
+                    np.float32)
+        d[name + '_cfg'] = np.array(list(pad) + [seed, nms_pre])
+        print(f'[infer] {name}: {time.time() - t0:.1f}s, dets',
+              [int(d[f"{name}_r0_labels_{i}"].shape[0])
+               for i in range(len(img_shapes))], 'candidates',
+              [int(d[f"{name}_candidates_{i}"]) for i in range(len(img_shapes))])
+    np.savez_compressed(os.path.join(OUT, 'infer.npz'), **d)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='kat,anchors,targets,lossblock,e2e')
+    ap.add_argument('--only', default='kat,anchors,targets,lossblock,e2e,infer')
     ap.add_argument('--e2e-cases', default='')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
@@ -514,6 +570,8 @@ def main():
         gen_lossblock()
     if 'e2e' in only:
         gen_e2e([c for c in args.e2e_cases.split(',') if c])
+    if 'infer' in only:
+        gen_infer()
 
 
 if __name__ == '__main__':

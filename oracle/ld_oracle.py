@@ -594,3 +594,122 @@ def ld_loss_block(cls, reg, t_cls, t_reg, x, t_x, targets, hp=None,
             grads['x'].append(_rows_to_nchw(st['g_x'], st['shapes'][2]))
         out['grads'] = grads
     return out
+
+
+# --------------------------------------------------------------------------
+# inference: GFLHead.get_bboxes  (oracle only --
+# the HIP path for this row is not built yet)
+#   anchor_head.py:497-589 -> gfl_head.py:354-451 (_get_bboxes)
+#   -> core/post_processing/bbox_nms.py:70-195 (multiclass_nms, type='nms')
+#   -> mmcv.ops.nms.batched_nms / nms (mmcv-full 1.2.x, compiled; published
+#      algorithm restated: greedy, IoU > thr suppresses, class offset trick,
+#      split_thr = 10000 -> per-class passes re-sorted by score).
+# Pinned on tests/golden/infer.npz (reference get_bboxes executed under the
+# shim).  Equal scores are ordered lower-index-first (the compiled op's order
+# for ties is an artefact of its unstable sort).
+# --------------------------------------------------------------------------
+def nms_greedy(boxes, scores, iou_thr):
+    """Indices kept, in descending-score order."""
+    order = np.argsort(-scores, kind='stable')
+    b = boxes[order].astype(F32)
+    areas = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    n = b.shape[0]
+    removed = np.zeros(n, dtype=bool)
+    keep = []
+    for i in range(n):
+        if removed[i]:
+            continue
+        keep.append(i)
+        if i + 1 == n:
+            break
+        r = b[i + 1:]
+        w = np.maximum(np.minimum(b[i, 2], r[:, 2]) - np.maximum(b[i, 0], r[:, 0]),
+                       F32(0))
+        h = np.maximum(np.minimum(b[i, 3], r[:, 3]) - np.maximum(b[i, 1], r[:, 1]),
+                       F32(0))
+        inter = (w * h).astype(F32)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            ovr = inter / (areas[i] + areas[i + 1:] - inter)
+        removed[i + 1:] |= ovr > F32(iou_thr)
+    return order[np.array(keep, dtype=np.int64)]
+
+
+def batched_nms(boxes, scores, labels, iou_thr, split_thr=10000):
+    """mmcv.ops.batched_nms (class_agnostic=False).  Returns kept indices in
+    output order."""
+    if boxes.shape[0] == 0:
+        return np.zeros(0, dtype=np.int64)
+    max_coordinate = boxes.max()
+    offsets = labels.astype(F32) * (max_coordinate + F32(1))
+    shifted = (boxes + offsets[:, None]).astype(F32)
+    if boxes.shape[0] < split_thr:
+        return nms_greedy(shifted, scores, iou_thr)
+    mask = np.zeros(scores.shape[0], dtype=bool)
+    for c in np.unique(labels):
+        idx = np.nonzero(labels == c)[0]
+        mask[idx[nms_greedy(shifted[idx], scores[idx], iou_thr)]] = True
+    keep = np.nonzero(mask)[0]
+    return keep[np.argsort(-scores[keep], kind='stable')]
+
+
+def multiclass_nms(bboxes, scores, score_thr, iou_thr, max_num):
+    """bbox_nms.py:70-195 with nms_cfg type 'nms'.  bboxes (n, 4), scores
+    (n, C) WITHOUT the padded background column.  -> dets (k, 5), labels (k)."""
+    n, C = scores.shape
+    flat_s = scores.reshape(-1)
+    valid = np.nonzero(flat_s > F32(score_thr))[0]  # row-major: anchor, class
+    if valid.size == 0:
+        return np.zeros((0, 5), F32), np.zeros(0, np.int64)
+    a_idx, labels = valid // C, valid % C
+    b, s = bboxes[a_idx].astype(F32), flat_s[valid].astype(F32)
+    keep = batched_nms(b, s, labels, iou_thr)
+    if max_num > 0:
+        keep = keep[:max_num]
+    dets = np.concatenate([b[keep], s[keep][:, None]], 1).astype(F32)
+    return dets, labels[keep].astype(np.int64)
+
+
+def get_bboxes_pre_nms(cls_scores, bbox_preds, img_shapes, nms_pre,
+                       strides=(8, 16, 32, 64, 128), reg_max=16):
+    """gfl_head.py:391-424: per level sigmoid scores, Integral * stride, top
+    nms_pre anchors by max class score (when the level has more), decode about
+    the anchor centres, clamp to the image.  Inputs NCHW per level.
+    -> per image (boxes (K, 4), scores (K, C)), levels concatenated in order."""
+    N = cls_scores[0].shape[0]
+    sizes = [tuple(c.shape[2:]) for c in cls_scores]
+    anchors = grid_anchors(sizes, strides)
+    boxes = [[] for _ in range(N)]
+    scores = [[] for _ in range(N)]
+    for l, (cls, reg, s) in enumerate(zip(cls_scores, bbox_preds, strides)):
+        C = cls.shape[1]
+        anc = anchors[l]
+        ctr = np.stack([(anc[:, 0] + anc[:, 2]) / F32(2),
+                        (anc[:, 1] + anc[:, 3]) / F32(2)], 1).astype(F32)
+        for n in range(N):
+            sc = _sigmoid(cls[n].transpose(1, 2, 0).reshape(-1, C).astype(F32))
+            rg = reg[n].transpose(1, 2, 0).reshape(-1, 4 * (reg_max + 1))
+            dist = (integral(rg.astype(F32), reg_max)[0] * F32(s)).astype(F32)
+            c = ctr
+            if nms_pre > 0 and sc.shape[0] > nms_pre:
+                top = np.argsort(-sc.max(1), kind='stable')[:nms_pre]
+                sc, dist, c = sc[top], dist[top], ctr[top]
+            bb = distance2bbox(c, dist).astype(F32)
+            H, W = F32(img_shapes[n][0]), F32(img_shapes[n][1])
+            bb[:, 0::2] = np.clip(bb[:, 0::2], F32(0), W)
+            bb[:, 1::2] = np.clip(bb[:, 1::2], F32(0), H)
+            boxes[n].append(bb)
+            scores[n].append(sc)
+    return [(np.concatenate(b), np.concatenate(s))
+            for b, s in zip(boxes, scores)]
+
+
+def get_bboxes(cls_scores, bbox_preds, img_shapes, scale_factors, nms_pre=1000,
+               score_thr=0.05, iou_thr=0.6, max_per_img=100, rescale=False):
+    """GFLHead.get_bboxes.  -> per image (dets (k, 5), labels (k))."""
+    out = []
+    pre = get_bboxes_pre_nms(cls_scores, bbox_preds, img_shapes, nms_pre)
+    for n, (bb, sc) in enumerate(pre):
+        if rescale:
+            bb = (bb / np.asarray(scale_factors[n], F32)[None]).astype(F32)
+        out.append(multiclass_nms(bb, sc, score_thr, iou_thr, max_per_img))
+    return out

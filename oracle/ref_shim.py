@@ -14,7 +14,7 @@ the reference relies on -- SURVEY.md section 8c):
   Registry / build_from_cfg / ConfigDict / Config.fromfile (with _base_),
   ConvModule (conv -> norm -> act, bias='auto'), build_conv_layer,
   build_norm_layer (BN / GN), Scale, the *_init helpers, force_fp32/auto_fp16
-  (identity), mmcv.jit (identity).
+  (identity), mmcv.jit (identity), mmcv.ops.nms / batched_nms (greedy NMS).
 Everything else reachable under the fabricated roots resolves to permissive
 dummies so `import mmdet` succeeds.
 """
@@ -324,7 +324,81 @@ def _load_checkpoint(*a, **k):
     raise RuntimeError('oracle shim: checkpoints are not available offline')
 
 
+# --------------------------------------------------------------------------
+# mmcv.ops.nms (mmcv-full 1.2.x; a compiled op there) -- restated.
+# nms: boxes sorted by score (descending), greedy suppression of every later box
+# with IoU > iou_threshold, IoU = inter / (area_i + area_j - inter) with
+# `offset` added to widths/heights (0 by default).  The compiled op sorts with
+# an unstable sort; equal scores are ordered lower-index-first here.
+# batched_nms: per-class NMS by shifting each class's boxes by
+# label * (max_coordinate + 1); with >= split_thr boxes the classes are run one
+# by one and the survivors re-sorted by score.
+# --------------------------------------------------------------------------
+def nms(boxes, scores, iou_threshold, offset=0, score_threshold=0, max_num=-1):
+    assert boxes.size(1) == 4 and boxes.size(0) == scores.size(0)
+    if boxes.numel() == 0:
+        keep = boxes.new_zeros((0, ), dtype=torch.long)
+        return torch.cat([boxes, scores[:, None]], -1), keep
+    order = torch.sort(scores, descending=True, stable=True)[1]
+    b = boxes[order]
+    x1, y1, x2, y2 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    areas = (x2 - x1 + offset) * (y2 - y1 + offset)
+    n = b.size(0)
+    removed = torch.zeros(n, dtype=torch.bool)
+    keep = []
+    for i in range(n):
+        if removed[i]:
+            continue
+        keep.append(i)
+        if i + 1 == n:
+            break
+        xx1 = torch.maximum(x1[i], x1[i + 1:])
+        yy1 = torch.maximum(y1[i], y1[i + 1:])
+        xx2 = torch.minimum(x2[i], x2[i + 1:])
+        yy2 = torch.minimum(y2[i], y2[i + 1:])
+        w = (xx2 - xx1 + offset).clamp(min=0)
+        h = (yy2 - yy1 + offset).clamp(min=0)
+        inter = w * h
+        ovr = inter / (areas[i] + areas[i + 1:] - inter)
+        removed[i + 1:] |= ovr > iou_threshold
+    keep = order[torch.tensor(keep, dtype=torch.long)]
+    if max_num > 0:
+        keep = keep[:max_num]
+    return torch.cat([boxes[keep], scores[keep][:, None]], -1), keep
+
+
+def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
+    nms_cfg_ = dict(nms_cfg)
+    class_agnostic = nms_cfg_.pop('class_agnostic', class_agnostic)
+    if class_agnostic:
+        boxes_for_nms = boxes
+    else:
+        max_coordinate = boxes.max()
+        offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+        boxes_for_nms = boxes + offsets[:, None]
+    nms_type = nms_cfg_.pop('type', 'nms')
+    assert nms_type == 'nms', nms_type
+    split_thr = nms_cfg_.pop('split_thr', 10000)
+    if boxes_for_nms.shape[0] < split_thr:
+        dets, keep = nms(boxes_for_nms, scores, **nms_cfg_)
+        boxes = boxes[keep]
+        scores = dets[:, -1]
+    else:
+        total_mask = scores.new_zeros(scores.size(), dtype=torch.bool)
+        for id in torch.unique(idxs):
+            mask = (idxs == id).nonzero(as_tuple=False).view(-1)
+            dets, keep = nms(boxes_for_nms[mask], scores[mask], **nms_cfg_)
+            total_mask[mask[keep]] = True
+        keep = total_mask.nonzero(as_tuple=False).view(-1)
+        keep = keep[scores[keep].argsort(descending=True, stable=True)]
+        boxes = boxes[keep]
+        scores = scores[keep]
+    return torch.cat([boxes, scores[:, None]], -1), keep
+
+
 _REAL = {
+    'mmcv.ops': dict(nms=nms, batched_nms=batched_nms),
+    'mmcv.ops.nms': dict(nms=nms, batched_nms=batched_nms),
     'mmcv': dict(
         __version__='1.2.7', Config=Config, ConfigDict=ConfigDict,
         jit=_identity_decorator_factory, is_tuple_of=is_tuple_of),
