@@ -400,6 +400,29 @@ int ld_sgd_step(float* params, const float* grads, float* momentum_buf, size_t n
                 float lr, float momentum, float weight_decay, float grad_scale,
                 ld_stream_t stream);
 
+/* ---- inference post-processing ---------------
+ * GFLHead.get_bboxes for a whole batch (gfl_head.py:354-451 ->
+ * post_processing/bbox_nms.py:70-195 -> mmcv.ops.batched_nms): sigmoid scores,
+ * Integral * stride, per-level top-nms_pre by max class score, distance2bbox +
+ * clamp to img_hw, optional division by scale_factors (rescale=True), score
+ * threshold, class-aware greedy NMS (IoU > iou_thr suppresses), best
+ * max_per_img (<= 1024) detections per image in descending score order.
+ *   cls / reg      NCHW-direct head maps, (N, num_classes, H_l, W_l) /
+ *                  (N, 4*(reg_max+1), H_l, W_l); reg_max must be 16
+ *   img_hw         device (N, 2): img_shape height, width
+ *   scale_factors  device (N, 4) or NULL
+ *   dets           device (N, max_per_img, 5): x1, y1, x2, y2, score
+ *   labels         device (N, max_per_img) int64;  counts device (N) int32
+ * Equal scores: lower (anchor, class) index first. */
+size_t ld_get_bboxes_workspace_bytes(const ld_geom_t* g, int num_classes,
+                                     int nms_pre);
+int ld_get_bboxes(const ld_geom_t* g, const ld_maps_t* cls, const ld_maps_t* reg,
+                  int num_classes, int reg_max, const float* img_hw,
+                  const float* scale_factors, int nms_pre, float score_thr,
+                  float iou_thr, int max_per_img, float* dets, int64_t* labels,
+                  int32_t* counts, void* workspace, size_t workspace_bytes,
+                  ld_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

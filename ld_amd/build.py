@@ -29,6 +29,7 @@ PER_FILE = {
     'targets.hip': ['-ffp-contract=off'],
     'loss.hip': ['-ffp-contract=off'],
     'rows.hip': ['-ffp-contract=off'],
+    'infer.hip': ['-ffp-contract=off'],
 }
 
 

@@ -1,0 +1,395 @@
+// Inference post-processing of the GFL / LD head on gfx950: everything between
+// the head's raw maps and the (k, 5) detections, on the device, NCHW-direct.
+//
+// Replaces (reference file:line)
+//   GFLHead._get_bboxes             dense_heads/gfl_head.py:354-451
+//     sigmoid scores, Integral * stride, per-level top-nms_pre by max class
+//     score, distance2bbox (core/bbox/transforms.py:119-156) + clamp, rescale
+//   multiclass_nms (type 'nms')     core/post_processing/bbox_nms.py:70-195
+//   mmcv.ops.batched_nms / nms      (mmcv-full 1.2.x compiled op; greedy NMS on
+//     class-shifted boxes, IoU > thr suppresses; its >= 10000-box per-class
+//     branch yields the same detections as the single pass run here)
+//
+// HBM/latency-bound integer + fp32 work, no GEMM shape anywhere:
+//   1. keys      one thread per (image, level, anchor): max class logit ->
+//                64-bit key (score bits << 32 | ~anchor) so ONE descending sort
+//                orders by score and breaks ties lower-index-first
+//   2. top-k     bitonic sort of each (image, level) key segment by one
+//                workgroup (only levels with more than nms_pre anchors)
+//   3. decode    one thread per selected anchor: 80 sigmoid scores, 4 x 17-bin
+//                softmax expectations, box, clamp, rescale; (anchor, class)
+//                pairs above score_thr are appended (atomic counter) as keys
+//                (score bits << 32 | ~pair index): order fixed by the next sort
+//   4. sort      bitonic sort of the candidate keys, one workgroup per image
+//   5. nms       one workgroup per image walks the sorted candidates in chunks
+//                of 256 against the kept list (<= max_per_img, in LDS) and
+//                stops at max_per_img: O(candidates examined x kept), not
+//                O(candidates^2)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ld_hip.h"
+#include "ld_math.h"
+
+namespace {
+
+using ld::sigmoidf_;
+using ld::softmax_expect;
+
+constexpr int kSortThreads = 1024;
+constexpr int kNmsThreads = 256;
+constexpr int kMaxKeep = 1024;  // max_per_img supported by the LDS kept list
+
+struct Plan {
+  int N, L, C, Ktot;
+  int H[LD_MAX_LEVELS], W[LD_MAX_LEVELS], stride[LD_MAX_LEVELS];
+  int A[LD_MAX_LEVELS];      // anchors of the level
+  int K[LD_MAX_LEVELS];      // selected anchors of the level
+  int koff[LD_MAX_LEVELS];   // first slot of the level among the Ktot slots
+  int pad[LD_MAX_LEVELS];    // pow2 sort length, 0 = level is not sorted
+  int keyoff[LD_MAX_LEVELS]; // first key of the level inside an image's keys
+  int keys_per_img;
+  int cand_cap;              // candidate capacity per image (pow2)
+};
+
+inline int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+__device__ __forceinline__ unsigned long long make_key(float score, unsigned idx) {
+  // score > 0: its bit pattern is monotonic; ~idx makes the lower index win ties
+  return ((unsigned long long)__float_as_uint(score) << 32) |
+         (unsigned long long)(0xFFFFFFFFu - idx);
+}
+
+// ---- 1. keys ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void infer_keys_kernel(Plan p, ld_maps_t cls,
+                                                        unsigned long long* keys) {
+  const int l = blockIdx.y, n = blockIdx.z;
+  if (p.pad[l] == 0) return;
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= p.pad[l]) return;
+  unsigned long long key = 0ull;
+  if (a < p.A[l]) {
+    const float* base = cls.ptr[l] + (size_t)n * cls.stride_n[l] + a;
+    float m = base[0];
+    for (int c = 1; c < p.C; ++c) m = fmaxf(m, base[(size_t)c * cls.stride_c[l]]);
+    key = make_key(sigmoidf_(m), (unsigned)a);
+  }
+  keys[(size_t)n * p.keys_per_img + p.keyoff[l] + a] = key;
+}
+
+// ---- 2./4. bitonic sort, descending, one workgroup per segment ---------------
+__device__ void bitonic_desc(unsigned long long* a, int n) {
+  for (int k = 2; k <= n; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long x = a[i], y = a[ixj];
+          const bool desc = (i & k) == 0;
+          if (desc ? (x < y) : (x > y)) {
+            a[i] = y;
+            a[ixj] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(kSortThreads) void infer_topk_sort_kernel(
+    Plan p, unsigned long long* keys) {
+  // blockIdx.x enumerates the sorted levels, blockIdx.y the images
+  int l = -1, seen = 0;
+  for (int i = 0; i < p.L; ++i)
+    if (p.pad[i] > 0) {
+      if (seen == (int)blockIdx.x) l = i;
+      ++seen;
+    }
+  if (l < 0) return;
+  bitonic_desc(keys + (size_t)blockIdx.y * p.keys_per_img + p.keyoff[l], p.pad[l]);
+}
+
+// ---- 3. decode -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void infer_decode_kernel(
+    Plan p, ld_maps_t cls, ld_maps_t reg, const unsigned long long* keys,
+    const float* img_hw, const float* scale_factors, float score_thr, float* boxes,
+    float* scores, unsigned long long* cand, int* cand_count, unsigned* max_coord) {
+  const int n = blockIdx.y;
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  if (slot >= p.Ktot) return;
+  int l = 0;
+  for (int i = 1; i < p.L; ++i)
+    if (slot >= p.koff[i]) l = i;
+  const int r = slot - p.koff[l];
+  int a = r;
+  if (p.pad[l] > 0) {
+    const unsigned long long key = keys[(size_t)n * p.keys_per_img + p.keyoff[l] + r];
+    a = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+  }
+  const int W = p.W[l], s = p.stride[l];
+  const int y = a / W, x = a - y * W;
+  // anchor centre (AnchorGenerator, center_offset 0: the cell's top-left corner)
+  const float cx = (float)(x * s), cy = (float)(y * s);
+  // Integral * stride (gfl_head.py:32-44, :405)
+  const float* rbase = reg.ptr[l] + (size_t)n * reg.stride_n[l] + a;
+  float d[4];
+#pragma unroll
+  for (int side = 0; side < 4; ++side) {
+    float sv[17], pv[17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k)
+      sv[k] = rbase[(size_t)(side * 17 + k) * reg.stride_c[l]];
+    d[side] = softmax_expect<17>(sv, pv) * (float)s;
+  }
+  // distance2bbox + clamp to the image (transforms.py:135-154)
+  const float Hi = img_hw[n * 2 + 0], Wi = img_hw[n * 2 + 1];
+  float bx[4] = {cx - d[0], cy - d[1], cx + d[2], cy + d[3]};
+  bx[0] = fminf(fmaxf(bx[0], 0.f), Wi);
+  bx[1] = fminf(fmaxf(bx[1], 0.f), Hi);
+  bx[2] = fminf(fmaxf(bx[2], 0.f), Wi);
+  bx[3] = fminf(fmaxf(bx[3], 0.f), Hi);
+  if (scale_factors) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bx[k] = bx[k] / scale_factors[n * 4 + k];
+  }
+  float* bo = boxes + ((size_t)n * p.Ktot + slot) * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bo[k] = bx[k];
+  // scores + candidates
+  const float* cbase = cls.ptr[l] + (size_t)n * cls.stride_n[l] + a;
+  float* so = scores + ((size_t)n * p.Ktot + slot) * p.C;
+  bool any = false;
+  for (int c = 0; c < p.C; ++c) {
+    const float sc = sigmoidf_(cbase[(size_t)c * cls.stride_c[l]]);
+    so[c] = sc;
+    if (sc > score_thr) {
+      any = true;
+      const int pos = atomicAdd(&cand_count[n], 1);
+      if (pos < p.cand_cap)
+        cand[(size_t)n * p.cand_cap + pos] = make_key(sc, (unsigned)(slot * p.C + c));
+    }
+  }
+  if (any) {
+    // boxes.max() over the candidate boxes (batched_nms); coordinates are >= 0
+    const float m = fmaxf(fmaxf(bx[0], bx[1]), fmaxf(bx[2], bx[3]));
+    atomicMax(&max_coord[n], __float_as_uint(m));
+  }
+}
+
+// ---- 4. candidate sort ----------------------------------------------------------
+__global__ __launch_bounds__(kSortThreads) void infer_cand_sort_kernel(
+    Plan p, unsigned long long* cand, const int* cand_count) {
+  const int n = blockIdx.x;
+  const int M = min(cand_count[n], p.cand_cap);
+  int len = 2;
+  while (len < M) len <<= 1;
+  unsigned long long* a = cand + (size_t)n * p.cand_cap;
+  for (int i = M + threadIdx.x; i < len; i += blockDim.x) a[i] = 0ull;
+  __syncthreads();
+  bitonic_desc(a, len);
+}
+
+// ---- 5. greedy NMS, stops at max_per_img ----------------------------------------
+__global__ __launch_bounds__(kNmsThreads) void infer_nms_kernel(
+    Plan p, const unsigned long long* cand, const int* cand_count,
+    const unsigned* max_coord, const float* boxes, float iou_thr, int max_keep,
+    float* dets, long long* labels, int* counts) {
+  __shared__ float k_box[kMaxKeep][4];  // class-shifted coordinates
+  __shared__ float k_area[kMaxKeep];
+  __shared__ int k_label[kMaxKeep];
+  __shared__ int s_alive[kNmsThreads];
+  __shared__ int s_nkept;
+  const int n = blockIdx.x, t = threadIdx.x;
+  const int M = min(cand_count[n], p.cand_cap);
+  const unsigned long long* keys = cand + (size_t)n * p.cand_cap;
+  const float shift_unit = __uint_as_float(max_coord[n]) + 1.0f;
+  if (t == 0) s_nkept = 0;
+  __syncthreads();
+  for (int base = 0; base < M; base += kNmsThreads) {
+    if (s_nkept >= max_keep) break;  // uniform: read after a barrier
+    const int i = base + t;
+    bool alive = i < M;
+    float sc = 0.f, ob[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    float area = 0.f;
+    int label = -1;
+    if (alive) {
+      const unsigned long long key = keys[i];
+      sc = __uint_as_float((unsigned)(key >> 32));
+      const unsigned pidx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+      const int slot = (int)(pidx / (unsigned)p.C);
+      label = (int)(pidx - (unsigned)slot * (unsigned)p.C);
+      const float* bo = boxes + ((size_t)n * p.Ktot + slot) * 4;
+      const float off = (float)label * shift_unit;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ob[k] = bo[k];
+        sb[k] = ob[k] + off;
+      }
+      area = (sb[2] - sb[0]) * (sb[3] - sb[1]);
+      // against everything kept so far
+      const int nk = s_nkept;
+      for (int q = 0; q < nk && alive; ++q) {
+        if (k_label[q] != label) continue;
+        const float w = fmaxf(fminf(sb[2], k_box[q][2]) - fmaxf(sb[0], k_box[q][0]), 0.f);
+        const float h = fmaxf(fminf(sb[3], k_box[q][3]) - fmaxf(sb[1], k_box[q][1]), 0.f);
+        const float inter = w * h;
+        const float ovr = inter / (k_area[q] + area - inter);
+        if (ovr > iou_thr) alive = false;
+      }
+    }
+    s_alive[t] = alive ? 1 : 0;
+    __syncthreads();
+    // resolve the chunk in score order: the next alive candidate is kept and
+    // suppresses the later ones of its class
+    for (int u = 0; u < kNmsThreads; ++u) {
+      if (!s_alive[u]) continue;           // uniform (LDS flag after a barrier)
+      if (s_nkept >= max_keep) break;      // uniform
+      const int q = s_nkept;
+      if (t == u) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) k_box[q][k] = sb[k];
+        k_area[q] = area;
+        k_label[q] = label;
+        float* d = dets + ((size_t)n * max_keep + q) * 5;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = ob[k];
+        d[4] = sc;
+        labels[(size_t)n * max_keep + q] = label;
+      }
+      __syncthreads();
+      if (t == 0) s_nkept = q + 1;
+      if (t > u && s_alive[t] && label == k_label[q]) {
+        const float w = fmaxf(fminf(sb[2], k_box[q][2]) - fmaxf(sb[0], k_box[q][0]), 0.f);
+        const float h = fmaxf(fminf(sb[3], k_box[q][3]) - fmaxf(sb[1], k_box[q][1]), 0.f);
+        const float inter = w * h;
+        const float ovr = inter / (k_area[q] + area - inter);
+        if (ovr > iou_thr) s_alive[t] = 0;
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (t == 0) counts[n] = s_nkept;
+}
+
+int make_plan(const ld_geom_t* g, int num_classes, int nms_pre, Plan* p) {
+  if (!g || g->num_levels < 1 || g->num_levels > LD_MAX_LEVELS || g->num_imgs < 1 ||
+      num_classes < 1)
+    return LD_EINVAL;
+  p->N = g->num_imgs;
+  p->L = g->num_levels;
+  p->C = num_classes;
+  int koff = 0, keyoff = 0;
+  for (int l = 0; l < p->L; ++l) {
+    p->H[l] = g->lv[l].H;
+    p->W[l] = g->lv[l].W;
+    p->stride[l] = g->lv[l].stride;
+    p->A[l] = g->lv[l].H * g->lv[l].W;
+    if (p->A[l] < 1) return LD_EINVAL;
+    const bool sorted = nms_pre > 0 && p->A[l] > nms_pre;
+    p->K[l] = sorted ? nms_pre : p->A[l];
+    p->koff[l] = koff;
+    koff += p->K[l];
+    p->pad[l] = sorted ? next_pow2(p->A[l]) : 0;
+    p->keyoff[l] = keyoff;
+    keyoff += p->pad[l];
+  }
+  for (int l = p->L; l < LD_MAX_LEVELS; ++l) {
+    p->H[l] = p->W[l] = p->stride[l] = p->A[l] = p->K[l] = p->pad[l] = 0;
+    p->koff[l] = koff;
+    p->keyoff[l] = keyoff;
+  }
+  p->Ktot = koff;
+  p->keys_per_img = keyoff;
+  const long long cap = (long long)koff * num_classes;
+  if (cap > (1LL << 30)) return LD_EUNSUPPORTED;
+  p->cand_cap = next_pow2((int)(cap < 2 ? 2 : cap));
+  return 0;
+}
+
+struct Offsets {
+  size_t keys, boxes, scores, cand, count, maxc, total;
+};
+
+Offsets layout(const Plan& p) {
+  Offsets o;
+  size_t at = 0;
+  auto take = [&](size_t bytes) {
+    const size_t r = at;
+    at += (bytes + 255) / 256 * 256;
+    return r;
+  };
+  o.keys = take((size_t)p.N * (p.keys_per_img > 0 ? p.keys_per_img : 1) * 8);
+  o.cand = take((size_t)p.N * p.cand_cap * 8);
+  o.boxes = take((size_t)p.N * p.Ktot * 4 * sizeof(float));
+  o.scores = take((size_t)p.N * p.Ktot * p.C * sizeof(float));
+  o.count = take((size_t)p.N * sizeof(int));
+  o.maxc = take((size_t)p.N * sizeof(unsigned));
+  o.total = at;
+  return o;
+}
+
+}  // namespace
+
+extern "C" size_t ld_get_bboxes_workspace_bytes(const ld_geom_t* g, int num_classes,
+                                                int nms_pre) {
+  Plan p;
+  if (make_plan(g, num_classes, nms_pre, &p) != 0) return 0;
+  return layout(p).total;
+}
+
+extern "C" int ld_get_bboxes(const ld_geom_t* g, const ld_maps_t* cls,
+                             const ld_maps_t* reg, int num_classes, int reg_max,
+                             const float* img_hw, const float* scale_factors,
+                             int nms_pre, float score_thr, float iou_thr,
+                             int max_per_img, float* dets, int64_t* labels,
+                             int32_t* counts, void* workspace, size_t workspace_bytes,
+                             ld_stream_t stream_) {
+  Plan p;
+  if (int e = make_plan(g, num_classes, nms_pre, &p)) return e;
+  if (!cls || !reg || !img_hw || !dets || !labels || !counts) return LD_EINVAL;
+  if (reg_max != 16) return LD_EUNSUPPORTED;  // 17-bin Integral only
+  if (max_per_img < 1 || max_per_img > kMaxKeep) return LD_EUNSUPPORTED;
+  const Offsets o = layout(p);
+  if (!workspace || workspace_bytes < o.total) return LD_ENOSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  char* ws = (char*)workspace;
+  unsigned long long* keys = (unsigned long long*)(ws + o.keys);
+  unsigned long long* cand = (unsigned long long*)(ws + o.cand);
+  float* boxes = (float*)(ws + o.boxes);
+  float* scores = (float*)(ws + o.scores);
+  int* count = (int*)(ws + o.count);
+  unsigned* maxc = (unsigned*)(ws + o.maxc);
+  hipError_t err;
+  if ((err = hipMemsetAsync(count, 0, (size_t)p.N * sizeof(int), stream)))
+    return (int)err;
+  if ((err = hipMemsetAsync(maxc, 0, (size_t)p.N * sizeof(unsigned), stream)))
+    return (int)err;
+  int nsorted = 0, maxpad = 0;
+  for (int l = 0; l < p.L; ++l)
+    if (p.pad[l] > 0) {
+      ++nsorted;
+      if (p.pad[l] > maxpad) maxpad = p.pad[l];
+    }
+  if (nsorted > 0) {
+    hipLaunchKernelGGL(infer_keys_kernel, dim3((maxpad + 255) / 256, p.L, p.N),
+                       dim3(256), 0, stream, p, *cls, keys);
+    hipLaunchKernelGGL(infer_topk_sort_kernel, dim3(nsorted, p.N), dim3(kSortThreads),
+                       0, stream, p, keys);
+  }
+  hipLaunchKernelGGL(infer_decode_kernel, dim3((p.Ktot + 255) / 256, p.N), dim3(256), 0,
+                     stream, p, *cls, *reg, keys, img_hw, scale_factors, score_thr,
+                     boxes, scores, cand, count, maxc);
+  hipLaunchKernelGGL(infer_cand_sort_kernel, dim3(p.N), dim3(kSortThreads), 0, stream,
+                     p, cand, count);
+  hipLaunchKernelGGL(infer_nms_kernel, dim3(p.N), dim3(kNmsThreads), 0, stream, p, cand,
+                     count, maxc, boxes, iou_thr, max_per_img, dets, (long long*)labels,
+                     counts);
+  return (int)hipGetLastError();
+}

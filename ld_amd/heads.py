@@ -326,9 +326,37 @@ class GFLHead(nn.Module):
                                       'of SURVEY.md section 8f')
         return losses
 
-    def get_bboxes(self, *args, **kwargs):
-        raise NotImplementedError('inference post-processing is a "next" row '
-                                  'of SURVEY.md section 8f')
+    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg=None,
+                   rescale=False, with_nms=True):
+        """anchor_head.py:497-589 + gfl_head.py:354-451 + multiclass_nms, one
+        C-ABI call for the whole batch (ld_get_bboxes).  Returns, per image,
+        ``(det_bboxes (k, 5), det_labels (k,))`` like the reference."""
+        cfg = self.test_cfg if cfg is None else cfg
+        if cfg is None:
+            raise ValueError('get_bboxes needs a test_cfg')
+        if not with_nms:
+            raise NotImplementedError('with_nms=False (raw per-level boxes) is '
+                                      'not wired; SURVEY.md section 8f')
+        nms = cfg['nms'] if isinstance(cfg, dict) else cfg.nms
+        if nms.get('type', 'nms') != 'nms':
+            raise NotImplementedError(
+                f"nms type {nms.get('type')!r}: only 'nms' is built (the "
+                'score-voting Cluster-DIoU-NMS of bbox_nms.py:141-176 is not)')
+        get = cfg.get if hasattr(cfg, 'get') else lambda k, d=None: cfg[k]
+        if get('min_bbox_size', 0) not in (0, -1):
+            raise NotImplementedError('min_bbox_size > 0')
+        strides = [s[0] if isinstance(s, (tuple, list)) else s
+                   for s in self.anchor_generator.strides]
+        N = cls_scores[0].shape[0]
+        shapes = [img_metas[i]['img_shape'] for i in range(N)]
+        sfs = [img_metas[i]['scale_factor'] for i in range(N)] if rescale \
+            else None
+        return LB.get_bboxes(
+            [c.detach() for c in cls_scores], [b.detach() for b in bbox_preds],
+            strides, shapes, sfs, nms_pre=get('nms_pre', -1),
+            score_thr=get('score_thr'), iou_thr=nms['iou_threshold'],
+            max_per_img=get('max_per_img'), num_classes=self.cls_out_channels,
+            reg_max=self.reg_max)
 
 
 @HEADS.register_module()

@@ -262,3 +262,43 @@ def kl_integral_dense(s_reg, t_reg, weight, T=10.0, scale=1.0, with_grad=True):
         L.ptr(integral), L.ptr(loss_rows), L.ptr(grad),
         L.stream_ptr(s_reg.device)), 'ld_kl_integral_dense')
     return integral, loss_rows, grad
+
+
+# ---------------------------------------------------------------------------
+# inference post-processing
+# ---------------------------------------------------------------------------
+def get_bboxes(cls_scores, bbox_preds, strides, img_shapes, scale_factors=None,
+               nms_pre=1000, score_thr=0.05, iou_thr=0.6, max_per_img=100,
+               num_classes=None, reg_max=16):
+    """GFLHead.get_bboxes on the device (ld_get_bboxes).  ``cls_scores`` /
+    ``bbox_preds``: per-level NCHW maps; ``img_shapes``: per image (h, w[, c]);
+    ``scale_factors``: per image 4 values (rescale=True) or None.
+    -> list of (dets (k, 5), labels (k,)) device tensors, one pair per image."""
+    lib = L.get_lib()
+    dev = cls_scores[0].device
+    N = cls_scores[0].shape[0]
+    C_ = int(num_classes or cls_scores[0].shape[1])
+    sizes = [tuple(int(v) for v in c.shape[-2:]) for c in cls_scores]
+    g = L.make_geom(sizes, strides, N)
+    cm, rm = L.make_maps(cls_scores), L.make_maps(bbox_preds)
+    hw = torch.tensor([[float(s[0]), float(s[1])] for s in img_shapes],
+                      dtype=torch.float32).to(dev)
+    sf = None
+    if scale_factors is not None:
+        sf = torch.tensor([[float(v) for v in f] for f in scale_factors],
+                          dtype=torch.float32).to(dev)
+    need = lib.ld_get_bboxes_workspace_bytes(C.byref(g), C_, int(nms_pre))
+    if need == 0:
+        raise L.LdError('ld_get_bboxes: bad geometry')
+    ws = workspace(dev, need, 'infer')
+    dets = torch.empty((N, max_per_img, 5), dtype=torch.float32, device=dev)
+    labels = torch.empty((N, max_per_img), dtype=torch.int64, device=dev)
+    counts = torch.empty((N, ), dtype=torch.int32, device=dev)
+    L.check(lib.ld_get_bboxes(C.byref(g), C.byref(cm), C.byref(rm), C_,
+                              int(reg_max), L.ptr(hw), L.ptr(sf), int(nms_pre),
+                              float(score_thr), float(iou_thr),
+                              int(max_per_img), L.ptr(dets), L.ptr(labels),
+                              L.ptr(counts), L.ptr(ws), ws.numel(),
+                              L.stream_ptr(dev)), 'ld_get_bboxes')
+    ks = counts.cpu().tolist()  # the one sync of the call
+    return [(dets[n, :k], labels[n, :k]) for n, k in enumerate(ks)]
