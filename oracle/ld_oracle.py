@@ -597,8 +597,8 @@ def ld_loss_block(cls, reg, t_cls, t_reg, x, t_x, targets, hp=None,
 
 
 # --------------------------------------------------------------------------
-# inference: GFLHead.get_bboxes  (oracle only --
-# the HIP path for this row is not built yet)
+# inference: GFLHead.get_bboxes  (the checker of
+# ld_amd/csrc/infer.hip)
 #   anchor_head.py:497-589 -> gfl_head.py:354-451 (_get_bboxes)
 #   -> core/post_processing/bbox_nms.py:70-195 (multiclass_nms, type='nms')
 #   -> mmcv.ops.nms.batched_nms / nms (mmcv-full 1.2.x, compiled; published

@@ -2,9 +2,9 @@
 restatement of GFLHead.get_bboxes -- sigmoid scores, Integral * stride, per-level
 top-nms_pre, distance2bbox + clamp, multiclass_nms / batched_nms -- against the
 outputs of the REFERENCE get_bboxes executed under the shim
-(tests/golden/infer.npz, oracle/gen_golden.py --only infer).  CPU only.  The
-HIP path of this row is not built yet; this pins the checker it will be held
-to (labels, order and counts exact; coordinates within 1e-3 px, scores 1e-6)."""
+(tests/golden/infer.npz, oracle/gen_golden.py --only infer).  CPU only: this
+pins the checker the HIP path (tests/test_gpu_infer.py) is held to (labels,
+order and counts exact; coordinates within 1e-3 px, scores 1e-6)."""
 import sys
 
 import numpy as np
