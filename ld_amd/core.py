@@ -76,6 +76,19 @@ def reduce_mean(tensor):
     return tensor
 
 
+def bbox2result(bboxes, labels, num_classes):
+    """core/bbox/transforms.py:99-116: (n, 5) detections + (n,) labels -> list
+    of per-class (k_c, 5) float32 numpy arrays (the format evaluation and
+    ``show_result`` consume)."""
+    import numpy as np
+    if bboxes.shape[0] == 0:
+        return [np.zeros((0, 5), dtype=np.float32) for _ in range(num_classes)]
+    if isinstance(bboxes, torch.Tensor):
+        bboxes = bboxes.detach().cpu().numpy()
+        labels = labels.detach().cpu().numpy()
+    return [bboxes[labels == i, :] for i in range(num_classes)]
+
+
 def distance2bbox(points, distance, max_shape=None):
     """mmdet/core/bbox/transforms.py:119-156 (glue on tiny tensors)."""
     x1 = points[:, 0] - distance[:, 0]

@@ -40,12 +40,14 @@ class SingleStageDetector(nn.Module):
 
     def init_weights(self, pretrained=None):
         """single_stage.py:35-50."""
-        if isinstance(pretrained, str) and ('://' in pretrained or
-                                            not os.path.isfile(pretrained)):
-            warnings.warn(
-                f'pretrained={pretrained!r} cannot be fetched offline; '
-                'initialising the backbone randomly instead')
-            pretrained = None
+        if isinstance(pretrained, str):
+            from .checkpoint import resolve_checkpoint_path
+            try:
+                pretrained = resolve_checkpoint_path(pretrained)
+            except FileNotFoundError as e:
+                warnings.warn(f'{e}; initialising the backbone randomly '
+                              'instead')
+                pretrained = None
         self.backbone.init_weights(pretrained=pretrained)
         if self.with_neck:
             self.neck.init_weights()
@@ -63,12 +65,43 @@ class SingleStageDetector(nn.Module):
         return self.bbox_head.forward_train(x, img_metas, gt_bboxes, gt_labels,
                                             gt_bboxes_ignore)
 
+    def simple_test(self, img, img_metas, rescale=False):
+        """single_stage.py:98-129: features -> head -> get_bboxes (one device
+        call, ld_get_bboxes) -> per-class numpy arrays."""
+        from .core import bbox2result
+        x = self.extract_feat(img)
+        outs = self.bbox_head(x)
+        bbox_list = self.bbox_head.get_bboxes(*outs, img_metas,
+                                              rescale=rescale)
+        return [bbox2result(b, l, self.bbox_head.num_classes)
+                for b, l in bbox_list]
+
+    def aug_test(self, imgs, img_metas, rescale=False):
+        raise NotImplementedError('test-time augmentation (single_stage.py:'
+                                  '131-160) is not on the SURVEY.md section 8 '
+                                  'scope')
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        """base.py:120-167: outer lists = test-time augmentations."""
+        for var, name in [(imgs, 'imgs'), (img_metas, 'img_metas')]:
+            if not isinstance(var, list):
+                raise TypeError(f'{name} must be a list, but got {type(var)}')
+        if len(imgs) != len(img_metas):
+            raise ValueError(f'num of augmentations ({len(imgs)}) '
+                             f'!= num of image meta ({len(img_metas)})')
+        for img, img_meta in zip(imgs, img_metas):
+            for m in img_meta:
+                m['batch_input_shape'] = tuple(img.size()[-2:])
+        if len(imgs) == 1:
+            return self.simple_test(imgs[0], img_metas[0], **kwargs)
+        return self.aug_test(imgs, img_metas, **kwargs)
+
     def forward(self, img, img_metas, return_loss=True, **kwargs):
         """base.py:169-183."""
         if return_loss:
             return self.forward_train(img, img_metas, **kwargs)
-        raise NotImplementedError('forward_test / simple_test is a "next" row '
-                                  'of SURVEY.md section 8f (inference)')
+        with torch.no_grad():
+            return self.forward_test(img, img_metas, **kwargs)
 
     def _parse_losses(self, losses):
         """base.py:185-218.  Same keys and values; computed on the device in

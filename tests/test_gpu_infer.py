@@ -111,3 +111,36 @@ def test_head_api_and_edge_cases(golden):
     with pytest.raises(NotImplementedError):
         head.get_bboxes(cls, reg, metas, cfg=dict(
             cfg, nms=dict(type='voting_cluster_diounms', iou_threshold=0.6)))
+
+
+def test_detector_simple_test():
+    """SingleStageDetector.forward(return_loss=False) -> forward_test ->
+    simple_test (single_stage.py:98-129, base.py:120-183): per image a list of
+    num_classes (k_c, 5) float32 arrays, equal to the head-level call."""
+    from ld_amd import model_zoo, synthetic as S
+    dev = torch.device('cuda:0')
+    det = model_zoo.build_seeded_ld_detector(18, 18, dev)
+    det.eval()
+    det.bbox_head.test_cfg['score_thr'] = 0.001  # seeded weights score low
+    batch = S.synthetic_batch(2, (120, 150), (128, 160), [2, 3], 7)
+    img = batch['img'].to(dev)
+    metas = batch['img_metas']
+    for m, sf in zip(metas, (1.0, 1.25)):
+        m['scale_factor'] = np.array([sf] * 4, dtype=np.float32)
+    res = det(img=[img], img_metas=[metas], return_loss=False, rescale=True)
+    assert len(res) == 2
+    with torch.no_grad():
+        outs = det.bbox_head(det.extract_feat(img))
+        ref = det.bbox_head.get_bboxes(*outs, metas, rescale=True)
+    total = 0
+    for per_cls, (db, dl) in zip(res, ref):
+        assert len(per_cls) == 80
+        db, dl = db.cpu().numpy(), dl.cpu().numpy()
+        for c, arr in enumerate(per_cls):
+            assert arr.dtype == np.float32 and arr.shape[1] == 5
+            assert np.array_equal(arr, db[dl == c])
+        assert sum(a.shape[0] for a in per_cls) == db.shape[0] <= 100
+        total += db.shape[0]
+    assert total > 0
+    with pytest.raises(TypeError):
+        det(img=img, img_metas=[metas], return_loss=False)
