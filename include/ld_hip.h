@@ -413,7 +413,9 @@ int ld_sgd_step(float* params, const float* grads, float* momentum_buf, size_t n
  *   scale_factors  device (N, 4) or NULL
  *   dets           device (N, max_per_img, 5): x1, y1, x2, y2, score
  *   labels         device (N, max_per_img) int64;  counts device (N) int32
- * Equal scores: lower (anchor, class) index first. */
+ * Equal scores: lower (anchor, class) index first.  iou_thr must be >= 0
+ * (LD_EINVAL otherwise: a negative threshold suppresses across classes in the
+ * reference's class-shift formulation).  Synchronises the stream once. */
 size_t ld_get_bboxes_workspace_bytes(const ld_geom_t* g, int num_classes,
                                      int nms_pre);
 int ld_get_bboxes(const ld_geom_t* g, const ld_maps_t* cls, const ld_maps_t* reg,

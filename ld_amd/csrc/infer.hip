@@ -14,19 +14,22 @@
 //   1. keys      one thread per (image, level, anchor): max class logit ->
 //                64-bit key (score bits << 32 | ~anchor) so ONE descending sort
 //                orders by score and breaks ties lower-index-first
-//   2. top-k     bitonic sort of each (image, level) key segment by one
-//                workgroup (only levels with more than nms_pre anchors)
+//   2. top-k     per (image, level) with more than nms_pre anchors: radix select
+//                of the nms_pre-th key + LDS sort of the selected keys (one
+//                workgroup; a global-memory bitonic sort is the fallback)
 //   3. decode    one thread per selected anchor: 80 sigmoid scores, 4 x 17-bin
 //                softmax expectations, box, clamp, rescale; (anchor, class)
 //                pairs above score_thr are appended (atomic counter) as keys
 //                (score bits << 32 | ~pair index): order fixed by the next sort
-//   4. sort      bitonic sort of the candidate keys, one workgroup per image
+//   4. sort      the 4096 best candidate keys per image (radix select + LDS
+//                sort); the full bitonic sort only if NMS runs out of them
 //   5. nms       one workgroup per image walks the sorted candidates in chunks
 //                of 256 against the kept list (<= max_per_img, in LDS) and
 //                stops at max_per_img: O(candidates examined x kept), not
 //                O(candidates^2)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/ld_hip.h"
 #include "ld_math.h"
@@ -99,6 +102,110 @@ __device__ void bitonic_desc(unsigned long long* a, int n) {
       __syncthreads();
     }
   }
+}
+
+// Workgroup-wide: the min(k, n) largest of in[0..n) in descending order -> out
+// (k <= kSelN).  n <= kSelN: stage everything in LDS and sort there.  Otherwise
+// an MSB-first radix select over the eight key bytes finds the k-th largest key
+// (keys are unique: score bits | ~index), the k keys >= it are gathered into
+// LDS and sorted there -- 8 counting passes + one 4096-wide LDS sort instead of
+// ~120 bitonic passes over global memory.  `out` may alias `in`: every read of
+// `in` precedes the first write of `out`.
+constexpr int kSelN = 4096;
+
+struct SelectLds {
+  unsigned long long keys[kSelN];
+  int hist[256];
+  unsigned long long prefix;
+  int rem, cnt;
+};
+
+__device__ int select_sort_desc(const unsigned long long* in, int n, int k,
+                                unsigned long long* out, SelectLds& s) {
+  const int T = blockDim.x, t = threadIdx.x;
+  int m;
+  if (n <= kSelN) {
+    for (int i = t; i < n; i += T) s.keys[i] = in[i];
+    m = n;
+  } else {
+    if (t == 0) {
+      s.prefix = 0ull;
+      s.rem = k;
+    }
+    __syncthreads();
+    for (int b = 7; b >= 0; --b) {
+      for (int i = t; i < 256; i += T) s.hist[i] = 0;
+      __syncthreads();
+      const unsigned long long prefix = s.prefix;
+      const int shift = 8 * b;
+      const unsigned long long himask = b == 7 ? 0ull : (~0ull << (8 * (b + 1)));
+      for (int i = t; i < n; i += T) {
+        const unsigned long long key = in[i];
+        if ((key & himask) == (prefix & himask))
+          atomicAdd(&s.hist[(int)((key >> shift) & 0xFFull)], 1);
+      }
+      __syncthreads();
+      if (t == 0) {
+        // largest byte value v with #(byte > v) < rem <= #(byte >= v)
+        int cum = 0, v = 255;
+        const int rem = s.rem;
+        for (; v > 0; --v) {
+          if (cum + s.hist[v] >= rem) break;
+          cum += s.hist[v];
+        }
+        s.prefix = prefix | ((unsigned long long)v << shift);
+        s.rem = rem - cum;
+      }
+      __syncthreads();
+    }
+    const unsigned long long kth = s.prefix;
+    if (t == 0) s.cnt = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += T) {
+      const unsigned long long key = in[i];
+      if (key >= kth) {
+        const int pos = atomicAdd(&s.cnt, 1);
+        if (pos < kSelN) s.keys[pos] = key;
+      }
+    }
+    __syncthreads();
+    m = min(s.cnt, kSelN);
+  }
+  int len = 2;
+  while (len < m) len <<= 1;
+  for (int i = m + t; i < len; i += T) s.keys[i] = 0ull;
+  __syncthreads();
+  bitonic_desc(s.keys, len);
+  const int w = min(k, m);
+  for (int i = t; i < w; i += T) out[i] = s.keys[i];
+  __syncthreads();
+  return w;
+}
+
+__global__ __launch_bounds__(kSortThreads) void infer_topk_select_kernel(
+    Plan p, unsigned long long* keys) {
+  __shared__ SelectLds s;
+  int l = -1, seen = 0;
+  for (int i = 0; i < p.L; ++i)
+    if (p.pad[i] > 0) {
+      if (seen == (int)blockIdx.x) l = i;
+      ++seen;
+    }
+  if (l < 0) return;
+  unsigned long long* seg = keys + (size_t)blockIdx.y * p.keys_per_img + p.keyoff[l];
+  select_sort_desc(seg, p.A[l], p.K[l], seg, s);
+}
+
+// the kSelN best candidates of an image, sorted, into their own buffer (the
+// full list stays intact for the rare fallback)
+__global__ __launch_bounds__(kSortThreads) void infer_cand_select_kernel(
+    Plan p, const unsigned long long* cand, const int* cand_count,
+    unsigned long long* cand_top) {
+  __shared__ SelectLds s;
+  const int n = blockIdx.x;
+  const int M = min(cand_count[n], p.cand_cap);
+  select_sort_desc(cand + (size_t)n * p.cand_cap, M, kSelN,
+                   cand_top + (size_t)n * kSelN, s);
 }
 
 __global__ __launch_bounds__(kSortThreads) void infer_topk_sort_kernel(
@@ -195,18 +302,23 @@ __global__ __launch_bounds__(kSortThreads) void infer_cand_sort_kernel(
 }
 
 // ---- 5. greedy NMS, stops at max_per_img ----------------------------------------
+// `cand` holds, per image (stride `cand_stride`), the best min(count, limit)
+// candidates in descending order.  exhausted[n] = the list ran out before
+// max_keep detections although more candidates exist (fast path only).
 __global__ __launch_bounds__(kNmsThreads) void infer_nms_kernel(
-    Plan p, const unsigned long long* cand, const int* cand_count,
-    const unsigned* max_coord, const float* boxes, float iou_thr, int max_keep,
-    float* dets, long long* labels, int* counts) {
+    Plan p, const unsigned long long* cand, size_t cand_stride, int limit,
+    const int* cand_count, const unsigned* max_coord, const float* boxes,
+    float iou_thr, int max_keep, float* dets, long long* labels, int* counts,
+    int* exhausted) {
   __shared__ float k_box[kMaxKeep][4];  // class-shifted coordinates
   __shared__ float k_area[kMaxKeep];
   __shared__ int k_label[kMaxKeep];
   __shared__ int s_alive[kNmsThreads];
   __shared__ int s_nkept;
   const int n = blockIdx.x, t = threadIdx.x;
-  const int M = min(cand_count[n], p.cand_cap);
-  const unsigned long long* keys = cand + (size_t)n * p.cand_cap;
+  const int Mall = min(cand_count[n], p.cand_cap);
+  const int M = min(Mall, limit);
+  const unsigned long long* keys = cand + (size_t)n * cand_stride;
   const float shift_unit = __uint_as_float(max_coord[n]) + 1.0f;
   if (t == 0) s_nkept = 0;
   __syncthreads();
@@ -275,7 +387,10 @@ __global__ __launch_bounds__(kNmsThreads) void infer_nms_kernel(
     __syncthreads();
   }
   __syncthreads();
-  if (t == 0) counts[n] = s_nkept;
+  if (t == 0) {
+    counts[n] = s_nkept;
+    if (exhausted) exhausted[n] = (s_nkept < max_keep && Mall > M) ? 1 : 0;
+  }
 }
 
 int make_plan(const ld_geom_t* g, int num_classes, int nms_pre, Plan* p) {
@@ -314,7 +429,7 @@ int make_plan(const ld_geom_t* g, int num_classes, int nms_pre, Plan* p) {
 }
 
 struct Offsets {
-  size_t keys, boxes, scores, cand, count, maxc, total;
+  size_t keys, boxes, scores, cand, cand_top, count, maxc, flags, total;
 };
 
 Offsets layout(const Plan& p) {
@@ -329,8 +444,10 @@ Offsets layout(const Plan& p) {
   o.cand = take((size_t)p.N * p.cand_cap * 8);
   o.boxes = take((size_t)p.N * p.Ktot * 4 * sizeof(float));
   o.scores = take((size_t)p.N * p.Ktot * p.C * sizeof(float));
+  o.cand_top = take((size_t)p.N * kSelN * 8);
   o.count = take((size_t)p.N * sizeof(int));
   o.maxc = take((size_t)p.N * sizeof(unsigned));
+  o.flags = take((size_t)p.N * sizeof(int));
   o.total = at;
   return o;
 }
@@ -356,6 +473,9 @@ extern "C" int ld_get_bboxes(const ld_geom_t* g, const ld_maps_t* cls,
   if (!cls || !reg || !img_hw || !dets || !labels || !counts) return LD_EINVAL;
   if (reg_max != 16) return LD_EUNSUPPORTED;  // 17-bin Integral only
   if (max_per_img < 1 || max_per_img > kMaxKeep) return LD_EUNSUPPORTED;
+  // a negative threshold would suppress ACROSS classes in the reference (IoU 0
+  // of class-shifted boxes > thr); only same-class pairs are compared here
+  if (!(iou_thr >= 0.0f)) return LD_EINVAL;
   const Offsets o = layout(p);
   if (!workspace || workspace_bytes < o.total) return LD_ENOSPACE;
   hipStream_t stream = (hipStream_t)stream_;
@@ -371,25 +491,65 @@ extern "C" int ld_get_bboxes(const ld_geom_t* g, const ld_maps_t* cls,
     return (int)err;
   if ((err = hipMemsetAsync(maxc, 0, (size_t)p.N * sizeof(unsigned), stream)))
     return (int)err;
+  unsigned long long* cand_top = (unsigned long long*)(ws + o.cand_top);
+  int* flags = (int*)(ws + o.flags);
   int nsorted = 0, maxpad = 0;
   for (int l = 0; l < p.L; ++l)
     if (p.pad[l] > 0) {
       ++nsorted;
       if (p.pad[l] > maxpad) maxpad = p.pad[l];
     }
+  // LD_INFER_SORT=global: the plain global-memory bitonic sorts everywhere
+  const char* env = getenv("LD_INFER_SORT");
+  const bool force_global = env && env[0] == 'g';
+  const bool fast_topk = !force_global && nms_pre <= kSelN;
   if (nsorted > 0) {
     hipLaunchKernelGGL(infer_keys_kernel, dim3((maxpad + 255) / 256, p.L, p.N),
                        dim3(256), 0, stream, p, *cls, keys);
-    hipLaunchKernelGGL(infer_topk_sort_kernel, dim3(nsorted, p.N), dim3(kSortThreads),
-                       0, stream, p, keys);
+    if (fast_topk)
+      hipLaunchKernelGGL(infer_topk_select_kernel, dim3(nsorted, p.N),
+                         dim3(kSortThreads), 0, stream, p, keys);
+    else
+      hipLaunchKernelGGL(infer_topk_sort_kernel, dim3(nsorted, p.N),
+                         dim3(kSortThreads), 0, stream, p, keys);
   }
   hipLaunchKernelGGL(infer_decode_kernel, dim3((p.Ktot + 255) / 256, p.N), dim3(256), 0,
                      stream, p, *cls, *reg, keys, img_hw, scale_factors, score_thr,
                      boxes, scores, cand, count, maxc);
-  hipLaunchKernelGGL(infer_cand_sort_kernel, dim3(p.N), dim3(kSortThreads), 0, stream,
-                     p, cand, count);
-  hipLaunchKernelGGL(infer_nms_kernel, dim3(p.N), dim3(kNmsThreads), 0, stream, p, cand,
-                     count, maxc, boxes, iou_thr, max_per_img, dets, (long long*)labels,
-                     counts);
+  bool need_global = force_global;
+  if (!force_global) {
+    // fast path: NMS over the kSelN best candidates of every image
+    hipLaunchKernelGGL(infer_cand_select_kernel, dim3(p.N), dim3(kSortThreads), 0,
+                       stream, p, cand, count, cand_top);
+    int limit = kSelN;  // LD_INFER_LIMIT: test hook to provoke the fallback
+    if (const char* lim = getenv("LD_INFER_LIMIT")) {
+      const int v = atoi(lim);
+      if (v >= 1 && v <= kSelN) limit = v;
+    }
+    hipLaunchKernelGGL(infer_nms_kernel, dim3(p.N), dim3(kNmsThreads), 0, stream, p,
+                       cand_top, (size_t)kSelN, limit, count, maxc, boxes, iou_thr,
+                       max_per_img, dets, (long long*)labels, counts, flags);
+    // rare: the best kSelN ran out before max_per_img detections -> redo the
+    // NMS over the fully sorted list (the caller reads `counts` next anyway)
+    int host_flags[64];
+    if (p.N > 64) {
+      need_global = true;
+    } else {
+      if ((err = hipMemcpyAsync(host_flags, flags, (size_t)p.N * sizeof(int),
+                                hipMemcpyDeviceToHost, stream)))
+        return (int)err;
+      if ((err = hipStreamSynchronize(stream))) return (int)err;
+      for (int n = 0; n < p.N; ++n)
+        if (host_flags[n]) need_global = true;
+    }
+  }
+  if (need_global) {
+    hipLaunchKernelGGL(infer_cand_sort_kernel, dim3(p.N), dim3(kSortThreads), 0, stream,
+                       p, cand, count);
+    hipLaunchKernelGGL(infer_nms_kernel, dim3(p.N), dim3(kNmsThreads), 0, stream, p,
+                       cand, (size_t)p.cand_cap, p.cand_cap, count, maxc, boxes,
+                       iou_thr, max_per_img, dets, (long long*)labels, counts,
+                       (int*)nullptr);
+  }
   return (int)hipGetLastError();
 }

@@ -144,3 +144,40 @@ def test_detector_simple_test():
     assert total > 0
     with pytest.raises(TypeError):
         det(img=img, img_metas=[metas], return_loss=False)
+
+
+def test_global_sort_path(golden, monkeypatch):
+    """LD_INFER_SORT=global: the plain global-memory bitonic sorts (the
+    fallback of the radix-select + LDS-sort fast path) give the same result."""
+    monkeypatch.setenv('LD_INFER_SORT', 'global')
+    dev = torch.device('cuda:0')
+    g = golden['infer']
+    for i, (dets, labels) in enumerate(_run(CASES['c2'], False, dev)):
+        _same(dets, labels, g[f'c2_r0_bboxes_{i}'], g[f'c2_r0_labels_{i}'],
+              f'global path image {i}')
+
+
+def test_fallback_when_best_candidates_run_out(monkeypatch):
+    """With the fast path's candidate window shrunk to 256 (LD_INFER_LIMIT, a
+    test hook) and max_per_img = 1024 the window runs out, so the call must
+    fall back to the fully sorted list (6.8 k candidates) -- and still equal
+    the oracle (iou_threshold 0: every overlap within a class suppresses)."""
+    import ld_oracle as O
+    from ld_amd import lossblock as LB
+    monkeypatch.setenv('LD_INFER_LIMIT', '256')
+    dev = torch.device('cuda:0')
+    case = CASES['c2']
+    cls, reg, metas = synthetic.infer_inputs(case)
+    shapes = [m['img_shape'] for m in metas]
+    ref = O.get_bboxes([c.numpy() for c in cls], [r.numpy() for r in reg],
+                       shapes, None, nms_pre=case[5], iou_thr=0.0,
+                       max_per_img=1024, rescale=False)
+    res = LB.get_bboxes([c.to(dev) for c in cls], [r.to(dev) for r in reg],
+                        STRIDES, shapes, None, nms_pre=case[5], score_thr=0.05,
+                        iou_thr=0.0, max_per_img=1024)
+    for i, ((d, l), (rd, rl)) in enumerate(zip(res, ref)):
+        assert rd.shape[0] > 256  # the premise: more keeps than the window
+        _same(d.cpu().numpy(), l.cpu().numpy(), rd, rl, f'fallback image {i}')
+    with pytest.raises(Exception):  # negative thresholds are rejected
+        LB.get_bboxes([c.to(dev) for c in cls], [r.to(dev) for r in reg],
+                      STRIDES, shapes, None, nms_pre=case[5], iou_thr=-1.0)
