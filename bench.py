@@ -236,9 +236,15 @@ def main():
                 'prime_steps': 1,
             },
         }
-    # kernel-level legs (rank 0 / single GPU only: they are per-device figures)
-    if rank == 0 and not args.no_kernel_roofline:
-        res['roofline'] = kernel_roofline(trainer, dbatch, args.profile_steps)
+    # kernel-level legs: per-device figures, reported by rank 0.  The
+    # instrumented steps are ordinary train steps, so with N > 1 EVERY rank runs
+    # them -- their gradient / normaliser all-reduces must be matched on all
+    # ranks (rank 0 alone would pair them with the other ranks' barrier).
+    roof = None
+    if not args.no_kernel_roofline:
+        roof = kernel_roofline(trainer, dbatch, args.profile_steps)
+    if rank == 0 and roof is not None:
+        res['roofline'] = roof
         # step-level view of the same bound: analytic conv FLOPs per image
         # (1835.7 GFLOP) / step time
         res['roofline']['step_tflops_analytic'] = \
