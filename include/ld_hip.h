@@ -290,16 +290,33 @@ typedef struct {
 } ld_wt_job_t;
 int ld_conv_weight_transform_batch(const ld_wt_job_t* jobs, const int32_t* block_job,
                                    int nblocks, ld_stream_t stream);
-/* y must not alias x or ep->residual: the first call for a new layer geometry
- * times several tile shapes by launching the (idempotent) kernel more than
- * once on the caller's buffers and synchronises the device (the same contract
- * as cudnn.benchmark = True; LD_CONV_AUTOTUNE=0 disables it).  Not capturable
- * into a hipGraph until the geometry has been seen once. */
+/* Enqueue only: no timing, no synchronisation, capturable into a hipGraph.
+ * The tile shape of a launch comes from the tuning table (below) and, for a
+ * geometry the table does not hold, from a model that is a pure function of the
+ * geometry -- so two processes with the same table produce the same bits (the
+ * KS = 4 split-K shapes sum in a different order than KS = 1). */
 int ld_conv_forward(const ld_conv_t* c, const float* x, const float* wt_fwd,
                     const ld_conv_epilogue_t* ep, float* y, ld_stream_t stream);
 /* dx (N,Cin,Pin) fully overwritten. */
 int ld_conv_dgrad(const ld_conv_t* c, const float* dy, const float* wt_bwd,
                   float* dx, ld_stream_t stream);
+/* ---- shape tuning (explicit; cudnn.benchmark's role, kept OUT of the launch
+ * path).  ld_conv_tune_* time every candidate tile shape of the geometry by
+ * launching the (idempotent) kernel on the caller's buffers -- y / dx must not
+ * alias an input -- and record the winner: they synchronise the device and
+ * must not be called on a capturing stream.  Return 0 = tuned now, 1 = the
+ * geometry was already in the table (nothing done), < 0 / hipError_t on error.
+ * ld_conv_tune_load merges a text table (one record per line: 18 key ints,
+ * then tm tn wvm d ks; '#' comments) and returns the number of records;
+ * ld_conv_tune_save writes the whole table; host paths. */
+int ld_conv_tune_forward(const ld_conv_t* c, const float* x, const float* wt_fwd,
+                         const ld_conv_epilogue_t* ep, float* y,
+                         ld_stream_t stream);
+int ld_conv_tune_dgrad(const ld_conv_t* c, const float* dy, const float* wt_bwd,
+                       float* dx, ld_stream_t stream);
+int ld_conv_tune_load(const char* path);
+int ld_conv_tune_save(const char* path);
+int ld_conv_tune_clear(void);
 size_t ld_conv_wgrad_workspace_bytes(const ld_conv_t* c);
 /* dw (Cout,Cin,KH,KW): overwritten, or += if accumulate != 0. */
 int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy, float* dw,

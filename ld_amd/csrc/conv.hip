@@ -43,112 +43,9 @@
 #include <mutex>
 #include <unordered_map>
 
-#include "../../include/ld_hip.h"
+#include "conv_common.h"
 
 namespace {
-
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-constexpr int kThreads = 256;
-constexpr int WBK = 32;   // wgrad k-slice (spatial positions) per step
-constexpr int WLD = WBK + 1;  // odd LDS row stride -> conflict-free columns
-
-// Weight-image rows per tap are padded with zero rows to a multiple of this,
-// so the k-tail of the GEMM needs no masking on the A side.
-constexpr int kKPad = 32;
-inline int kpad_rows(int k) { return (k + kKPad - 1) / kKPad * kKPad; }
-
-// A voffset at/above this is out of range for every descriptor we build
-// (extents are checked < 2 GiB on the host): buffer loads return 0 there.
-constexpr unsigned kOOB = 0x80000000u;
-
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
-  // descriptor inputs pinned wave-uniform (cdna_hip_programming.md T20)
-  const uintptr_t u = (uintptr_t)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-  void* q = (void*)(((uintptr_t)hi << 32) | lo);
-  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes),
-                                           0x00020000);
-}
-
-__device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(float,
-                            __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-
-struct Geo {  // pyramid geometry as the gather sees it
-  int stride, pad, num_levels;
-  ld_conv_level_t lv[LD_MAX_LEVELS];
-};
-
-struct ConvK {  // kernel-side view of ld_conv_t + pointers
-  const float* x;
-  const float* wt;
-  float* y;
-  const float* bias;
-  const float* scale;
-  const float* shift;
-  const float* residual;
-  int relu;
-  int N, Cin, Cout, KH, KW;
-  int Pin, Pout;
-  int J;  // N * Pout
-  int Kpad;               // rows per tap of the weight image (Cin rounded up)
-  int pipe;               // use the software-pipelined main loop
-  unsigned x_bytes, wt_bytes;  // buffer-descriptor extents
-  // MODE 1 (data-gradient of a stride-2 conv, one output-parity class per
-  // launch): g.lv[].Hout/Wout/off_out describe the COMPACT grid of the class;
-  // the class is (ph, pw); only taps kh = kh0 + 2*i (i < nth), kw = kw0 + 2*j
-  // (j < ntw) reach it; input row = hc + ch0 + i, col = wc + cw0 + j.
-  int ph, pw, kh0, kw0, nth, ntw, ch0, cw0;
-  int Pfull;                       // positions per (n, c) row of the output
-  int fW[LD_MAX_LEVELS], foff[LD_MAX_LEVELS];  // full output row length/offset
-  Geo g;
-};
-
-__device__ __forceinline__ int xcd_swizzle(int b, int nb) {
-  // consecutive logical tiles -> same XCD (block b runs on XCD b % 8)
-  const int q = nb >> 3, r = nb & 7;
-  const int xcd = b & 7, idx = b >> 3;
-  return xcd * q + min(xcd, r) + idx;
-}
-
-// position p in [0, Pout) -> level and (ho, wo)
-__device__ __forceinline__ void locate_out(const Geo& a, int p, int& l, int& ho,
-                                           int& wo) {
-  l = 0;
-#pragma unroll
-  for (int i = 1; i < LD_MAX_LEVELS; ++i)
-    if (i < a.num_levels && p >= a.lv[i].off_out) l = i;
-  const int r = p - a.lv[l].off_out;
-  ho = r / a.lv[l].Wout;
-  wo = r - ho * a.lv[l].Wout;
-}
-
-// MODE 0: y = conv(x)            in = ho*S - P + kh
-// MODE 1: transposed gather for the data-gradient of a stride-2 conv:
-//         in position (ho - pad + kh) must be even; in = that / 2
-template <int MODE>
-__device__ __forceinline__ bool tap_offset(const Geo& a, int l, int ho, int wo,
-                                           int kh, int kw, int& off) {
-  const int Hin = a.lv[l].Hin, Win = a.lv[l].Win;
-  int hi, wi;
-  if (MODE == 0) {
-    hi = ho * a.stride - a.pad + kh;
-    wi = wo * a.stride - a.pad + kw;
-  } else {
-    const int hn = ho - a.pad + kh, wn = wo - a.pad + kw;
-    if ((hn | wn) < 0 || ((hn | wn) & 1)) return false;
-    hi = hn >> 1;
-    wi = wn >> 1;
-  }
-  if (hi < 0 || hi >= Hin || wi < 0 || wi >= Win) return false;
-  off = a.lv[l].off_in + hi * Win + wi;
-  return true;
-}
 
 // ------------------------------------------------------------ forward/dgrad
 // Tile shape is a template parameter: BM x BNT block tile, BKT k-slice.  Four
@@ -1338,149 +1235,114 @@ inline int stream_cfg_model(const ConvK& k) {
   return best;
 }
 
-struct TuneKey {
-  int v[16];
-  bool operator==(const TuneKey& o) const {
-    for (int i = 0; i < 16; ++i)
-      if (v[i] != o.v[i]) return false;
-    return true;
-  }
-};
-struct TuneKeyHash {
-  size_t operator()(const TuneKey& k) const {
-    size_t h = 1469598103934665603ull;
-    for (int i = 0; i < 16; ++i) h = (h ^ (size_t)(unsigned)k.v[i]) * 1099511628211ull;
-    return h;
-  }
-};
 constexpr int kTuneReps = 3;
-std::mutex g_tune_mu;
-std::unordered_map<TuneKey, int, TuneKeyHash> g_tune;
-bool g_tune_file_loaded = false;
 
-// LD_CONV_TUNE_FILE: text file of "16 key ints  tm tn wvm d ks" lines.  Loaded once
-// per process, appended to whenever a new geometry is tuned -- lets a profiling
-// run (or every rank after the first) start from the picks of an earlier run
-// instead of re-timing the candidates.  Caller holds g_tune_mu.
-void tune_file_load_locked() {
-  if (g_tune_file_loaded) return;
-  g_tune_file_loaded = true;
-  const char* path = getenv("LD_CONV_TUNE_FILE");
-  if (!path || !*path) return;
-  FILE* f = fopen(path, "r");
-  if (!f) return;
-  for (;;) {
-    TuneKey k;
-    StreamCfg c;
-    int got = 0;
-    for (int i = 0; i < 16; ++i) got += fscanf(f, "%d", &k.v[i]) == 1;
-    got += fscanf(f, "%d %d %d %d %d", &c.tm, &c.tn, &c.wvm, &c.d, &c.ks) == 5;
-    if (got != 17) break;
-    for (int i = 0; i < kNumStreamCfgs; ++i)
-      if (kStreamCfgs[i].tm == c.tm && kStreamCfgs[i].tn == c.tn &&
-          kStreamCfgs[i].wvm == c.wvm && kStreamCfgs[i].d == c.d &&
-          kStreamCfgs[i].ks == c.ks)
-        g_tune[k] = i;
-  }
-  fclose(f);
+inline int stream_cfg_index(const LdTuneCfg& c) {
+  for (int i = 0; i < kNumStreamCfgs; ++i)
+    if (kStreamCfgs[i].tm == c.tm && kStreamCfgs[i].tn == c.tn &&
+        kStreamCfgs[i].wvm == c.wvm && kStreamCfgs[i].d == c.d &&
+        kStreamCfgs[i].ks == c.ks)
+      return i;
+  return -1;
 }
 
-void tune_file_append_locked(const TuneKey& k, int pick) {
-  const char* path = getenv("LD_CONV_TUNE_FILE");
-  if (!path || !*path) return;
-  // one write() per record: several ranks may append to the same file
-  char line[512];
-  int n = 0;
-  for (int i = 0; i < 16; ++i) n += snprintf(line + n, sizeof(line) - n, "%d ", k.v[i]);
-  const StreamCfg& c = kStreamCfgs[pick];
-  n += snprintf(line + n, sizeof(line) - n, " %d %d %d %d %d\n", c.tm, c.tn, c.wvm, c.d,
-                c.ks);
-  FILE* f = fopen(path, "a");
-  if (!f) return;
-  fwrite(line, 1, (size_t)n, f);
-  fclose(f);
-}
-
+// Shape choice of a launch: forced by LD_CONV_STREAM, else the tuning table
+// (ld_conv_tune_load / ld_conv_tune_*), else the round-count model -- a pure
+// function of the geometry.  Never times anything and never synchronises: the
+// launch entry points only enqueue.  *forced gets the LD_CONV_STREAM override.
 template <int MODE>
-int launch_stream(const ConvK& k, hipStream_t stream) {
-  if (k.Cin % 8 != 0) return LD_EUNSUPPORTED;
+int pick_stream_cfg(const ConvK& k, StreamCfg* forced) {
+  if (k.Cin % 8 != 0) return -1;
   if (const char* env = getenv("LD_CONV_STREAM")) {
-    if (env[0] == '0' && env[1] == 0) return LD_EUNSUPPORTED;
+    if (env[0] == '0' && env[1] == 0) return -1;
     StreamCfg c;
     c.ks = 1;
     if (sscanf(env, "%dx%dx%dx%dx%d", &c.tm, &c.tn, &c.wvm, &c.d, &c.ks) >= 4) {
       if (k.Cin % (2 * c.d) != 0) c.d = 4;
-      const int rc = launch_stream_cfg<MODE>(k, c, stream);
-      if (rc != LD_EUNSUPPORTED) return rc;
-      c.ks = 1;  // no split-K instance at this ring depth
-      return launch_stream_cfg<MODE>(k, c, stream);
+      *forced = c;
+      return -2;
     }
   }
-  const TuneKey key = {{MODE, k.Cin, k.Cout, k.KH, k.KW, k.g.stride, k.g.pad, k.J,
-                        k.g.num_levels, k.g.lv[0].Hin, k.g.lv[0].Win, k.ph, k.pw,
-                        k.relu, k.residual != nullptr, k.scale != nullptr}};
-  int pick = -1;
-  {
-    std::lock_guard<std::mutex> lock(g_tune_mu);
-    tune_file_load_locked();
-    auto it = g_tune.find(key);
-    if (it != g_tune.end()) pick = it->second;
+  LdTuneCfg t;
+  if (ld_tune_lookup(make_tune_key(MODE, 0, k), &t)) {
+    const int i = stream_cfg_index(t);
+    if (i >= 0 && stream_cfg_fits(k, kStreamCfgs[i])) return i;
   }
-  if (pick < 0) {
-    pick = stream_cfg_model(k);
-    if (pick < 0) return LD_EUNSUPPORTED;
-    const char* at = getenv("LD_CONV_AUTOTUNE");
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(stream, &cap);
-    float best_ms = -1.0f;
-    if (!(at && at[0] == '0') && cap == hipStreamCaptureStatusNone) {
-      // quiesce the device first: work queued on other streams (the teacher's
-      // forward) would otherwise share the CUs with some candidates and not
-      // others
-      (void)hipDeviceSynchronize();
-      hipEvent_t e0, e1;
-      (void)hipEventCreate(&e0);
-      (void)hipEventCreate(&e1);
-      for (int i = 0; i < kNumStreamCfgs; ++i) {
-        if (!stream_cfg_fits(k, kStreamCfgs[i])) continue;
-        if (launch_stream_cfg<MODE>(k, kStreamCfgs[i], stream) != 0) continue;
-        float ms = -1.0f;
-        for (int trial = 0; trial < 2; ++trial) {  // best of two: clocks wander
-          (void)hipEventRecord(e0, stream);
-          for (int rep = 0; rep < kTuneReps; ++rep)
-            launch_stream_cfg<MODE>(k, kStreamCfgs[i], stream);
-          (void)hipEventRecord(e1, stream);
-          if (hipEventSynchronize(e1) != hipSuccess) break;
-          float t = 0.0f;
-          (void)hipEventElapsedTime(&t, e0, e1);
-          if (ms < 0.0f || t < ms) ms = t;
-        }
-        if (ms < 0.0f) continue;
-        if (best_ms < 0.0f || ms < best_ms) {
-          best_ms = ms;
-          pick = i;
-        }
-      }
-      (void)hipEventDestroy(e0);
-      (void)hipEventDestroy(e1);
-    }
-    if (const char* lg = getenv("LD_CONV_TUNE_LOG"))
-      if (lg[0] == '1') {
-        const StreamCfg& c = kStreamCfgs[pick];
-        const double fl = 2.0 * k.J * k.Cout * k.Cin *
-                          (MODE == 1 ? k.nth * k.ntw : k.KH * k.KW);
-        fprintf(stderr,
-                "[ld_conv] mode %d Cin %d Cout %d k %dx%d s%d J %d lv %d -> "
-                "%dx%dx%dx%dx%d  %.1f TFLOP/s\n",
-                MODE, k.Cin, k.Cout, k.KH, k.KW, k.g.stride, k.J, k.g.num_levels,
-                c.tm, c.tn, c.wvm, c.d, c.ks,
-                best_ms > 0 ? fl / (best_ms * 1e-3 / kTuneReps) / 1e12 : 0.0);
-      }
-    std::lock_guard<std::mutex> lock(g_tune_mu);
-    g_tune[key] = pick;
-    if (best_ms > 0.0f) tune_file_append_locked(key, pick);
+  return stream_cfg_model(k);
+}
+
+template <int MODE>
+int launch_stream(const ConvK& k, hipStream_t stream) {
+  StreamCfg forced;
+  const int pick = pick_stream_cfg<MODE>(k, &forced);
+  if (pick == -1) return LD_EUNSUPPORTED;
+  if (pick == -2) {
+    const int rc = launch_stream_cfg<MODE>(k, forced, stream);
+    if (rc != LD_EUNSUPPORTED) return rc;
+    forced.ks = 1;  // no split-K instance at this ring depth
+    return launch_stream_cfg<MODE>(k, forced, stream);
   }
   return launch_stream_cfg<MODE>(k, kStreamCfgs[pick], stream);
+}
+
+// Explicit tuning (ld_conv_tune_forward / ld_conv_tune_dgrad): times every
+// candidate shape of the geometry on the caller's buffers (the launch is
+// idempotent), records the winner in the table.  This is the ONLY place that
+// synchronises; returns 0 (tuned), 1 (already in the table / nothing to tune).
+template <int MODE>
+int tune_stream(const ConvK& k, hipStream_t stream) {
+  if (k.Cin % 8 != 0) return 1;
+  const LdTuneKey key = make_tune_key(MODE, 0, k);
+  LdTuneCfg have;
+  if (ld_tune_lookup(key, &have)) return 1;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(stream, &cap);
+  if (cap != hipStreamCaptureStatusNone) return LD_EUNSUPPORTED;
+  int pick = stream_cfg_model(k);
+  if (pick < 0) return 1;
+  // quiesce the device first: work queued on other streams (the teacher's
+  // forward) would otherwise share the CUs with some candidates and not others
+  (void)hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  float best_ms = -1.0f;
+  for (int i = 0; i < kNumStreamCfgs; ++i) {
+    if (!stream_cfg_fits(k, kStreamCfgs[i])) continue;
+    if (launch_stream_cfg<MODE>(k, kStreamCfgs[i], stream) != 0) continue;
+    float ms = -1.0f;
+    for (int trial = 0; trial < 2; ++trial) {  // best of two: clocks wander
+      (void)hipEventRecord(e0, stream);
+      for (int rep = 0; rep < kTuneReps; ++rep)
+        launch_stream_cfg<MODE>(k, kStreamCfgs[i], stream);
+      (void)hipEventRecord(e1, stream);
+      if (hipEventSynchronize(e1) != hipSuccess) break;
+      float t = 0.0f;
+      (void)hipEventElapsedTime(&t, e0, e1);
+      if (ms < 0.0f || t < ms) ms = t;
+    }
+    if (ms < 0.0f) continue;
+    if (best_ms < 0.0f || ms < best_ms) {
+      best_ms = ms;
+      pick = i;
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  const StreamCfg& c = kStreamCfgs[pick];
+  if (const char* lg = getenv("LD_CONV_TUNE_LOG"))
+    if (lg[0] == '1') {
+      const double fl = 2.0 * k.J * k.Cout * k.Cin *
+                        (MODE == 1 ? k.nth * k.ntw : k.KH * k.KW);
+      fprintf(stderr,
+              "[ld_conv] mode %d Cin %d Cout %d k %dx%d s%d J %d lv %d -> "
+              "%dx%dx%dx%dx%d  %.1f TFLOP/s\n",
+              MODE, k.Cin, k.Cout, k.KH, k.KW, k.g.stride, k.J, k.g.num_levels,
+              c.tm, c.tn, c.wvm, c.d, c.ks,
+              best_ms > 0 ? fl / (best_ms * 1e-3 / kTuneReps) / 1e12 : 0.0);
+    }
+  if (best_ms > 0.0f) ld_tune_store(key, LdTuneCfg{c.tm, c.tn, c.wvm, c.d, c.ks});
+  return 0;
 }
 
 template <int MODE>
@@ -1546,6 +1408,89 @@ int launch_igemm(const ConvK& k_in, hipStream_t stream) {
 
 }  // namespace
 
+// ---- the tuning table -------------------------------------------------------
+namespace {
+struct TuneKeyHash {
+  size_t operator()(const LdTuneKey& k) const {
+    size_t h = 1469598103934665603ull;
+    for (int i = 0; i < 18; ++i) h = (h ^ (size_t)(unsigned)k.v[i]) * 1099511628211ull;
+    return h;
+  }
+};
+struct TuneKeyEq {
+  bool operator()(const LdTuneKey& a, const LdTuneKey& b) const {
+    for (int i = 0; i < 18; ++i)
+      if (a.v[i] != b.v[i]) return false;
+    return true;
+  }
+};
+std::mutex g_tune_mu;
+std::unordered_map<LdTuneKey, LdTuneCfg, TuneKeyHash, TuneKeyEq> g_tune;
+}  // namespace
+
+bool ld_tune_lookup(const LdTuneKey& key, LdTuneCfg* out) {
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  auto it = g_tune.find(key);
+  if (it == g_tune.end()) return false;
+  *out = it->second;
+  return true;
+}
+
+void ld_tune_store(const LdTuneKey& key, const LdTuneCfg& cfg) {
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  g_tune[key] = cfg;
+}
+
+// Text format: one record per line, "18 key ints  tm tn wvm d ks"; '#' starts a
+// comment line.  Returns the number of records read, or LD_EINVAL.
+extern "C" int ld_conv_tune_load(const char* path) {
+  if (!path || !*path) return LD_EINVAL;
+  FILE* f = fopen(path, "r");
+  if (!f) return LD_EINVAL;
+  int n = 0;
+  char line[1024];
+  while (fgets(line, sizeof(line), f)) {
+    if (line[0] == '#' || line[0] == '\n') continue;
+    LdTuneKey k;
+    LdTuneCfg c;
+    int pos = 0, adv = 0, got = 0;
+    for (int i = 0; i < 18; ++i)
+      if (sscanf(line + pos, "%d%n", &k.v[i], &adv) == 1) {
+        pos += adv;
+        ++got;
+      }
+    if (got == 18 &&
+        sscanf(line + pos, "%d %d %d %d %d", &c.tm, &c.tn, &c.wvm, &c.d, &c.ks) == 5) {
+      ld_tune_store(k, c);
+      ++n;
+    }
+  }
+  fclose(f);
+  return n;
+}
+
+extern "C" int ld_conv_tune_save(const char* path) {
+  if (!path || !*path) return LD_EINVAL;
+  FILE* f = fopen(path, "w");
+  if (!f) return LD_EINVAL;
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  fprintf(f, "# ld_amd conv shape table: MODE Cin Cout KH KW stride pad J levels Hin0 "
+             "Win0 ph pw relu res affine family 0 | tm tn wvm d ks\n");
+  for (const auto& kv : g_tune) {
+    for (int i = 0; i < 18; ++i) fprintf(f, "%d ", kv.first.v[i]);
+    fprintf(f, " %d %d %d %d %d\n", kv.second.tm, kv.second.tn, kv.second.wvm,
+            kv.second.d, kv.second.ks);
+  }
+  fclose(f);
+  return (int)g_tune.size();
+}
+
+extern "C" int ld_conv_tune_clear(void) {
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  g_tune.clear();
+  return 0;
+}
+
 extern "C" size_t ld_conv_weight_image_floats(int Cout, int Cin, int KH, int KW,
                                              int backward) {
   if (Cout < 1 || Cin < 1 || KH < 1 || KW < 1) return 0;
@@ -1578,12 +1523,12 @@ extern "C" int ld_conv_weight_transform_batch(const ld_wt_job_t* jobs,
   return (int)hipGetLastError();
 }
 
-extern "C" int ld_conv_forward(const ld_conv_t* c, const float* x,
-                               const float* wt_fwd, const ld_conv_epilogue_t* ep,
-                               float* y, ld_stream_t stream) {
+namespace {
+int build_forward(const ld_conv_t* c, const float* x, const float* wt_fwd,
+                  const ld_conv_epilogue_t* ep, float* y, ConvK& k) {
   if (int e = check_conv(c)) return e;
   if (!x || !wt_fwd || !y) return LD_EINVAL;
-  ConvK k{};
+  k = ConvK{};
   k.x = x;
   k.wt = wt_fwd;
   k.y = y;
@@ -1599,10 +1544,26 @@ extern "C" int ld_conv_forward(const ld_conv_t* c, const float* x,
   k.J = c->N * c->Pout;
   for (int l = 0; l < LD_MAX_LEVELS; ++l) k.g.lv[l] = c->lv[l];
   k.Kpad = kpad_rows(c->Cin);
-  if (int e = set_extents(k, (size_t)c->N * c->Cin * c->Pin,
-                          (size_t)c->KH * c->KW * k.Kpad * c->Cout))
-    return e;
+  return set_extents(k, (size_t)c->N * c->Cin * c->Pin,
+                     (size_t)c->KH * c->KW * k.Kpad * c->Cout);
+}
+}  // namespace
+
+extern "C" int ld_conv_forward(const ld_conv_t* c, const float* x,
+                               const float* wt_fwd, const ld_conv_epilogue_t* ep,
+                               float* y, ld_stream_t stream) {
+  ConvK k;
+  if (int e = build_forward(c, x, wt_fwd, ep, y, k)) return e;
   return launch_igemm<0>(k, (hipStream_t)stream);
+}
+
+extern "C" int ld_conv_tune_forward(const ld_conv_t* c, const float* x,
+                                    const float* wt_fwd,
+                                    const ld_conv_epilogue_t* ep, float* y,
+                                    ld_stream_t stream) {
+  ConvK k;
+  if (int e = build_forward(c, x, wt_fwd, ep, y, k)) return e;
+  return tune_stream<0>(k, (hipStream_t)stream);
 }
 
 // Small-Cin convolution (the 7x7 stem, Cin = 3): the reduction index is the
@@ -1640,12 +1601,14 @@ extern "C" int ld_conv_forward_smallc(const ld_conv_t* c, const float* x,
 // Stride 2: the output positions are split into their four (row, col) parity
 // classes; each class sees only the taps of matching parity (1, 2, 2 or 4 of
 // the 9 for a 3x3), so no MFMA work is spent on the dilation zeros.
-extern "C" int ld_conv_dgrad(const ld_conv_t* c, const float* dy,
-                             const float* wt_bwd, float* dx, ld_stream_t stream_) {
+namespace {
+int dgrad_walk(const ld_conv_t* c, const float* dy, const float* wt_bwd, float* dx,
+               ld_stream_t stream_, bool tune) {
   if (int e = check_conv(c)) return e;
   if (!dy || !wt_bwd || !dx) return LD_EINVAL;
   if (c->KH != c->KW) return LD_EUNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
+  bool all_known = true;
   ConvK k{};
   k.x = dy;
   k.wt = wt_bwd;
@@ -1673,7 +1636,7 @@ extern "C" int ld_conv_dgrad(const ld_conv_t* c, const float* dy,
   if (int e = set_extents(k, (size_t)c->N * c->Cout * c->Pout,
                           (size_t)c->KH * c->KW * k.Kpad * c->Cin))
     return e;
-  if (c->stride == 1) return launch_igemm<0>(k, stream);
+  if (c->stride == 1) return tune ? tune_stream<0>(k, stream) : launch_igemm<0>(k, stream);
 
   const int padp = c->KH - 1 - c->pad;
   // a class no tap reaches (1x1 stride 2: every odd row / column) is all
@@ -1683,7 +1646,7 @@ extern "C" int ld_conv_dgrad(const ld_conv_t* c, const float* dy,
     const int k0 = ((ph - padp) % 2 + 2) % 2;
     if (k0 >= c->KH) any_empty = true;
   }
-  if (any_empty) {
+  if (any_empty && !tune) {
     hipError_t err = hipMemsetAsync(
         dx, 0, (size_t)c->N * c->Cin * c->Pin * sizeof(float), stream);
     if (err) return (int)err;
@@ -1715,9 +1678,27 @@ extern "C" int ld_conv_dgrad(const ld_conv_t* c, const float* dy,
       q.Pout = pc;
       q.J = c->N * pc;
       if (q.nth * q.ntw == 0) continue;  // zero class, cleared above
-      if (int e = launch_igemm<1>(q, stream)) return e;
+      if (tune) {
+        const int e = tune_stream<1>(q, stream);
+        if (e < 0 || e > 1) return e;
+        all_known = all_known && e == 1;
+      } else if (int e = launch_igemm<1>(q, stream)) {
+        return e;
+      }
     }
-  return 0;
+  return tune && all_known ? 1 : 0;
+}
+}  // namespace
+
+extern "C" int ld_conv_dgrad(const ld_conv_t* c, const float* dy,
+                             const float* wt_bwd, float* dx, ld_stream_t stream) {
+  return dgrad_walk(c, dy, wt_bwd, dx, stream, false);
+}
+
+extern "C" int ld_conv_tune_dgrad(const ld_conv_t* c, const float* dy,
+                                  const float* wt_bwd, float* dx,
+                                  ld_stream_t stream) {
+  return dgrad_walk(c, dy, wt_bwd, dx, stream, true);
 }
 
 // which wgrad kernel: 0 = 128x128 workgroup tiles (LDS shared by 4 waves),

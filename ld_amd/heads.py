@@ -78,7 +78,13 @@ class LossDict(dict):
 
 class LazyScalars(dict):
     """dict of python floats backed by one device tensor; the single D2H copy
-    happens on first access (the reference syncs 9 times per step)."""
+    happens on first access (the reference syncs 9 times per step).
+
+    It stays a ``dict`` subclass because mmcv's LogBuffer.update asserts
+    ``isinstance(vars, dict)``; every read path -- including the ones CPython
+    serves from the raw table for plain dicts (``dict(x)``, ``{**x}``,
+    ``OrderedDict(x)``, ``copy()``) -- is routed through the sync: overriding
+    ``__iter__``/``keys`` takes ``dict_merge`` off its fast path."""
 
     def __init__(self, keys, tensor):
         super().__init__()
@@ -97,6 +103,18 @@ class LazyScalars(dict):
         self._sync()
         return dict.__getitem__(self, k)
 
+    def get(self, k, default=None):
+        self._sync()
+        return dict.get(self, k, default)
+
+    def __iter__(self):
+        self._sync()
+        return dict.__iter__(self)
+
+    def keys(self):
+        self._sync()
+        return dict.keys(self)
+
     def items(self):
         self._sync()
         return dict.items(self)
@@ -104,6 +122,35 @@ class LazyScalars(dict):
     def values(self):
         self._sync()
         return dict.values(self)
+
+    def copy(self):
+        self._sync()
+        return dict(dict.items(self))
+
+    def pop(self, *a):
+        self._sync()
+        return dict.pop(self, *a)
+
+    def setdefault(self, k, default=None):
+        self._sync()
+        return dict.setdefault(self, k, default)
+
+    def __eq__(self, other):
+        self._sync()
+        return dict.__eq__(self, other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        self._sync()
+        return dict.__repr__(self)
+
+    def __reduce__(self):
+        self._sync()
+        return (dict, (dict(dict.items(self)), ))
 
 
 @HEADS.register_module()
@@ -158,6 +205,8 @@ class GFLHead(nn.Module):
         self._init_layers()
         self.integral = Integral(self.reg_max)
         self.loss_dfl = build_loss(loss_dfl)
+        # see SGDTrainer.step: only set for the duration of a train step
+        self.unit_upstream = False
 
     def _init_layers(self):
         """gfl_head.py:102-133."""
@@ -311,7 +360,7 @@ class GFLHead(nn.Module):
                    [b.detach() for b in bbox_preds], dummy_x)
         table, _ = LB.LDLossBlock.apply(hp, targets, teacher,
                                         self._norm_reducer(),
-                                        getattr(self, 'unit_upstream', False),
+                                        self.unit_upstream,
                                         *cls_scores, *bbox_preds, *dummy_x)
         return self._loss_dict(table, ('loss_cls', 'loss_bbox', 'loss_dfl'))
 

@@ -265,6 +265,38 @@ def weight_images(w, need_bwd, smallc=False):
     return cache['fwd'], cache['bwd']
 
 
+# ---------------------------------------------------------------------------
+# explicit shape tuning (cudnn.benchmark's role, outside the launch path)
+# ---------------------------------------------------------------------------
+# The launch entry points only enqueue.  With tuning switched on
+# (``autotune(True)`` or LD_CONV_AUTOTUNE=1) the FIRST time a conv geometry is
+# seen the host calls ld_conv_tune_* once -- it times the candidate shapes on
+# the buffers of that very call (idempotent launches), synchronises, and
+# records the winner in the library's table, which ``save_tune_table`` writes
+# out.  Off by default: the shipped table covers the benchmark shapes and
+# everything else uses the library's deterministic model.
+import os  # noqa: E402
+
+_AUTOTUNE = [os.environ.get('LD_CONV_AUTOTUNE', '0') == '1']
+_TUNED = set()
+
+
+def autotune(on=True):
+    _AUTOTUNE[0] = bool(on)
+
+
+def _tune_once(kind, d, ep_flags, call):
+    if not _AUTOTUNE[0]:
+        return
+    key = (kind, bytes(d), ep_flags)
+    if key in _TUNED:
+        return
+    _TUNED.add(key)
+    rc = call()
+    if rc not in (0, 1):
+        L.check(rc, 'ld_conv_tune_' + kind)
+
+
 def _epilogue(bias=None, scale=None, shift=None, residual=None, relu=False):
     ep = L.ConvEpilogueT()
     ep.bias = bias.data_ptr() if bias is not None else None
@@ -295,6 +327,12 @@ def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
         assert residual.shape == y3.shape
     ep = _epilogue(bias, scale, shift, residual, relu)
     fn = lib.ld_conv_forward_smallc if smallc else lib.ld_conv_forward
+    if not smallc:
+        _tune_once('forward', d, (bias is not None, scale is not None,
+                                  residual is not None, bool(relu)),
+                   lambda: lib.ld_conv_tune_forward(
+                       C.byref(d), L.ptr(x3), L.ptr(wt_fwd), C.byref(ep),
+                       L.ptr(y3), L.stream_ptr(x3.device)))
     with _timed('conv_fwd', _conv_flops(d)):
         L.check(fn(C.byref(d), L.ptr(x3), L.ptr(wt_fwd), C.byref(ep),
                    L.ptr(y3), L.stream_ptr(x3.device)), 'ld_conv_forward')
@@ -364,6 +402,8 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             _, wt_bwd = weight_images(w, True)
             dx = torch.empty_like(x3)
+            _tune_once('dgrad', d, (), lambda: lib.ld_conv_tune_dgrad(
+                C.byref(d), L.ptr(dy), L.ptr(wt_bwd), L.ptr(dx), st))
             with _timed('conv_dgrad', _conv_flops(d)):
                 L.check(lib.ld_conv_dgrad(C.byref(d), L.ptr(dy),
                                           L.ptr(wt_bwd), L.ptr(dx), st),

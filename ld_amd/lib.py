@@ -109,11 +109,33 @@ def get_lib():
     _declare(lib)
     if lib.ld_abi_version() != ABI_VERSION:
         raise LdError('libldhip.so ABI version mismatch; rebuild')
+    _load_tune_tables(lib)
     _lib = lib
     return lib
 
 
-ABI_VERSION = 1
+TUNE_TABLE = os.path.join(_HERE, 'tune', 'gfx950.txt')
+
+
+def _load_tune_tables(lib):
+    """Conv tile shapes: the table shipped in-tree (picked on an MI355X), then
+    LD_CONV_TUNE_FILE on top of it.  With the same tables every process and
+    every rank launches the same shapes, so results are bit-reproducible; a
+    geometry in neither falls back to a deterministic model inside the
+    library.  Timing new geometries is explicit: ld_amd.layers.autotune()."""
+    if os.environ.get('LD_CONV_TUNE_TABLE', '1') != '0' and \
+            os.path.exists(TUNE_TABLE):
+        lib.ld_conv_tune_load(TUNE_TABLE.encode())
+    extra = os.environ.get('LD_CONV_TUNE_FILE')
+    if extra and os.path.exists(extra):
+        lib.ld_conv_tune_load(extra.encode())
+
+
+def save_tune_table(path):
+    return get_lib().ld_conv_tune_save(str(path).encode())
+
+
+ABI_VERSION = 2
 _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 _G, _H, _M = C.POINTER(GeomT), C.POINTER(LossHpT), C.POINTER(MapsT)
 _CV, _EP, _LV = C.POINTER(ConvT), C.POINTER(ConvEpilogueT), C.POINTER(LevelsT)
@@ -163,6 +185,11 @@ SIGNATURES = {
     'ld_conv_forward': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
     'ld_conv_forward_smallc': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
     'ld_conv_dgrad': (C.c_int, [_CV, _vp, _vp, _vp, _vp]),
+    'ld_conv_tune_forward': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
+    'ld_conv_tune_dgrad': (C.c_int, [_CV, _vp, _vp, _vp, _vp]),
+    'ld_conv_tune_load': (C.c_int, [C.c_char_p]),
+    'ld_conv_tune_save': (C.c_int, [C.c_char_p]),
+    'ld_conv_tune_clear': (C.c_int, []),
     'ld_conv_wgrad_workspace_bytes': (_sz, [_CV]),
     'ld_conv_wgrad': (C.c_int, [_CV, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     'ld_bn_prepare': (C.c_int, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp,

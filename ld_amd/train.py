@@ -45,10 +45,33 @@ def collectives_on():
         os.environ.get('LD_FORCE_COLLECTIVES', '0') == '1'
 
 
-class GradArena:
-    """Flat parameter / gradient arenas + bucketed all-reduce."""
+def broadcast_tensors(tensors, src=0):
+    """Rank ``src``'s values of ``tensors`` on every rank, one collective per
+    dtype (flatten -> broadcast -> scatter back).  The counterpart of the
+    parameter/buffer broadcast in MMDistributedDataParallel's constructor
+    (mmdet/apis/train.py:74-84): the reference seeds nothing by default, so
+    without it every rank would keep its own random initialisation."""
+    by_dtype = {}
+    for t in tensors:
+        if t.numel():
+            by_dtype.setdefault(t.dtype, []).append(t)
+    for dtype, ts in by_dtype.items():
+        flat = torch.cat([t.detach().reshape(-1) for t in ts])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for t in ts:
+            t.detach().copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
 
-    def __init__(self, params, bucket_bytes=32 << 20, align=64):
+
+class GradArena:
+    """Flat parameter / gradient arenas + bucketed all-reduce.
+
+    ``extra_state``: tensors outside the arena (frozen parameters, buffers)
+    that must also start from rank 0's values."""
+
+    def __init__(self, params, bucket_bytes=32 << 20, align=64,
+                 extra_state=()):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError('no trainable parameters')
@@ -71,6 +94,11 @@ class GradArena:
             p._ld_grad = p.grad
             p._ld_ready = self._on_grad
             p._ld_pending = 0
+        if collectives_on():
+            # DDP's constructor broadcast: the whole trainable arena is one
+            # message; frozen parameters and buffers go packed per dtype
+            dist.broadcast(self.flat_param, src=0)
+            broadcast_tensors(list(extra_state), src=0)
         # buckets: contiguous [start, end) ranges of the arena
         self.buckets, start, count = [], 0, 0
         cap = max(bucket_bytes // 4, 1)
@@ -142,11 +170,11 @@ class SGDTrainer:
                  bucket_bytes=32 << 20):
         self.model = model
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
-        self.arena = GradArena(list(model.parameters()), bucket_bytes)
+        frozen = [p for p in model.parameters() if not p.requires_grad]
+        self.arena = GradArena(list(model.parameters()), bucket_bytes,
+                               extra_state=frozen + list(model.buffers()))
         self.flat_momentum = torch.zeros_like(self.arena.flat_param)
-        head = getattr(model, 'bbox_head', None)
-        if head is not None and hasattr(head, 'unit_upstream'):
-            head.unit_upstream = True  # _parse_losses sums the keys
+        self.check_grads = os.environ.get('LD_CHECK_GRADS', '0') == '1'
         self.iter = 0
         self.epoch = 0
 
@@ -205,9 +233,33 @@ class SGDTrainer:
 
     def step(self, data):
         self.arena.zero_grad()
-        losses = self.model(**data)
-        loss, log_vars = self.model._parse_losses(losses)
-        loss.backward()
+        # _parse_losses sums the loss keys with unit coefficients, so the fused
+        # loss block may hand back the gradient its forward launch already
+        # produced.  The promise holds for THIS backward only: the flag is
+        # scoped to the step (any other consumer of the head's losses gets the
+        # general rerun-with-upstream path).
+        head = getattr(self.model, 'bbox_head', None)
+        scoped = head is not None and hasattr(head, 'unit_upstream')
+        if scoped:
+            head.unit_upstream = True
+        try:
+            losses = self.model(**data)
+            loss, log_vars = self.model._parse_losses(losses)
+            loss.backward()
+        finally:
+            if scoped:
+                head.unit_upstream = False
+        if self.check_grads:
+            # the single SGD launch applies weight decay / momentum to every
+            # arena parameter; torch.optim.SGD skips parameters whose grad is
+            # None.  Equal only if every trainable parameter got a gradient.
+            missing = [i for i, p in enumerate(self.arena.order)
+                       if id(p) not in self.arena._seen]
+            if missing:
+                raise RuntimeError(
+                    f'{len(missing)} trainable parameters received no '
+                    'gradient this step; the fused SGD launch would still '
+                    'decay them (torch.optim.SGD would not)')
         self.arena.finish()
         Y.sgd_step(self.arena.flat_param, self.arena.flat_grad,
                    self.flat_momentum, self.lr, self.momentum,

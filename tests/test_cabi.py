@@ -67,3 +67,23 @@ def test_job_table_struct_layout():
     assert C.sizeof(L.BnJobT) == 7 * 8 + 4 + 3 * 4 == 72
     assert L.WtJobT.first_block.offset == 36
     assert L.BnJobT.eps.offset == 56 and L.BnJobT.first_block.offset == 64
+
+
+def test_tune_table_round_trip(tmp_path):
+    """The shipped conv shape table loads at import, survives save -> clear ->
+    load, and the launch entry points never consult the clock: choosing a
+    shape is table lookup or a pure function of the geometry (host logic,
+    callable without a GPU)."""
+    from ld_amd import lib as L
+    lib = L.get_lib()
+    assert os.path.exists(L.TUNE_TABLE)
+    records = [l for l in open(L.TUNE_TABLE) if l.strip() and l[0] != '#']
+    assert all(len(l.split()) == 23 for l in records)
+    f = str(tmp_path / 'table.txt').encode()
+    n = lib.ld_conv_tune_save(f)
+    assert n >= len(records) > 50
+    assert lib.ld_conv_tune_clear() == 0
+    assert lib.ld_conv_tune_save(str(tmp_path / 'empty.txt').encode()) == 0
+    assert lib.ld_conv_tune_load(f) == n
+    assert lib.ld_conv_tune_load(b'/nonexistent/table') == -1
+    assert lib.ld_conv_tune_load(None) == -1

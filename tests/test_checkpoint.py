@@ -199,9 +199,24 @@ def test_teacher_checkpoint_call_site(tmp_path, monkeypatch):
     assert not any(k.startswith('teacher') for k in det.state_dict())
     n_student = sum(1 for _ in det.parameters())
     assert n_student == sum(1 for _ in t_src.parameters())
+    # a missing teacher checkpoint raises, as mmcv's load_checkpoint does
+    # (a random teacher would distil finite, meaningless losses) ...
     cfg = model_zoo.ld_detector(18, 18)
+    cfg['teacher_ckpt'] = str(tmp_path / 'nope.pth')
+    monkeypatch.delenv('LD_ALLOW_MISSING_CKPT', raising=False)
+    with pytest.raises(FileNotFoundError):
+        build_detector(cfg)
+    cfg['pretrained'] = 'torchvision://resnet18'
+    cfg['teacher_ckpt'] = None
+    monkeypatch.setenv('TORCH_HOME', str(tmp_path / 'empty_hub'))
+    monkeypatch.delenv('LD_CHECKPOINT_DIR', raising=False)
+    with pytest.raises(FileNotFoundError):
+        build_detector(cfg)
+    # ... unless the caller opts in (synthetic-throughput runs)
+    monkeypatch.setenv('LD_ALLOW_MISSING_CKPT', '1')
     cfg['teacher_ckpt'] = str(tmp_path / 'nope.pth')
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
         build_detector(cfg)
     assert any('teacher_ckpt not loaded' in str(x.message) for x in w)
+    assert any('backbone randomly' in str(x.message) for x in w)

@@ -2,8 +2,11 @@
  (i) GradArena's bucketed hook-driven all-reduce produces the gradients a
      single process gets on the concatenated batch,
  (ii) the loss normalisers are averaged across ranks the way the reference's
-     reduce_mean does (ld_head.py:338-341,362-365), and
- (iii) _parse_losses' single packed all-reduce equals per-key means."""
+     reduce_mean does (ld_head.py:338-341,362-365),
+ (iii) _parse_losses' single packed all-reduce equals per-key means, and
+ (iv) ranks that were initialised with DIFFERENT seeds hold rank 0's
+     parameters, frozen parameters and buffers after GradArena's constructor
+     (the broadcast MMDistributedDataParallel does, apis/train.py:74-84)."""
 import os
 import socket
 
@@ -67,6 +70,28 @@ def _worker(rank, world, port, ret):
         assert float(loss) == (3.0 + rank) + (rank + 2.0)
         assert abs(lv['loss_a'] - 3.5) < 1e-6 and abs(lv['loss_b'] - 2.5) < 1e-6
         assert abs(lv['acc'] - 5.0) < 1e-6 and abs(lv['loss'] - 6.0) < 1e-6
+        # (iv) different per-rank initialisation -> rank 0's state everywhere
+        torch.manual_seed(100 + rank)
+        m2 = torch.nn.Sequential(torch.nn.Linear(6, 5),
+                                 torch.nn.BatchNorm1d(5),
+                                 torch.nn.Linear(5, 3))
+        m2[1].running_mean.normal_()
+        m2[1].num_batches_tracked.fill_(7 + rank)
+        m2[2].weight.requires_grad_(False)  # a frozen parameter
+        frozen = [p for p in m2.parameters() if not p.requires_grad]
+        arena2 = GradArena(list(m2.parameters()),
+                           extra_state=frozen + list(m2.buffers()))
+        state = torch.cat([arena2.flat_param, m2[2].weight.reshape(-1),
+                           m2[1].running_mean,
+                           m2[1].num_batches_tracked.reshape(1).float()])
+        got = [torch.empty_like(state) for _ in range(world)]
+        dist.all_gather(got, state)
+        assert all(torch.equal(g, got[0]) for g in got)
+        torch.manual_seed(100)  # what rank 0 drew
+        ref2 = torch.nn.Linear(6, 5)
+        assert torch.equal(m2[0].weight, ref2.weight)
+        assert int(m2[1].num_batches_tracked) == 7
+        assert m2[0].weight.data_ptr() >= arena2.flat_param.data_ptr()
         ret[rank] = 'ok'
     finally:
         dist.destroy_process_group()
