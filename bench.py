@@ -36,6 +36,7 @@ import torch.distributed as dist  # noqa: E402
 METRIC = 'images/sec (1333x800) GFocal-R50<-R101 LD train step'
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 
 
 def parse():
@@ -48,6 +49,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-roofline', action='store_true')
     ap.add_argument('--profile-steps', type=int, default=2)
+    ap.add_argument('--no-bf16', action='store_true',
+                    help='skip the bf16 (BASELINE config 3) leg')
     return ap.parse_args()
 
 
@@ -60,7 +63,7 @@ def make_batch(bs, num_gt, seed, dev):
     return b, d
 
 
-def kernel_roofline(trainer, dbatch, steps):
+def kernel_roofline(trainer, dbatch, steps, bf16=False):
     """Instrumented pass: HIP events around every conv launch, teacher on the
     main stream so durations do not overlap."""
     from ld_amd import layers as Y
@@ -74,65 +77,132 @@ def kernel_roofline(trainer, dbatch, steps):
             trainer.step(dbatch)
     agg = prof.summary()
     model.use_teacher_stream = prev
-    tot_t = sum(v[0] for v in agg.values())
-    tot_f = sum(v[1] for v in agg.values())
-    tot_n = sum(v[2] for v in agg.values())
+    by_kind = {k: dict(ms_per_step=v[0] / steps * 1e3,
+                       tflops=v[1] / v[0] / 1e12 if v[0] else 0.0,
+                       launches=v[2] / steps) for k, v in agg.items()}
+    if bf16:
+        main = {k: v for k, v in agg.items() if k.endswith('_bf16')}
+        rest = {k: v for k, v in agg.items() if not k.endswith('_bf16')}
+        peak = PEAK_BF16_MFMA_TFLOPS
+        kernel = ('conv (bf16 MFMA 32x32x16, fp32 accumulate: streaming '
+                  'fwd/dgrad + wave-private wgrad, conv_bf16.hip)')
+    else:
+        main, rest, peak = agg, {}, PEAK_FP32_MFMA_TFLOPS
+        kernel = ('conv (fp32 MFMA 32x32x2 implicit GEMM: streaming fwd/dgrad '
+                  '+ wave-private wgrad)')
+    tot_t = sum(v[0] for v in main.values())
+    tot_f = sum(v[1] for v in main.values())
+    tot_n = sum(v[2] for v in main.values())
     ach = tot_f / tot_t / 1e12 if tot_t > 0 else 0.0
-    return dict(
-        kernel='conv (fp32 MFMA 32x32x2 implicit GEMM: streaming fwd/dgrad + wave-private wgrad)',
-        bound='mfma', achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS,
-        unit='TFLOP/s', frac=ach / PEAK_FP32_MFMA_TFLOPS,
-        # PMC passes on the largest launch of the step (head-tower forward,
-        # 52.8 GFLOP, 48.3 MB in + 45.9 MB out algorithmic): raw FETCH_SIZE
-        # 196.5 MB (L2 fabric side, Infinity-Cache hits included: each of the 8
-        # XCD L2s pulls the image) + WRITE_SIZE 45.9 MB
-        traffic=242.4e6,
-        traffic_source='profiles/r01_pmc_stream (separate --pmc passes, '
-                       'head-tower forward launch, bytes per launch)',
+    out = dict(
+        kernel=kernel, bound='mfma', achieved=ach, peak=peak,
+        unit='TFLOP/s', frac=ach / peak,
+        traffic=None,
+        traffic_note='not measured inside bench.py; PMC passes of the conv '
+                     'kernels are under profiles/ (rocprofv3 --pmc, separate '
+                     'runs)',
         launches_per_step=tot_n / steps,
         avg_launch_us=tot_t / max(tot_n, 1) * 1e6,
         conv_ms_per_step=tot_t / steps * 1e3,
         gflop_per_step=tot_f / steps / 1e9,
-        by_kind={k: dict(ms_per_step=v[0] / steps * 1e3,
-                         tflops=v[1] / v[0] / 1e12 if v[0] else 0.0,
-                         launches=v[2] / steps) for k, v in agg.items()})
+        by_kind=by_kind)
+    if rest:
+        out['fp32_fallback_conv_ms_per_step'] = \
+            sum(v[0] for v in rest.values()) / steps * 1e3
+    return out
 
 
-def ldkl_roofline(dev):
+def _reg_dense_launcher(dev, sizes, strides, n_img, density, seed=0):
+    """A callable that enqueues the train step's reg-side dense kernel
+    (loss_reg_dense_kernel through ld_loss_main_parts(LD_LOSS_PART_REG)) on
+    synthetic maps of the given pyramid; ``density`` = fraction of anchors in
+    the valuable-localisation region (weight > 0), no positives."""
+    import ctypes as C
+    from ld_amd import lib as L
     from ld_amd import lossblock as LB
-    rows = 1 << 22  # anchors -> 2^24 anchor-side rows
-    s = torch.randn(68, rows, device=dev) * 3
-    t = torch.randn(68, rows, device=dev) * 3
-    w = torch.rand(rows, device=dev)
-    for _ in range(3):
-        LB.kl_integral_dense(s, t, w, 10.0, 1.0, True)
+    lib = L.get_lib()
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    geom = L.make_geom(sizes, strides, n_img)
+    A = geom.num_anchors
+    s_reg = [torch.randn(n_img, 68, h, w, device=dev) * 3 for h, w in sizes]
+    t_reg = [torch.randn(n_img, 68, h, w, device=dev) * 3 for h, w in sizes]
+    g_reg = [torch.empty_like(t) for t in s_reg]
+    labels = torch.full((n_img, A), 80, dtype=torch.int64, device=dev)
+    lw = torch.ones((n_img, A), device=dev)
+    bt = torch.zeros((n_img, A, 4), device=dev)
+    vlr = torch.rand((n_img, A), device=dev) + 1e-3
+    if density < 1.0:
+        vlr = vlr * (torch.rand((n_img, A), device=dev) < density)
+    zeros = torch.zeros((n_img, A), device=dev)
+    counts = torch.zeros(n_img + 2 * len(sizes) + 1, dtype=torch.int32,
+                         device=dev)
+    norm = torch.ones(4, device=dev)
+    hp = LB.make_hp()
+    ws = LB.workspace(dev, lib.ld_loss_workspace_bytes(C.byref(geom)),
+                      'bench_loss')
+    m_s, m_t, m_g = L.make_maps(s_reg), L.make_maps(t_reg), L.make_maps(g_reg)
+    st = L.stream_ptr(dev)
+    keep = (s_reg, t_reg, g_reg, labels, lw, bt, vlr, zeros, counts, norm, ws)
+
+    def launch():
+        L.check(lib.ld_loss_main_parts(
+            C.byref(geom), C.byref(hp), C.byref(m_s), C.byref(m_s),
+            C.byref(m_t), C.byref(m_t), C.byref(m_s), C.byref(m_t),
+            L.ptr(labels), L.ptr(lw), L.ptr(bt), L.ptr(vlr), L.ptr(zeros),
+            L.ptr(counts), L.ptr(zeros), L.ptr(zeros), L.ptr(norm), None,
+            C.byref(m_g), C.byref(m_g), C.byref(m_g), L.ptr(ws), ws.numel(),
+            2, st), 'ld_loss_main_parts')
+
+    launch.keep = keep
+    return launch, n_img * A * 4
+
+
+def _median_launch_us(launch, warm, iters):
+    for _ in range(warm):
+        launch()
     torch.cuda.synchronize()
-    iters = 11
     evs = [(torch.cuda.Event(enable_timing=True),
             torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for a, b in evs:
         a.record()
-        LB.kl_integral_dense(s, t, w, 10.0, 1.0, True)
+        launch()
         b.record()
     torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) * 1e-3 for a, b in evs)
-    dt = ts[len(ts) // 2]  # median launch duration
-    # algorithmic bytes per anchor-side row: 136 logits in + 4 weight + 4
-    # integral out + 4 loss out + 68 grad out = 216 B
-    nbytes = rows * 4 * 216.0
-    ach = nbytes / dt / 1e9
-    return dict(kernel='kl_integral_dense (fused LD-KL + Integral fwd+grad)',
+    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+    return ts[len(ts) // 2], ts[0]
+
+
+def ldkl_roofline(dev):
+    """North-star kernel = the reg-side dense kernel THE TRAIN STEP LAUNCHES
+    (fused LD-KL + VLR-LD + Integral chain, forward + gradient), timed with HIP
+    events at a saturating size (2^24 anchor-side rows, every anchor in the
+    VLR region) against the HBM roofline, and at the C2 step size (launch
+    bound: absolute microseconds only).  Algorithmic bytes per anchor-side row:
+    136 (17 student + 17 teacher logits) + 68 (gradient) + 3 (label int64 +
+    VLR weight per anchor, / 4 sides) = 207."""
+    bytes_per_row = 207.0
+    launch, rows = _reg_dense_launcher(dev, [(2048, 2048)], [8], 1, 1.0)
+    us, us_min = _median_launch_us(launch, 10, 31)
+    ach = rows * bytes_per_row / (us * 1e-6) / 1e9
+    sparse, _ = _reg_dense_launcher(dev, [(2048, 2048)], [8], 1, 0.09, seed=1)
+    us_sparse, _ = _median_launch_us(sparse, 5, 15)
+    del launch, sparse
+    c2, rows_c2 = _reg_dense_launcher(
+        dev, [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)],
+        [8, 16, 32, 64, 128], 2, 0.09, seed=2)
+    us_c2, _ = _median_launch_us(c2, 10, 51)
+    return dict(kernel='loss_reg_dense_kernel (the train step\'s fused LD-KL + '
+                       'VLR-LD + Integral chain, fwd+grad) via '
+                       'ld_loss_main_parts(LD_LOSS_PART_REG)',
                 bound='hbm', achieved=ach, peak=PEAK_HBM_GBPS, unit='GB/s',
                 frac=ach / PEAK_HBM_GBPS,
-                # PMC pass (profiles/r01_pmc_traffic/kl_*.csv): WRITE_SIZE
-                # 1 245 184 KB + 2 x FETCH_SIZE 1 122 379 KB (gfx950 FETCH_SIZE
-                # counts half the bytes of a coalesced stream,
-                # MI355X_MICROARCH.md "HBM") = 3.57 GB per launch vs 3.62 GB
-                # algorithmic: no wasted re-reads
-                traffic=(1245184 + 2 * 1122379) * 1024.0,
-                traffic_source='profiles/r01_pmc_traffic (separate --pmc '
-                               'passes, same kernel and size)',
-                rows=rows * 4, bytes_per_row=216, us=dt * 1e6)
+                traffic=None,
+                traffic_note='not measured inside bench.py (PMC needs rocprofv3 '
+                             'around the process): see profiles/ for the '
+                             'FETCH_SIZE / WRITE_SIZE passes of this kernel',
+                rows=rows, bytes_per_row=bytes_per_row, us=us, us_min=us_min,
+                us_vlr_density_0p09=us_sparse,
+                c2_rows=rows_c2, c2_us=us_c2)
 
 
 def cpu_baseline(batch, sdepth=50, tdepth=101):
@@ -188,30 +258,34 @@ def main():
     cpu_batch, dbatch = make_batch(args.batch_per_gpu, args.num_gt,
                                    1234 + rank, dev)
 
-    # one priming step outside the W warm-up steps: the conv library times its
-    # register-tile candidates on the first launch of every layer geometry
-    # (cudnn.benchmark-style, ld_amd/csrc/conv.hip) -- a one-off per process,
-    # like compilation, that must not fall into the timed region when W = 0
-    out = trainer.step(dbatch)
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
+    def timed(n_warm, n_steps):
+        # one priming step outside the W warm-up steps: first-call work of a
+        # process (weight images, workspaces, allocator growth) must not fall
+        # into the timed region when W = 0.  Conv shapes come from the shipped
+        # table (ld_amd/tune/gfx950.txt), identical on every rank; nothing is
+        # timed or synchronised inside the launches.
         out = trainer.step(dbatch)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = trainer.step(dbatch)
-    t_enq = time.perf_counter() - t0  # host time to enqueue K steps
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt)
-    loss_val = float(out['log_vars']['loss'])
+        torch.cuda.synchronize()
+        for _ in range(n_warm):
+            out = trainer.step(dbatch)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            out = trainer.step(dbatch)
+        t_enq = time.perf_counter() - t0  # host time to enqueue K steps
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt)
+        return dt, t_enq, float(out['log_vars']['loss'])
+
+    dt, t_enq, loss_val = timed(args.warmup, args.steps)
 
     res = None
     if rank == 0:
@@ -250,6 +324,32 @@ def main():
         res['roofline']['step_tflops_analytic'] = \
             1835.7e9 * args.batch_per_gpu / (res['ms_per_step'] * 1e-3) / 1e12
         res['roofline_ldkl'] = ldkl_roofline(dev)
+    # ---- bf16 leg (BASELINE config 3's arithmetic on this rank count): the
+    # same step with bf16 matrix operands.  The headline `value` above stays
+    # the fp32 config; this is reported beside it.
+    if not args.no_bf16:
+        from ld_amd import layers as Y
+        Y.set_precision('bf16')
+        dtb, tenqb, lossb = timed(args.warmup, args.steps)
+        roofb = None
+        if not args.no_kernel_roofline:
+            roofb = kernel_roofline(trainer, dbatch, args.profile_steps,
+                                    bf16=True)
+        Y.set_precision('fp32')
+        if rank == 0:
+            res['bf16'] = {
+                'workload': 'same step, conv matrix operands in bf16 '
+                            '(v_mfma_f32_32x32x16_bf16, fp32 accumulate; fp32 '
+                            'master weights, activations, norms, loss block)',
+                'value': args.batch_per_gpu * world * args.steps / dtb,
+                'unit': 'images/sec', 'ms_per_step': dtb / args.steps * 1e3,
+                'host_enqueue_ms_per_step': tenqb / args.steps * 1e3,
+                'last_loss': lossb, 'dtype': 'bf16 operands / f32 accumulate',
+            }
+            if roofb is not None:
+                roofb['step_tflops_analytic'] = \
+                    1835.7e9 * args.batch_per_gpu / (dtb / args.steps) / 1e12
+                res['roofline_bf16'] = roofb
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

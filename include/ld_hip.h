@@ -180,6 +180,30 @@ int ld_loss_main(const ld_geom_t* geom, const ld_loss_hp_t* hp,
                  const ld_maps_t* grad_x, void* workspace,
                  size_t workspace_bytes, ld_stream_t stream);
 
+/* The same with a launch mask: ld_loss_main runs four dense launches --
+ * POS (the positive anchors: GIoU + class-softmax statistics), REG (thread =
+ * anchor x side: LD-KL + VLR-LD + DFL + the GIoU chain through Integral,
+ * forward and gradient -- the north-star fused LD-KL + Integral sweep), CLS
+ * (anchor x 16 classes: QFL + KD), IM (anchor x 32 channels: masked MSE).
+ * `parts` selects which of them run (benchmarking one kernel of the step at a
+ * saturating size; REG/CLS read what POS wrote for the positive anchors). */
+#define LD_LOSS_PART_POS 1
+#define LD_LOSS_PART_REG 2
+#define LD_LOSS_PART_CLS 4
+#define LD_LOSS_PART_IM 8
+#define LD_LOSS_PART_ALL 15
+int ld_loss_main_parts(const ld_geom_t* geom, const ld_loss_hp_t* hp,
+                       const ld_maps_t* cls, const ld_maps_t* reg,
+                       const ld_maps_t* t_cls, const ld_maps_t* t_reg,
+                       const ld_maps_t* x, const ld_maps_t* t_x,
+                       const int64_t* labels, const float* label_weights,
+                       const float* bbox_targets, const float* vlr, const float* im,
+                       const int32_t* counts, const float* weight_targets,
+                       const float* score, const float* norm, const float* upstream,
+                       const ld_maps_t* grad_cls, const ld_maps_t* grad_reg,
+                       const ld_maps_t* grad_x, void* workspace,
+                       size_t workspace_bytes, int parts, ld_stream_t stream);
+
 /* losses: device float[8 * num_levels], key-major (loss_cls[0..L), ...). */
 int ld_loss_finalize(const ld_geom_t* geom, const ld_loss_hp_t* hp,
                      const int32_t* counts, const float* norm,
@@ -322,6 +346,41 @@ size_t ld_conv_wgrad_workspace_bytes(const ld_conv_t* c);
 int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy, float* dw,
                   int accumulate, void* workspace, size_t workspace_bytes,
                   ld_stream_t stream);
+
+/* ---- convolution, bf16 matrix operands (BASELINE.json config 3) -----------
+ * The same three GEMMs on v_mfma_f32_32x32x16_bf16 (16x the f32-MFMA rate).
+ * Counterpart of the reference's mixed-precision mode for these layers (mmcv
+ * auto_fp16 around ResNet / FPN / GFLHead forward; the reg output is cast back
+ * by .float(), gfl_head.py:181-183; the loss block is @force_fp32,
+ * ld_head.py:284).  Contract: x / dy / y / dx / dw, the epilogue operands and
+ * the accumulators are fp32 exactly as in the fp32 entry points; only the two
+ * MFMA operands are rounded to bf16 (round-to-nearest-even) on the way in.
+ * Weight images: wt_fwd bf16 [tap][Cin16/8][Cout][8], wt_bwd bf16
+ * [KH*KW-1-tap][Cout16/8][Cin][8] (C16 = channels rounded up to 16, zero
+ * filled), sizes in bf16 ELEMENTS from ld_conv_bf16_weight_image_elems.
+ * forward needs Cin % 16 == 0, dgrad Cout % 16 == 0 (LD_EUNSUPPORTED otherwise:
+ * use the fp32 entry point); wgrad takes any channel counts and the workspace of
+ * ld_conv_wgrad_workspace_bytes.  ld_conv_bf16_tune_* = ld_conv_tune_* for the
+ * bf16 kernel family (same table, family field 1). */
+size_t ld_conv_bf16_weight_image_elems(int Cout, int Cin, int KH, int KW,
+                                       int backward);
+int ld_conv_bf16_weight_transform(const float* w, int Cout, int Cin, int KH, int KW,
+                                  void* wt_fwd, void* wt_bwd, ld_stream_t stream);
+int ld_conv_bf16_weight_transform_batch(const ld_wt_job_t* jobs,
+                                        const int32_t* block_job, int nblocks,
+                                        ld_stream_t stream);
+int ld_conv_bf16_forward(const ld_conv_t* c, const float* x, const void* wt_fwd,
+                         const ld_conv_epilogue_t* ep, float* y, ld_stream_t stream);
+int ld_conv_bf16_tune_forward(const ld_conv_t* c, const float* x, const void* wt_fwd,
+                              const ld_conv_epilogue_t* ep, float* y,
+                              ld_stream_t stream);
+int ld_conv_bf16_dgrad(const ld_conv_t* c, const float* dy, const void* wt_bwd,
+                       float* dx, ld_stream_t stream);
+int ld_conv_bf16_tune_dgrad(const ld_conv_t* c, const float* dy, const void* wt_bwd,
+                            float* dx, ld_stream_t stream);
+int ld_conv_bf16_wgrad(const ld_conv_t* c, const float* x, const float* dy, float* dw,
+                       int accumulate, void* workspace, size_t workspace_bytes,
+                       ld_stream_t stream);
 
 /* Small-Cin variant (the 7x7 stride-2 stem, resnet.py:558-570): flat
  * (ci,kh,kw) reduction; wt = [pad32(Cin*KH*KW)][Cout] image obtained with

@@ -686,17 +686,6 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_kernel(ConvK a) {
 }
 
 // ------------------------------------------------------------------ wgrad --
-struct WgradK {
-  const float* x;    // (N, Cin, Pin)
-  const float* dy;   // (N, Cout, Pout)
-  float* slabs;      // [split][tap][Cout][Cin]
-  int N, Cin, Cout, KH, KW;
-  int Pin, Pout;
-  int J, splits, jchunk;  // jchunk: columns per split (multiple of WBK)
-  unsigned x_bytes, dy_bytes;
-  Geo g;
-};
-
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(WgradK a) {
   constexpr int BM = 128, BNc = 128;  // co x ci tile
   constexpr int ROWS_PER = BM / 8;    // rows per thread (8 row-groups of 32 lanes)
@@ -1524,13 +1513,13 @@ extern "C" int ld_conv_weight_transform_batch(const ld_wt_job_t* jobs,
 }
 
 namespace {
-int build_forward(const ld_conv_t* c, const float* x, const float* wt_fwd,
-                  const ld_conv_epilogue_t* ep, float* y, ConvK& k) {
+int build_forward(const ld_conv_t* c, const float* x, const void* wt_fwd,
+                  const ld_conv_epilogue_t* ep, float* y, ConvK& k, int family = 0) {
   if (int e = check_conv(c)) return e;
   if (!x || !wt_fwd || !y) return LD_EINVAL;
   k = ConvK{};
   k.x = x;
-  k.wt = wt_fwd;
+  k.wt = (const float*)wt_fwd;
   k.y = y;
   k.bias = ep ? ep->bias : nullptr;
   k.scale = ep ? ep->scale : nullptr;
@@ -1543,11 +1532,38 @@ int build_forward(const ld_conv_t* c, const float* x, const float* wt_fwd,
   k.g.num_levels = c->num_levels;
   k.J = c->N * c->Pout;
   for (int l = 0; l < LD_MAX_LEVELS; ++l) k.g.lv[l] = c->lv[l];
+  if (family == 1) {
+    // bf16 image: [tap][Cin16 / 8][Cout][8] bf16 = 4 floats per (8-block, co)
+    k.Kpad = (c->Cin + 15) / 16 * 2;
+    return set_extents(k, (size_t)c->N * c->Cin * c->Pin,
+                       (size_t)c->KH * c->KW * k.Kpad * c->Cout * 4);
+  }
   k.Kpad = kpad_rows(c->Cin);
   return set_extents(k, (size_t)c->N * c->Cin * c->Pin,
                      (size_t)c->KH * c->KW * k.Kpad * c->Cout);
 }
 }  // namespace
+
+// bf16-MFMA forward (conv_bf16.hip): x, epilogue operands and y are fp32 exactly
+// as in ld_conv_forward; wt_fwd is the bf16 image of
+// ld_conv_bf16_weight_transform.  Cin must be a multiple of 16
+// (LD_EUNSUPPORTED otherwise: use ld_conv_forward).
+extern "C" int ld_conv_bf16_forward(const ld_conv_t* c, const float* x,
+                                    const void* wt_fwd, const ld_conv_epilogue_t* ep,
+                                    float* y, ld_stream_t stream) {
+  ConvK k;
+  if (int e = build_forward(c, x, wt_fwd, ep, y, k, 1)) return e;
+  return ld_bf16_stream_launch(0, k, (hipStream_t)stream);
+}
+
+extern "C" int ld_conv_bf16_tune_forward(const ld_conv_t* c, const float* x,
+                                         const void* wt_fwd,
+                                         const ld_conv_epilogue_t* ep, float* y,
+                                         ld_stream_t stream) {
+  ConvK k;
+  if (int e = build_forward(c, x, wt_fwd, ep, y, k, 1)) return e;
+  return ld_bf16_stream_tune(0, k, (hipStream_t)stream);
+}
 
 extern "C" int ld_conv_forward(const ld_conv_t* c, const float* x,
                                const float* wt_fwd, const ld_conv_epilogue_t* ep,
@@ -1602,8 +1618,8 @@ extern "C" int ld_conv_forward_smallc(const ld_conv_t* c, const float* x,
 // classes; each class sees only the taps of matching parity (1, 2, 2 or 4 of
 // the 9 for a 3x3), so no MFMA work is spent on the dilation zeros.
 namespace {
-int dgrad_walk(const ld_conv_t* c, const float* dy, const float* wt_bwd, float* dx,
-               ld_stream_t stream_, bool tune) {
+int dgrad_walk(const ld_conv_t* c, const float* dy, const void* wt_bwd, float* dx,
+               ld_stream_t stream_, bool tune, int family = 0) {
   if (int e = check_conv(c)) return e;
   if (!dy || !wt_bwd || !dx) return LD_EINVAL;
   if (c->KH != c->KW) return LD_EUNSUPPORTED;
@@ -1611,7 +1627,7 @@ int dgrad_walk(const ld_conv_t* c, const float* dy, const float* wt_bwd, float* 
   bool all_known = true;
   ConvK k{};
   k.x = dy;
-  k.wt = wt_bwd;
+  k.wt = (const float*)wt_bwd;
   k.y = dx;
   k.bias = k.scale = k.shift = k.residual = nullptr;
   k.relu = 0;
@@ -1632,11 +1648,19 @@ int dgrad_walk(const ld_conv_t* c, const float* dy, const float* wt_bwd, float* 
     k.fW[l] = c->lv[l].Win;
     k.foff[l] = c->lv[l].off_in;
   }
-  k.Kpad = kpad_rows(c->Cout);
+  k.Kpad = family == 1 ? (c->Cout + 15) / 16 * 2 : kpad_rows(c->Cout);
   if (int e = set_extents(k, (size_t)c->N * c->Cout * c->Pout,
-                          (size_t)c->KH * c->KW * k.Kpad * c->Cin))
+                          (size_t)c->KH * c->KW * k.Kpad * c->Cin * (family == 1 ? 4 : 1)))
     return e;
-  if (c->stride == 1) return tune ? tune_stream<0>(k, stream) : launch_igemm<0>(k, stream);
+  if (family == 1 && c->Cout % 16 != 0) return LD_EUNSUPPORTED;
+  auto run = [&](int mode, const ConvK& q) -> int {
+    if (family == 1)
+      return tune ? ld_bf16_stream_tune(mode, q, stream)
+                  : ld_bf16_stream_launch(mode, q, stream);
+    if (mode == 1) return tune ? tune_stream<1>(q, stream) : launch_igemm<1>(q, stream);
+    return tune ? tune_stream<0>(q, stream) : launch_igemm<0>(q, stream);
+  };
+  if (c->stride == 1) return run(0, k);
 
   const int padp = c->KH - 1 - c->pad;
   // a class no tap reaches (1x1 stride 2: every odd row / column) is all
@@ -1678,11 +1702,11 @@ int dgrad_walk(const ld_conv_t* c, const float* dy, const float* wt_bwd, float* 
       q.Pout = pc;
       q.J = c->N * pc;
       if (q.nth * q.ntw == 0) continue;  // zero class, cleared above
+      const int e = run(1, q);
       if (tune) {
-        const int e = tune_stream<1>(q, stream);
         if (e < 0 || e > 1) return e;
         all_known = all_known && e == 1;
-      } else if (int e = launch_igemm<1>(q, stream)) {
+      } else if (e) {
         return e;
       }
     }
@@ -1699,6 +1723,18 @@ extern "C" int ld_conv_tune_dgrad(const ld_conv_t* c, const float* dy,
                                   const float* wt_bwd, float* dx,
                                   ld_stream_t stream) {
   return dgrad_walk(c, dy, wt_bwd, dx, stream, true);
+}
+
+// bf16-MFMA data gradient: Cout must be a multiple of 16 (it is the reduction).
+extern "C" int ld_conv_bf16_dgrad(const ld_conv_t* c, const float* dy,
+                                  const void* wt_bwd, float* dx, ld_stream_t stream) {
+  return dgrad_walk(c, dy, wt_bwd, dx, stream, false, 1);
+}
+
+extern "C" int ld_conv_bf16_tune_dgrad(const ld_conv_t* c, const float* dy,
+                                       const void* wt_bwd, float* dx,
+                                       ld_stream_t stream) {
+  return dgrad_walk(c, dy, wt_bwd, dx, stream, true, 1);
 }
 
 // which wgrad kernel: 0 = 128x128 workgroup tiles (LDS shared by 4 waves),
@@ -1763,9 +1799,10 @@ extern "C" size_t ld_conv_wgrad_workspace_bytes(const ld_conv_t* c) {
   return (size_t)wgrad_splits(c) * c->KH * c->KW * c->Cout * c->Cin * sizeof(float);
 }
 
-extern "C" int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy,
-                             float* dw, int accumulate, void* workspace,
-                             size_t workspace_bytes, ld_stream_t stream_) {
+namespace {
+int wgrad_run(const ld_conv_t* c, const float* x, const float* dy, float* dw,
+              int accumulate, void* workspace, size_t workspace_bytes,
+              ld_stream_t stream_, int family) {
   if (int e = check_conv(c)) return e;
   if (!x || !dy || !dw) return LD_EINVAL;
   if (!workspace || workspace_bytes < ld_conv_wgrad_workspace_bytes(c))
@@ -1779,7 +1816,7 @@ extern "C" int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy
   k.J = c->N * c->Pout;
   k.splits = wgrad_splits(c);
   const int wmode = wgrad_mode();
-  const int wbk = wmode ? wmode : WBK;
+  const int wbk = family == 1 ? 32 : (wmode ? wmode : WBK);
   int jchunk = (k.J + k.splits - 1) / k.splits;
   jchunk = (jchunk + wbk - 1) / wbk * wbk;
   k.jchunk = jchunk;
@@ -1792,7 +1829,9 @@ extern "C" int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy
     k.dy_bytes = (unsigned)(yf * 4);
   }
   const int ntaps = c->KH * c->KW;
-  if (wmode) {
+  if (family == 1) {
+    if (int e = ld_bf16_wgrad_launch(k, stream)) return e;
+  } else if (wmode) {
     const int blocks = ((c->Cout + 63) / 64) * ((c->Cin + 63) / 64) * ntaps * k.splits;
     if (wmode == 32)
       hipLaunchKernelGGL(conv_wgrad_wave_kernel<32>, dim3(blocks), dim3(64), 0,
@@ -1805,9 +1844,31 @@ extern "C" int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy
         ((c->Cout + 127) / 128) * ((c->Cin + 127) / 128) * ntaps * k.splits;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(blocks), dim3(kThreads), 0, stream, k);
   }
-  const size_t per = (size_t)ntaps * c->Cout * c->Cin;
+  return ld_wgrad_reduce_launch(k.slabs, k.splits, ntaps, c->Cout, c->Cin, dw,
+                                accumulate, stream);
+}
+}  // namespace
+
+int ld_wgrad_reduce_launch(const float* slabs, int splits, int ntaps, int Cout, int Cin,
+                           float* dw, int accumulate, hipStream_t stream) {
+  const size_t per = (size_t)ntaps * Cout * Cin;
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)),
-                     dim3(256), 0, stream, k.slabs, k.splits, ntaps, c->Cout, c->Cin,
-                     dw, accumulate);
+                     dim3(256), 0, stream, slabs, splits, ntaps, Cout, Cin, dw,
+                     accumulate);
   return (int)hipGetLastError();
+}
+
+extern "C" int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy,
+                             float* dw, int accumulate, void* workspace,
+                             size_t workspace_bytes, ld_stream_t stream) {
+  return wgrad_run(c, x, dy, dw, accumulate, workspace, workspace_bytes, stream, 0);
+}
+
+// bf16-MFMA weight gradient: fp32 x / dy / dw, operands rounded to bf16 on the
+// way into the matrix core, fp32 slabs summed in fixed order.  Same workspace
+// as ld_conv_wgrad.
+extern "C" int ld_conv_bf16_wgrad(const ld_conv_t* c, const float* x, const float* dy,
+                                  float* dw, int accumulate, void* workspace,
+                                  size_t workspace_bytes, ld_stream_t stream) {
+  return wgrad_run(c, x, dy, dw, accumulate, workspace, workspace_bytes, stream, 1);
 }

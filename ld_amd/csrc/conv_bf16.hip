@@ -1,0 +1,722 @@
+// bf16 convolution for gfx950: the same implicit GEMMs as conv.hip on
+// v_mfma_f32_32x32x16_bf16 (16x the f32-MFMA rate, fp32 accumulate) -- the
+// compute path of BASELINE.json config 3 (ld_r50_gflv1_r101_fpn_coco_1x, bf16).
+// Reference: the fp16 mode of the same layers (mmcv auto_fp16 around
+// backbone / neck / head forward; the head's reg output is cast back with
+// .float() at mmdet/models/dense_heads/gfl_head.py:181-183 and the loss block
+// is @force_fp32, ld_head.py:284): low-precision matrix operands, fp32
+// everything else.
+//
+// Precision contract of this file: operands are rounded to bf16 (RNE) on the
+// way into the matrix core, products are exact, accumulation is fp32 in one
+// accumulator per output element; master weights, activations in HBM,
+// epilogue arithmetic (BN affine, bias, residual, ReLU) and all gradients
+// stay fp32.
+//
+// Layouts
+//   activations  (N, C, P) fp32, as conv.hip (level-concatenated where needed)
+//   weight image bf16 [tap][K/8][Cout][8]: the eight k (input channels) an MFMA
+//                lane feeds are ONE 16-byte load; K = Cin rounded up to 16, zero
+//                filled.  The dgrad image swaps the channel roles and flips taps.
+//   fwd/dgrad    conv_stream_bf16_kernel: LDS-free like conv_stream_kernel.  The
+//                32x32x16 operand layouts are  A lane l <- Wt[tap][ci/8 + (l>>5)][co0 + (l&31)][0..7]
+//                (16 B per lane, 512 B contiguous per half-wave) and
+//                B lane l <- X[n][ci + 8*(l>>5) + e][pos(j0 + (l&31))], e = 0..7:
+//                eight 128-byte rows per half-wave, converted in registers
+//                (v_cvt_pk_bf16_f32).  A D-deep register ring of k16-steps per
+//                wavefront, no barriers (KS = 4: one LDS meeting before the
+//                epilogue), shapes picked from the shared tuning table.
+//   wgrad        conv_wgrad_wave_bf16_kernel: wave-private 64x64 tile; operand
+//                tiles go global (coalesced along j) -> bf16 -> PRIVATE LDS
+//                [row][j] with an 80-byte row pitch -> 16-byte fragment reads
+//                (conflict-free), 8 MFMAs per 32 positions.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "conv_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx8 __attribute__((ext_vector_type(8)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+inline int k8_blocks(int k) { return (k + 15) / 16 * 2; }  // 8-blocks per tap
+
+__device__ __forceinline__ uintx4 buf_load16(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(uintx4,
+                            __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+// ------------------------------------------------- forward/dgrad, streaming
+template <int TM, int TN, int WVM, int MODE, int D, int OCC, int KS>
+__global__ __launch_bounds__(256, OCC) void conv_stream_bf16_kernel(ConvK a) {
+  static_assert(KS == 1 || (KS == 4 && WVM == 1), "KS is 1 or 4");
+  static_assert(D * (TM + 8 * TN) < 64, "ring exceeds the vmcnt range");
+  constexpr int WVN = 4 / WVM;
+  constexpr int WM = TM * 32, WN = TN * 32;
+  constexpr int BM = KS == 4 ? WM : WVM * WM, BNT = KS == 4 ? WN : WVN * WN;
+  __shared__ float red[KS == 4 ? 2 * TM * TN * 16 * 64 : 1];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wm = KS == 4 ? 0 : wave / WVN, wn = KS == 4 ? 0 : wave % WVN;
+  const int kslice = KS == 4 ? wave : 0;
+  const int l31 = lane & 31, lk = lane >> 5;
+  const int mtiles = (a.Cout + BM - 1) / BM;
+  const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int m0 = (tile % mtiles) * BM + wm * WM;
+  const int n0 = (tile / mtiles) * BNT + wn * WN;
+  // KS == 1: no barriers below, waves are independent.  KS == 4: the condition
+  // is uniform over the workgroup.
+  if (m0 >= a.Cout || n0 >= a.J) return;
+
+  const int Cin = __builtin_amdgcn_readfirstlane(a.Cin);
+  const int Cout = __builtin_amdgcn_readfirstlane(a.Cout);
+  const int KW = __builtin_amdgcn_readfirstlane(a.KW);
+  const int Pin = __builtin_amdgcn_readfirstlane(a.Pin);
+  const int Kp8 = __builtin_amdgcn_readfirstlane(a.Kpad);  // 8-blocks per tap
+  const int ntw = __builtin_amdgcn_readfirstlane(MODE == 1 ? a.ntw : a.KW);
+  const int ntaps = __builtin_amdgcn_readfirstlane(
+      MODE == 1 ? a.nth * a.ntw : a.KH * a.KW);
+
+  // ---- per-lane column geometry, resolved once ----------------------------
+  int bHin[TN], bWin[TN], boff[TN], bh0[TN], bw0[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int jb = n0 + j * 32 + l31;
+    bHin[j] = 0;  // Hin = 0 -> every tap out of range -> kOOB -> zeros
+    bWin[j] = 0;
+    boff[j] = 0;
+    bh0[j] = 0;
+    bw0[j] = 0;
+    if (jb < a.J) {
+      const int n = jb / a.Pout, p = jb - n * a.Pout;
+      int bl, bho, bwo;
+      locate_out(a.g, p, bl, bho, bwo);
+      bHin[j] = a.g.lv[bl].Hin;
+      bWin[j] = a.g.lv[bl].Win;
+      // this lane's eight k rows start at channel 8 * lk of the k16-step
+      boff[j] = n * Cin * Pin + a.g.lv[bl].off_in + 8 * lk * Pin;
+      if (MODE == 1) {
+        bh0[j] = bho + a.ch0;
+        bw0[j] = bwo + a.cw0;
+      } else {
+        bh0[j] = bho * a.g.stride - a.g.pad;
+        bw0[j] = bwo * a.g.stride - a.g.pad;
+      }
+    }
+  }
+  unsigned va[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int co = m0 + i * 32 + l31;
+    va[i] = co < Cout ? (unsigned)(lk * Cout + co) * 16u : kOOB;
+  }
+  const rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  const rsrc_t rw = make_rsrc(a.wt, a.wt_bytes);
+
+  unsigned vb[TN];
+  int wtap = 0;  // weight-image tap of the cursor
+  auto set_tap = [&](int tap) {
+    int kh = tap / ntw, kw = tap - kh * ntw;
+    if (MODE == 1) {
+      wtap = (a.kh0 + 2 * kh) * KW + a.kw0 + 2 * kw;
+    } else {
+      wtap = tap;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int hi = bh0[j] + kh, wi = bw0[j] + kw;
+      const bool ok = hi >= 0 && hi < bHin[j] && wi >= 0 && wi < bWin[j];
+      vb[j] = ok ? (unsigned)(boff[j] + hi * bWin[j] + wi) * 4u : kOOB;
+    }
+  };
+  uintx4 ra[D][TM];
+  float rb[D][TN][8];
+  // one k16-step: sa = byte offset of 8-block (tap, ci/8) in the weight image,
+  // sb = byte offset of channel row ci in the activation tensor
+  auto load_k16 = [&](int d, unsigned sa, unsigned sb) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ra[d][i] = buf_load16(rw, va[i], sa);
+    const unsigned prow = (unsigned)Pin * 4u;
+    unsigned so = sb;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) rb[d][j][e] = buf_load(rx, vb[j], so);
+      so += prow;
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  auto mfma_k16 = [&](int d) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      floatx8 f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = rb[d][j][e];
+      const bf16x8 b = __builtin_convertvector(f, bf16x8);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(bf16x8, ra[d][i]), b, acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int cchunks = (Cin >> 4) / D;  // host guarantees (Cin / 16) % D == 0
+  const int nchunks = ntaps * cchunks;
+  // this wave's chunks: kslice, kslice + KS, ...
+  const int mychunks = nchunks > kslice ? (nchunks - kslice + KS - 1) / KS : 0;
+  int ltap = 0, lci = 0;
+  auto advance = [&](int n) {
+    lci += 16 * D * n;
+    const int t0 = ltap;
+    while (lci >= Cin) {
+      lci -= Cin;
+      ++ltap;
+    }
+    if (ltap != t0 && ltap < ntaps) set_tap(ltap);
+  };
+  set_tap(0);
+  if (KS > 1) advance(kslice);
+  const unsigned astep = (unsigned)(2 * Cout) * 16u;  // two 8-blocks per k16-step
+  const unsigned bstep = (unsigned)(16 * Pin) * 4u;
+  if (mychunks > 0) {
+    {
+      const unsigned sa = (unsigned)((wtap * Kp8 + (lci >> 3)) * Cout) * 16u;
+      const unsigned sb = (unsigned)lci * Pin * 4u;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        load_k16(d, sa + (unsigned)d * astep, sb + (unsigned)d * bstep);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      advance(KS);
+    }
+    for (int c = 0; c + 1 < mychunks; ++c) {
+      const unsigned sa = (unsigned)((wtap * Kp8 + (lci >> 3)) * Cout) * 16u;
+      const unsigned sb = (unsigned)lci * Pin * 4u;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        // pin the ring order (see conv_stream_kernel): MFMAs of slot d, then
+        // the refill of slot d, so D - 1 slots of loads stay in flight
+        mfma_k16(d);
+        __builtin_amdgcn_sched_barrier(0);
+        load_k16(d, sa + (unsigned)d * astep, sb + (unsigned)d * bstep);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      advance(KS);
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) mfma_k16(d);
+  }
+  if (KS == 4) {
+    // pairwise tree through LDS, fixed order ((w0 + w2) + (w1 + w3))
+    constexpr int NACC = TM * TN * 16;
+    auto put = [&](float* dst) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            dst[((i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    };
+    auto add = [&](const float* src) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            acc[i][j][r] += src[((i * TN + j) * 16 + r) * 64 + lane];
+    };
+    if (wave >= 2) put(red + (size_t)(wave - 2) * NACC * 64);
+    __syncthreads();
+    if (wave < 2) add(red + (size_t)wave * NACC * 64);
+    __syncthreads();
+    if (wave == 1) put(red);
+    __syncthreads();
+    if (wave != 0) return;
+    add(red);
+  }
+
+  // ---- epilogue: direct stores, 32 consecutive positions per accumulator row
+  const bool has_res = a.residual != nullptr;
+  const bool relu = a.relu != 0;
+  const bool has_aff = a.scale != nullptr, has_bias = a.bias != nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int rbase = m0 + i * 32 + 4 * lk;
+    float sc[16], sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = min(rbase + (r & 3) + 8 * (r >> 2), Cout - 1);
+      sc[r] = has_aff ? a.scale[row] : 1.0f;
+      sh[r] = has_aff ? a.shift[row] : 0.0f;
+      if (has_bias) sh[r] += a.bias[row];
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int jc = n0 + j * 32 + l31;
+      if (jc >= a.J) continue;
+      const int n = jc / a.Pout;
+      int p = jc - n * a.Pout;
+      int prow = a.Pout;
+      if (MODE == 1) {
+        int l, hc, wc;
+        locate_out(a.g, p, l, hc, wc);
+        p = a.foff[l] + (2 * hc + a.ph) * a.fW[l] + 2 * wc + a.pw;
+        prow = a.Pfull;
+      }
+      const size_t colbase = (size_t)n * Cout * prow + p;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        if (row >= Cout) continue;
+        float v = acc[i][j][r] * sc[r] + sh[r];
+        if (has_res) v += a.residual[colbase + (size_t)row * prow];
+        if (relu) v = fmaxf(v, 0.0f);
+        a.y[colbase + (size_t)row * prow] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------- wgrad, wave-private --
+// One wavefront per workgroup, a 64(co) x 64(ci) tile of one tap and one
+// j-split, 32 positions per step.  Both operand tiles are loaded coalesced
+// along j (lane = position), rounded to bf16 and written to the wave's PRIVATE
+// LDS tile as [row][j] with an 80-byte row pitch; a fragment (8 consecutive j
+// of one row) is then ONE 16-byte read, and sixteen lanes x 80 B hit sixteen
+// disjoint groups of four banks (conflict-free ds_read_b128).  LDS operations
+// of one wave execute in order: no s_barrier anywhere.
+constexpr int WB_J = 32;             // positions per step
+constexpr int WB_PITCH = 2 * WB_J + 16;  // bytes per LDS row
+__global__ __launch_bounds__(64, 2) void conv_wgrad_wave_bf16_kernel(WgradK a) {
+  constexpr int TB = 64;
+  constexpr int RG = 64 / WB_J;   // rows covered by one load instruction (2)
+  constexpr int RPER = TB / RG;   // rows per lane and operand (32)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TB * WB_PITCH];
+  __shared__ int s_geo[LD_MAX_LEVELS * 6];
+  unsigned char* As = lds;                  // [TB][WB_PITCH]  dY rows (co)
+  unsigned char* Bs = lds + TB * WB_PITCH;  // [TB][WB_PITCH]  X rows (ci)
+
+  const int lane = threadIdx.x;
+  const int Cin = __builtin_amdgcn_readfirstlane(a.Cin);
+  const int Cout = __builtin_amdgcn_readfirstlane(a.Cout);
+  const int Pin = __builtin_amdgcn_readfirstlane(a.Pin);
+  const int Pout = __builtin_amdgcn_readfirstlane(a.Pout);
+  const int nlev = __builtin_amdgcn_readfirstlane(a.g.num_levels);
+  const int stride = __builtin_amdgcn_readfirstlane(a.g.stride);
+  const int pad = __builtin_amdgcn_readfirstlane(a.g.pad);
+  const int mt = (Cout + TB - 1) / TB, nt = (Cin + TB - 1) / TB;
+  const int ntaps = a.KH * a.KW;
+  int b = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int ntile = b % nt;
+  b /= nt;
+  const int mtile = b % mt;
+  b /= mt;
+  const int tap = b % ntaps;
+  const int split = b / ntaps;
+  const int m0 = mtile * TB, c0 = ntile * TB;
+  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int jbeg = split * a.jchunk;
+  const int jend = min(a.J, jbeg + a.jchunk);
+
+  if (lane < LD_MAX_LEVELS) {
+    const ld_conv_level_t lv = a.g.lv[lane];
+    s_geo[lane * 6 + 0] = lv.Hin;
+    s_geo[lane * 6 + 1] = lv.Win;
+    s_geo[lane * 6 + 2] = lv.Hout;
+    s_geo[lane * 6 + 3] = lv.Wout;
+    s_geo[lane * 6 + 4] = lv.off_in;
+    s_geo[lane * 6 + 5] = lv.off_out;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  const int kq = lane % WB_J;  // this lane's j offset within a step
+  const int r0 = lane / WB_J;  // first row; rows r0 + RG*i
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  const rsrc_t ry = make_rsrc(a.dy, a.dy_bytes);
+  float a_st[RPER], b_st[RPER];
+  const bool rows_full = (m0 + TB <= Cout) && (c0 + TB <= Cin);
+
+  auto load_tile = [&](int j0) {
+    const int j = j0 + kq;
+    unsigned vy = kOOB, vx = kOOB;
+    if (j < jend) {
+      const int n = j / Pout, p = j - n * Pout;
+      int l = 0;
+      for (int i = 1; i < nlev; ++i)
+        if (p >= s_geo[i * 6 + 5]) l = i;
+      const int Hin = s_geo[l * 6 + 0], Win = s_geo[l * 6 + 1];
+      const int Wout = s_geo[l * 6 + 3];
+      const int r = p - s_geo[l * 6 + 5];
+      const int ho = r / Wout, wo = r - ho * Wout;
+      const int hi = ho * stride - pad + kh, wi = wo * stride - pad + kw;
+      vy = (unsigned)(n * Cout * Pout + (m0 + r0) * Pout + p) * 4u;
+      if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win)
+        vx = (unsigned)(n * Cin * Pin + (c0 + r0) * Pin + s_geo[l * 6 + 4] +
+                        hi * Win + wi) * 4u;
+    }
+    // row offsets advance in SGPRs inside the step (see conv_wgrad_wave_kernel)
+    unsigned da = (unsigned)RG * Pout * 4u, db = (unsigned)RG * Pin * 4u;
+    asm volatile("" : "+s"(da), "+s"(db));
+    unsigned sa = 0, sb = 0;
+    if (rows_full) {
+#pragma unroll
+      for (int i = 0; i < RPER; ++i) {
+        a_st[i] = buf_load(ry, vy, sa);
+        b_st[i] = buf_load(rx, vx, sb);
+        sa += da;
+        sb += db;
+      }
+    } else {
+      int na = (Cout - m0 - r0 + RG - 1) / RG, nb = (Cin - c0 - r0 + RG - 1) / RG;
+      asm volatile("" : "+v"(na), "+v"(nb));
+#pragma unroll
+      for (int i = 0; i < RPER; ++i) {
+        a_st[i] = buf_load(ry, i < na ? vy : kOOB, sa);
+        b_st[i] = buf_load(rx, i < nb ? vx : kOOB, sb);
+        sa += da;
+        sb += db;
+      }
+    }
+  };
+  auto store_tile = [&]() {
+    __bf16* ap = (__bf16*)(As + r0 * WB_PITCH) + kq;
+    __bf16* bp = (__bf16*)(Bs + r0 * WB_PITCH) + kq;
+#pragma unroll
+    for (int i = 0; i < RPER; ++i) {
+      ap[RG * i * (WB_PITCH / 2)] = (__bf16)a_st[i];
+      bp[RG * i * (WB_PITCH / 2)] = (__bf16)b_st[i];
+    }
+  };
+
+  const int nsteps = (jend - jbeg + WB_J - 1) / WB_J;
+  const int l31 = lane & 31, lk = lane >> 5;
+  if (nsteps > 0) load_tile(jbeg);
+  for (int step = 0; step < nsteps; ++step) {
+    store_tile();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (step + 1 < nsteps) load_tile(jbeg + (step + 1) * WB_J);
+    // fragment of row (32 i + l31), positions 16 s + 8 lk + 0..7
+    const unsigned char* ap = As + l31 * WB_PITCH + 16 * lk;
+    const unsigned char* bp = Bs + l31 * WB_PITCH + 16 * lk;
+    bf16x8 af[2][2], bfr[2][2];  // [k16-step][tile]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        af[s][i] = *(const bf16x8*)(ap + i * 32 * WB_PITCH + s * 32);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bfr[s][j] = *(const bf16x8*)(bp + j * 32 * WB_PITCH + s * 32);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i], bfr[s][j],
+                                                              acc[i][j], 0, 0, 0);
+    // all fragment reads of this tile are issued before the next tile's
+    // ds_writes (LDS executes one wave's operations in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  // slab store: [split][tap][co][ci], ci fastest (= lane & 31)
+  float* slab = a.slabs + ((size_t)split * ntaps + tap) * Cout * Cin;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ci = c0 + j * 32 + l31;
+    if (ci >= Cin) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (co < Cout) slab[(size_t)co * Cin + ci] = acc[i][j][r];
+      }
+  }
+}
+
+// ---- weight images ----------------------------------------------------------
+// (Cout, Cin, KH, KW) fp32 -> fwd [tap][Cin16/8][Cout][8] bf16 and/or
+// bwd [KH*KW-1-tap][Cout16/8][Cin][8] bf16 (k rows beyond the channel count 0).
+__device__ __forceinline__ void weight_transform_bf16_at(
+    const float* __restrict__ w, int Cout, int Cin, int ntaps, __bf16* __restrict__ wt_fwd,
+    __bf16* __restrict__ wt_bwd, size_t i) {
+  const int ci8 = (Cin + 15) / 16 * 2, co8 = (Cout + 15) / 16 * 2;
+  if (wt_fwd && i < (size_t)ntaps * ci8 * Cout * 8) {
+    const int e = (int)(i & 7);
+    size_t q = i >> 3;
+    const int co = (int)(q % Cout);
+    q /= Cout;
+    const int kb = (int)(q % ci8), tap = (int)(q / ci8);
+    const int ci = kb * 8 + e;
+    wt_fwd[i] = (__bf16)(ci < Cin ? w[((size_t)co * Cin + ci) * ntaps + tap] : 0.0f);
+  }
+  if (wt_bwd && i < (size_t)ntaps * co8 * Cin * 8) {
+    const int e = (int)(i & 7);
+    size_t q = i >> 3;
+    const int ci = (int)(q % Cin);
+    q /= Cin;
+    const int kb = (int)(q % co8), tapf = (int)(q / co8);
+    const int co = kb * 8 + e;
+    wt_bwd[i] = (__bf16)(co < Cout
+                             ? w[((size_t)co * Cin + ci) * ntaps + (ntaps - 1 - tapf)]
+                             : 0.0f);
+  }
+}
+
+__global__ void conv_weight_transform_bf16_kernel(const float* __restrict__ w, int Cout,
+                                                  int Cin, int ntaps,
+                                                  __bf16* __restrict__ wt_fwd,
+                                                  __bf16* __restrict__ wt_bwd) {
+  weight_transform_bf16_at(w, Cout, Cin, ntaps, wt_fwd, wt_bwd,
+                           (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void conv_weight_transform_bf16_batch_kernel(
+    const ld_wt_job_t* __restrict__ jobs, const int32_t* __restrict__ block_job) {
+  const ld_wt_job_t j = jobs[block_job[blockIdx.x]];
+  weight_transform_bf16_at(j.w, j.Cout, j.Cin, j.ntaps, (__bf16*)j.wt_fwd,
+                           (__bf16*)j.wt_bwd,
+                           (size_t)(blockIdx.x - j.first_block) * 256 + threadIdx.x);
+}
+
+// ---- shape dispatch ---------------------------------------------------------
+struct StreamCfg {
+  int tm, tn, wvm, d, ks;
+};
+// Ring depth is bounded by the 6-bit vmcnt counter: D * (TM + 8 * TN) loads are
+// in flight per wavefront and must stay below 64 (2x2 tiles: D = 2, 36 loads).
+#define LD_BF16_SHAPES(X)                                                          \
+  X(2, 2, 2, 2, 1) X(2, 2, 1, 2, 1) X(2, 1, 2, 4, 1) X(1, 2, 2, 2, 1)              \
+  X(1, 1, 2, 4, 1) X(1, 1, 1, 4, 1) X(1, 1, 4, 4, 1) X(2, 1, 4, 4, 1)              \
+  X(1, 1, 1, 4, 4) X(2, 1, 1, 4, 4) X(1, 2, 1, 2, 4) X(2, 2, 1, 2, 4)              \
+  X(2, 2, 2, 1, 1) X(1, 1, 2, 1, 1) X(1, 1, 1, 1, 4)
+constexpr StreamCfg kCfgs[] = {
+#define LD_ROW(TM_, TN_, WVM_, D_, KS_) {TM_, TN_, WVM_, D_, KS_},
+    LD_BF16_SHAPES(LD_ROW)
+#undef LD_ROW
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+template <int MODE>
+int launch_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream) {
+  const int bm = (c.ks == 4 ? 1 : c.wvm) * c.tm * 32;
+  const int bn = (c.ks == 4 ? 1 : 4 / c.wvm) * c.tn * 32;
+  const int nb = ((k.Cout + bm - 1) / bm) * ((k.J + bn - 1) / bn);
+#define LD_CASE(TM_, TN_, WVM_, D_, KS_)                                           \
+  if (c.tm == TM_ && c.tn == TN_ && c.wvm == WVM_ && c.d == D_ && c.ks == KS_) {   \
+    hipLaunchKernelGGL(                                                            \
+        (conv_stream_bf16_kernel<TM_, TN_, WVM_, MODE, D_,                         \
+                                 (KS_ == 4 ? (TM_ * TN_ < 2 ? 4 : TM_ * TN_ < 4 ? 3 : 2) : 2), KS_>),       \
+        dim3(nb), dim3(256), 0, stream, k);                                        \
+    return (int)hipGetLastError();                                                 \
+  }
+  LD_BF16_SHAPES(LD_CASE)
+#undef LD_CASE
+  return LD_EUNSUPPORTED;
+}
+
+inline int mode_taps(const ConvK& k) {
+  return k.nth > 0 ? k.nth * k.ntw : k.KH * k.KW;
+}
+
+inline bool cfg_fits(const ConvK& k, const StreamCfg& c) {
+  const int steps = k.Cin / 16;
+  if (steps % c.d != 0) return false;
+  if (c.d == 1 && steps % 2 == 0) return false;  // a deeper ring covers it
+  const int bm = c.wvm * c.tm * 32;
+  const int cout32 = (k.Cout + 31) / 32 * 32;
+  if (c.ks == 4) {
+    const int nchunks = mode_taps(k) * (steps / c.d);
+    if (nchunks < 16) return false;
+  }
+  if (c.wvm > 1 && bm > cout32) return false;  // whole waves of padding rows
+  if (c.wvm == 1 && c.tm * 32 >= cout32 + 32) return false;
+  return true;
+}
+
+// model-based pick: workgroup rounds over 256 CUs x per-shape efficiency
+inline int cfg_model(const ConvK& k) {
+  int best = -1;
+  double best_t = 0;
+  for (int i = 0; i < kNumCfgs; ++i) {
+    const StreamCfg& c = kCfgs[i];
+    if (!cfg_fits(k, c)) continue;
+    const int bm = (c.ks == 4 ? 1 : c.wvm) * c.tm * 32;
+    const int bn = (c.ks == 4 ? 1 : 4 / c.wvm) * c.tn * 32;
+    const long nb = (long)((k.Cout + bm - 1) / bm) * ((k.J + bn - 1) / bn);
+    const int area = c.tm * c.tn;
+    // operand reuse matters more than at fp32 rates: the loads per MFMA of a
+    // 1x1 wave tile are twice those of a 2x2 one
+    const double eff = (area >= 4 ? 0.90 : area >= 2 ? 0.70 : 0.50) *
+                       (c.ks == 4 ? 0.95 : 1.0) * (c.d >= 2 ? 1.0 : 0.6);
+    const int occ = area >= 4 ? 2 : 4;  // resident workgroups per CU
+    const double rounds =
+        nb <= 256L * occ ? (double)((nb + 255) / 256) : (double)nb / 256.0;
+    const double t = rounds * (c.ks == 4 ? 1 : 4) * area / eff;
+    if (best < 0 || t < best_t) {
+      best = i;
+      best_t = t;
+    }
+  }
+  return best;
+}
+
+inline int cfg_index(const LdTuneCfg& c) {
+  for (int i = 0; i < kNumCfgs; ++i)
+    if (kCfgs[i].tm == c.tm && kCfgs[i].tn == c.tn && kCfgs[i].wvm == c.wvm &&
+        kCfgs[i].d == c.d && kCfgs[i].ks == c.ks)
+      return i;
+  return -1;
+}
+
+template <int MODE>
+int launch_bf16(const ConvK& k, hipStream_t stream) {
+  if (k.Cin % 16 != 0) return LD_EUNSUPPORTED;
+  if (const char* env = getenv("LD_CONV_BF16_SHAPE")) {  // "2x2x2x4x1": force a shape
+    StreamCfg c;
+    if (sscanf(env, "%dx%dx%dx%dx%d", &c.tm, &c.tn, &c.wvm, &c.d, &c.ks) == 5 &&
+        (k.Cin / 16) % c.d == 0) {
+      const int rc = launch_cfg<MODE>(k, c, stream);
+      if (rc != LD_EUNSUPPORTED) return rc;
+    }
+  }
+  int pick = -1;
+  LdTuneCfg t;
+  if (ld_tune_lookup(make_tune_key(MODE, 1, k), &t)) {
+    pick = cfg_index(t);
+    if (pick >= 0 && !cfg_fits(k, kCfgs[pick])) pick = -1;
+  }
+  if (pick < 0) pick = cfg_model(k);
+  if (pick < 0) return LD_EUNSUPPORTED;
+  return launch_cfg<MODE>(k, kCfgs[pick], stream);
+}
+
+template <int MODE>
+int tune_bf16(const ConvK& k, hipStream_t stream) {
+  if (k.Cin % 16 != 0) return 1;
+  const LdTuneKey key = make_tune_key(MODE, 1, k);
+  LdTuneCfg have;
+  if (ld_tune_lookup(key, &have)) return 1;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(stream, &cap);
+  if (cap != hipStreamCaptureStatusNone) return LD_EUNSUPPORTED;
+  int pick = cfg_model(k);
+  if (pick < 0) return 1;
+  (void)hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  constexpr int kReps = 3;
+  float best_ms = -1.0f;
+  for (int i = 0; i < kNumCfgs; ++i) {
+    if (!cfg_fits(k, kCfgs[i])) continue;
+    if (launch_cfg<MODE>(k, kCfgs[i], stream) != 0) continue;
+    float ms = -1.0f;
+    for (int trial = 0; trial < 2; ++trial) {
+      (void)hipEventRecord(e0, stream);
+      for (int rep = 0; rep < kReps; ++rep) launch_cfg<MODE>(k, kCfgs[i], stream);
+      (void)hipEventRecord(e1, stream);
+      if (hipEventSynchronize(e1) != hipSuccess) break;
+      float t = 0.0f;
+      (void)hipEventElapsedTime(&t, e0, e1);
+      if (ms < 0.0f || t < ms) ms = t;
+    }
+    if (ms < 0.0f) continue;
+    if (best_ms < 0.0f || ms < best_ms) {
+      best_ms = ms;
+      pick = i;
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  const StreamCfg& c = kCfgs[pick];
+  if (const char* lg = getenv("LD_CONV_TUNE_LOG"))
+    if (lg[0] == '1') {
+      const double fl = 2.0 * k.J * k.Cout * k.Cin * mode_taps(k);
+      fprintf(stderr,
+              "[ld_conv bf16] mode %d Cin %d Cout %d k %dx%d s%d J %d lv %d -> "
+              "%dx%dx%dx%dx%d  %.1f TFLOP/s\n",
+              MODE, k.Cin, k.Cout, k.KH, k.KW, k.g.stride, k.J, k.g.num_levels, c.tm,
+              c.tn, c.wvm, c.d, c.ks,
+              best_ms > 0 ? fl / (best_ms * 1e-3 / kReps) / 1e12 : 0.0);
+    }
+  if (best_ms > 0.0f) ld_tune_store(key, LdTuneCfg{c.tm, c.tn, c.wvm, c.d, c.ks});
+  return 0;
+}
+
+}  // namespace
+
+int ld_bf16_stream_launch(int mode, const ConvK& k, hipStream_t stream) {
+  return mode == 1 ? launch_bf16<1>(k, stream) : launch_bf16<0>(k, stream);
+}
+
+int ld_bf16_stream_tune(int mode, const ConvK& k, hipStream_t stream) {
+  return mode == 1 ? tune_bf16<1>(k, stream) : tune_bf16<0>(k, stream);
+}
+
+int ld_bf16_wgrad_launch(const WgradK& k, hipStream_t stream) {
+  const int ntaps = k.KH * k.KW;
+  const int blocks = ((k.Cout + 63) / 64) * ((k.Cin + 63) / 64) * ntaps * k.splits;
+  hipLaunchKernelGGL(conv_wgrad_wave_bf16_kernel, dim3(blocks), dim3(64), 0, stream, k);
+  return (int)hipGetLastError();
+}
+
+extern "C" size_t ld_conv_bf16_weight_image_elems(int Cout, int Cin, int KH, int KW,
+                                                 int backward) {
+  if (Cout < 1 || Cin < 1 || KH < 1 || KW < 1) return 0;
+  return backward ? (size_t)KH * KW * k8_blocks(Cout) * Cin * 8
+                  : (size_t)KH * KW * k8_blocks(Cin) * Cout * 8;
+}
+
+extern "C" int ld_conv_bf16_weight_transform(const float* w, int Cout, int Cin, int KH,
+                                             int KW, void* wt_fwd, void* wt_bwd,
+                                             ld_stream_t stream) {
+  if (!w || Cout < 1 || Cin < 1 || KH < 1 || KW < 1 || (!wt_fwd && !wt_bwd))
+    return LD_EINVAL;
+  size_t total = 0;
+  if (wt_fwd) total = ld_conv_bf16_weight_image_elems(Cout, Cin, KH, KW, 0);
+  if (wt_bwd) total = max(total, ld_conv_bf16_weight_image_elems(Cout, Cin, KH, KW, 1));
+  hipLaunchKernelGGL(conv_weight_transform_bf16_kernel,
+                     dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w, Cout, Cin, KH * KW, (__bf16*)wt_fwd,
+                     (__bf16*)wt_bwd);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_conv_bf16_weight_transform_batch(const ld_wt_job_t* jobs,
+                                                   const int32_t* block_job, int nblocks,
+                                                   ld_stream_t stream) {
+  if (!jobs || !block_job || nblocks < 1) return LD_EINVAL;
+  hipLaunchKernelGGL(conv_weight_transform_bf16_batch_kernel, dim3(nblocks), dim3(256),
+                     0, (hipStream_t)stream, jobs, block_job);
+  return (int)hipGetLastError();
+}

@@ -8,6 +8,58 @@
 
 #include "../../include/ld_hip.h"
 
+struct Geo {  // pyramid geometry as the gather sees it
+  int stride, pad, num_levels;
+  ld_conv_level_t lv[LD_MAX_LEVELS];
+};
+
+struct ConvK {  // kernel-side view of ld_conv_t + pointers
+  const float* x;
+  const float* wt;
+  float* y;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const float* residual;
+  int relu;
+  int N, Cin, Cout, KH, KW;
+  int Pin, Pout;
+  int J;  // N * Pout
+  int Kpad;               // rows per tap of the weight image (Cin rounded up)
+  int pipe;               // use the software-pipelined main loop
+  unsigned x_bytes, wt_bytes;  // buffer-descriptor extents
+  // MODE 1 (data-gradient of a stride-2 conv, one output-parity class per
+  // launch): g.lv[].Hout/Wout/off_out describe the COMPACT grid of the class;
+  // the class is (ph, pw); only taps kh = kh0 + 2*i (i < nth), kw = kw0 + 2*j
+  // (j < ntw) reach it; input row = hc + ch0 + i, col = wc + cw0 + j.
+  int ph, pw, kh0, kw0, nth, ntw, ch0, cw0;
+  int Pfull;                       // positions per (n, c) row of the output
+  int fW[LD_MAX_LEVELS], foff[LD_MAX_LEVELS];  // full output row length/offset
+  Geo g;
+};
+
+
+struct WgradK {
+  const float* x;    // (N, Cin, Pin)
+  const float* dy;   // (N, Cout, Pout)
+  float* slabs;      // [split][tap][Cout][Cin]
+  int N, Cin, Cout, KH, KW;
+  int Pin, Pout;
+  int J, splits, jchunk;  // jchunk: columns per split (multiple of the j-step)
+  unsigned x_bytes, dy_bytes;
+  Geo g;
+};
+
+// ---- cross-file hooks (external linkage) -------------------------------------
+// conv_bf16.hip: bf16-MFMA streaming forward / data-gradient launch + tuning
+// (mode 0 = conv, 1 = stride-2 dgrad parity class), wave-private bf16 wgrad.
+int ld_bf16_stream_launch(int mode, const ConvK& k, hipStream_t stream);
+int ld_bf16_stream_tune(int mode, const ConvK& k, hipStream_t stream);
+int ld_bf16_wgrad_launch(const WgradK& k, hipStream_t stream);
+// conv.hip: fixed-order sum of the wgrad slabs into dW (shared by both families)
+int ld_wgrad_reduce_launch(const float* slabs, int splits, int ntaps, int Cout,
+                           int Cin, float* dw, int accumulate, hipStream_t stream);
+
 namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -40,36 +92,6 @@ __device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff, unsigned soff
   return __builtin_bit_cast(float,
                             __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
-
-struct Geo {  // pyramid geometry as the gather sees it
-  int stride, pad, num_levels;
-  ld_conv_level_t lv[LD_MAX_LEVELS];
-};
-
-struct ConvK {  // kernel-side view of ld_conv_t + pointers
-  const float* x;
-  const float* wt;
-  float* y;
-  const float* bias;
-  const float* scale;
-  const float* shift;
-  const float* residual;
-  int relu;
-  int N, Cin, Cout, KH, KW;
-  int Pin, Pout;
-  int J;  // N * Pout
-  int Kpad;               // rows per tap of the weight image (Cin rounded up)
-  int pipe;               // use the software-pipelined main loop
-  unsigned x_bytes, wt_bytes;  // buffer-descriptor extents
-  // MODE 1 (data-gradient of a stride-2 conv, one output-parity class per
-  // launch): g.lv[].Hout/Wout/off_out describe the COMPACT grid of the class;
-  // the class is (ph, pw); only taps kh = kh0 + 2*i (i < nth), kw = kw0 + 2*j
-  // (j < ntw) reach it; input row = hc + ch0 + i, col = wc + cw0 + j.
-  int ph, pw, kh0, kw0, nth, ntw, ch0, cw0;
-  int Pfull;                       // positions per (n, c) row of the output
-  int fW[LD_MAX_LEVELS], foff[LD_MAX_LEVELS];  // full output row length/offset
-  Geo g;
-};
 
 __device__ __forceinline__ int xcd_swizzle(int b, int nb) {
   // consecutive logical tiles -> same XCD (block b runs on XCD b % 8)

@@ -160,145 +160,237 @@ __global__ __launch_bounds__(256) void loss_norm_kernel(
   }
 }
 
-// ------------------------------------------- reg side: LD + VLR + DFL + GIoU
-__global__ __launch_bounds__(kWave) void loss_reg_kernel(
+// ===================== main block: four dense launches =======================
+// Work is split so that EVERY launch is a dense, coalesced sweep with
+// 256-thread workgroups and one thread per (anchor, channel group):
+//   loss_pos_kernel        the few positive anchors only: Integral of the four
+//                          sides -> GIoU loss + d/dE, softmax statistics of the
+//                          80 class logits for KD -> an 8-float record per anchor
+//   loss_reg_dense_kernel  thread = (anchor, SIDE): LD-KL + VLR-LD (+ DFL and the
+//                          GIoU chain for positives) over one 17-bin side, forward
+//                          and gradient.  This is the north-star fused LD-KL +
+//                          Integral sweep of the train step: 34 input streams per
+//                          thread, 17 gradient streams out (bench.py measures this
+//                          very kernel at a saturating size)
+//   loss_cls_dense_kernel  thread = (anchor, 16 class channels): QFL (+ KD)
+//   loss_im_dense_kernel   thread = (anchor, 32 feature channels): masked MSE
+// Round 1 ran one thread per anchor over all channels in 64-thread blocks: ~700
+// wavefronts for 1024 SIMDs and 68-256 dependent iterations each (3-5 % of the
+// HBM rate); the (anchor, group) split gives 2 800 / 3 500 / 5 600 wavefronts.
+constexpr int kBlk = 256;
+constexpr int kZMax = 8;     // channel groups per anchor (sides, class/feature chunks)
+constexpr int kClsChunk = 16;
+constexpr int kPosRec = 8;   // floats per anchor in the positives record
+
+__device__ __forceinline__ Cell locate256(const ld_geom_t& g, const BlockMap& bm) {
+  Cell c;
+  c.n = blockIdx.y;
+  c.l = block_level(bm, g.num_levels, blockIdx.x);
+  const ld_level_t lv = g.lv[c.l];
+  c.r = (blockIdx.x - bm.blk_start[c.l]) * kBlk + threadIdx.x;
+  c.active = c.r < lv.H * lv.W;
+  c.a = lv.offset + c.r;
+  c.y = c.r / lv.W;
+  c.x = c.r - c.y * lv.W;
+  c.o = (size_t)c.n * g.num_anchors + c.a;
+  return c;
+}
+
+// fixed-order sum over the 256 threads of a block; result valid in thread 0
+__device__ __forceinline__ float block_sum(float v, float* lds4) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();  // lds4 may still be read from the previous call
+  if ((threadIdx.x & 63) == 0) lds4[w] = v;
+  __syncthreads();
+  return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+}
+
+// partial[(slot * kZMax + z) * nb + n * blocks_per_img + b]
+__device__ __forceinline__ size_t part_idx(int slot, int z, const BlockMap& bm, int n) {
+  const size_t nb = (size_t)gridDim.y * bm.blocks_per_img;
+  return ((size_t)slot * kZMax + z) * nb + (size_t)n * bm.blocks_per_img + blockIdx.x;
+}
+
+// ------------------------------------------------ positives: GIoU + KD stats
+__global__ __launch_bounds__(kBlk) void loss_pos_kernel(
+    ld_geom_t geom, ld_loss_hp_t hp, BlockMap bm, ld_maps_t cls, ld_maps_t t_cls,
+    ld_maps_t reg, const int64_t* __restrict__ labels,
+    const float* __restrict__ bbox_targets, const float* __restrict__ weight_targets,
+    const float* __restrict__ norm, const float* __restrict__ upstream,
+    float* __restrict__ posrec, float* __restrict__ partial) {
+  __shared__ float lds4[4];
+  const Cell c = locate256(geom, bm);
+  float s_bbox = 0.0f;
+  if (c.active) {
+    const int64_t lab = labels[c.o];
+    if (lab >= 0 && lab < hp.num_classes) {
+      const int L = geom.num_levels;
+      const float up_bbox = upstream ? upstream[1 * L + c.l] : 1.0f;
+      const float inv_avg = 1.0f / (norm[1] + 1e-6f);
+      const float wt = weight_targets[c.o];
+      const float c_bbox = up_bbox * hp.lw_bbox * wt * inv_avg;
+      float e[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float sv[K17], p[K17];
+        load_side(reg, c, s, sv);
+        e[s] = ld::softmax_expect<K17>(sv, p);
+      }
+      const float stride = (float)geom.lv[c.l].stride;
+      const float cx = (float)c.x, cy = (float)c.y;
+      const Box box{cx - e[0], cy - e[1], cx + e[2], cy + e[3]};
+      const float4 t = reinterpret_cast<const float4*>(bbox_targets)[c.o];
+      const Box tgt{t.x / stride, t.y / stride, t.z / stride, t.w / stride};
+      float iou, g[4];
+      const float gl = ld::giou_loss_grad(box, tgt, hp.giou_eps, &iou, g);
+      s_bbox = wt * gl;
+      // softmax statistics of the class logits at temperature T_kd
+      const int C = hp.num_classes;
+      const float invT = 1.0f / hp.T_kd;
+      float ms = *chan_ptr(cls, c, 0), mt = *chan_ptr(t_cls, c, 0);
+      for (int ch = 1; ch < C; ++ch) {
+        ms = fmaxf(ms, *chan_ptr(cls, c, ch));
+        mt = fmaxf(mt, *chan_ptr(t_cls, c, ch));
+      }
+      float zs = 0.0f, zt = 0.0f;
+      for (int ch = 0; ch < C; ++ch) {
+        zs += expf((*chan_ptr(cls, c, ch) - ms) * invT);
+        zt += expf((*chan_ptr(t_cls, c, ch) - mt) * invT);
+      }
+      float4* rec = reinterpret_cast<float4*>(posrec + c.o * kPosRec);
+      rec[0] = make_float4(-g[0] * c_bbox, -g[1] * c_bbox, g[2] * c_bbox, g[3] * c_bbox);
+      rec[1] = make_float4(ms, zs, mt, zt);
+    }
+  }
+  s_bbox = block_sum(s_bbox, lds4);
+  if (threadIdx.x == 0) partial[part_idx(S_BBOX, 0, bm, c.n)] = s_bbox;
+}
+
+// --------------------------- reg side, dense: LD + VLR-LD (+ DFL, GIoU chain)
+template <bool NT>
+__global__ __launch_bounds__(kBlk) void loss_reg_dense_kernel(
     ld_geom_t geom, ld_loss_hp_t hp, BlockMap bm, ld_maps_t reg, ld_maps_t t_reg,
     const int64_t* __restrict__ labels, const float* __restrict__ bbox_targets,
     const float* __restrict__ vlr, const float* __restrict__ weight_targets,
     const float* __restrict__ norm, const float* __restrict__ upstream,
-    ld_maps_t grad_reg, float* __restrict__ partial) {
-  const Cell c = locate(geom, bm);
-  float s_bbox = 0.0f, s_dfl = 0.0f, s_ld = 0.0f, s_vlr = 0.0f;
+    const float* __restrict__ posrec, ld_maps_t grad_reg, float* __restrict__ partial) {
+  __shared__ float lds4[4];
+  const Cell c = locate256(geom, bm);
+  const int side = blockIdx.z;
+  float s_dfl = 0.0f, s_ld = 0.0f, s_vlr = 0.0f;
   if (c.active) {
     const int64_t lab = labels[c.o];
     const bool pos = lab >= 0 && lab < hp.num_classes;
     const float v = vlr[c.o];
     const bool rem = v > 0.0f;
-    if (!pos && !rem) {
-#pragma unroll 4
-      for (int ch = 0; ch < 4 * K17; ++ch) *chan_ptr_w(grad_reg, c, ch) = 0.0f;
-    } else {
+    float gr[K17];
+#pragma unroll
+    for (int k = 0; k < K17; ++k) gr[k] = 0.0f;
+    if (pos || rem) {
       const int L = geom.num_levels;
-      const float up_bbox = upstream ? upstream[1 * L + c.l] : 1.0f;
       const float up_dfl = upstream ? upstream[2 * L + c.l] : 1.0f;
       const float up_ld = upstream ? upstream[3 * L + c.l] : 1.0f;
       const float up_vlr = upstream ? upstream[4 * L + c.l] : 1.0f;
-      const float inv_avg = 1.0f / (norm[1] + 1e-6f);
       const float wt = pos ? weight_targets[c.o] : 0.0f;
-      // per-anchor coefficients of d(total)/d(term)
-      const float c_ld = up_ld * hp.lw_ld * wt * 0.25f;           // /4.0
-      const float c_vlr = up_vlr * hp.lw_ld_vlr * v * 0.0625f;    // /16.0
-      const float c_dfl = up_dfl * hp.lw_dfl * wt * 0.25f * inv_avg;
-      const float c_bbox = up_bbox * hp.lw_bbox * wt * inv_avg;
-      float gd[4] = {0, 0, 0, 0};  // d(total)/d(E_side) through GIoU
-      float ytgt[4] = {0, 0, 0, 0};
-      if (pos) {
-        float e[4];
+      const float c_ld = up_ld * hp.lw_ld * wt * 0.25f;         // /4.0
+      const float c_vlr = up_vlr * hp.lw_ld_vlr * v * 0.0625f;  // /16.0
+      float sv[K17], tv[K17], d[K17];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          float sv[K17], p[K17];
-          load_side(reg, c, s, sv);
-          e[s] = ld::softmax_expect<K17>(sv, p);
-        }
-        const float stride = (float)geom.lv[c.l].stride;
-        const float cx = (float)c.x, cy = (float)c.y;
-        const Box box{cx - e[0], cy - e[1], cx + e[2], cy + e[3]};
-        const float4 t = reinterpret_cast<const float4*>(bbox_targets)[c.o];
-        const Box tgt{t.x / stride, t.y / stride, t.z / stride, t.w / stride};
-        float iou, g[4];
-        const float gl = ld::giou_loss_grad(box, tgt, hp.giou_eps, &iou, g);
-        s_bbox = wt * gl;
-        gd[0] = -g[0] * c_bbox;
-        gd[1] = -g[1] * c_bbox;
-        gd[2] = g[2] * c_bbox;
-        gd[3] = g[3] * c_bbox;
-        const float rm = (float)hp.reg_max;
-        ytgt[0] = ld::clamp_dist(cx - tgt.x1, rm);
-        ytgt[1] = ld::clamp_dist(cy - tgt.y1, rm);
-        ytgt[2] = ld::clamp_dist(tgt.x2 - cx, rm);
-        ytgt[3] = ld::clamp_dist(tgt.y2 - cy, rm);
+      for (int k = 0; k < K17; ++k) {
+        const float* ps = chan_ptr(reg, c, side * K17 + k);
+        const float* pt = chan_ptr(t_reg, c, side * K17 + k);
+        sv[k] = NT ? __builtin_nontemporal_load(ps) : *ps;
+        tv[k] = NT ? __builtin_nontemporal_load(pt) : *pt;
       }
-      const bool same_T = hp.T_ld == hp.T_ld_vlr;
-#pragma unroll 1
-      for (int s = 0; s < 4; ++s) {
-        float sv[K17], tv[K17], d[K17], gr[K17];
-        load_side(reg, c, s, sv);
-        load_side(t_reg, c, s, tv);
+      if (hp.T_ld == hp.T_ld_vlr) {
+        const float T = hp.T_ld;
+        const float kl = ld::kl_rows<K17>(sv, tv, 1.0f / T, T, d);
+        s_ld = wt * kl;
+        s_vlr = v * kl;
+        const float cg = (c_ld + (rem ? c_vlr : 0.0f)) * (T / (float)K17);
 #pragma unroll
-        for (int k = 0; k < K17; ++k) gr[k] = 0.0f;
-        if (same_T) {
+        for (int k = 0; k < K17; ++k) gr[k] = cg * d[k];
+      } else {
+        if (pos) {
           const float T = hp.T_ld;
           const float kl = ld::kl_rows<K17>(sv, tv, 1.0f / T, T, d);
-          s_ld += wt * kl;
-          s_vlr += v * kl;
-          const float cg = (c_ld + (rem ? c_vlr : 0.0f)) * (T / (float)K17);
+          s_ld = wt * kl;
+          const float cg = c_ld * (T / (float)K17);
 #pragma unroll
-          for (int k = 0; k < K17; ++k) gr[k] = cg * d[k];
-        } else {
-          if (pos) {
-            const float T = hp.T_ld;
-            const float kl = ld::kl_rows<K17>(sv, tv, 1.0f / T, T, d);
-            s_ld += wt * kl;
-            const float cg = c_ld * (T / (float)K17);
-#pragma unroll
-            for (int k = 0; k < K17; ++k) gr[k] += cg * d[k];
-          }
-          if (rem) {
-            const float T = hp.T_ld_vlr;
-            const float kl = ld::kl_rows<K17>(sv, tv, 1.0f / T, T, d);
-            s_vlr += v * kl;
-            const float cg = c_vlr * (T / (float)K17);
-#pragma unroll
-            for (int k = 0; k < K17; ++k) gr[k] += cg * d[k];
-          }
+          for (int k = 0; k < K17; ++k) gr[k] += cg * d[k];
         }
-        if (pos) {
-          float p[K17];
-          const float e = ld::softmax_expect<K17>(sv, p);
-          float wl, wr;
-          int yl;
-          const float dl = ld::dfl_side<K17>(sv, p, ytgt[s], &wl, &wr, &yl);
-          s_dfl += wt * dl;
+        if (rem) {
+          const float T = hp.T_ld_vlr;
+          const float kl = ld::kl_rows<K17>(sv, tv, 1.0f / T, T, d);
+          s_vlr = v * kl;
+          const float cg = c_vlr * (T / (float)K17);
 #pragma unroll
-          for (int k = 0; k < K17; ++k) {
-            float gk = p[k] - (k == yl ? wl : 0.0f) - (k == yl + 1 ? wr : 0.0f);
-            gr[k] += c_dfl * gk + gd[s] * p[k] * ((float)k - e);
-          }
+          for (int k = 0; k < K17; ++k) gr[k] += cg * d[k];
         }
+      }
+      if (pos) {
+        const float inv_avg = 1.0f / (norm[1] + 1e-6f);
+        const float c_dfl = up_dfl * hp.lw_dfl * wt * 0.25f * inv_avg;
+        const float stride = (float)geom.lv[c.l].stride;
+        const float cx = (float)c.x, cy = (float)c.y;
+        const float4 t = reinterpret_cast<const float4*>(bbox_targets)[c.o];
+        const float rm = (float)hp.reg_max;
+        const float dist = side == 0   ? cx - t.x / stride
+                           : side == 1 ? cy - t.y / stride
+                           : side == 2 ? t.z / stride - cx
+                                       : t.w / stride - cy;
+        const float ytgt = ld::clamp_dist(dist, rm);
+        float p[K17];
+        const float e = ld::softmax_expect<K17>(sv, p);
+        float wl, wr;
+        int yl;
+        const float dl = ld::dfl_side<K17>(sv, p, ytgt, &wl, &wr, &yl);
+        s_dfl = wt * dl;
+        const float gd = posrec[c.o * kPosRec + side];  // d total / d E_side (GIoU)
 #pragma unroll
-        for (int k = 0; k < K17; ++k) *chan_ptr_w(grad_reg, c, s * K17 + k) = gr[k];
+        for (int k = 0; k < K17; ++k) {
+          const float gk = p[k] - (k == yl ? wl : 0.0f) - (k == yl + 1 ? wr : 0.0f);
+          gr[k] += c_dfl * gk + gd * p[k] * ((float)k - e);
+        }
       }
     }
+#pragma unroll
+    for (int k = 0; k < K17; ++k) {
+      float* pg = chan_ptr_w(grad_reg, c, side * K17 + k);
+      if (NT)
+        __builtin_nontemporal_store(gr[k], pg);
+      else
+        *pg = gr[k];
+    }
   }
-  const size_t nb = (size_t)gridDim.y * bm.blocks_per_img;
-  const size_t bi = (size_t)c.n * bm.blocks_per_img + blockIdx.x;
-  s_bbox = wave_sum(s_bbox);
-  s_dfl = wave_sum(s_dfl);
-  s_ld = wave_sum(s_ld);
-  s_vlr = wave_sum(s_vlr);
+  s_dfl = block_sum(s_dfl, lds4);
+  s_ld = block_sum(s_ld, lds4);
+  s_vlr = block_sum(s_vlr, lds4);
   if (threadIdx.x == 0) {
-    partial[S_BBOX * nb + bi] = s_bbox;
-    partial[S_DFL * nb + bi] = s_dfl;
-    partial[S_LD * nb + bi] = s_ld;
-    partial[S_VLR * nb + bi] = s_vlr;
+    partial[part_idx(S_DFL, side, bm, c.n)] = s_dfl;
+    partial[part_idx(S_LD, side, bm, c.n)] = s_ld;
+    partial[part_idx(S_VLR, side, bm, c.n)] = s_vlr;
   }
 }
 
-// ------------------------------------------------- cls side: QFL + KD -------
-__global__ __launch_bounds__(kWave) void loss_cls_kernel(
+// ------------------------------------------- cls side, dense: QFL (+ KD) -----
+__global__ __launch_bounds__(kBlk) void loss_cls_dense_kernel(
     ld_geom_t geom, ld_loss_hp_t hp, BlockMap bm, ld_maps_t cls, ld_maps_t t_cls,
     const int64_t* __restrict__ labels, const float* __restrict__ label_weights,
     const float* __restrict__ score, const int32_t* __restrict__ counts,
     const float* __restrict__ norm, const float* __restrict__ upstream,
-    ld_maps_t grad_cls, float* __restrict__ partial) {
-  const Cell c = locate(geom, bm);
-  float s_cls = 0.0f, s_kd = 0.0f;
+    const float* __restrict__ posrec, ld_maps_t grad_cls, float* __restrict__ partial) {
+  __shared__ float lds4[4];
+  const Cell c = locate256(geom, bm);
   const int C = hp.num_classes;
+  const int ch0 = blockIdx.z * kClsChunk;
+  const int ch1 = min(C, ch0 + kClsChunk);
+  float s_cls = 0.0f, s_kd = 0.0f;
   if (c.active) {
     const float lw = label_weights[c.o];
     if (lw == 0.0f) {  // outside the image's valid region
-#pragma unroll 4
-      for (int ch = 0; ch < C; ++ch) *chan_ptr_w(grad_cls, c, ch) = 0.0f;
+      for (int ch = ch0; ch < ch1; ++ch) *chan_ptr_w(grad_cls, c, ch) = 0.0f;
     } else {
       const int64_t lab = labels[c.o];
       const bool pos = lab >= 0 && lab < C;
@@ -307,34 +399,24 @@ __global__ __launch_bounds__(kWave) void loss_cls_kernel(
       const float nts = fmaxf(norm[0], 1.0f);  // ld_head.py:341
       const float c_cls = up_cls * hp.lw_cls * lw / nts;
       const float sc = pos ? score[c.o] : 0.0f;
-      // KD statistics over the 80 class logits (positives only)
-      float ms = 0, mt = 0, rzs = 0, rzt = 0, lzs = 0, lzt = 0, c_kd = 0;
       const float T = hp.T_kd, invT = 1.0f / hp.T_kd;
+      float ms = 0, mt = 0, rzs = 0, rzt = 0, lzs = 0, lzt = 0, c_kd = 0;
       if (pos) {
-        ms = *chan_ptr(cls, c, 0);
-        mt = *chan_ptr(t_cls, c, 0);
-        for (int ch = 1; ch < C; ++ch) {
-          ms = fmaxf(ms, *chan_ptr(cls, c, ch));
-          mt = fmaxf(mt, *chan_ptr(t_cls, c, ch));
-        }
-        float zs = 0.0f, zt = 0.0f;
-        for (int ch = 0; ch < C; ++ch) {
-          zs += expf((*chan_ptr(cls, c, ch) - ms) * invT);
-          zt += expf((*chan_ptr(t_cls, c, ch) - mt) * invT);
-        }
-        rzs = 1.0f / zs;
-        rzt = 1.0f / zt;
-        lzs = logf(zs);
-        lzt = logf(zt);
+        const float4 st = reinterpret_cast<const float4*>(posrec + c.o * kPosRec)[1];
+        ms = st.x;
+        mt = st.z;
+        rzs = 1.0f / st.y;
+        rzt = 1.0f / st.w;
+        lzs = logf(st.y);
+        lzt = logf(st.w);
         const int P_l = counts[geom.num_imgs + c.l];  // >= 1 here
         c_kd = up_kd * hp.lw_kd * lw / (float)P_l * (T / (float)C);
       }
       float rowsum = 0.0f, kl = 0.0f;
 #pragma unroll 4
-      for (int ch = 0; ch < C; ++ch) {
+      for (int ch = ch0; ch < ch1; ++ch) {
         const float x = *chan_ptr(cls, c, ch);
-        float dq;
-        float q;
+        float dq, q;
         if (pos && ch == (int)lab)
           q = ld::qfl_pos(x, sc, &dq);
         else
@@ -354,25 +436,25 @@ __global__ __launch_bounds__(kWave) void loss_cls_kernel(
       if (pos) s_kd = lw * kl * (T * T) / (float)C;
     }
   }
-  const size_t nb = (size_t)gridDim.y * bm.blocks_per_img;
-  const size_t bi = (size_t)c.n * bm.blocks_per_img + blockIdx.x;
-  s_cls = wave_sum(s_cls);
-  s_kd = wave_sum(s_kd);
+  s_cls = block_sum(s_cls, lds4);
+  s_kd = block_sum(s_kd, lds4);
   if (threadIdx.x == 0) {
-    partial[S_CLS * nb + bi] = s_cls;
-    partial[S_KD * nb + bi] = s_kd;
+    partial[part_idx(S_CLS, blockIdx.z, bm, c.n)] = s_cls;
+    partial[part_idx(S_KD, blockIdx.z, bm, c.n)] = s_kd;
   }
 }
 
-// ------------------------------------------------------------- IM (MSE) -----
-__global__ __launch_bounds__(kWave) void loss_im_kernel(
+// ------------------------------------------------------ IM (MSE), dense ------
+__global__ __launch_bounds__(kBlk) void loss_im_dense_kernel(
     ld_geom_t geom, ld_loss_hp_t hp, BlockMap bm, ld_maps_t x, ld_maps_t t_x,
     const float* __restrict__ im, const int32_t* __restrict__ counts,
-    const float* __restrict__ upstream, ld_maps_t grad_x,
+    const float* __restrict__ upstream, ld_maps_t grad_x, int chunk,
     float* __restrict__ partial) {
-  const Cell c = locate(geom, bm);
-  float s_im = 0.0f;
+  __shared__ float lds4[4];
+  const Cell c = locate256(geom, bm);
   const int CH = hp.feat_channels;
+  const int ch0 = blockIdx.z * chunk, ch1 = min(CH, ch0 + chunk);
+  float s_im = 0.0f;
   if (c.active) {
     const int P_l = counts[geom.num_imgs + c.l];
     const int F_l = counts[geom.num_imgs + geom.num_levels + c.l];
@@ -381,27 +463,26 @@ __global__ __launch_bounds__(kWave) void loss_im_kernel(
     const bool sel = enabled && im[c.o] > 0.0f;
     if (!sel) {
 #pragma unroll 8
-      for (int ch = 0; ch < CH; ++ch) *chan_ptr_w(grad_x, c, ch) = 0.0f;
+      for (int ch = ch0; ch < ch1; ++ch) *chan_ptr_w(grad_x, c, ch) = 0.0f;
     } else {
       const float up = upstream ? upstream[7 * geom.num_levels + c.l] : 1.0f;
       const float cg = up * hp.lw_im * 2.0f / ((float)F_l * (float)CH);
 #pragma unroll 8
-      for (int ch = 0; ch < CH; ++ch) {
+      for (int ch = ch0; ch < ch1; ++ch) {
         const float d = *chan_ptr(x, c, ch) - *chan_ptr(t_x, c, ch);
         s_im += d * d;
         *chan_ptr_w(grad_x, c, ch) = cg * d;
       }
     }
   }
-  const size_t nb = (size_t)gridDim.y * bm.blocks_per_img;
-  const size_t bi = (size_t)c.n * bm.blocks_per_img + blockIdx.x;
-  s_im = wave_sum(s_im);
-  if (threadIdx.x == 0) partial[S_IM * nb + bi] = s_im;
+  s_im = block_sum(s_im, lds4);
+  if (threadIdx.x == 0) partial[part_idx(S_IM, blockIdx.z, bm, c.n)] = s_im;
 }
 
 // ------------------------------------------------------------ finalise ------
+// Fixed-order sum of the per-block partials of level l: [slot][z][n][b].
 __global__ __launch_bounds__(kWave) void loss_finalize_kernel(
-    ld_geom_t geom, ld_loss_hp_t hp, BlockMap bm,
+    ld_geom_t geom, ld_loss_hp_t hp, BlockMap bm, int zcls, int zim,
     const int32_t* __restrict__ counts, const float* __restrict__ norm,
     const float* __restrict__ partial, float* __restrict__ losses) {
   const int L = geom.num_levels, N = geom.num_imgs;
@@ -412,10 +493,12 @@ __global__ __launch_bounds__(kWave) void loss_finalize_kernel(
   float acc[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) {
+    const int Z = k == S_BBOX ? 1 : (k == S_CLS || k == S_KD) ? zcls : k == S_IM ? zim : 4;
     float a = 0.0f;
-    for (int i = threadIdx.x; i < per * N; i += kWave) {
-      const int n = i / per, b = b0 + (i - n * per);
-      a += partial[(size_t)k * nb + (size_t)n * bm.blocks_per_img + b];
+    for (int i = threadIdx.x; i < per * N * Z; i += kWave) {
+      const int z = i / (per * N), r = i - z * per * N;
+      const int n = r / per, b = b0 + (r - n * per);
+      a += partial[((size_t)k * kZMax + z) * nb + (size_t)n * bm.blocks_per_img + b];
     }
     acc[k] = wave_sum(a);
   }
@@ -544,11 +627,29 @@ int check_hp(const ld_loss_hp_t* hp) {
 
 }  // namespace
 
+namespace {
+// workspace = [prepass partials | main partials | positives record]
+struct LossWs {
+  size_t pre_floats, main_floats, pos_floats;
+  BlockMap bm64, bm256;
+};
+LossWs loss_ws(const ld_geom_t& g) {
+  LossWs w;
+  w.bm64 = make_block_map(g, kWave);
+  w.bm256 = make_block_map(g, kBlk);
+  w.pre_floats = align_up((size_t)S_COUNT * g.num_imgs * w.bm64.blocks_per_img, 64);
+  w.main_floats =
+      align_up((size_t)S_COUNT * kZMax * g.num_imgs * w.bm256.blocks_per_img, 64);
+  w.pos_floats = (size_t)g.num_imgs * g.num_anchors * kPosRec;
+  return w;
+}
+inline int im_chunk(int ch) { return max(32, (ch + kZMax - 1) / kZMax); }
+}  // namespace
+
 extern "C" size_t ld_loss_workspace_bytes(const ld_geom_t* geom) {
   if (check_geom(geom) != 0) return 0;
-  const BlockMap bm = make_block_map(*geom, kWave);
-  return align_up((size_t)S_COUNT * geom->num_imgs * bm.blocks_per_img * sizeof(float),
-                  256);
+  const LossWs w = loss_ws(*geom);
+  return align_up((w.pre_floats + w.main_floats + w.pos_floats) * sizeof(float), 256);
 }
 
 extern "C" int ld_loss_prepass(const ld_geom_t* geom, const ld_loss_hp_t* hp,
@@ -578,6 +679,64 @@ extern "C" int ld_loss_prepass(const ld_geom_t* geom, const ld_loss_hp_t* hp,
   return (int)hipGetLastError();
 }
 
+extern "C" int ld_loss_main_parts(
+    const ld_geom_t* geom, const ld_loss_hp_t* hp, const ld_maps_t* cls,
+    const ld_maps_t* reg, const ld_maps_t* t_cls, const ld_maps_t* t_reg,
+    const ld_maps_t* x, const ld_maps_t* t_x, const int64_t* labels,
+    const float* label_weights, const float* bbox_targets, const float* vlr,
+    const float* im, const int32_t* counts, const float* weight_targets,
+    const float* score, const float* norm, const float* upstream,
+    const ld_maps_t* grad_cls, const ld_maps_t* grad_reg, const ld_maps_t* grad_x,
+    void* workspace, size_t workspace_bytes, int parts, ld_stream_t stream_) {
+  if (int e = check_geom(geom)) return e;
+  if (int e = check_hp(hp)) return e;
+  if (!cls || !reg || !t_cls || !t_reg || !x || !t_x || !labels ||
+      !label_weights || !bbox_targets || !vlr || !im || !counts ||
+      !weight_targets || !score || !norm || !grad_cls || !grad_reg || !grad_x)
+    return LD_EINVAL;
+  if (!workspace || workspace_bytes < ld_loss_workspace_bytes(geom))
+    return LD_ENOSPACE;
+  if ((hp->num_classes + kClsChunk - 1) / kClsChunk > kZMax) return LD_EUNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  const LossWs w = loss_ws(*geom);
+  const BlockMap& bm = w.bm256;
+  float* partial = (float*)workspace + w.pre_floats;
+  float* posrec = partial + w.main_floats;
+  const unsigned bx = bm.blocks_per_img, by = geom->num_imgs;
+  if (parts & LD_LOSS_PART_POS)
+    hipLaunchKernelGGL(loss_pos_kernel, dim3(bx, by), dim3(kBlk), 0, stream, *geom, *hp,
+                       bm, *cls, *t_cls, *reg, labels, bbox_targets, weight_targets,
+                       norm, upstream, posrec, partial);
+  if (parts & LD_LOSS_PART_REG) {
+    // streaming (non-temporal) access once the three 68-channel maps exceed what
+    // the 256 MiB Infinity Cache can hold; at train-step sizes the gradient is
+    // re-read by the next kernel and should stay cached
+    const size_t bytes = (size_t)geom->num_imgs * geom->num_anchors * 68 * 4 * 3;
+    if (bytes > ((size_t)192 << 20))
+      hipLaunchKernelGGL(loss_reg_dense_kernel<true>, dim3(bx, by, 4), dim3(kBlk), 0,
+                         stream, *geom, *hp, bm, *reg, *t_reg, labels, bbox_targets, vlr,
+                         weight_targets, norm, upstream, posrec, *grad_reg, partial);
+    else
+      hipLaunchKernelGGL(loss_reg_dense_kernel<false>, dim3(bx, by, 4), dim3(kBlk), 0,
+                         stream, *geom, *hp, bm, *reg, *t_reg, labels, bbox_targets, vlr,
+                         weight_targets, norm, upstream, posrec, *grad_reg, partial);
+  }
+  if (parts & LD_LOSS_PART_CLS) {
+    const unsigned zc = (hp->num_classes + kClsChunk - 1) / kClsChunk;
+    hipLaunchKernelGGL(loss_cls_dense_kernel, dim3(bx, by, zc), dim3(kBlk), 0, stream,
+                       *geom, *hp, bm, *cls, *t_cls, labels, label_weights, score,
+                       counts, norm, upstream, posrec, *grad_cls, partial);
+  }
+  if (parts & LD_LOSS_PART_IM) {
+    const int chunk = im_chunk(hp->feat_channels);
+    const unsigned zi = (hp->feat_channels + chunk - 1) / chunk;
+    hipLaunchKernelGGL(loss_im_dense_kernel, dim3(bx, by, zi), dim3(kBlk), 0, stream,
+                       *geom, *hp, bm, *x, *t_x, im, counts, upstream, *grad_x, chunk,
+                       partial);
+  }
+  return (int)hipGetLastError();
+}
+
 extern "C" int ld_loss_main(const ld_geom_t* geom, const ld_loss_hp_t* hp,
                             const ld_maps_t* cls, const ld_maps_t* reg,
                             const ld_maps_t* t_cls, const ld_maps_t* t_reg,
@@ -589,28 +748,11 @@ extern "C" int ld_loss_main(const ld_geom_t* geom, const ld_loss_hp_t* hp,
                             const float* norm, const float* upstream,
                             const ld_maps_t* grad_cls, const ld_maps_t* grad_reg,
                             const ld_maps_t* grad_x, void* workspace,
-                            size_t workspace_bytes, ld_stream_t stream_) {
-  if (int e = check_geom(geom)) return e;
-  if (int e = check_hp(hp)) return e;
-  if (!cls || !reg || !t_cls || !t_reg || !x || !t_x || !labels ||
-      !label_weights || !bbox_targets || !vlr || !im || !counts ||
-      !weight_targets || !score || !norm || !grad_cls || !grad_reg || !grad_x)
-    return LD_EINVAL;
-  if (!workspace || workspace_bytes < ld_loss_workspace_bytes(geom))
-    return LD_ENOSPACE;
-  hipStream_t stream = (hipStream_t)stream_;
-  const BlockMap bm = make_block_map(*geom, kWave);
-  float* partial = (float*)workspace;
-  dim3 grid(bm.blocks_per_img, geom->num_imgs);
-  hipLaunchKernelGGL(loss_reg_kernel, grid, dim3(kWave), 0, stream, *geom, *hp,
-                     bm, *reg, *t_reg, labels, bbox_targets, vlr,
-                     weight_targets, norm, upstream, *grad_reg, partial);
-  hipLaunchKernelGGL(loss_cls_kernel, grid, dim3(kWave), 0, stream, *geom, *hp,
-                     bm, *cls, *t_cls, labels, label_weights, score, counts,
-                     norm, upstream, *grad_cls, partial);
-  hipLaunchKernelGGL(loss_im_kernel, grid, dim3(kWave), 0, stream, *geom, *hp,
-                     bm, *x, *t_x, im, counts, upstream, *grad_x, partial);
-  return (int)hipGetLastError();
+                            size_t workspace_bytes, ld_stream_t stream) {
+  return ld_loss_main_parts(geom, hp, cls, reg, t_cls, t_reg, x, t_x, labels,
+                            label_weights, bbox_targets, vlr, im, counts,
+                            weight_targets, score, norm, upstream, grad_cls, grad_reg,
+                            grad_x, workspace, workspace_bytes, LD_LOSS_PART_ALL, stream);
 }
 
 extern "C" int ld_loss_finalize(const ld_geom_t* geom, const ld_loss_hp_t* hp,
@@ -620,10 +762,13 @@ extern "C" int ld_loss_finalize(const ld_geom_t* geom, const ld_loss_hp_t* hp,
   if (int e = check_geom(geom)) return e;
   if (int e = check_hp(hp)) return e;
   if (!counts || !norm || !workspace || !losses) return LD_EINVAL;
-  const BlockMap bm = make_block_map(*geom, kWave);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(geom->num_levels), dim3(kWave),
-                     0, (hipStream_t)stream_, *geom, *hp, bm, counts, norm,
-                     (const float*)workspace, losses);
+  const LossWs w = loss_ws(*geom);
+  const int chunk = im_chunk(hp->feat_channels);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(geom->num_levels), dim3(kWave), 0,
+                     (hipStream_t)stream_, *geom, *hp, w.bm256,
+                     (hp->num_classes + kClsChunk - 1) / kClsChunk,
+                     (hp->feat_channels + chunk - 1) / chunk, counts, norm,
+                     (const float*)workspace + w.pre_floats, losses);
   return (int)hipGetLastError();
 }
 

@@ -112,10 +112,42 @@ def levels_desc(levels):
 # microseconds each on the C2 step.  Tensors that went through
 # weight_images() / bn_prepare() once are remembered (weakly) and refreshed by
 # ONE launch per kind from device-resident job tables.
+import os  # noqa: E402
 import weakref  # noqa: E402
 
 _WT_REG, _BN_REG = {}, {}
+_WT_REG_BF16 = {}
 _TABLES = {}
+
+# Matrix-operand precision of the convolutions: 'fp32' (v_mfma_f32_32x32x2_f32,
+# exact fp32: BASELINE configs 1-2) or 'bf16' (v_mfma_f32_32x32x16_bf16 with
+# fp32 accumulate: config 3).  Everything outside the matrix core -- master
+# weights, activations, BN/GN, the loss block, gradients, SGD -- is fp32 in both
+# modes (the reference's fp16 mode casts the same way: auto_fp16 around the
+# nets, .float() on the head's reg output gfl_head.py:181-183, @force_fp32 on
+# the loss ld_head.py:284).  Convs whose reduction is not a multiple of 16
+# channels (the 3-channel stem, the data gradient of the 68-channel gfl_reg)
+# stay on the fp32 kernels.
+_PRECISION = [os.environ.get('LD_PRECISION', 'fp32')]
+
+
+def set_precision(mode):
+    if mode not in ('fp32', 'bf16'):
+        raise ValueError(f'precision {mode!r}: expected fp32 or bf16')
+    if mode != _PRECISION[0]:
+        _PRECISION[0] = mode
+        # only the images the new mode uses should be refreshed per step
+        _WT_REG.clear()
+        _WT_REG_BF16.clear()
+        _TABLES.clear()
+
+
+def get_precision():
+    return _PRECISION[0]
+
+
+def _use_bf16(reduction_channels):
+    return _PRECISION[0] == 'bf16' and reduction_channels % 16 == 0
 
 
 def _register(reg, t):
@@ -145,26 +177,33 @@ def refresh_params(device):
     key = str(device)
     tabs = _TABLES.get(key)
     if tabs is None:
-        live_w, wjobs, wblocks = [], [], []
-        for ref in list(_WT_REG.values()):
-            w = ref()
-            cache = getattr(w, '_ld_images', None) if w is not None else None
-            if w is None or cache is None or w.device != device or \
-                    cache['ident'] != (w.data_ptr(), False) or \
-                    cache['fwd'] is None:
-                continue
-            cout, cin, kh, kw = w.shape
-            j = L.WtJobT()
-            j.w, j.wt_fwd = w.data_ptr(), cache['fwd'].data_ptr()
-            j.wt_bwd = cache['bwd'].data_ptr() if cache['bwd'] is not None \
-                else None
-            j.Cout, j.Cin, j.ntaps = cout, cin, kh * kw
-            n = cache['fwd'].numel()
-            if cache['bwd'] is not None:
-                n = max(n, cache['bwd'].numel())
-            live_w.append((w, cache, cache['bwd'] is not None))
-            wjobs.append(j)
-            wblocks.append((n + 255) // 256)
+        def _wt_jobs(reg, attr):
+            live, jobs, blocks = [], [], []
+            for ref in list(reg.values()):
+                w = ref()
+                cache = getattr(w, attr, None) if w is not None else None
+                if w is None or cache is None or w.device != device or \
+                        cache['ident'] != (w.data_ptr(), False) or \
+                        (cache['fwd'] is None and cache['bwd'] is None):
+                    continue
+                cout, cin, kh, kw = w.shape
+                j = L.WtJobT()
+                j.w = w.data_ptr()
+                j.wt_fwd = cache['fwd'].data_ptr() \
+                    if cache['fwd'] is not None else None
+                j.wt_bwd = cache['bwd'].data_ptr() \
+                    if cache['bwd'] is not None else None
+                j.Cout, j.Cin, j.ntaps = cout, cin, kh * kw
+                n = max(t.numel() for t in (cache['fwd'], cache['bwd'])
+                        if t is not None)
+                live.append((w, cache, cache['fwd'] is not None,
+                             cache['bwd'] is not None))
+                jobs.append(j)
+                blocks.append((n + 255) // 256)
+            return live, jobs, blocks
+
+        live_w, wjobs, wblocks = _wt_jobs(_WT_REG, '_ld_images')
+        live_wb, wbjobs, wbblocks = _wt_jobs(_WT_REG_BF16, '_ld_images_bf16')
         live_b, bjobs, bblocks = [], [], []
         for ref in list(_BN_REG.values()):
             g = ref()
@@ -184,19 +223,25 @@ def refresh_params(device):
             bblocks.append((g.numel() + 255) // 256)
         tabs = dict(
             w=_job_table(wjobs, wblocks, device) if wjobs else None,
+            wb=_job_table(wbjobs, wbblocks, device) if wbjobs else None,
             b=_job_table(bjobs, bblocks, device) if bjobs else None,
-            live_w=live_w, live_b=live_b)
+            live_w=live_w, live_wb=live_wb, live_b=live_b)
         _TABLES[key] = tabs
     st = L.stream_ptr(device)
-    if tabs['w'] is not None:
-        jobs, bmap, nb = tabs['w']
-        L.check(lib.ld_conv_weight_transform_batch(L.ptr(jobs), L.ptr(bmap),
-                                                   nb, st),
-                'ld_conv_weight_transform_batch')
-        for w, cache, has_bwd in tabs['live_w']:
+    for tkey, lkey, fn, what in (
+            ('w', 'live_w', lib.ld_conv_weight_transform_batch,
+             'ld_conv_weight_transform_batch'),
+            ('wb', 'live_wb', lib.ld_conv_bf16_weight_transform_batch,
+             'ld_conv_bf16_weight_transform_batch')):
+        if tabs[tkey] is None:
+            continue
+        jobs, bmap, nb = tabs[tkey]
+        L.check(fn(L.ptr(jobs), L.ptr(bmap), nb, st), what)
+        for w, cache, has_fwd, has_bwd in tabs[lkey]:
             stamp = (w._version, gen, w.data_ptr(), False)
             if cache['ident'] == stamp[2:]:
-                cache['stamp'] = stamp
+                if has_fwd and cache['fwd'] is not None:
+                    cache['stamp'] = stamp
                 if has_bwd and cache['bwd'] is not None:
                     cache['bwd_stamp'] = stamp
     if tabs['b'] is not None:
@@ -215,53 +260,73 @@ def refresh_params(device):
 # ---------------------------------------------------------------------------
 # GEMM weight images (cached on the parameter)
 # ---------------------------------------------------------------------------
-def weight_images(w, need_bwd, smallc=False):
-    """[tap][Cin][Cout] (and, on demand, [flipped tap][Cout][Cin]) images of a
-    conv parameter; rebuilt when the parameter changed."""
+def weight_images(w, need_bwd, smallc=False, bf16=False, need_fwd=True):
+    """GEMM images of a conv parameter, rebuilt when the parameter changed:
+    fp32 [tap][Cin][Cout] / [flipped tap][Cout][Cin] (conv.hip), or with
+    ``bf16`` the [tap][K/8][C][8] bf16 images of conv_bf16.hip."""
     lib = L.get_lib()
     _dev_f32(w, 'conv weight')
     dynamic = w.requires_grad and not getattr(w, '_ld_static', False)
     stamp = (w._version, _PARAM_GEN[0] if dynamic else -1,
              w.data_ptr(), smallc)
-    cache = getattr(w, '_ld_images', None)
+    attr = '_ld_images_bf16' if bf16 else '_ld_images'
+    reg = _WT_REG_BF16 if bf16 else _WT_REG
+    cache = getattr(w, attr, None)
     if cache is None or cache['ident'] != stamp[2:]:
         cache = dict(ident=stamp[2:], stamp=None, fwd=None, bwd=None,
                      bwd_stamp=None)
-        w._ld_images = cache
+        setattr(w, attr, cache)
     cout, cin, kh, kw = w.shape
     st = L.stream_ptr(w.device)
-    if cache['stamp'] != stamp:
+    if bf16:
+        assert not smallc
+
+        def _alloc(backward):
+            n = lib.ld_conv_bf16_weight_image_elems(cout, cin, kh, kw,
+                                                    backward)
+            return torch.empty(n, dtype=torch.bfloat16, device=w.device)
+
+        def _xform(fwd, bwd):
+            L.check(lib.ld_conv_bf16_weight_transform(
+                L.ptr(w), cout, cin, kh, kw, L.ptr(fwd), L.ptr(bwd), st),
+                'ld_conv_bf16_weight_transform')
+    else:
+        def _alloc(backward):
+            if backward:
+                n = lib.ld_conv_weight_image_floats(cout, cin, kh, kw, 1)
+            else:
+                n = lib.ld_conv_weight_image_floats(
+                    cout, cin * kh * kw if smallc else cin,
+                    1 if smallc else kh, 1 if smallc else kw, 0)
+            return torch.empty(n, dtype=torch.float32, device=w.device)
+
+        def _xform(fwd, bwd):
+            if smallc:
+                rc = lib.ld_conv_weight_transform(
+                    L.ptr(w), cout, cin * kh * kw, 1, 1, L.ptr(fwd), None, st)
+            else:
+                rc = lib.ld_conv_weight_transform(
+                    L.ptr(w), cout, cin, kh, kw, L.ptr(fwd), L.ptr(bwd), st)
+            L.check(rc, 'ld_conv_weight_transform')
+
+    if need_fwd and cache['stamp'] != stamp:
         if cache['fwd'] is None:
-            n = lib.ld_conv_weight_image_floats(
-                cout, cin * kh * kw if smallc else cin, 1 if smallc else kh,
-                1 if smallc else kw, 0)
-            cache['fwd'] = torch.empty(n, dtype=torch.float32,
-                                       device=w.device)
-        if smallc:
-            rc = lib.ld_conv_weight_transform(L.ptr(w), cout, cin * kh * kw,
-                                              1, 1, L.ptr(cache['fwd']), None,
-                                              st)
-        else:
-            rc = lib.ld_conv_weight_transform(L.ptr(w), cout, cin, kh, kw,
-                                              L.ptr(cache['fwd']), None, st)
-        L.check(rc, 'ld_conv_weight_transform')
+            cache['fwd'] = _alloc(0)
+            _TABLES.clear()
+        _xform(cache['fwd'], None)
         cache['stamp'] = stamp
         if dynamic and not smallc:
-            _register(_WT_REG, w)
+            _register(reg, w)
     if need_bwd and cache['bwd_stamp'] != stamp:
         if smallc:
             raise L.LdError('small-Cin (stem) conv has no data gradient')
         if cache['bwd'] is None:
-            n = lib.ld_conv_weight_image_floats(cout, cin, kh, kw, 1)
-            cache['bwd'] = torch.empty(n, dtype=torch.float32,
-                                       device=w.device)
+            cache['bwd'] = _alloc(1)
             _TABLES.clear()  # the refresh job of this weight gains an output
-        L.check(lib.ld_conv_weight_transform(L.ptr(w), cout, cin, kh, kw, None,
-                                             L.ptr(cache['bwd']), st),
-                'ld_conv_weight_transform')
+        _xform(None, cache['bwd'])
         cache['bwd_stamp'] = stamp
         if dynamic:
-            _register(_WT_REG, w)
+            _register(reg, w)
     return cache['fwd'], cache['bwd']
 
 
@@ -275,8 +340,6 @@ def weight_images(w, need_bwd, smallc=False):
 # records the winner in the library's table, which ``save_tune_table`` writes
 # out.  Off by default: the shipped table covers the benchmark shapes and
 # everything else uses the library's deterministic model.
-import os  # noqa: E402
-
 _AUTOTUNE = [os.environ.get('LD_CONV_AUTOTUNE', '0') == '1']
 _TUNED = set()
 
@@ -320,20 +383,25 @@ def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
     if d.Pin != P:
         raise L.LdError(f'conv: input has {P} positions, levels say {d.Pin}')
     smallc = cin < 16
-    wt_fwd, _ = weight_images(w, False, smallc)
+    bf16 = not smallc and _use_bf16(cin)
+    wt_fwd, _ = weight_images(w, False, smallc, bf16)
     y3 = torch.empty((N, cout, d.Pout), dtype=torch.float32, device=x3.device)
     if residual is not None:
         _dev_f32(residual, 'residual')
         assert residual.shape == y3.shape
     ep = _epilogue(bias, scale, shift, residual, relu)
-    fn = lib.ld_conv_forward_smallc if smallc else lib.ld_conv_forward
+    fn = lib.ld_conv_forward_smallc if smallc else (
+        lib.ld_conv_bf16_forward if bf16 else lib.ld_conv_forward)
     if not smallc:
-        _tune_once('forward', d, (bias is not None, scale is not None,
-                                  residual is not None, bool(relu)),
-                   lambda: lib.ld_conv_tune_forward(
-                       C.byref(d), L.ptr(x3), L.ptr(wt_fwd), C.byref(ep),
-                       L.ptr(y3), L.stream_ptr(x3.device)))
-    with _timed('conv_fwd', _conv_flops(d)):
+        tune = lib.ld_conv_bf16_tune_forward if bf16 else \
+            lib.ld_conv_tune_forward
+        _tune_once('bf16_forward' if bf16 else 'forward', d,
+                   (bias is not None, scale is not None,
+                    residual is not None, bool(relu)),
+                   lambda: tune(C.byref(d), L.ptr(x3), L.ptr(wt_fwd),
+                                C.byref(ep), L.ptr(y3),
+                                L.stream_ptr(x3.device)))
+    with _timed('conv_fwd_bf16' if bf16 else 'conv_fwd', _conv_flops(d)):
         L.check(fn(C.byref(d), L.ptr(x3), L.ptr(wt_fwd), C.byref(ep),
                    L.ptr(y3), L.stream_ptr(x3.device)), 'ld_conv_forward')
     return y3, out_levels
@@ -400,25 +468,32 @@ class ConvFn(torch.autograd.Function):
         st = L.stream_ptr(x3.device)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            _, wt_bwd = weight_images(w, True)
+            bf16 = _use_bf16(cout)  # the data gradient reduces over Cout
+            _, wt_bwd = weight_images(w, True, bf16=bf16, need_fwd=False)
             dx = torch.empty_like(x3)
-            _tune_once('dgrad', d, (), lambda: lib.ld_conv_tune_dgrad(
-                C.byref(d), L.ptr(dy), L.ptr(wt_bwd), L.ptr(dx), st))
-            with _timed('conv_dgrad', _conv_flops(d)):
-                L.check(lib.ld_conv_dgrad(C.byref(d), L.ptr(dy),
-                                          L.ptr(wt_bwd), L.ptr(dx), st),
-                        'ld_conv_dgrad')
+            tune = lib.ld_conv_bf16_tune_dgrad if bf16 else \
+                lib.ld_conv_tune_dgrad
+            dgrad = lib.ld_conv_bf16_dgrad if bf16 else lib.ld_conv_dgrad
+            _tune_once('bf16_dgrad' if bf16 else 'dgrad', d, (),
+                       lambda: tune(C.byref(d), L.ptr(dy), L.ptr(wt_bwd),
+                                    L.ptr(dx), st))
+            with _timed('conv_dgrad_bf16' if bf16 else 'conv_dgrad',
+                        _conv_flops(d)):
+                L.check(dgrad(C.byref(d), L.ptr(dy), L.ptr(wt_bwd),
+                              L.ptr(dx), st), 'ld_conv_dgrad')
         pw, pb = ctx.params
         if ctx.needs_input_grad[1]:
             sink = _sink(pw)
             dw = sink if sink is not None else torch.empty_like(w)
             need = lib.ld_conv_wgrad_workspace_bytes(C.byref(d))
             ws = workspace(x3.device, need, 'wgrad')
-            with _timed('conv_wgrad', _conv_flops(d)):
-                L.check(lib.ld_conv_wgrad(C.byref(d), L.ptr(x3), L.ptr(dy),
-                                          L.ptr(dw), 0 if sink is None else 1,
-                                          L.ptr(ws), ws.numel(), st),
-                        'ld_conv_wgrad')
+            bf16 = _PRECISION[0] == 'bf16' and cin >= 16
+            wgrad = lib.ld_conv_bf16_wgrad if bf16 else lib.ld_conv_wgrad
+            with _timed('conv_wgrad_bf16' if bf16 else 'conv_wgrad',
+                        _conv_flops(d)):
+                L.check(wgrad(C.byref(d), L.ptr(x3), L.ptr(dy), L.ptr(dw),
+                              0 if sink is None else 1, L.ptr(ws),
+                              ws.numel(), st), 'ld_conv_wgrad')
             if sink is not None:
                 dw = None
                 _emit(pw)

@@ -158,6 +158,9 @@ SIGNATURES = {
     'ld_loss_main': (C.c_int, [_G, _H, _M, _M, _M, _M, _M, _M, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _M, _M, _M,
                                _vp, _sz, _vp]),
+    'ld_loss_main_parts': (C.c_int, [_G, _H, _M, _M, _M, _M, _M, _M, _vp, _vp,
+                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _M, _M, _M, _vp, _sz, _i32, _vp]),
     'ld_loss_finalize': (C.c_int, [_G, _H, _vp, _vp, _vp, _vp, _vp]),
     'ld_kl_integral_dense': (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _vp,
                                        _vp, _vp, _vp]),
@@ -187,6 +190,16 @@ SIGNATURES = {
     'ld_conv_dgrad': (C.c_int, [_CV, _vp, _vp, _vp, _vp]),
     'ld_conv_tune_forward': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
     'ld_conv_tune_dgrad': (C.c_int, [_CV, _vp, _vp, _vp, _vp]),
+    'ld_conv_bf16_weight_image_elems': (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    'ld_conv_bf16_weight_transform': (C.c_int, [_vp, _i32, _i32, _i32, _i32,
+                                                _vp, _vp, _vp]),
+    'ld_conv_bf16_weight_transform_batch': (C.c_int, [_vp, _vp, _i32, _vp]),
+    'ld_conv_bf16_forward': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
+    'ld_conv_bf16_tune_forward': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
+    'ld_conv_bf16_dgrad': (C.c_int, [_CV, _vp, _vp, _vp, _vp]),
+    'ld_conv_bf16_tune_dgrad': (C.c_int, [_CV, _vp, _vp, _vp, _vp]),
+    'ld_conv_bf16_wgrad': (C.c_int, [_CV, _vp, _vp, _vp, _i32, _vp, _sz,
+                                     _vp]),
     'ld_conv_tune_load': (C.c_int, [C.c_char_p]),
     'ld_conv_tune_save': (C.c_int, [C.c_char_p]),
     'ld_conv_tune_clear': (C.c_int, []),

@@ -218,6 +218,68 @@ def bench_conv(out, with_miopen=True):
     out['conv'] = res
 
 
+BF16_CFGS = ['2x2x2x2x1', '2x2x1x2x1', '2x1x2x4x1', '1x2x2x2x1', '1x1x2x4x1',
+             '1x1x1x4x1', '1x1x4x4x1', '2x1x4x4x1', '1x1x1x4x4', '2x1x1x4x4',
+             '1x2x1x2x4', '2x2x1x2x4']
+
+
+def bench_bf16(out):
+    """bf16-MFMA conv (conv_bf16.hip) per C2 layer shape: forward under every
+    streaming shape (LD_CONV_BF16_SHAPE), then forward / dgrad / wgrad with the
+    library's own pick, next to the fp32 kernels on the same tensors."""
+    import ctypes as C
+    from ld_amd import lib as L
+    lib = L.get_lib()
+    dev = torch.device('cuda:0')
+    res = []
+    for name, N, cin, cout, k, stride, pad, levels in CONV_SHAPES:
+        P = sum(h * w for h, w in levels)
+        x = torch.randn(N, cin, P, device=dev)
+        w = (torch.randn(cout, cin, k, k, device=dev) * 0.05).requires_grad_(True)
+        d, _ = Y.conv_desc(N, cin, cout, k, k, stride, pad, levels)
+        flops = 2.0 * N * d.Pout * cout * cin * k * k
+        r = dict(name=name, J=N * d.Pout, cout=cout, K=cin * k * k,
+                 gflop=flops / 1e9)
+        go = torch.randn(N, cout, d.Pout, device=dev)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        st = L.stream_ptr(dev)
+        ws = LB.workspace(dev, lib.ld_conv_wgrad_workspace_bytes(C.byref(d)),
+                          'wgrad')
+        for mode in ('fp32', 'bf16'):
+            Y.set_precision(mode)
+            bf = mode == 'bf16'
+            if bf and (cin % 16 or cout % 16):
+                continue
+            t = timeit(lambda: Y.conv_forward_raw(x, w, stride, pad, levels), 2, 7)
+            r[mode + '_fwd'] = round(flops / t / 1e12, 1)
+            _, wt_bwd = Y.weight_images(w, True, bf16=bf, need_fwd=False)
+            dg = lib.ld_conv_bf16_dgrad if bf else lib.ld_conv_dgrad
+            t = timeit(lambda: dg(C.byref(d), L.ptr(go), L.ptr(wt_bwd), L.ptr(dx),
+                                  st), 2, 7)
+            r[mode + '_dgrad'] = round(flops / t / 1e12, 1)
+            wg = lib.ld_conv_bf16_wgrad if bf else lib.ld_conv_wgrad
+            t = timeit(lambda: wg(C.byref(d), L.ptr(x), L.ptr(go), L.ptr(dw), 0,
+                                  L.ptr(ws), ws.numel(), st), 2, 7)
+            r[mode + '_wgrad'] = round(flops / t / 1e12, 1)
+        Y.set_precision('bf16')
+        if cin % 16 == 0:
+            steps = cin // 16
+            for cfg in BF16_CFGS:
+                dd = int(cfg.split('x')[3])
+                if steps % dd:
+                    continue
+                os.environ['LD_CONV_BF16_SHAPE'] = cfg
+                t = timeit(lambda: Y.conv_forward_raw(x, w, stride, pad, levels),
+                           2, 5)
+                r[cfg] = round(flops / t / 1e12, 1)
+            os.environ.pop('LD_CONV_BF16_SHAPE', None)
+        Y.set_precision('fp32')
+        res.append(r)
+        print(' '.join(f'{k_}={v}' for k_, v in r.items()), flush=True)
+    out['conv_bf16'] = res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--tag', default='r01')
@@ -233,6 +295,8 @@ def main():
         bench_conv_tiles(out)
     if 'stream' in args.only.split(','):
         bench_stream_sweep(out)
+    if 'bf16' in args.only.split(','):
+        bench_bf16(out)
     os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
     path = os.path.join(REPO, 'gpurun_out', f'kernels_{args.tag}.json')
     with open(path, 'w') as f:
