@@ -2,12 +2,10 @@
 signatures: AnchorGenerator, BboxOverlaps2D,
 ATSSAssigner (+ get_vlr_region), PseudoSampler, AssignResult, SamplingResult,
 DeltaXYWHBBoxCoder (constructed by AnchorHead's default, never called here),
-multi_apply / unmap / images_to_levels / reduce_mean, distance2bbox /
-bbox2distance.  Arithmetic goes through libldhip.so.
+reduce_mean, distance2bbox / bbox2distance.  Arithmetic goes through libldhip.so.
 """
 import ctypes as C
 import math
-from functools import partial
 
 import torch
 import torch.distributed as dist
@@ -21,52 +19,10 @@ INF = 100000000
 
 
 # --------------------------------------------------------------- utilities --
-def multi_apply(func, *args, **kwargs):
-    """mmdet/core/utils/misc.py:10-29."""
-    pfunc = partial(func, **kwargs) if kwargs else func
-    map_results = map(pfunc, *args)
-    return tuple(map(list, zip(*map_results)))
-
-
-def unmap(data, count, inds, fill=0):
-    """mmdet/core/utils/misc.py:32-42 (device-side index plumbing)."""
-    if data.dim() == 1:
-        ret = data.new_full((count, ), fill)
-        ret[inds.type(torch.bool)] = data
-    else:
-        new_size = (count, ) + data.size()[1:]
-        ret = data.new_full(new_size, fill)
-        ret[inds.type(torch.bool), :] = data
-    return ret
-
-
-def images_to_levels(target, num_levels):
-    """mmdet/core/anchor/utils.py:4-17."""
-    target = torch.stack(target, 0)
-    level_targets = []
-    start = 0
-    for n in num_levels:
-        end = start + n
-        level_targets.append(target[:, start:end])
-        start = end
-    return level_targets
-
-
-def anchor_inside_flags(flat_anchors, valid_flags, img_shape,
-                        allowed_border=0):
-    """mmdet/core/anchor/utils.py:20-46."""
-    img_h, img_w = img_shape[:2]
-    if allowed_border >= 0:
-        inside_flags = valid_flags & \
-            (flat_anchors[:, 0] >= -allowed_border) & \
-            (flat_anchors[:, 1] >= -allowed_border) & \
-            (flat_anchors[:, 2] < img_w + allowed_border) & \
-            (flat_anchors[:, 3] < img_h + allowed_border)
-    else:
-        inside_flags = valid_flags
-    return inside_flags
-
-
+# The reference's host-side glue around target assignment -- multi_apply,
+# unmap, images_to_levels, anchor_inside_flags (core/utils/misc.py:10-42,
+# core/anchor/utils.py:4-46) -- has no counterpart here: ld_atss_targets writes
+# the dense, level-major target tensors of the whole batch directly.
 def reduce_mean(tensor):
     """mmdet/core/utils/dist_utils.py:63-69."""
     if not (dist.is_available() and dist.is_initialized()):
@@ -89,32 +45,26 @@ def bbox2result(bboxes, labels, num_classes):
     return [bboxes[labels == i, :] for i in range(num_classes)]
 
 
+_LTRB_SIGN = (-1.0, -1.0, 1.0, 1.0)
+
+
 def distance2bbox(points, distance, max_shape=None):
-    """mmdet/core/bbox/transforms.py:119-156 (glue on tiny tensors)."""
-    x1 = points[:, 0] - distance[:, 0]
-    y1 = points[:, 1] - distance[:, 1]
-    x2 = points[:, 0] + distance[:, 2]
-    y2 = points[:, 1] + distance[:, 3]
+    """(x, y) points + (l, t, r, b) distances -> xyxy boxes, optionally clipped
+    to ``max_shape = (h, w)`` (semantics of core/bbox/transforms.py:119-156)."""
+    boxes = points[:, (0, 1, 0, 1)] + distance * distance.new_tensor(_LTRB_SIGN)
     if max_shape is not None:
-        x1 = x1.clamp(min=0, max=max_shape[1])
-        y1 = y1.clamp(min=0, max=max_shape[0])
-        x2 = x2.clamp(min=0, max=max_shape[1])
-        y2 = y2.clamp(min=0, max=max_shape[0])
-    return torch.stack([x1, y1, x2, y2], -1)
+        hi = boxes.new_tensor((max_shape[1], max_shape[0]) * 2)
+        boxes = torch.minimum(boxes.clamp(min=0), hi)
+    return boxes
 
 
 def bbox2distance(points, bbox, max_dis=None, eps=0.1):
-    """mmdet/core/bbox/transforms.py:159-180."""
-    left = points[:, 0] - bbox[:, 0]
-    top = points[:, 1] - bbox[:, 1]
-    right = bbox[:, 2] - points[:, 0]
-    bottom = bbox[:, 3] - points[:, 1]
+    """xyxy boxes -> (l, t, r, b) distances from ``points``, clamped to
+    [0, max_dis - eps] (semantics of core/bbox/transforms.py:159-180)."""
+    dist_ = (bbox - points[:, (0, 1, 0, 1)]) * bbox.new_tensor(_LTRB_SIGN)
     if max_dis is not None:
-        left = left.clamp(min=0, max=max_dis - eps)
-        top = top.clamp(min=0, max=max_dis - eps)
-        right = right.clamp(min=0, max=max_dis - eps)
-        bottom = bottom.clamp(min=0, max=max_dis - eps)
-    return torch.stack([left, top, right, bottom], -1)
+        dist_ = dist_.clamp(min=0, max=max_dis - eps)
+    return dist_
 
 
 # ---------------------------------------------------------- IoU calculator --
@@ -272,26 +222,25 @@ class AssignResult:
 
 
 class SamplingResult:
-    """mmdet/core/bbox/samplers/sampling_result.py:25-49."""
+    """Positive / negative index sets of one image with the boxes they select
+    (attribute names of samplers/sampling_result.py:25-49, which LD code reads:
+    pos_inds, neg_inds, pos_bboxes, neg_bboxes, pos_is_gt, num_gts,
+    pos_assigned_gt_inds (0-based), pos_gt_bboxes, pos_gt_labels)."""
 
     def __init__(self, pos_inds, neg_inds, bboxes, gt_bboxes, assign_result,
                  gt_flags):
-        self.pos_inds = pos_inds
-        self.neg_inds = neg_inds
-        self.pos_bboxes = bboxes[pos_inds]
-        self.neg_bboxes = bboxes[neg_inds]
+        gt = gt_bboxes.reshape(-1, 4)
+        matched = assign_result.gt_inds[pos_inds] - 1  # 1-based -> 0-based
+        if gt.shape[0] == 0 and matched.numel() != 0:
+            raise AssertionError('positives without any ground-truth box')
+        self.pos_inds, self.neg_inds = pos_inds, neg_inds
+        self.pos_bboxes, self.neg_bboxes = bboxes[pos_inds], bboxes[neg_inds]
         self.pos_is_gt = gt_flags[pos_inds]
-        self.num_gts = gt_bboxes.shape[0]
-        self.pos_assigned_gt_inds = assign_result.gt_inds[pos_inds] - 1
-        if gt_bboxes.numel() == 0:
-            assert self.pos_assigned_gt_inds.numel() == 0
-            self.pos_gt_bboxes = torch.empty_like(gt_bboxes).view(-1, 4)
-        else:
-            if len(gt_bboxes.shape) < 2:
-                gt_bboxes = gt_bboxes.view(-1, 4)
-            self.pos_gt_bboxes = gt_bboxes[self.pos_assigned_gt_inds, :]
-        self.pos_gt_labels = assign_result.labels[pos_inds] \
-            if assign_result.labels is not None else None
+        self.num_gts = gt.shape[0]
+        self.pos_assigned_gt_inds = matched
+        self.pos_gt_bboxes = gt[matched] if gt.shape[0] else gt
+        lab = assign_result.labels
+        self.pos_gt_labels = None if lab is None else lab[pos_inds]
 
     @property
     def bboxes(self):
@@ -300,19 +249,20 @@ class SamplingResult:
 
 @BBOX_SAMPLERS.register_module()
 class PseudoSampler:
-    """mmdet/core/bbox/samplers/pseudo_sampler.py:8-41."""
+    """No sampling: every assigned anchor is positive, every unassigned one
+    negative, both in ascending index order (what the reference obtains with
+    nonzero().unique(), samplers/pseudo_sampler.py:24-41)."""
 
     def __init__(self, **kwargs):
         pass
 
     def sample(self, assign_result, bboxes, gt_bboxes, **kwargs):
-        pos_inds = torch.nonzero(assign_result.gt_inds > 0,
-                                 as_tuple=False).squeeze(-1).unique()
-        neg_inds = torch.nonzero(assign_result.gt_inds == 0,
-                                 as_tuple=False).squeeze(-1).unique()
-        gt_flags = bboxes.new_zeros(bboxes.shape[0], dtype=torch.uint8)
+        assigned = assign_result.gt_inds
+        pos_inds = (assigned > 0).nonzero(as_tuple=True)[0]
+        neg_inds = (assigned == 0).nonzero(as_tuple=True)[0]
+        no_gt_proposals = bboxes.new_zeros(bboxes.shape[0], dtype=torch.uint8)
         return SamplingResult(pos_inds, neg_inds, bboxes, gt_bboxes,
-                              assign_result, gt_flags)
+                              assign_result, no_gt_proposals)
 
 
 @BBOX_CODERS.register_module()

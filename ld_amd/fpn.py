@@ -15,55 +15,56 @@ class FPN(nn.Module):
                  extra_convs_on_inputs=True, relu_before_extra_convs=False,
                  no_norm_on_lateral=False, conv_cfg=None, norm_cfg=None,
                  act_cfg=None, upsample_cfg=dict(mode='nearest')):
+        """Constructor arguments and module names (``lateral_convs.i.conv``,
+        ``fpn_convs.i.conv``) of mmdet/models/necks/fpn.py:66-160."""
         super().__init__()
-        assert isinstance(in_channels, list)
-        self.in_channels, self.out_channels = in_channels, out_channels
-        self.num_ins, self.num_outs = len(in_channels), num_outs
-        self.relu_before_extra_convs = relu_before_extra_convs
-        self.no_norm_on_lateral = no_norm_on_lateral
-        self.upsample_cfg = dict(upsample_cfg)
-        if self.upsample_cfg != dict(mode='nearest'):
+        if not isinstance(in_channels, list):
+            raise AssertionError('in_channels must be a list')
+        if dict(upsample_cfg) != dict(mode='nearest'):
             raise NotImplementedError('only nearest top-down upsampling')
         if relu_before_extra_convs:
             raise NotImplementedError('relu_before_extra_convs')
+        if not isinstance(add_extra_convs, (str, bool)):
+            raise AssertionError('add_extra_convs: str or bool')
+        n_in = len(in_channels)
+        last = n_in if end_level == -1 else end_level
+        used = last - start_level  # backbone levels that get a lateral conv
         if end_level == -1:
-            self.backbone_end_level = self.num_ins
-            assert num_outs >= self.num_ins - start_level
+            assert num_outs >= used
         else:
-            self.backbone_end_level = end_level
-            assert end_level <= len(in_channels)
-            assert num_outs == end_level - start_level
+            assert end_level <= n_in and num_outs == used
+        # where the extra (stride-2) levels take their input from
+        source = add_extra_convs
+        if isinstance(source, str):
+            assert source in ('on_input', 'on_lateral', 'on_output')
+        elif source:
+            source = 'on_input' if extra_convs_on_inputs else 'on_output'
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_ins, self.num_outs = n_in, num_outs
         self.start_level, self.end_level = start_level, end_level
-        self.add_extra_convs = add_extra_convs
-        assert isinstance(add_extra_convs, (str, bool))
-        if isinstance(add_extra_convs, str):
-            assert add_extra_convs in ('on_input', 'on_lateral', 'on_output')
-        elif add_extra_convs:
-            self.add_extra_convs = 'on_input' if extra_convs_on_inputs \
-                else 'on_output'
+        self.backbone_end_level = last
+        self.add_extra_convs = source
+        self.relu_before_extra_convs = relu_before_extra_convs
+        self.no_norm_on_lateral = no_norm_on_lateral
+        self.upsample_cfg = dict(upsample_cfg)
 
-        self.lateral_convs = nn.ModuleList()
-        self.fpn_convs = nn.ModuleList()
-        for i in range(self.start_level, self.backbone_end_level):
-            self.lateral_convs.append(
-                ConvModule(in_channels[i], out_channels, 1, conv_cfg=conv_cfg,
-                           norm_cfg=norm_cfg if not no_norm_on_lateral else
-                           None, act_cfg=act_cfg, inplace=False))
-            self.fpn_convs.append(
-                ConvModule(out_channels, out_channels, 3, padding=1,
-                           conv_cfg=conv_cfg, norm_cfg=norm_cfg,
-                           act_cfg=act_cfg, inplace=False))
-        extra_levels = num_outs - self.backbone_end_level + self.start_level
-        if self.add_extra_convs and extra_levels >= 1:
-            for i in range(extra_levels):
-                if i == 0 and self.add_extra_convs == 'on_input':
-                    ch = self.in_channels[self.backbone_end_level - 1]
-                else:
-                    ch = out_channels
-                self.fpn_convs.append(
-                    ConvModule(ch, out_channels, 3, stride=2, padding=1,
-                               conv_cfg=conv_cfg, norm_cfg=norm_cfg,
-                               act_cfg=act_cfg, inplace=False))
+        def block(cin, k, **kw):
+            return ConvModule(cin, out_channels, k, conv_cfg=conv_cfg,
+                              act_cfg=act_cfg, inplace=False, **kw)
+
+        lateral_norm = None if no_norm_on_lateral else norm_cfg
+        self.lateral_convs = nn.ModuleList(
+            block(in_channels[i], 1, norm_cfg=lateral_norm)
+            for i in range(start_level, last))
+        self.fpn_convs = nn.ModuleList(
+            block(out_channels, 3, padding=1, norm_cfg=norm_cfg)
+            for _ in range(used))
+        if source:
+            for j in range(num_outs - used):
+                cin = in_channels[last - 1] \
+                    if (j == 0 and source == 'on_input') else out_channels
+                self.fpn_convs.append(block(cin, 3, stride=2, padding=1,
+                                            norm_cfg=norm_cfg))
 
     def init_weights(self):
         for m in self.modules():

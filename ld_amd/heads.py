@@ -19,7 +19,6 @@ from . import layers as Y
 from . import lib as L
 from . import lossblock as LB
 from .cnn import ConvModule, Conv2d, Scale, bias_init_with_prob, normal_init
-from .core import multi_apply, reduce_mean
 from .registry import (HEADS, build_anchor_generator, build_assigner,
                        build_bbox_coder, build_iou_calculator, build_loss,
                        build_sampler)
