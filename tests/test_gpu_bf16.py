@@ -149,10 +149,13 @@ def test_bf16_train_step_vs_fp32_golden(golden, bf16_mode):
     10^-3 in the logits.  Target assignment does not depend on the logits, so
     labels / positive sets are bit-exact.  Loss terms that are sums of O(1)
     per-anchor values (loss_cls, loss_bbox, loss_dfl, loss_im) move by < 2 %;
-    the distillation KLs are DIFFERENCES of student and teacher log-softmaxes
-    (loss_ld ~ 4e-3 per level), so the same absolute logit error is a larger
-    relative one: they get rtol 10 % + atol 2e-3.  Gradient norms per parameter
-    are checked at 5 % (10 % for the smallest decile)."""
+    the distillation KLs are DIFFERENCES of student and teacher log-softmaxes,
+    so the same absolute logit error is a larger relative one: they get rtol
+    10 % + atol 2e-3.  Gradient norms per parameter: 90th percentile of the
+    relative error < 5 %, maximum < 25 %.
+    Measured on an MI355X (profiles/r02_pytest_gpu_s1_bf16_rccl.txt): loss
+    table within 1.2 % everywhere, gradient norms median 0.65 %, p90 0.87 %,
+    max 1.2 %."""
     from test_gpu_e2e import LOSS_KEYS, _setup
     name = 'c2_r50'
     g, det, batch, dbatch = _setup(golden, name, 50, 2.0)
