@@ -143,19 +143,16 @@ def test_bf16_train_step_vs_fp32_golden(golden, bf16_mode):
     against the REFERENCE's fp32 loss table.
 
     Stated tolerance.  Every conv input is rounded to 8 significant bits
-    (relative error <= 2^-9 per operand); rounding errors are independent across
-    the K = 576...4608 terms of a dot product, so one layer perturbs its output
-    by ~2^-9 relative and ~60 layers of student (and ~110 of teacher) by a few
-    10^-3 in the logits.  Target assignment does not depend on the logits, so
-    labels / positive sets are bit-exact.  Loss terms that are sums of O(1)
-    per-anchor values (loss_cls, loss_bbox, loss_dfl, loss_im) move by < 2 %;
-    the distillation KLs are DIFFERENCES of student and teacher log-softmaxes,
-    so the same absolute logit error is a larger relative one: they get rtol
-    10 % + atol 2e-3.  Gradient norms per parameter: 90th percentile of the
-    relative error < 5 %, maximum < 25 %.
-    Measured on an MI355X (profiles/r02_pytest_gpu_s1_bf16_rccl.txt): loss
-    table within 1.2 % everywhere, gradient norms median 0.65 %, p90 0.87 %,
-    max 1.2 %."""
+    (relative error <= 2^-9 per operand); the rounding errors are independent
+    across the K = 576 ... 4608 terms of a dot product, so a layer perturbs its
+    output by ~2^-9 relative and the ~60 student / ~110 teacher layers
+    accumulate to a few 10^-3 in the logits.  Target assignment does not depend
+    on the logits, so labels / positive sets are the fp32 ones bit for bit.
+    Measured on an MI355X (profiles/r02_pytest_gpu_s1_bf16_rccl.txt): every
+    entry of the (8 keys x 5 levels) loss table within 0.41 % of the fp32
+    reference, per-parameter gradient norms median 0.65 % / p90 0.87 % / max
+    1.2 % off.  Asserted at ~5x that: loss table rtol 2 % (+ atol 1e-3 for the
+    near-empty coarse levels), gradient norms p90 < 3 %, max < 6 %."""
     from test_gpu_e2e import LOSS_KEYS, _setup
     name = 'c2_r50'
     g, det, batch, dbatch = _setup(golden, name, 50, 2.0)
@@ -169,10 +166,7 @@ def test_bf16_train_step_vs_fp32_golden(golden, bf16_mode):
     rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)
     print('bf16 loss table\n', got, '\nfp32 reference\n', ref,
           '\nrelative error per (key, level)\n', rel)
-    tight = [LOSS_KEYS.index(k) for k in ('loss_cls', 'loss_bbox', 'loss_dfl',
-                                          'loss_im')]
-    np.testing.assert_allclose(got[tight], ref[tight], rtol=2e-2, atol=2e-3)
-    np.testing.assert_allclose(got, ref, rtol=1e-1, atol=2e-3)
+    np.testing.assert_allclose(got, ref, rtol=2e-2, atol=1e-3)
     # targets do not depend on the precision mode (bit-exactness of labels /
     # positive sets is test_gpu_lossblock.py's job): loss_kd_neg stays exactly 0
     assert not got[LOSS_KEYS.index('loss_kd_neg')].any()
@@ -187,6 +181,6 @@ def test_bf16_train_step_vs_fp32_golden(golden, bf16_mode):
     print('grad-norm relative error: median %.3e  p90 %.3e  max %.3e (%s)' %
           (np.median(rels), np.quantile(rels, 0.9), rels.max(),
            names[int(rels.argmax())]))
-    assert np.quantile(rels, 0.9) < 5e-2
-    assert rels.max() < 2.5e-1
+    assert np.quantile(rels, 0.9) < 3e-2
+    assert rels.max() < 6e-2
     assert np.isfinite(float(loss))
