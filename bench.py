@@ -150,8 +150,8 @@ def _reg_dense_launcher(dev, sizes, strides, n_img, density, seed=0):
             C.byref(m_t), C.byref(m_t), C.byref(m_s), C.byref(m_t),
             L.ptr(labels), L.ptr(lw), L.ptr(bt), L.ptr(vlr), L.ptr(zeros),
             L.ptr(counts), L.ptr(zeros), L.ptr(zeros), L.ptr(norm), None,
-            C.byref(m_g), C.byref(m_g), C.byref(m_g), L.ptr(ws), ws.numel(),
-            2, st), 'ld_loss_main_parts')
+            C.byref(m_g), C.byref(m_g), C.byref(m_g), None, None, None,
+            L.ptr(ws), ws.numel(), 2, st), 'ld_loss_main_parts')
 
     launch.keep = keep
     return launch, n_img * A * 4

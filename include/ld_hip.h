@@ -79,7 +79,18 @@ typedef struct {
   float lw_ld_vlr, T_ld_vlr;    /* ... (VLR LD)    */
   float lw_kd, T_kd;            /* ... (cls KD)    */
   float lw_im;                  /* IMLoss          */
+  /* GFLv2 / LDv2 (gfocal_head.py:201-217, ld_gflv2.py:116-282): the class
+   * map is cls_score = sigmoid(cls_feat) * quality, a PROBABILITY with
+   * cls_channels = num_classes + 1 channels (use_sigmoid=False,
+   * anchor_head.py:68-71).  With LD_LOSS_PROB_CLS: QFL uses
+   * binary_cross_entropy on probabilities (gfocal_loss.py:27-30),
+   * weight_targets = max_c cls_score without a sigmoid (ld_gflv2.py:200) and
+   * the KD term runs on the separate kd_* maps (raw cls_feat, ld_gflv2.py:243).
+   * cls_channels = 0 means num_classes. */
+  int32_t cls_channels;
+  int32_t flags;
 } ld_loss_hp_t;
+#define LD_LOSS_PROB_CLS 1
 
 /* ---- library ------------------------------------------------------------ */
 /* ABI version of this header; bump on any signature change. */
@@ -186,7 +197,10 @@ int ld_loss_main(const ld_geom_t* geom, const ld_loss_hp_t* hp,
  * forward and gradient -- the north-star fused LD-KL + Integral sweep), CLS
  * (anchor x 16 classes: QFL + KD), IM (anchor x 32 channels: masked MSE).
  * `parts` selects which of them run (benchmarking one kernel of the step at a
- * saturating size; REG/CLS read what POS wrote for the positive anchors). */
+ * saturating size; REG/CLS read what POS wrote for the positive anchors).
+ * kd_s / kd_t / grad_kd: student / teacher maps of the KD term and its
+ * gradient map when they are not the class maps themselves (LDv2: raw
+ * cls_feat); NULL = cls / t_cls / grad_cls (LDHead: KD adds into grad_cls). */
 #define LD_LOSS_PART_POS 1
 #define LD_LOSS_PART_REG 2
 #define LD_LOSS_PART_CLS 4
@@ -201,8 +215,10 @@ int ld_loss_main_parts(const ld_geom_t* geom, const ld_loss_hp_t* hp,
                        const int32_t* counts, const float* weight_targets,
                        const float* score, const float* norm, const float* upstream,
                        const ld_maps_t* grad_cls, const ld_maps_t* grad_reg,
-                       const ld_maps_t* grad_x, void* workspace,
-                       size_t workspace_bytes, int parts, ld_stream_t stream);
+                       const ld_maps_t* grad_x, const ld_maps_t* kd_s,
+                       const ld_maps_t* kd_t, const ld_maps_t* grad_kd,
+                       void* workspace, size_t workspace_bytes, int parts,
+                       ld_stream_t stream);
 
 /* losses: device float[8 * num_levels], key-major (loss_cls[0..L), ...). */
 int ld_loss_finalize(const ld_geom_t* geom, const ld_loss_hp_t* hp,
@@ -475,6 +491,47 @@ int ld_scale_levels_backward(const ld_levels_t* lv, const float* dy, const float
 int ld_sgd_step(float* params, const float* grads, float* momentum_buf, size_t n,
                 float lr, float momentum, float weight_decay, float grad_scale,
                 ld_stream_t stream);
+
+/* ---- GFLv2 distribution-guided quality branch (config 5, R-V2) ----------------
+ * GFocalHead.forward_single's tail (gfocal_head.py:201-217) for all levels and
+ * images in one launch, on the level-concatenated (N, C, P) tensors:
+ *   prob = softmax over the 17 bins of each side of reg (N, 68, P)
+ *   stat = [top-4 probabilities (descending), their mean] per side -> 20 values
+ *   quality = sigmoid(w2 . relu(w1 stat + b1) + b2)       reg_conf, :140-144
+ *   cls_score[c] = sigmoid(cls_feat[c]) * quality          (N, C, P)
+ * w1 (64, 20) row-major, b1 (64), w2 (64), b2 (1); reg_topk = 4, add_mean,
+ * reg_channels = 64 are compiled in.  quality (N, P) is kept for the backward.
+ * Backward: g_cls_feat = g_cls_score * quality * sigma'(cls_feat);
+ * g_reg (N, 68, P) through sigmoid, the MLP, top-k scatter and the softmax
+ * (both fully overwritten); parameter gradients summed over all anchors in a
+ * fixed order (per-block partials in the workspace), written or accumulated. */
+int ld_quality_forward(const float* reg, const float* cls_feat, int N, int C, int P,
+                       const float* w1, const float* b1, const float* w2,
+                       const float* b2, float* cls_score, float* quality,
+                       ld_stream_t stream);
+size_t ld_quality_backward_workspace_bytes(int N, int P);
+int ld_quality_backward(const float* reg, const float* cls_feat, const float* quality,
+                        const float* g_cls_score, int N, int C, int P,
+                        const float* w1, const float* b1, const float* w2,
+                        const float* b2, float* g_cls_feat, float* g_reg,
+                        float* g_w1, float* g_b1, float* g_w2, float* g_b2,
+                        int accumulate, void* workspace, size_t workspace_bytes,
+                        ld_stream_t stream);
+
+/* ---- deformable convolution v1, forward only (config 4's R101-DCN teacher) ---
+ * mmcv.ops.DeformConv2dPack under resnet.py:171-194 (deform_groups = 1,
+ * groups = 1).  ld_deform_im2col samples x (N, Cin, Hin, Win) bilinearly at
+ * p*stride - pad + k*dilation + offset and writes the column tensor
+ * col (N, Cin*KH*KW, Hout*Wout), channel = ci*KH*KW + k (= the order of
+ * weight.view(Cout, Cin*KH*KW)); offset (N, 2*KH*KW, Hout, Wout) holds (dy, dx)
+ * per tap, from the layer's own conv_offset 3x3 conv (ld_conv_forward).  The
+ * product with the weights is ld_conv_forward as a 1x1 conv over Cin*KH*KW
+ * channels.  Outside (-1, H) x (-1, W) the sample is 0; neighbours outside the
+ * map contribute 0 (mmcv deform_conv_cuda_kernel.cuh; parity unpinned, the op
+ * is not in the reference checkout). */
+int ld_deform_im2col(const float* x, const float* offset, int N, int Cin, int Hin,
+                     int Win, int KH, int KW, int stride, int pad, int dilation,
+                     float* col, ld_stream_t stream);
 
 /* ---- inference post-processing ---------------
  * GFLHead.get_bboxes for a whole batch (gfl_head.py:354-451 ->

@@ -30,6 +30,7 @@ PER_FILE = {
     'loss.hip': ['-ffp-contract=off'],
     'rows.hip': ['-ffp-contract=off'],
     'infer.hip': ['-ffp-contract=off'],
+    'quality.hip': ['-ffp-contract=off'],
 }
 
 

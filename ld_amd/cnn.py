@@ -107,6 +107,92 @@ class Conv2d(nn.Module):
                 f'padding={self.padding}, bias={self.bias is not None}')
 
 
+class DeformConv2dPack(nn.Module):
+    """mmcv.ops.DeformConv2dPack (conv type 'DCN'): deformable convolution v1
+    whose offsets come from its own ``conv_offset`` 3x3 conv (zero-initialised,
+    with bias).  Parameter names / shapes as mmcv's: ``weight`` (Cout, Cin, k,
+    k), no bias, ``conv_offset.weight`` (2*k*k*deform_groups, Cin, k, k),
+    ``conv_offset.bias``.  FORWARD ONLY: it exists for the frozen R101-DCN
+    teacher of config 4 (resnet.py:171-194); deform_groups = groups = 1."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1,
+                 padding=0, dilation=1, groups=1, deform_groups=1, bias=False,
+                 **kwargs):
+        super().__init__()
+        k, s, p, d = (_pair(kernel_size), _pair(stride), _pair(padding),
+                      _pair(dilation))
+        if k[0] != k[1] or s[0] != s[1] or p[0] != p[1] or d[0] != d[1]:
+            raise NotImplementedError('only square kernels/strides/pads')
+        if groups != 1 or deform_groups != 1 or bias:
+            raise NotImplementedError(
+                'DCN: groups = deform_groups = 1 and no bias (the '
+                'configs/gfl/*dconv* settings) are built')
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.dilation = k, s, p, d
+        self.groups, self.deform_groups = groups, deform_groups
+        self.weight = nn.Parameter(
+            torch.empty(out_channels, in_channels, k[0], k[1]))
+        self.bias = None
+        self.conv_offset = Conv2d(in_channels, deform_groups * 2 * k[0] * k[1],
+                                  k[0], stride=s[0], padding=p[0], bias=True)
+        if d != (1, 1):
+            raise NotImplementedError('dilated DCN')
+        self.reset_parameters()
+        self._w2d = None
+
+    def reset_parameters(self):
+        # mmcv: uniform(-stdv, stdv), stdv = 1/sqrt(Cin*k*k); offsets start at 0
+        n = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+        stdv = 1.0 / math.sqrt(n)
+        nn.init.uniform_(self.weight, -stdv, stdv)
+        nn.init.zeros_(self.conv_offset.weight)
+        nn.init.zeros_(self.conv_offset.bias)
+
+    def _weight_2d(self):
+        """(Cout, Cin*k*k, 1, 1) view of the weight, kept alive so the GEMM
+        weight image cached on it survives between calls."""
+        w, v = self.weight, self._w2d
+        if v is None or v.data_ptr() != w.data_ptr() or v.device != w.device \
+                or v._version != w._version:
+            v = w.detach().view(self.out_channels, -1, 1, 1)
+            v._ld_static = getattr(w, '_ld_static', False) or \
+                not w.requires_grad
+            self._w2d = v
+        return v
+
+    def forward3_fused(self, x3, levels, scale=None, shift=None, residual=None,
+                       relu=False):
+        """offset conv -> deformable im2col -> 1x1 GEMM with the fused epilogue
+        (BN affine / residual / ReLU)."""
+        if torch.is_grad_enabled() and (x3.requires_grad or
+                                        self.weight.requires_grad):
+            raise NotImplementedError(
+                'DeformConv2dPack is forward-only here (the frozen teacher of '
+                'config 4): call it under torch.no_grad()')
+        if len(levels) != 1:
+            raise NotImplementedError('DCN on level-concatenated tensors')
+        (h, w), = levels
+        N, cin, P = x3.shape
+        k, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
+        off3, out_levels = Y.conv_forward_raw(
+            x3, self.conv_offset.weight, s, p, levels,
+            bias=self.conv_offset.bias)
+        (ho, wo), = out_levels
+        col = Y.deform_im2col(x3, off3, h, w, k, s, p, 1)
+        y3, _ = Y.conv_forward_raw(col, self._weight_2d(), 1, 0,
+                                   ((ho, wo), ), scale=scale, shift=shift,
+                                   residual=residual, relu=relu)
+        return y3, out_levels
+
+    def forward3(self, x3, levels):
+        return self.forward3_fused(x3, levels)
+
+    def forward(self, x):
+        n, c, h, w = x.shape
+        y3, lv = self.forward3(x.reshape(n, c, h * w), ((h, w), ))
+        return y3.view(n, self.out_channels, lv[0][0], lv[0][1])
+
+
 class BatchNorm2d(nn.Module):
     """BatchNorm2d evaluated with its running statistics (the LD configs run
     every BN with norm_eval=True, resnet.py:639-648); affine stays trainable.
@@ -169,9 +255,13 @@ def build_conv_layer(cfg, *args, **kwargs):
     layer_type = cfg['type'] if isinstance(cfg, dict) else cfg
     if layer_type in ('Conv2d', 'Conv'):
         return Conv2d(*args, **kwargs)
+    if layer_type == 'DCN':
+        kw = {k: v for k, v in cfg.items() if k != 'type'}
+        kw.update(kwargs)
+        return DeformConv2dPack(*args, **kw)
     raise NotImplementedError(
         f'conv layer type {layer_type} is not implemented on the MI355X path '
-        '(DCN is the config-4 teacher, a later row of SURVEY.md section 8)')
+        '(DCNv2 / grouped convs are outside SURVEY.md section 8)')
 
 
 def build_norm_layer(cfg, num_features, postfix=''):

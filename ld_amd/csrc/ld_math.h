@@ -104,6 +104,32 @@ LD_HD float qfl_pos(float x, float score, float* dq) {
   return bce * d * d;
 }
 
+// Quality focal loss on PROBABILITIES (use_sigmoid=False: GFLv2, where the
+// prediction is sigmoid(cls_feat) * quality; gfocal_loss.py:27-46 with
+// F.binary_cross_entropy).  torch clamps the two logs at -100 in the forward
+// and differentiates BCE as (p - t) / max(p (1 - p), 1e-12) in the backward
+// (aten binary_cross_entropy / _backward), which is reproduced here.
+//   negative entry : q = bce(p, 0) * p^2
+//   positive entry : q = bce(p, s) * |s - p|^2
+LD_HD float bce_prob(float p, float t, float* dbce) {
+  float lp = fmaxf_(logf(p), -100.0f), l1p = fmaxf_(logf(1.0f - p), -100.0f);
+  *dbce = (p - t) / fmaxf_((1.0f - p) * p, 1e-12f);
+  return -(t * lp + (1.0f - t) * l1p);
+}
+LD_HD float qfl_prob_neg(float p, float* dq) {
+  float db;
+  float bce = bce_prob(p, 0.0f, &db);
+  *dq = db * p * p + bce * 2.0f * p;
+  return bce * p * p;
+}
+LD_HD float qfl_prob_pos(float p, float score, float* dq) {
+  float db;
+  float bce = bce_prob(p, score, &db);
+  float d = score - p;
+  *dq = db * d * d - 2.0f * d * bce;
+  return bce * d * d;
+}
+
 // GIoU loss 1 - GIoU(pred, target) on aligned boxes (iou_loss.py:85-102,
 // iou2d_calculator.py:117-177) and d(loss)/d(pred box), taking the same
 // sub-gradients autograd takes through clamp(min=0) / max(., eps) / min / max

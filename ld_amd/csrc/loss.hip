@@ -113,10 +113,12 @@ __global__ __launch_bounds__(kWave) void loss_prepass_kernel(
   if (c.active) {
     const int64_t lab = labels[c.o];
     if (lab >= 0 && lab < hp.num_classes) {
+      const int CC = hp.cls_channels > 0 ? hp.cls_channels : hp.num_classes;
       float m = *chan_ptr(cls, c, 0);
-      for (int ch = 1; ch < hp.num_classes; ++ch)
-        m = fmaxf(m, *chan_ptr(cls, c, ch));
-      wt = ld::sigmoidf_(m);  // max_c sigmoid(x_c) == sigmoid(max_c x_c)
+      for (int ch = 1; ch < CC; ++ch) m = fmaxf(m, *chan_ptr(cls, c, ch));
+      // LDHead: max_c sigmoid(x_c) == sigmoid(max_c x_c) (ld_head.py:198-199);
+      // LDv2Head: the map already holds probabilities (ld_gflv2.py:200)
+      wt = (hp.flags & LD_LOSS_PROB_CLS) ? m : ld::sigmoidf_(m);
       float e[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -219,6 +221,8 @@ __global__ __launch_bounds__(kBlk) void loss_pos_kernel(
     const float* __restrict__ bbox_targets, const float* __restrict__ weight_targets,
     const float* __restrict__ norm, const float* __restrict__ upstream,
     float* __restrict__ posrec, float* __restrict__ partial) {
+  // cls / t_cls here are the maps of the KD term (LDHead: the class logits;
+  // LDv2Head: the raw cls_feat of student and teacher)
   __shared__ float lds4[4];
   const Cell c = locate256(geom, bm);
   float s_bbox = 0.0f;
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(kBlk) void loss_pos_kernel(
       const float gl = ld::giou_loss_grad(box, tgt, hp.giou_eps, &iou, g);
       s_bbox = wt * gl;
       // softmax statistics of the class logits at temperature T_kd
-      const int C = hp.num_classes;
+      const int C = hp.cls_channels > 0 ? hp.cls_channels : hp.num_classes;
       const float invT = 1.0f / hp.T_kd;
       float ms = *chan_ptr(cls, c, 0), mt = *chan_ptr(t_cls, c, 0);
       for (int ch = 1; ch < C; ++ch) {
@@ -375,25 +379,37 @@ __global__ __launch_bounds__(kBlk) void loss_reg_dense_kernel(
 }
 
 // ------------------------------------------- cls side, dense: QFL (+ KD) -----
+// SPLIT_KD = false (LDHead): KD runs on the class logits themselves and its
+// gradient adds into grad_cls.  SPLIT_KD = true (LDv2Head): cls holds the
+// probabilities cls_score (QFL via binary_cross_entropy), the KD term runs on
+// kd_s / kd_t (raw cls_feat) and its gradient is written to grad_kd (zeros away
+// from the positives).
+template <bool SPLIT_KD>
 __global__ __launch_bounds__(kBlk) void loss_cls_dense_kernel(
-    ld_geom_t geom, ld_loss_hp_t hp, BlockMap bm, ld_maps_t cls, ld_maps_t t_cls,
-    const int64_t* __restrict__ labels, const float* __restrict__ label_weights,
-    const float* __restrict__ score, const int32_t* __restrict__ counts,
-    const float* __restrict__ norm, const float* __restrict__ upstream,
-    const float* __restrict__ posrec, ld_maps_t grad_cls, float* __restrict__ partial) {
+    ld_geom_t geom, ld_loss_hp_t hp, BlockMap bm, ld_maps_t cls, ld_maps_t kd_s,
+    ld_maps_t kd_t, const int64_t* __restrict__ labels,
+    const float* __restrict__ label_weights, const float* __restrict__ score,
+    const int32_t* __restrict__ counts, const float* __restrict__ norm,
+    const float* __restrict__ upstream, const float* __restrict__ posrec,
+    ld_maps_t grad_cls, ld_maps_t grad_kd, float* __restrict__ partial) {
   __shared__ float lds4[4];
   const Cell c = locate256(geom, bm);
-  const int C = hp.num_classes;
+  const int NC = hp.num_classes;  // foreground classes: labels in [0, NC)
+  const int C = hp.cls_channels > 0 ? hp.cls_channels : NC;
+  const bool prob = (hp.flags & LD_LOSS_PROB_CLS) != 0;
   const int ch0 = blockIdx.z * kClsChunk;
   const int ch1 = min(C, ch0 + kClsChunk);
   float s_cls = 0.0f, s_kd = 0.0f;
   if (c.active) {
     const float lw = label_weights[c.o];
     if (lw == 0.0f) {  // outside the image's valid region
-      for (int ch = ch0; ch < ch1; ++ch) *chan_ptr_w(grad_cls, c, ch) = 0.0f;
+      for (int ch = ch0; ch < ch1; ++ch) {
+        *chan_ptr_w(grad_cls, c, ch) = 0.0f;
+        if (SPLIT_KD) *chan_ptr_w(grad_kd, c, ch) = 0.0f;
+      }
     } else {
       const int64_t lab = labels[c.o];
-      const bool pos = lab >= 0 && lab < C;
+      const bool pos = lab >= 0 && lab < NC;
       const float up_cls = upstream ? upstream[0 * geom.num_levels + c.l] : 1.0f;
       const float up_kd = upstream ? upstream[5 * geom.num_levels + c.l] : 1.0f;
       const float nts = fmaxf(norm[0], 1.0f);  // ld_head.py:341
@@ -417,18 +433,34 @@ __global__ __launch_bounds__(kBlk) void loss_cls_dense_kernel(
       for (int ch = ch0; ch < ch1; ++ch) {
         const float x = *chan_ptr(cls, c, ch);
         float dq, q;
-        if (pos && ch == (int)lab)
+        if (prob) {
+          // gfocal_loss.py:41 takes every label < pred.size(1) as "positive",
+          // background (label = num_classes, score 0) included; for it the
+          // positive formula bce(p, 0) |0 - p|^2 IS the negative one
+          if (pos && ch == (int)lab)
+            q = ld::qfl_prob_pos(x, sc, &dq);
+          else
+            q = ld::qfl_prob_neg(x, &dq);
+        } else if (pos && ch == (int)lab) {
           q = ld::qfl_pos(x, sc, &dq);
-        else
+        } else {
           q = ld::qfl_neg(x, &dq);
+        }
         rowsum += q;
         float g = c_cls * dq;
+        float gk = 0.0f;
         if (pos) {
-          const float t = *chan_ptr(t_cls, c, ch);
-          const float ps = expf((x - ms) * invT) * rzs;
+          const float xs = SPLIT_KD ? *chan_ptr(kd_s, c, ch) : x;
+          const float t = *chan_ptr(kd_t, c, ch);
+          const float ps = expf((xs - ms) * invT) * rzs;
           const float pt = expf((t - mt) * invT) * rzt;
-          kl += pt * (((t - mt) * invT - lzt) - ((x - ms) * invT - lzs));
-          g += c_kd * (ps - pt);
+          kl += pt * (((t - mt) * invT - lzt) - ((xs - ms) * invT - lzs));
+          gk = c_kd * (ps - pt);
+        }
+        if (SPLIT_KD) {
+          *chan_ptr_w(grad_kd, c, ch) = gk;
+        } else {
+          g += gk;
         }
         *chan_ptr_w(grad_cls, c, ch) = g;
       }
@@ -687,6 +719,7 @@ extern "C" int ld_loss_main_parts(
     const float* im, const int32_t* counts, const float* weight_targets,
     const float* score, const float* norm, const float* upstream,
     const ld_maps_t* grad_cls, const ld_maps_t* grad_reg, const ld_maps_t* grad_x,
+    const ld_maps_t* kd_s, const ld_maps_t* kd_t, const ld_maps_t* grad_kd,
     void* workspace, size_t workspace_bytes, int parts, ld_stream_t stream_) {
   if (int e = check_geom(geom)) return e;
   if (int e = check_hp(hp)) return e;
@@ -696,7 +729,12 @@ extern "C" int ld_loss_main_parts(
     return LD_EINVAL;
   if (!workspace || workspace_bytes < ld_loss_workspace_bytes(geom))
     return LD_ENOSPACE;
-  if ((hp->num_classes + kClsChunk - 1) / kClsChunk > kZMax) return LD_EUNSUPPORTED;
+  const int CC = hp->cls_channels > 0 ? hp->cls_channels : hp->num_classes;
+  if ((CC + kClsChunk - 1) / kClsChunk > kZMax) return LD_EUNSUPPORTED;
+  const bool split = kd_s != nullptr;
+  if (split != (kd_t != nullptr) || split != (grad_kd != nullptr)) return LD_EINVAL;
+  if (((hp->flags & LD_LOSS_PROB_CLS) != 0) != split)
+    return LD_EINVAL;  // probabilities cannot carry the KD logits, and vice versa
   hipStream_t stream = (hipStream_t)stream_;
   const LossWs w = loss_ws(*geom);
   const BlockMap& bm = w.bm256;
@@ -705,8 +743,8 @@ extern "C" int ld_loss_main_parts(
   const unsigned bx = bm.blocks_per_img, by = geom->num_imgs;
   if (parts & LD_LOSS_PART_POS)
     hipLaunchKernelGGL(loss_pos_kernel, dim3(bx, by), dim3(kBlk), 0, stream, *geom, *hp,
-                       bm, *cls, *t_cls, *reg, labels, bbox_targets, weight_targets,
-                       norm, upstream, posrec, partial);
+                       bm, split ? *kd_s : *cls, split ? *kd_t : *t_cls, *reg, labels,
+                       bbox_targets, weight_targets, norm, upstream, posrec, partial);
   if (parts & LD_LOSS_PART_REG) {
     // streaming (non-temporal) access once the three 68-channel maps exceed what
     // the 256 MiB Infinity Cache can hold; at train-step sizes the gradient is
@@ -722,10 +760,17 @@ extern "C" int ld_loss_main_parts(
                          weight_targets, norm, upstream, posrec, *grad_reg, partial);
   }
   if (parts & LD_LOSS_PART_CLS) {
-    const unsigned zc = (hp->num_classes + kClsChunk - 1) / kClsChunk;
-    hipLaunchKernelGGL(loss_cls_dense_kernel, dim3(bx, by, zc), dim3(kBlk), 0, stream,
-                       *geom, *hp, bm, *cls, *t_cls, labels, label_weights, score,
-                       counts, norm, upstream, posrec, *grad_cls, partial);
+    const unsigned zc = (CC + kClsChunk - 1) / kClsChunk;
+    if (split)
+      hipLaunchKernelGGL(loss_cls_dense_kernel<true>, dim3(bx, by, zc), dim3(kBlk), 0,
+                         stream, *geom, *hp, bm, *cls, *kd_s, *kd_t, labels,
+                         label_weights, score, counts, norm, upstream, posrec,
+                         *grad_cls, *grad_kd, partial);
+    else
+      hipLaunchKernelGGL(loss_cls_dense_kernel<false>, dim3(bx, by, zc), dim3(kBlk), 0,
+                         stream, *geom, *hp, bm, *cls, *cls, *t_cls, labels,
+                         label_weights, score, counts, norm, upstream, posrec,
+                         *grad_cls, *grad_cls, partial);
   }
   if (parts & LD_LOSS_PART_IM) {
     const int chunk = im_chunk(hp->feat_channels);
@@ -752,7 +797,8 @@ extern "C" int ld_loss_main(const ld_geom_t* geom, const ld_loss_hp_t* hp,
   return ld_loss_main_parts(geom, hp, cls, reg, t_cls, t_reg, x, t_x, labels,
                             label_weights, bbox_targets, vlr, im, counts,
                             weight_targets, score, norm, upstream, grad_cls, grad_reg,
-                            grad_x, workspace, workspace_bytes, LD_LOSS_PART_ALL, stream);
+                            grad_x, nullptr, nullptr, nullptr, workspace,
+                            workspace_bytes, LD_LOSS_PART_ALL, stream);
 }
 
 extern "C" int ld_loss_finalize(const ld_geom_t* geom, const ld_loss_hp_t* hp,
@@ -766,7 +812,8 @@ extern "C" int ld_loss_finalize(const ld_geom_t* geom, const ld_loss_hp_t* hp,
   const int chunk = im_chunk(hp->feat_channels);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(geom->num_levels), dim3(kWave), 0,
                      (hipStream_t)stream_, *geom, *hp, w.bm256,
-                     (hp->num_classes + kClsChunk - 1) / kClsChunk,
+                     ((hp->cls_channels > 0 ? hp->cls_channels : hp->num_classes) +
+                      kClsChunk - 1) / kClsChunk,
                      (hp->feat_channels + chunk - 1) / chunk, counts, norm,
                      (const float*)workspace + w.pre_floats, losses);
   return (int)hipGetLastError();

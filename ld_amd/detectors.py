@@ -225,8 +225,8 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
         x = self.extract_feat(img)
         if side is not None:
             main.wait_stream(side)
-            for t in list(teacher_x) + list(out_teacher[0]) + \
-                    list(out_teacher[1]):
+            # GFLHead returns (cls, reg), GFocalHead (cls_score, reg, cls_feat)
+            for t in list(teacher_x) + [t for lvl in out_teacher for t in lvl]:
                 t.record_stream(main)
         else:
             teacher_x, out_teacher = self._teacher_forward(img)

@@ -483,3 +483,204 @@ class LDHead(GFLHead):
                                         *bbox_preds, *x)
         self.last_targets = targets
         return self._loss_dict(table)
+
+
+class _Marker(nn.Module):
+    """Parameter-free placeholder that keeps nn.Sequential's indices (and with
+    them the state_dict keys ``reg_conf.0.*`` / ``reg_conf.2.*``) identical to
+    the reference's [Conv2d, ReLU, Conv2d, Sigmoid]; the arithmetic of all four
+    stages is the fused quality kernel."""
+
+    def __init__(self, what):
+        super().__init__()
+        self.what = what
+
+    def extra_repr(self):
+        return self.what
+
+
+@HEADS.register_module()
+class GFocalHead(GFLHead):
+    """GFLv2 head (gfocal_head.py:14-217): GFLHead's towers + the
+    distribution-guided quality estimator ``reg_conf``; cls_out_channels is
+    num_classes + 1 because its QFL runs with use_sigmoid=False
+    (anchor_head.py:68-71).  forward returns (cls_scores, bbox_preds,
+    cls_feats) like the reference."""
+
+    def __init__(self, num_classes, in_channels, stacked_convs=4,
+                 conv_cfg=None,
+                 norm_cfg=dict(type='GN', num_groups=32, requires_grad=True),
+                 loss_dfl=dict(type='DistributionFocalLoss', loss_weight=0.25),
+                 reg_max=16, reg_topk=4, reg_channels=64, add_mean=True,
+                 **kwargs):
+        if (reg_topk, reg_channels, bool(add_mean), reg_max) != (4, 64, True,
+                                                                 16):
+            raise NotImplementedError(
+                'GFocalHead: the fused quality kernel is compiled for '
+                'reg_topk=4, reg_channels=64, add_mean=True, reg_max=16 '
+                '(the values of configs/gfl/gflv2_*.py and configs/ldv2)')
+        self.reg_topk, self.reg_channels, self.add_mean = (reg_topk,
+                                                           reg_channels,
+                                                           add_mean)
+        self.total_dim = reg_topk + (1 if add_mean else 0)
+        super().__init__(num_classes, in_channels, stacked_convs=stacked_convs,
+                         conv_cfg=conv_cfg, norm_cfg=norm_cfg,
+                         loss_dfl=loss_dfl, reg_max=reg_max, **kwargs)
+
+    def _init_layers(self):
+        """gfocal_head.py:102-144."""
+        super()._init_layers()
+        self.reg_conf = nn.Sequential(
+            Conv2d(4 * self.total_dim, self.reg_channels, 1), _Marker('ReLU'),
+            Conv2d(self.reg_channels, 1, 1), _Marker('Sigmoid'))
+
+    def init_weights(self):
+        """gfocal_head.py:146-158."""
+        super().init_weights()
+        for m in self.reg_conf:
+            if isinstance(m, Conv2d):
+                normal_init(m, std=0.01)
+
+    def forward(self, feats):
+        """gfocal_head.py:160-217, all levels per launch: towers, predictors,
+        per-level Scale, then the fused quality kernel."""
+        assert len(feats) == len(self.scales)
+        x3, levels = Y.pack_levels(feats)
+        cls_feat = reg_feat = x3
+        for m in self.cls_convs:
+            cls_feat, _ = m.forward3(cls_feat, levels)
+        for m in self.reg_convs:
+            reg_feat, _ = m.forward3(reg_feat, levels)
+        cls3, _ = self.gfl_cls.forward3(cls_feat, levels)
+        reg3, _ = self.gfl_reg.forward3(reg_feat, levels)
+        scales = torch.stack([s.scale for s in self.scales])
+        reg3 = Y.scale_levels(reg3, scales, levels)
+        c0, c2 = self.reg_conf[0], self.reg_conf[2]
+        score3, _ = Y.QualityFn.apply(reg3, cls3, c0.weight, c0.bias,
+                                      c2.weight, c2.bias)
+        return (Y.split_levels(score3, levels), Y.split_levels(reg3, levels),
+                Y.split_levels(cls3, levels))
+
+    def _hp(self, **over):
+        over.setdefault('cls_channels', self.cls_out_channels)
+        over.setdefault('flags', L.LD_LOSS_PROB_CLS)
+        return super()._hp(**over)
+
+    def _check_loss_cfg(self):
+        super()._check_loss_cfg()
+        if getattr(self.loss_cls, 'use_sigmoid', True):
+            raise NotImplementedError(
+                'GFocalHead multiplies sigmoid(cls_feat) by the quality score '
+                'itself: its QualityFocalLoss must have use_sigmoid=False '
+                '(configs/gfl/gflv2_*.py)')
+
+    def loss(self, cls_scores, bbox_preds, cls_feat, gt_bboxes, gt_labels,
+             img_metas, gt_bboxes_ignore=None):
+        """gfocal_head.py:230-352 (plain GFLv2: QFL on probabilities + GIoU +
+        DFL); the distillation terms of the fused block run with weight 0 on
+        the student's own detached maps."""
+        self._check_loss_cfg()
+        sizes = [tuple(int(v) for v in f.shape[-2:]) for f in cls_scores]
+        device = cls_scores[0].device
+        hp = self._hp()
+        targets = self.get_targets_batched(sizes, img_metas, gt_bboxes,
+                                           gt_labels, hp, device)
+        det = [c.detach() for c in cls_feat]
+        hp.feat_channels = cls_feat[0].shape[1]
+        teacher = (det, [b.detach() for b in bbox_preds], det, det)
+        table, _ = LB.LDLossBlock.apply(hp, targets, teacher,
+                                        self._norm_reducer(),
+                                        self.unit_upstream, *cls_scores,
+                                        *bbox_preds, *det, *cls_feat)
+        return self._loss_dict(table, ('loss_cls', 'loss_bbox', 'loss_dfl'))
+
+    def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None,
+                      gt_bboxes_ignore=None, proposal_cfg=None, **kwargs):
+        outs = self(x)
+        if proposal_cfg is not None:
+            raise NotImplementedError('proposal_cfg')
+        return self.loss(*outs, gt_bboxes, gt_labels, img_metas,
+                         gt_bboxes_ignore=gt_bboxes_ignore)
+
+    def get_bboxes(self, *args, **kwargs):
+        raise NotImplementedError(
+            'GFocalHead.get_bboxes (gfocal_head.py:354-451) is not wired to '
+            'ld_get_bboxes yet: inference is a "next" row of SURVEY.md '
+            'section 8f and is built for GFLHead / LDHead only')
+
+
+@HEADS.register_module()
+class LDv2Head(GFocalHead):
+    """ld_gflv2.py:44-644: LDHead's distillation terms on a GFocalHead.
+    Differences from LDHead that the fused block is told through its hp flags
+    (ld_gflv2.py:200,243,326): weight_targets = max_c cls_score with no
+    sigmoid, QFL on probabilities over 81 channels, KD on the raw cls_feat of
+    student and teacher (``soft_teacher`` = (cls_score, bbox_pred, cls_feat),
+    of which the first is ignored)."""
+
+    def __init__(self, num_classes, in_channels,
+                 loss_ld=dict(type='KnowledgeDistillationKLDivLoss',
+                              loss_weight=0.25, T=10),
+                 loss_ld_vlr=dict(type='KnowledgeDistillationKLDivLoss',
+                                  loss_weight=0.25, T=10),
+                 loss_kd=dict(type='KnowledgeDistillationKLDivLoss',
+                              loss_weight=10, T=2),
+                 loss_im=dict(type='IMLoss', loss_weight=0),
+                 imitation_method='gibox', **kwargs):
+        super().__init__(num_classes, in_channels, **kwargs)
+        assert imitation_method in ['gibox', 'finegrained', 'fitnet',
+                                    'decouple']
+        self.imitation_method = imitation_method
+        self.loss_im = build_loss(loss_im)
+        self.loss_ld = build_loss(loss_ld)
+        self.loss_ld_vlr = build_loss(loss_ld_vlr)
+        self.loss_kd = build_loss(loss_kd)
+        self.iou_calculator = build_iou_calculator(dict(type='BboxOverlaps2D'))
+
+    def forward_train(self, x, out_teacher, teacher_x, img_metas, gt_bboxes,
+                      gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None,
+                      **kwargs):
+        """ld_gflv2.py:74-114."""
+        outs = self(x)
+        if gt_labels is None:
+            raise NotImplementedError('LDv2Head needs gt_labels')
+        if proposal_cfg is not None:
+            raise NotImplementedError('proposal_cfg')
+        return self.loss(*outs, gt_bboxes, gt_labels, out_teacher, x,
+                         teacher_x, img_metas,
+                         gt_bboxes_ignore=gt_bboxes_ignore)
+
+    def loss(self, cls_scores, bbox_preds, cls_feat, gt_bboxes, gt_labels,
+             soft_teacher, x, teacher_x, img_metas, gt_bboxes_ignore=None):
+        """ld_gflv2.py:286-380 -> dict of 8 lists of per-level scalars."""
+        self._check_loss_cfg()
+        lw_im = float(self.loss_im.loss_weight)
+        if self.imitation_method != 'finegrained' and lw_im != 0.0:
+            raise NotImplementedError(
+                f"imitation_method='{self.imitation_method}' with a non-zero "
+                'loss_im weight: SURVEY.md section 8(f)-4 (gibox is CUDA-only '
+                'in the reference, quirk Q3); use imitation_method='
+                "'finegrained'")
+        if x[0].shape[1] != 256:
+            raise ValueError('LDv2Head hard-codes 256 feature channels '
+                             '(ld_gflv2.py:155-156)')
+        _, soft_target, soft_label = soft_teacher  # ld_gflv2.py:326
+        sizes = [tuple(int(v) for v in f.shape[-2:]) for f in cls_scores]
+        assert len(sizes) == self.anchor_generator.num_levels
+        device = cls_scores[0].device
+        hp = self._hp(lw_ld=self.loss_ld.loss_weight, T_ld=self.loss_ld.T,
+                      lw_ld_vlr=self.loss_ld_vlr.loss_weight,
+                      T_ld_vlr=self.loss_ld_vlr.T,
+                      lw_kd=self.loss_kd.loss_weight, T_kd=self.loss_kd.T,
+                      lw_im=lw_im)
+        targets = self.get_targets_batched(sizes, img_metas, gt_bboxes,
+                                           gt_labels, hp, device)
+        t_kd = [t.detach() for t in soft_label]
+        teacher = (t_kd, [t.detach() for t in soft_target],
+                   [t.detach() for t in teacher_x], t_kd)
+        table, _ = LB.LDLossBlock.apply(hp, targets, teacher,
+                                        self._norm_reducer(),
+                                        self.unit_upstream, *cls_scores,
+                                        *bbox_preds, *x, *cls_feat)
+        self.last_targets = targets
+        return self._loss_dict(table)

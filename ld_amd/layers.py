@@ -828,6 +828,81 @@ def scale_levels(x3, scales, levels):
     return ScaleLevelsFn.apply(x3, scales, levels)
 
 
+def deform_im2col(x3, off3, h, w, k, stride, pad, dilation):
+    """(N, Cin, H*W) + offsets (N, 2*k*k, Hout*Wout) -> column tensor
+    (N, Cin*k*k, Hout*Wout), forward only (ld_deform_im2col)."""
+    lib = L.get_lib()
+    _dev_f32(x3, 'dcn input')
+    _dev_f32(off3, 'dcn offset')
+    N, cin, P = x3.shape
+    ho, wo = out_size(h, k, stride, pad), out_size(w, k, stride, pad)
+    if P != h * w or off3.shape != (N, 2 * k * k, ho * wo):
+        raise L.LdError('deform_im2col: shape mismatch')
+    col = torch.empty((N, cin * k * k, ho * wo), dtype=torch.float32,
+                      device=x3.device)
+    L.check(lib.ld_deform_im2col(L.ptr(x3), L.ptr(off3), N, cin, h, w, k, k,
+                                 stride, pad, dilation, L.ptr(col),
+                                 L.stream_ptr(x3.device)), 'ld_deform_im2col')
+    return col
+
+
+class QualityFn(torch.autograd.Function):
+    """GFLv2's distribution-guided quality branch on level-concatenated
+    tensors (gfocal_head.py:201-217): (reg3 (N, 68, P), cls_feat3 (N, C, P),
+    reg_conf parameters) -> cls_score3 = sigmoid(cls_feat3) * quality."""
+
+    @staticmethod
+    def forward(ctx, reg3, cls_feat3, w1, b1, w2, b2):
+        lib = L.get_lib()
+        for t, n in ((reg3, 'reg'), (cls_feat3, 'cls_feat'), (w1, 'w1'),
+                     (b1, 'b1'), (w2, 'w2'), (b2, 'b2')):
+            _dev_f32(t, 'quality ' + n)
+        N, c, P = cls_feat3.shape
+        if reg3.shape != (N, 68, P) or w1.shape[:2] != (64, 20) or \
+                w2.numel() != 64:
+            raise L.LdError('quality branch: reg_max=16, reg_topk=4, add_mean, '
+                            'reg_channels=64 are compiled in')
+        cls_score = torch.empty_like(cls_feat3)
+        quality = torch.empty((N, P), dtype=torch.float32, device=reg3.device)
+        L.check(lib.ld_quality_forward(
+            L.ptr(reg3), L.ptr(cls_feat3), N, c, P, L.ptr(w1), L.ptr(b1),
+            L.ptr(w2), L.ptr(b2), L.ptr(cls_score), L.ptr(quality),
+            L.stream_ptr(reg3.device)), 'ld_quality_forward')
+        ctx.save_for_backward(reg3, cls_feat3, quality, w1, b1, w2, b2)
+        ctx.params = (w1, b1, w2, b2)
+        _note_use(w1, b1, w2, b2)
+        ctx.mark_non_differentiable(quality)
+        return cls_score, quality
+
+    @staticmethod
+    def backward(ctx, g_cls_score, _g_quality):
+        lib = L.get_lib()
+        reg3, cls_feat3, quality, w1, b1, w2, b2 = ctx.saved_tensors
+        N, c, P = cls_feat3.shape
+        g = g_cls_score.contiguous()
+        g_cf = torch.empty_like(cls_feat3)
+        g_reg = torch.empty_like(reg3)
+        sinks = [_sink(p) for p in ctx.params]
+        direct = all(s is not None for s in sinks)
+        if direct:
+            gp = sinks
+        else:
+            gp = [torch.empty_like(p) for p in ctx.params]
+        need = lib.ld_quality_backward_workspace_bytes(N, P)
+        ws = workspace(reg3.device, need, 'quality_bwd')
+        L.check(lib.ld_quality_backward(
+            L.ptr(reg3), L.ptr(cls_feat3), L.ptr(quality), L.ptr(g), N, c, P,
+            L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(g_cf),
+            L.ptr(g_reg), L.ptr(gp[0]), L.ptr(gp[1]), L.ptr(gp[2]),
+            L.ptr(gp[3]), 1 if direct else 0, L.ptr(ws), ws.numel(),
+            L.stream_ptr(reg3.device)), 'ld_quality_backward')
+        if direct:
+            for p in ctx.params:
+                _emit(p)
+            gp = [None] * 4
+        return (g_reg, g_cf) + tuple(gp)
+
+
 def sgd_step(params_flat, grads_flat, momentum_flat, lr, momentum,
              weight_decay, grad_scale=1.0):
     lib = L.get_lib()

@@ -46,7 +46,11 @@ class LossHpT(C.Structure):
                 ('lw_dfl', C.c_float), ('lw_ld', C.c_float),
                 ('T_ld', C.c_float), ('lw_ld_vlr', C.c_float),
                 ('T_ld_vlr', C.c_float), ('lw_kd', C.c_float),
-                ('T_kd', C.c_float), ('lw_im', C.c_float)]
+                ('T_kd', C.c_float), ('lw_im', C.c_float),
+                ('cls_channels', C.c_int32), ('flags', C.c_int32)]
+
+
+LD_LOSS_PROB_CLS = 1
 
 
 class ConvLevelT(C.Structure):
@@ -135,7 +139,7 @@ def save_tune_table(path):
     return get_lib().ld_conv_tune_save(str(path).encode())
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 _G, _H, _M = C.POINTER(GeomT), C.POINTER(LossHpT), C.POINTER(MapsT)
 _CV, _EP, _LV = C.POINTER(ConvT), C.POINTER(ConvEpilogueT), C.POINTER(LevelsT)
@@ -160,7 +164,16 @@ SIGNATURES = {
                                _vp, _sz, _vp]),
     'ld_loss_main_parts': (C.c_int, [_G, _H, _M, _M, _M, _M, _M, _M, _vp, _vp,
                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                     _M, _M, _M, _vp, _sz, _i32, _vp]),
+                                     _M, _M, _M, _M, _M, _M, _vp, _sz, _i32,
+                                     _vp]),
+    'ld_deform_im2col': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32,
+                                   _i32, _i32, _i32, _i32, _vp, _vp]),
+    'ld_quality_forward': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp,
+                                     _vp, _vp, _vp, _vp]),
+    'ld_quality_backward_workspace_bytes': (_sz, [_i32, _i32]),
+    'ld_quality_backward': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32,
+                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _i32, _vp, _sz, _vp]),
     'ld_loss_finalize': (C.c_int, [_G, _H, _vp, _vp, _vp, _vp, _vp]),
     'ld_kl_integral_dense': (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _vp,
                                        _vp, _vp, _vp]),

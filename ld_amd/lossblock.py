@@ -29,8 +29,9 @@ def workspace(device, nbytes, tag='ws'):
 def make_hp(num_classes=80, reg_max=16, topk=9, feat_channels=256, lw_cls=1.0,
             qfl_beta=2.0, lw_bbox=2.0, giou_eps=1e-6, lw_dfl=0.25, lw_ld=0.25,
             T_ld=10.0, lw_ld_vlr=0.25, T_ld_vlr=10.0, lw_kd=10.0, T_kd=2.0,
-            lw_im=2.0):
+            lw_im=2.0, cls_channels=0, flags=0):
     hp = L.LossHpT()
+    hp.cls_channels, hp.flags = cls_channels, flags
     hp.num_classes, hp.reg_max, hp.topk = num_classes, reg_max, topk
     hp.feat_channels = feat_channels
     hp.lw_cls, hp.qfl_beta, hp.lw_bbox, hp.giou_eps = (lw_cls, qfl_beta,
@@ -133,10 +134,13 @@ class _LossState:
 
 
 def loss_block_forward(hp, targets, cls, reg, t_cls, t_reg, x, t_x,
-                       reduce_norm=None, upstream=None):
+                       reduce_norm=None, upstream=None, kd_s=None, kd_t=None):
     """Run prepass -> (normaliser reduction) -> main -> finalise.
 
     cls/reg/x: student per-level NCHW tensors; t_*: teacher's.
+    kd_s / kd_t (LDv2): student / teacher maps of the KD term when it does not
+    run on ``cls`` itself (raw cls_feat, ld_gflv2.py:243); ``cls`` then holds
+    probabilities and ``t_cls`` is unused.
     reduce_norm: optional callable(norm_tensor[2]) doing the cross-rank MEAN
     in place (core/utils/dist_utils.py:63-69) -- device side, no host sync.
     Returns (losses (8, L) tensor, grads dict of lists, norm tensor).
@@ -156,6 +160,13 @@ def loss_block_forward(hp, targets, cls, reg, t_cls, t_reg, x, t_x,
            for t in x]
     mg_cls, mg_reg, mg_x = L.make_maps(g_cls), L.make_maps(g_reg), \
         L.make_maps(g_x)
+    split = kd_s is not None
+    g_kd = m_kds = m_kdt = mg_kd = None
+    if split:
+        g_kd = [torch.empty_like(t, memory_format=torch.contiguous_format)
+                for t in kd_s]
+        m_kds, m_kdt, mg_kd = (L.make_maps(kd_s), L.make_maps(kd_t),
+                               L.make_maps(g_kd))
     wt = torch.empty((N, A), dtype=torch.float32, device=device)
     score = torch.empty((N, A), dtype=torch.float32, device=device)
     norm = torch.zeros(4, dtype=torch.float32, device=device)
@@ -175,19 +186,21 @@ def loss_block_forward(hp, targets, cls, reg, t_cls, t_reg, x, t_x,
     if upstream is not None:
         up = L.require_device(upstream.contiguous(), torch.float32,
                               'upstream')
-    L.check(lib.ld_loss_main(
+    L.check(lib.ld_loss_main_parts(
         C.byref(geom), C.byref(hp), C.byref(m_cls), C.byref(m_reg),
         C.byref(m_tcls), C.byref(m_treg), C.byref(m_x), C.byref(m_tx),
         L.ptr(targets['labels']), L.ptr(targets['label_weights']),
         L.ptr(targets['bbox_targets']), L.ptr(targets['vlr']),
         L.ptr(targets['im']), L.ptr(targets['counts']), L.ptr(wt),
         L.ptr(score), L.ptr(norm), L.ptr(up), C.byref(mg_cls),
-        C.byref(mg_reg), C.byref(mg_x), L.ptr(ws), ws.numel(), st),
+        C.byref(mg_reg), C.byref(mg_x),
+        C.byref(m_kds) if split else None, C.byref(m_kdt) if split else None,
+        C.byref(mg_kd) if split else None, L.ptr(ws), ws.numel(), 15, st),
         'ld_loss_main')
     L.check(lib.ld_loss_finalize(
         C.byref(geom), C.byref(hp), L.ptr(targets['counts']), L.ptr(norm),
         L.ptr(ws), L.ptr(losses), st), 'ld_loss_finalize')
-    return losses, dict(cls=g_cls, reg=g_reg, x=g_x), norm, dict(
+    return losses, dict(cls=g_cls, reg=g_reg, x=g_x, kd=g_kd), norm, dict(
         weight_targets=wt, score=score)
 
 
@@ -201,10 +214,14 @@ class LDLossBlock(torch.autograd.Function):
     def forward(ctx, hp, targets, teacher, reduce_norm, unit_upstream,
                 *student):
         nl = targets['geom'].num_levels
-        cls, reg, x = student[:nl], student[nl:2 * nl], student[2 * nl:]
-        t_cls, t_reg, t_x = teacher
+        cls, reg, x = (student[:nl], student[nl:2 * nl],
+                       student[2 * nl:3 * nl])
+        kd_s = student[3 * nl:] or None  # LDv2: raw cls_feat
+        t_cls, t_reg, t_x = teacher[:3]
+        kd_t = teacher[3] if len(teacher) > 3 else None
         losses, grads, norm, aux = loss_block_forward(
-            hp, targets, cls, reg, t_cls, t_reg, x, t_x, reduce_norm)
+            hp, targets, cls, reg, t_cls, t_reg, x, t_x, reduce_norm,
+            kd_s=kd_s, kd_t=kd_t)
         ctx.unit_upstream = unit_upstream
         ctx.pack = (hp, targets, teacher, norm)
         ctx.nl = nl
@@ -220,24 +237,31 @@ class LDLossBlock(torch.autograd.Function):
             hp, targets, teacher, norm = ctx.pack
             student = ctx.saved_tensors
             nl = ctx.nl
-            cls, reg, x = student[:nl], student[nl:2 * nl], student[2 * nl:]
+            cls, reg, x = (student[:nl], student[nl:2 * nl],
+                           student[2 * nl:3 * nl])
+            kd_s = student[3 * nl:] or None
             # the normalisers are constants of the graph (the reference takes
             # them through .item(), ld_head.py:340-341,363): reuse them
             _, grads, _, _ = _rerun_with_upstream(hp, targets, teacher, norm,
-                                                  cls, reg, x, g_losses)
+                                                  cls, reg, x, g_losses, kd_s)
         out = tuple(grads['cls']) + tuple(grads['reg']) + tuple(grads['x'])
+        if grads.get('kd') is not None:
+            out = out + tuple(grads['kd'])
         return (None, None, None, None, None) + out
 
 
-def _rerun_with_upstream(hp, targets, teacher, norm, cls, reg, x, upstream):
-    t_cls, t_reg, t_x = teacher
+def _rerun_with_upstream(hp, targets, teacher, norm, cls, reg, x, upstream,
+                         kd_s=None):
+    t_cls, t_reg, t_x = teacher[:3]
+    kd_t = teacher[3] if len(teacher) > 3 else None
     fixed = norm.clone()
 
     def _restore(n):
         n.copy_(fixed)
 
     return loss_block_forward(hp, targets, cls, reg, t_cls, t_reg, x, t_x,
-                              reduce_norm=_restore, upstream=upstream)
+                              reduce_norm=_restore, upstream=upstream,
+                              kd_s=kd_s, kd_t=kd_t)
 
 
 # ---------------------------------------------------------------------------

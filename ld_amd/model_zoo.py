@@ -84,6 +84,49 @@ def ld_detector(student_depth=50, teacher_depth=101,
                 test_cfg=copy.deepcopy(_TEST_CFG))
 
 
+def _gflv2_head_common():
+    """configs/gfl/gflv2_r50_fpn_1x_coco.py:20-40: GFLv2's QFL runs on the
+    joint probability (use_sigmoid=False)."""
+    h = _gfl_head_common()
+    h['loss_cls'] = dict(type='QualityFocalLoss', use_sigmoid=False, beta=2.0,
+                         loss_weight=1.0)
+    h.update(reg_topk=4, reg_channels=64, add_mean=True)
+    return h
+
+
+def gflv2_detector(depth=101):
+    """A GFLv2 teacher (configs/gfl/gflv2_r101_fpn_2x_coco.py)."""
+    head = dict(type='GFocalHead', loss_bbox=dict(type='GIoULoss',
+                                                  loss_weight=2.0),
+                **_gflv2_head_common())
+    return dict(type='GFL', pretrained=None, backbone=_backbone(depth),
+                neck=_neck(depth), bbox_head=head,
+                train_cfg=copy.deepcopy(_TRAIN_CFG),
+                test_cfg=copy.deepcopy(_TEST_CFG))
+
+
+def ldv2_detector(student_depth=50, teacher_depth=101,
+                  imitation_method='finegrained', loss_im_weight=2.0):
+    """configs/ldv2/ld_r50_gflv2_r101_fpn_1x.py with the device-clean
+    imitation method (its own 'gibox' is CUDA-only in the reference, SURVEY
+    quirk Q3)."""
+    head = dict(type='LDv2Head', loss_bbox=dict(type='GIoULoss',
+                                                loss_weight=2.0),
+                loss_ld=dict(type='KnowledgeDistillationKLDivLoss',
+                             loss_weight=0.25, T=10),
+                loss_kd=dict(type='KnowledgeDistillationKLDivLoss',
+                             loss_weight=10, T=2),
+                loss_im=dict(type='IMLoss', loss_weight=loss_im_weight),
+                imitation_method=imitation_method, **_gflv2_head_common())
+    return dict(type='KnowledgeDistillationSingleStageDetector',
+                pretrained=None,
+                teacher_config=dict(model=gflv2_detector(teacher_depth)),
+                teacher_ckpt=None, output_feature=True,
+                backbone=_backbone(student_depth), neck=_neck(student_depth),
+                bbox_head=head, train_cfg=copy.deepcopy(_TRAIN_CFG),
+                test_cfg=copy.deepcopy(_TEST_CFG))
+
+
 OPTIMIZER = dict(type='SGD', lr=0.0025, momentum=0.9, weight_decay=0.0001)
 
 

@@ -28,6 +28,10 @@ def _conv_bn(x3, levels, conv, bn, residual=None, relu=True):
     if bn.training:
         raise NotImplementedError('BatchNorm in training mode (use '
                                   'norm_eval=True; resnet.py:639-648)')
+    if hasattr(conv, 'forward3_fused'):  # DCN: forward-only, fused epilogue
+        scale, shift, _ = Y.bn_prepare(bn.weight, bn.bias, bn.running_mean,
+                                       bn.running_var, bn.eps)
+        return conv.forward3_fused(x3, levels, scale, shift, residual, relu)
     if not need_grad:
         return Y.conv_bn_act_infer(x3, w, bn.weight, bn.bias, bn.running_mean,
                                    bn.running_var, bn.eps, conv.stride[0],
@@ -80,10 +84,9 @@ class Bottleneck(nn.Module):
                  norm_cfg=dict(type='BN'), dcn=None, plugins=None):
         super().__init__()
         assert style in ['pytorch', 'caffe']
-        if dcn is not None:
-            raise NotImplementedError(
-                'DCN (config 4 teacher) is a later row of SURVEY.md section 8')
+        assert dcn is None or isinstance(dcn, dict)
         assert plugins is None and dilation == 1
+        self.dcn, self.with_dcn = dcn, dcn is not None
         self.conv1_stride, self.conv2_stride = (1, stride) \
             if style == 'pytorch' else (stride, 1)
         self.norm1_name, norm1 = build_norm_layer(norm_cfg, planes, postfix=1)
@@ -93,9 +96,19 @@ class Bottleneck(nn.Module):
         self.conv1 = build_conv_layer(conv_cfg, inplanes, planes, 1,
                                       stride=self.conv1_stride, bias=False)
         self.add_module(self.norm1_name, norm1)
-        self.conv2 = build_conv_layer(conv_cfg, planes, planes, 3,
-                                      stride=self.conv2_stride, padding=1,
-                                      bias=False)
+        fallback_on_stride = False
+        if self.with_dcn:  # resnet.py:171-194
+            dcn = dict(dcn)
+            fallback_on_stride = dcn.pop('fallback_on_stride', False)
+        if not self.with_dcn or fallback_on_stride:
+            self.conv2 = build_conv_layer(conv_cfg, planes, planes, 3,
+                                          stride=self.conv2_stride, padding=1,
+                                          bias=False)
+        else:
+            assert conv_cfg is None, 'conv_cfg must be None for DCN'
+            self.conv2 = build_conv_layer(dcn, planes, planes, 3,
+                                          stride=self.conv2_stride, padding=1,
+                                          bias=False)
         self.add_module(self.norm2_name, norm2)
         self.conv3 = build_conv_layer(conv_cfg, planes,
                                       planes * self.expansion, 1, bias=False)
@@ -172,9 +185,11 @@ class ResNet(nn.Module):
         if deep_stem or avg_down or plugins is not None or \
                 tuple(dilations) != (1, 1, 1, 1):
             raise NotImplementedError('ResNet variant outside the LD configs')
+        self.dcn, self.stage_with_dcn = dcn, stage_with_dcn
         if dcn is not None:
-            raise NotImplementedError(
-                'DCN (config 4 teacher) is a later row of SURVEY.md section 8')
+            assert len(stage_with_dcn) == num_stages
+            if self.arch_settings[depth][0] is BasicBlock:
+                raise NotImplementedError('DCN in BasicBlock ResNets')
         self.depth, self.stem_channels = depth, stem_channels
         self.base_channels, self.num_stages = base_channels, num_stages
         assert 1 <= num_stages <= 4
@@ -197,9 +212,12 @@ class ResNet(nn.Module):
         self.res_layers = []
         for i, num_blocks in enumerate(self.stage_blocks):
             planes = base_channels * 2**i
+            stage_dcn = dcn if (dcn is not None and stage_with_dcn[i]) \
+                else None
             res_layer = ResLayer(self.block, self.inplanes, planes, num_blocks,
                                  stride=strides[i], style=self.style,
-                                 conv_cfg=conv_cfg, norm_cfg=norm_cfg)
+                                 conv_cfg=conv_cfg, norm_cfg=norm_cfg,
+                                 dcn=stage_dcn)
             self.inplanes = planes * self.block.expansion
             layer_name = f'layer{i + 1}'
             self.add_module(layer_name, res_layer)
@@ -237,6 +255,11 @@ class ResNet(nn.Module):
                     kaiming_init(m)
                 elif isinstance(m, BatchNorm2d):
                     constant_init(m, 1)
+            if self.dcn is not None:  # resnet.py:607-611
+                for m in self.modules():
+                    if isinstance(m, Bottleneck) and \
+                            hasattr(m.conv2, 'conv_offset'):
+                        constant_init(m.conv2.conv_offset, 0)
             if self.zero_init_residual:
                 for m in self.modules():
                     if isinstance(m, Bottleneck):

@@ -21,6 +21,8 @@ Reference entry points exercised (file:line under /root/reference):
   mmdet/models/detectors/kd_one_stage.py:46-81  forward_train
   mmdet/models/detectors/base.py:185-218        _parse_losses
   mmdet/models/dense_heads/gfl_head.py:354-451  GFLHead._get_bboxes (+ multiclass_nms)
+  mmdet/models/dense_heads/gfocal_head.py:145-217 GFocalHead.forward_single (GFLv2)
+  mmdet/models/dense_heads/ld_gflv2.py:116-380  LDv2Head.loss / loss_single
 """
 import argparse
 import os
@@ -497,6 +499,186 @@ def gen_e2e(cases=None):
     print('e2e.npz')
 
 
+# ------------------------------------------------------- GFLv2 / LDv2 (R-V2) --
+def _ldv2_head(imitation_method='finegrained'):
+    """LDv2Head as configs/ldv2/ld_r50_gflv2_r101_fpn_1x.py:27-57 builds it
+    (imitation 'finegrained': 'gibox' is CUDA-only in the reference, quirk Q3)."""
+    from mmdet.models import build_head
+    cfg = dict(
+        type='LDv2Head', num_classes=80, in_channels=256, stacked_convs=4,
+        feat_channels=256,
+        anchor_generator=dict(type='AnchorGenerator', ratios=[1.0],
+                              octave_base_scale=8, scales_per_octave=1,
+                              strides=[8, 16, 32, 64, 128]),
+        loss_cls=dict(type='QualityFocalLoss', use_sigmoid=False, beta=2.0,
+                      loss_weight=1.0),
+        loss_dfl=dict(type='DistributionFocalLoss', loss_weight=0.25),
+        reg_topk=4, reg_channels=64, add_mean=True,
+        loss_ld=dict(type='KnowledgeDistillationKLDivLoss', loss_weight=0.25,
+                     T=10),
+        reg_max=16,
+        loss_kd=dict(type='KnowledgeDistillationKLDivLoss', loss_weight=10,
+                     T=2),
+        loss_im=dict(type='IMLoss', loss_weight=2),
+        loss_bbox=dict(type='GIoULoss', loss_weight=2.0),
+        imitation_method=imitation_method,
+        train_cfg=ref_shim.ConfigDict(
+            assigner=dict(type='ATSSAssigner', topk=9), allowed_border=-1,
+            pos_weight=-1, debug=False),
+        test_cfg=ref_shim.ConfigDict(
+            nms_pre=1000, min_bbox_size=0, score_thr=0.05,
+            nms=dict(type='nms', iou_threshold=0.6), max_per_img=100))
+    return build_head(cfg)
+
+
+def _v2_quality_tail(head, cls_feat, bbox_pred):
+    """The tail of GFocalHead.forward_single (gfocal_head.py:201-217) applied
+    to given tower outputs, through the head's own reg_conf modules."""
+    import torch.nn.functional as F
+    N, C, H, W = bbox_pred.size()
+    prob = F.softmax(bbox_pred.reshape(N, 4, head.reg_max + 1, H, W), dim=2)
+    prob_topk, _ = prob.topk(head.reg_topk, dim=2)
+    stat = torch.cat([prob_topk, prob_topk.mean(dim=2, keepdim=True)], dim=2) \
+        if head.add_mean else prob_topk
+    quality_score = head.reg_conf(stat.reshape(N, -1, H, W))
+    return cls_feat.sigmoid() * quality_score, quality_score
+
+
+LOSSBLOCK_V2_CASES = [
+    # name, pad_shape, img_shape, num_gt, batch seed, head-input seed, store grads
+    ('v2_small', (160, 224), (160, 224), [3, 1], 11, 201, True),
+    ('v2_small_crowd', (160, 224), (150, 200), [20, 7], 12, 202, True),
+    ('v2_c2', (800, 1344), (800, 1333), [7, 7], 1234, 203, False),
+]
+
+
+def gen_lossblock_v2():
+    head = _ldv2_head()
+    head.load_state_dict(synthetic.seeded_state_dict(head.state_dict(), seed=5))
+    conf = [p for n, p in head.named_parameters() if n.startswith('reg_conf')]
+    d = {}
+    d['reg_conf_keys'] = np.array(
+        [n for n, _ in head.named_parameters() if n.startswith('reg_conf')])
+    for name, pad, img_shape, num_gt, bseed, hseed, store in LOSSBLOCK_V2_CASES:
+        batch = synthetic.synthetic_batch(
+            num_imgs=len(num_gt), img_shape=img_shape, pad_shape=pad,
+            num_gt=num_gt, seed=bseed)
+        sizes = synthetic.level_shapes(pad)
+        hi = synthetic.synthetic_head_inputs(len(num_gt), sizes, seed=hseed,
+                                             num_classes=81)
+        for k in ('cls', 'reg', 'x'):
+            for t in hi[k]:
+                t.requires_grad_(True)
+        for p in conf:
+            p.grad = None
+        t0 = time.time()
+        tails = [_v2_quality_tail(head, c, r)
+                 for c, r in zip(hi['cls'], hi['reg'])]
+        cls_scores = [t[0] for t in tails]
+        losses = head.loss(cls_scores, hi['reg'], hi['cls'],
+                           batch['gt_bboxes'], batch['gt_labels'],
+                           (None, hi['t_reg'], hi['t_cls']), hi['x'],
+                           hi['t_x'], batch['img_metas'])
+        table = np.stack(
+            [np.array([float(v.detach()) for v in losses[k]]) for k in LOSS_KEYS])
+        total = sum(sum(v) for v in losses.values())
+        total.backward()
+        d[name + '_cfg'] = np.array(list(pad) + list(img_shape) + [bseed, hseed])
+        d[name + '_num_gt'] = np.array(num_gt)
+        d[name + '_losses'] = table.astype(np.float64)
+        d[name + '_quality_abs_mean'] = np.array(
+            [float(t[1].double().abs().mean()) for t in tails])
+        d[name + '_cls_score_abs_sum'] = np.array(
+            [float(t[0].double().abs().sum()) for t in tails])
+        if store:
+            for l, t in enumerate(tails):
+                d[f'{name}_quality_{l}'] = _np(t[1])
+        for n, p in head.named_parameters():
+            if n.startswith('reg_conf'):
+                d[f'{name}_gparam_{n}'] = _np(p.grad)
+        for k in ('cls', 'reg', 'x'):
+            gs = [t.grad if t.grad is not None else torch.zeros_like(t)
+                  for t in hi[k]]
+            d[f'{name}_g{k}_abs_sum'] = np.array(
+                [float(g.double().abs().sum()) for g in gs])
+            d[f'{name}_g{k}_sum'] = np.array(
+                [float(g.double().sum()) for g in gs])
+            if store:
+                for l, g in enumerate(gs):
+                    d[f'{name}_g{k}_{l}'] = _np(g)
+            else:
+                for l, g in enumerate(gs):
+                    flat = _np(g).reshape(-1)
+                    d[f'{name}_g{k}_{l}_sample'] = flat[np.arange(0, flat.size,
+                                                                  1009)]
+        print(f'  lossblock {name}: {time.time() - t0:.2f}s  total='
+              f'{float(total):.6f}')
+    np.savez_compressed(os.path.join(OUT, 'lossblock_v2.npz'), **d)
+    print('lossblock_v2.npz')
+
+
+E2E_V2_CASES = [
+    ('v2_tiny_r50', 'configs/ldv2/ld_r50_gflv2_r101_fpn_1x.py', (128, 160),
+     (128, 150), [3, 2], 21),
+    ('v2_small_r50', 'configs/ldv2/ld_r50_gflv2_r101_fpn_1x.py', (256, 320),
+     (256, 320), [5, 2], 22),
+]
+
+
+def gen_e2e_v2():
+    """Whole-model LDv2 step (kd_one_stage.py:46-81 with LDv2Head / a
+    GFocalHead teacher) from the reference's own config file."""
+    d = {}
+    for name, cfg_path, pad, img_shape, num_gt, bseed in E2E_V2_CASES:
+        torch.manual_seed(0)
+        det = build_reference_detector(cfg_path, imitation_method='finegrained')
+        det.load_state_dict(
+            synthetic.seeded_state_dict(det.state_dict(), seed=1))
+        det.teacher_model.load_state_dict(
+            synthetic.seeded_state_dict(det.teacher_model.state_dict(), seed=2))
+        det.train()
+        batch = synthetic.synthetic_batch(
+            num_imgs=len(num_gt), img_shape=img_shape, pad_shape=pad,
+            num_gt=num_gt, seed=bseed)
+        t0 = time.time()
+        losses = det.forward_train(batch['img'], batch['img_metas'],
+                                   batch['gt_bboxes'], batch['gt_labels'])
+        table = np.stack(
+            [np.array([float(v.detach()) for v in losses[k]]) for k in LOSS_KEYS])
+        loss, log_vars = det._parse_losses(losses)
+        loss.backward()
+        d[name + '_cfg'] = np.array(list(pad) + list(img_shape) + [bseed])
+        d[name + '_num_gt'] = np.array(num_gt)
+        d[name + '_losses'] = table.astype(np.float64)
+        d[name + '_log_vars'] = np.array(
+            [log_vars[k] for k in LOSS_KEYS + ['loss']], dtype=np.float64)
+        names, norms = [], []
+        for k, p in det.named_parameters():
+            if p.grad is not None:
+                names.append(k)
+                norms.append(float(p.grad.double().norm()))
+        d[name + '_grad_names'] = np.array(names)
+        d[name + '_grad_norms'] = np.array(norms)
+        for tag, mod in (('student', det), ('teacher', det.teacher_model)):
+            sd = mod.state_dict()
+            d[f'{name}_{tag}_keys'] = np.array(list(sd.keys()))
+            d[f'{name}_{tag}_shapes'] = np.array(
+                ['x'.join(str(v) for v in t.shape) for t in sd.values()])
+            d[f'{name}_{tag}_trainable'] = np.array(
+                [k for k, p in mod.named_parameters() if p.requires_grad])
+        with torch.no_grad():
+            x = det.extract_feat(batch['img'])
+            cls, reg, feat = det.bbox_head(x)
+            d[name + '_cls_score_abs_mean'] = np.array(
+                [float(f.double().abs().mean()) for f in cls])
+            d[name + '_cls_feat_abs_mean'] = np.array(
+                [float(f.double().abs().mean()) for f in feat])
+        print(f'  e2e {name}: {time.time() - t0:.1f}s',
+              {k: round(v, 6) for k, v in log_vars.items()})
+    np.savez_compressed(os.path.join(OUT, 'e2e_v2.npz'), **d)
+    print('e2e_v2.npz')
+
+
 # ------------------------------------------------------------ inference ----
 # GFLHead.get_bboxes (anchor_head.py:497-589 -> gfl_head.py:354-451 ->
 # post_processing/bbox_nms.py:70-195 multiclass_nms -> mmcv.ops.batched_nms,
@@ -554,7 +736,8 @@ def gen_infer():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='kat,anchors,targets,lossblock,e2e,infer')
+    ap.add_argument('--only', default='kat,anchors,targets,lossblock,e2e,infer,'
+                    'lossblock_v2,e2e_v2')
     ap.add_argument('--e2e-cases', default='')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
@@ -572,6 +755,10 @@ def main():
         gen_e2e([c for c in args.e2e_cases.split(',') if c])
     if 'infer' in only:
         gen_infer()
+    if 'lossblock_v2' in only:
+        gen_lossblock_v2()
+    if 'e2e_v2' in only:
+        gen_e2e_v2()
 
 
 if __name__ == '__main__':

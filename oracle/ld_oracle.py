@@ -354,6 +354,26 @@ def qfl_elements(x, score_at_label=None):
     return q.astype(F32), dq.astype(F32)
 
 
+def qfl_prob_elements(p, score_at_label=None):
+    """quality_focal_loss with use_sigmoid=False (gfocal_loss.py:27-46, GFLv2):
+    the prediction is a probability and the BCE is F.binary_cross_entropy --
+    logs clamped at -100 forward, d bce / dp = (p - t) / max(p (1 - p), 1e-12)
+    backward (aten).  Negative entries bce(p, 0) p^2; positive entry (score s)
+    bce(p, s) |s - p|^2.  Returns (q, dq/dp)."""
+    p = p.astype(F32)
+    t = np.zeros_like(p) if score_at_label is None else \
+        score_at_label.astype(F32)
+    with np.errstate(divide='ignore'):
+        lp = np.maximum(np.log(p, dtype=F32), F32(-100))
+        l1p = np.maximum(np.log(F32(1) - p, dtype=F32), F32(-100))
+    bce = -(t * lp + (F32(1) - t) * l1p)
+    dbce = (p - t) / np.maximum((F32(1) - p) * p, F32(1e-12))
+    d = t - p
+    q = bce * d * d
+    dq = dbce * d * d - F32(2) * d * bce
+    return q.astype(F32), dq.astype(F32)
+
+
 def giou_loss_rows(pred, target, eps=1e-6):
     """iou_loss.py:85-102 on aligned boxes: 1 - GIoU, and d/dpred with the
     sub-gradients autograd takes through clamp(min=0)/max(.,eps)
@@ -459,8 +479,15 @@ def _rows_to_nchw(r, shape):
 
 
 def ld_loss_block(cls, reg, t_cls, t_reg, x, t_x, targets, hp=None,
-                  reduce_mean=None, with_grad=True):
+                  reduce_mean=None, with_grad=True, kd=None):
     """LDHead.loss on per-level NCHW numpy arrays (lists of 5).
+
+    ``kd = (kd_s, kd_t)`` switches to LDv2Head.loss (ld_gflv2.py:116-380):
+    ``cls`` then holds the probabilities cls_score = sigmoid(cls_feat) *
+    quality over num_classes + 1 channels (QFL via binary_cross_entropy,
+    weight_targets = max_c cls_score without a sigmoid, :200), the KD term runs
+    on the raw cls_feat maps kd_s / kd_t (:243) and its gradient is returned as
+    grads['kd']; t_cls is ignored.
 
     targets: output of :func:`get_targets`.
     reduce_mean: optional callable(float)->float emulating the cross-rank mean
@@ -494,7 +521,12 @@ def ld_loss_block(cls, reg, t_cls, t_reg, x, t_x, targets, hp=None,
         vlr = targets['vlr'][:, sl].reshape(-1)
         im = targets['im'][:, sl].reshape(-1)
         c_r, r_r = _nchw_to_rows(cls[l]), _nchw_to_rows(reg[l])
-        tc_r, tr_r = _nchw_to_rows(t_cls[l]), _nchw_to_rows(t_reg[l])
+        tr_r = _nchw_to_rows(t_reg[l])
+        if kd is not None:
+            ks_r, tc_r = _nchw_to_rows(kd[0][l]), _nchw_to_rows(kd[1][l])
+            g_k = np.zeros_like(ks_r)
+        else:
+            ks_r, tc_r, g_k = c_r, _nchw_to_rows(t_cls[l]), None
         x_r, tx_r = _nchw_to_rows(x[l]), _nchw_to_rows(t_x[l])
         g_c = np.zeros_like(c_r)
         g_r = np.zeros_like(r_r)
@@ -503,9 +535,8 @@ def ld_loss_block(cls, reg, t_cls, t_reg, x, t_x, targets, hp=None,
         rem = np.nonzero(vlr > 0)[0]
         fg = np.nonzero(im > 0)[0]
         score = np.zeros(labels.shape[0], dtype=F32)
-        st = dict(g_c=g_c, g_r=g_r, g_x=g_x, shapes=(cls[l].shape,
-                                                      reg[l].shape,
-                                                      x[l].shape))
+        st = dict(g_c=g_c, g_r=g_r, g_x=g_x, g_k=g_k,
+                  shapes=(cls[l].shape, reg[l].shape, x[l].shape))
         # ---- IM (ld_head.py:186-191, kd_loss.py:91-96)
         loss_im = F32(0)
         if fg.size:
@@ -516,7 +547,8 @@ def ld_loss_block(cls, reg, t_cls, t_reg, x, t_x, targets, hp=None,
             ctr = np.stack([(anchors[pos, 0] + anchors[pos, 2]) / F32(2),
                             (anchors[pos, 1] + anchors[pos, 3]) / F32(2)],
                            -1) / stride
-            wt = _sigmoid(c_r).max(1)[pos]
+            wt = c_r.max(1)[pos] if kd is not None else \
+                _sigmoid(c_r).max(1)[pos]
             dist, p_soft = integral(r_r[pos], H['reg_max'])
             box = distance2bbox(ctr, dist)
             tgt = bt[pos] / stride
@@ -545,11 +577,11 @@ def ld_loss_block(cls, reg, t_cls, t_reg, x, t_x, targets, hp=None,
             g_r[pos] += (kg * (w4 * F32(H['lw_ld']) /
                                F32(4))[:, None]).reshape(-1, 4 * R)
             # KD on class logits (ld_head.py:240-244, avg_factor=P)
-            kl, kg = kd_kl_rows(c_r[pos], tc_r[pos], H['T_kd'])
+            kl, kg = kd_kl_rows(ks_r[pos], tc_r[pos], H['T_kd'])
             loss_kd = F32(H['lw_kd']) * (kl * lw[pos]).sum(
                 dtype=F32) / F32(pos.size)
-            g_c[pos] += kg * (lw[pos] * F32(H['lw_kd']) /
-                              F32(pos.size))[:, None]
+            (g_c if kd is None else g_k)[pos] += kg * (
+                lw[pos] * F32(H['lw_kd']) / F32(pos.size))[:, None]
             st['pos'] = pos
             wsum = wsum + wt.sum(dtype=F32)
         else:  # ld_head.py:246-252 (quirk Q5: loss_im zeroed too)
@@ -567,9 +599,10 @@ def ld_loss_block(cls, reg, t_cls, t_reg, x, t_x, targets, hp=None,
             g_r[rem] += (kg * (w4 * F32(H['lw_ld_vlr']) /
                                F32(16))[:, None]).reshape(-1, 4 * R)
         # ---- QFL (ld_head.py:276-279, gfocal_loss.py:8-50)
-        q, dq = qfl_elements(c_r)
+        qfl = qfl_prob_elements if kd is not None else qfl_elements
+        q, dq = qfl(c_r)
         if pos.size:
-            qp, dqp = qfl_elements(c_r[pos, labels[pos]], score[pos])
+            qp, dqp = qfl(c_r[pos, labels[pos]], score[pos])
             q[pos, labels[pos]] = qp
             dq[pos, labels[pos]] = dqp
         loss_cls = F32(H['lw_cls']) * (q.sum(1, dtype=F32) * lw).sum(
@@ -585,6 +618,9 @@ def ld_loss_block(cls, reg, t_cls, t_reg, x, t_x, targets, hp=None,
     out = dict(losses=losses, num_total_samples=nts, avg_factor=avg)
     if with_grad:
         grads = dict(cls=[], reg=[], x=[])
+        if kd is not None:
+            grads['kd'] = [_rows_to_nchw(st['g_k'], st['shapes'][0])
+                           for st in level_state]
         for st in level_state:
             if 'pos' in st:
                 st['g_r'][st['pos']] += (st['bbox_grad'] +

@@ -13,6 +13,9 @@ Follows (reference file:line):
   FPN               mmdet/models/necks/fpn.py:170-221
   GFLHead.forward   mmdet/models/dense_heads/gfl_head.py:145-183
   forward_train     mmdet/models/detectors/kd_one_stage.py:46-81
+  GFocalHead.forward_single (GFLv2 quality branch)
+                    mmdet/models/dense_heads/gfocal_head.py:201-217
+                    (pinned through tests/golden/lossblock_v2.npz / e2e_v2.npz)
 """
 import numpy as np
 import torch
@@ -156,6 +159,102 @@ def ld_train_step(student_sd, teacher_sd, batch, student_depth, teacher_depth,
         heads = list(cls) + list(reg) + list(feats)
         gs = [torch.from_numpy(g) for g in out['grads']['cls'] +
               out['grads']['reg'] + out['grads']['x']]
+        torch.autograd.backward(heads, gs)
+        res['grads'] = {k: sd[k].grad for k in keys}
+    return res
+
+
+# --------------------------------------------------------------------------
+# GFLv2 / LDv2
+# --------------------------------------------------------------------------
+def quality_tail(sd, cls_feat, bbox_pred, prefix='bbox_head.', reg_max=16,
+                 topk=4):
+    """gfocal_head.py:201-217: softmax over the 17 bins of each side, top-4 +
+    their mean -> 20 statistics -> reg_conf (1x1 20->64, ReLU, 1x1 64->1,
+    sigmoid); cls_score = sigmoid(cls_feat) * quality."""
+    N, _, H, W = bbox_pred.shape
+    prob = F.softmax(bbox_pred.reshape(N, 4, reg_max + 1, H, W), dim=2)
+    top, _ = prob.topk(topk, dim=2)
+    stat = torch.cat([top, top.mean(dim=2, keepdim=True)], dim=2)
+    h = F.relu(F.conv2d(stat.reshape(N, -1, H, W),
+                        sd[prefix + 'reg_conf.0.weight'],
+                        sd[prefix + 'reg_conf.0.bias']))
+    q = torch.sigmoid(F.conv2d(h, sd[prefix + 'reg_conf.2.weight'],
+                               sd[prefix + 'reg_conf.2.bias']))
+    return cls_feat.sigmoid() * q, q
+
+
+def gfocal_head_forward(sd, feats, prefix='bbox_head.'):
+    cls_feats, bbox_preds = gfl_head_forward(sd, feats, prefix)
+    scores = [quality_tail(sd, c, r, prefix)[0]
+              for c, r in zip(cls_feats, bbox_preds)]
+    return scores, bbox_preds, cls_feats
+
+
+def ldv2_loss_step(head_sd, hi, batch, hp=None, prefix=''):
+    """LDv2Head.loss on given tower outputs: ``hi`` = dict of lists cls
+    (cls_feat, 81 ch), reg, x, t_cls (teacher cls_feat), t_reg, t_x.  torch
+    autograd for the quality branch, the numpy oracle for targets + loss
+    block.  Returns losses (8, L), grads wrt cls_feat / reg / x and the
+    reg_conf parameters."""
+    names = [k for k in head_sd if k.startswith(prefix + 'reg_conf')]
+    sd = dict(head_sd)
+    for k in names:
+        sd[k] = head_sd[k].detach().clone().requires_grad_(True)
+    cf = [t.detach().clone().requires_grad_(True) for t in hi['cls']]
+    rg = [t.detach().clone().requires_grad_(True) for t in hi['reg']]
+    tails = [quality_tail(sd, c, r, prefix) for c, r in zip(cf, rg)]
+    scores = [t[0] for t in tails]
+    sizes = [tuple(f.shape[2:]) for f in cf]
+    targets = O.get_targets(sizes, batch['img_metas'],
+                            [b.numpy() for b in batch['gt_bboxes']],
+                            [l.numpy() for l in batch['gt_labels']])
+    npy = lambda ts: [t.detach().numpy() for t in ts]  # noqa: E731
+    out = O.ld_loss_block(npy(scores), npy(rg), None, npy(hi['t_reg']),
+                          npy(hi['x']), npy(hi['t_x']), targets, hp,
+                          kd=(npy(cf), npy(hi['t_cls'])))
+    g = out['grads']
+    # cls_feat gets the KD gradient directly and the QFL one through the tail;
+    # reg gets the loss gradient directly and the quality one through the tail
+    torch.autograd.backward(scores, [torch.from_numpy(a) for a in g['cls']])
+    gcf = [c.grad + torch.from_numpy(a) for c, a in zip(cf, g['kd'])]
+    grg = [r.grad + torch.from_numpy(a) for r, a in zip(rg, g['reg'])]
+    return dict(losses=out['losses'], g_cls_feat=gcf, g_reg=grg,
+                g_x=[torch.from_numpy(a) for a in g['x']],
+                g_params={k: sd[k].grad for k in names},
+                quality=[t[1].detach() for t in tails], scores=scores)
+
+
+def ldv2_train_step(student_sd, teacher_sd, batch, student_depth,
+                    teacher_depth, hp=None, with_backward=True):
+    """One LDv2 forward (+backward) on the CPU (kd_one_stage.py:46-81 with an
+    LDv2Head student and a GFocalHead teacher)."""
+    keys = trainable_keys(student_sd)
+    sd = dict(student_sd)
+    for k in keys:
+        sd[k] = student_sd[k].detach().clone().requires_grad_(with_backward)
+    img = batch['img']
+    feats = fpn_forward(sd, resnet_forward(sd, img, student_depth))
+    scores, reg, cls_feat = gfocal_head_forward(sd, feats)
+    with torch.no_grad():
+        t_feats = fpn_forward(teacher_sd,
+                              resnet_forward(teacher_sd, img, teacher_depth))
+        _, t_reg, t_cls_feat = gfocal_head_forward(teacher_sd, t_feats)
+    sizes = [tuple(f.shape[2:]) for f in scores]
+    targets = O.get_targets(sizes, batch['img_metas'],
+                            [b.numpy() for b in batch['gt_bboxes']],
+                            [l.numpy() for l in batch['gt_labels']])
+    npy = lambda ts: [t.detach().numpy() for t in ts]  # noqa: E731
+    out = O.ld_loss_block(npy(scores), npy(reg), None, npy(t_reg), npy(feats),
+                          npy(t_feats), targets, hp, with_grad=with_backward,
+                          kd=(npy(cls_feat), npy(t_cls_feat)))
+    res = dict(losses=out['losses'], feats=feats, scores=scores, reg=reg,
+               cls_feat=cls_feat, targets=targets)
+    if with_backward:
+        g = out['grads']
+        heads = list(scores) + list(reg) + list(feats) + list(cls_feat)
+        gs = [torch.from_numpy(a) for a in g['cls'] + g['reg'] + g['x'] +
+              g['kd']]
         torch.autograd.backward(heads, gs)
         res['grads'] = {k: sd[k].grad for k in keys}
     return res

@@ -18,7 +18,7 @@ def test_registry_names():
         registry.DETECTORS: ['KnowledgeDistillationSingleStageDetector', 'GFL',
                              'SingleStageDetector'],
         registry.BACKBONES: ['ResNet'], registry.NECKS: ['FPN'],
-        registry.HEADS: ['LDHead', 'GFLHead'],
+        registry.HEADS: ['LDHead', 'GFLHead', 'LDv2Head', 'GFocalHead'],
         registry.LOSSES: ['QualityFocalLoss', 'DistributionFocalLoss',
                           'GIoULoss', 'CIoULoss',
                           'KnowledgeDistillationKLDivLoss', 'IMLoss',
@@ -80,10 +80,8 @@ REFERENCE_CONFIGS = [
     # broken in the reference itself: its teacher_config
     # (configs/gfl/gfl_r18_fpn4x_voc.py) is not in the checkout
     ('configs/ld/ld_r18_self_2x_3x_voc.py', FileNotFoundError),
-    ('configs/ld/ld_r101_gflv1_r101dcn_fpn_coco_2x.py',
-     'config 4: DCNv1 teacher not built yet'),
-    ('configs/ldv2/ld_r50_gflv2_r101_fpn_1x.py',
-     'section 8(a) R-V2: GFocalHead / LDv2Head not built yet'),
+    ('configs/ld/ld_r101_gflv1_r101dcn_fpn_coco_2x.py', None),
+    ('configs/ldv2/ld_r50_gflv2_r101_fpn_1x.py', None),
     ('configs/ld/ld_r50_atss_r101_1x.py',
      'section 8(f)-4: LDATSSHead (other LD heads) is not built'),
     ('configs/ld/ld_r50_fcos_r101_1x.py',
@@ -126,6 +124,17 @@ def test_reference_configs_resolve(path, missing, monkeypatch):
     assert type(det.teacher_model).__name__ == 'GFL'
     assert 'teacher_model' not in dict(det.named_modules())
     assert not any(k.startswith('teacher') for k in det.state_dict())
+    if 'r101dcn' in path:
+        from ld_amd.cnn import DeformConv2dPack
+        tb = det.teacher_model.backbone
+        assert isinstance(tb.layer2[0].conv2, DeformConv2dPack)
+        assert not isinstance(tb.layer1[0].conv2, DeformConv2dPack)
+        assert 'backbone.layer3.22.conv2.conv_offset.bias' in \
+            det.teacher_model.state_dict()
+        assert det.backbone.depth == 101
+    if 'ldv2' in path:
+        assert type(det.teacher_model.bbox_head).__name__ == 'GFocalHead'
+        assert det.bbox_head.cls_out_channels == 81
     opt = cfg.optimizer
     assert opt['type'] == 'SGD' and opt['momentum'] == 0.9
 
