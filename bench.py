@@ -205,26 +205,63 @@ def ldkl_roofline(dev):
                 c2_rows=rows_c2, c2_us=us_c2)
 
 
-def cpu_baseline(batch, sdepth=50, tdepth=101):
-    """The oracle ("port") timed on the host cores: one full LD step."""
+def _host_cpu():
+    model, phys = 'unknown', None
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False)
+    except Exception:
+        pass
+    return model, phys, os.cpu_count() or 1
+
+
+def cpu_baseline(batch, sdepth=50, tdepth=101, reps=3):
+    """BASELINE.md section 3 on the GPU box's host cores: the CPU oracle
+    ("port": torch-CPU fp32 nets with the reference's layer sequence + the
+    numpy loss block) on the SAME batch and seeded weights -- 1 warm-up step,
+    median of `reps`, per-stage split.  The reference itself cannot run here
+    (/root/reference does not exist on the GPU box); the port is calibrated
+    against the reference's own step in the build container:
+    profiles/r02_cpu_reference_baseline.json (tools/cpu_reference_baseline.py).
+    """
     sys.path.insert(0, os.path.join(REPO, 'oracle'))
     import net_oracle as NO
     from ld_amd import build_detector, model_zoo, synthetic
     det = build_detector(model_zoo.ld_detector(sdepth, tdepth))
     ssd = synthetic.seeded_state_dict(det.state_dict(), seed=1)
     tsd = synthetic.seeded_state_dict(det.teacher_model.state_dict(), seed=2)
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    model, phys, logical = _host_cpu()
+    threads = min(phys or logical, 64)  # oneDNN stops scaling past one socket
     torch.set_num_threads(threads)
-    small = dict(batch)
-    t0 = time.time()
-    NO.ld_train_step(ssd, tsd, small, sdepth, tdepth, with_backward=True)
-    dt = time.time() - t0
     n = batch['img'].shape[0]
-    return dict(value=n / dt, unit='images/sec', cores=threads, kind='port',
-                sample=f'1 LD train step (fwd+loss+bwd), {n} images '
-                f'800x1344, torch-CPU fp32 + numpy loss oracle, no warm-up, '
-                f'{dt:.1f} s on {threads} of {cores} host threads')
+    NO.ld_train_step(ssd, tsd, batch, sdepth, tdepth, with_backward=True)
+    runs = []
+    for _ in range(reps):
+        tm = {}
+        t0 = time.time()
+        NO.ld_train_step(ssd, tsd, batch, sdepth, tdepth, with_backward=True,
+                         timings=tm)
+        tm['total'] = time.time() - t0
+        runs.append(tm)
+    runs.sort(key=lambda r: r['total'])
+    med = runs[len(runs) // 2]
+    return dict(value=n / med['total'], unit='images/sec', cores=threads,
+                kind='port', cpu_model=model, physical_cores=phys,
+                logical_cpus=logical,
+                stages_s={k: round(v, 3) for k, v in med.items()},
+                loss_block_s=round(med.get('loss_block', 0.0), 4),
+                sample=f'LD train step (student net + teacher net + targets/'
+                f'loss block + backward), {n} images 800x1344, torch-CPU fp32 '
+                f'+ numpy loss oracle; 1 warm-up + median of {reps} steps, '
+                f'{med["total"]:.1f} s/step on {threads} threads of '
+                f'{model} ({phys} physical / {logical} logical)')
 
 
 def main():

@@ -289,6 +289,211 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_bf16_kernel(ConvK a) {
   }
 }
 
+// ---------------------------------------------- forward/dgrad, LDS-tiled --
+// The streaming kernel above loads every operand element once PER WAVEFRONT and
+// is capped by the CU's vector-cache rate at bf16 MFMA speed (16x the f32 rate:
+// a 2x2 wave tile asks for ~190 B/clk/CU, the L1 delivers ~64).  Here the four
+// wavefronts of a workgroup share one (BM x BN) tile: every element is fetched
+// from L1/L2 ONCE per workgroup, rounded to bf16 on the way into LDS, and read
+// back as MFMA fragments by the two waves that need it.
+//   LDS image (both operands) [BK/8][rows][8] bf16: the eight k of one row are 16
+//   contiguous bytes -- the A image is a straight copy of the weight image rows,
+//   the B image is built from 16 (BN = 128) coalesced fp32 row loads per thread,
+//   packed with v_cvt_pk_bf16_f32 and stored as ds_write_b128; a fragment is ONE
+//   ds_read_b128 whose 32 lanes x 16 B are consecutive (conflict-free, no swizzle
+//   needed because the row pitch is 16 B).
+//   Pipeline: double-buffered LDS, global loads of step s+1 issued before the
+//   MFMAs of step s (register-staged, T14), one barrier per 32-deep k-step.
+//   Waves 2 x 2, wave tile (BM/2) x (BN/2) = TM x TN MFMA 32x32x16 tiles.
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_tile_bf16_kernel(ConvK a) {
+  constexpr int BK = 32, KB = BK / 8;      // k rows per step, 8-blocks per step
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int A_U = BM * KB / 256;       // 16-byte units of A per thread
+  constexpr int CG = 256 / BN;             // channel groups across the block
+  constexpr int CPT = BK / CG;             // channels per thread (8 or 16)
+  static_assert(CPT % 8 == 0 && A_U >= 1, "tile shape");
+  __shared__ __attribute__((aligned(16))) uintx4 lds[2 * KB * (BM + BN)];
+  uintx4* As = lds;                   // [2][KB][BM]
+  uintx4* Bs = lds + 2 * KB * BM;     // [2][KB][BN]
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lk = lane >> 5;
+  const int mtiles = (a.Cout + BM - 1) / BM;
+  const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int m0 = (tile % mtiles) * BM;
+  const int n0 = (tile / mtiles) * BN;
+
+  const int Cin = __builtin_amdgcn_readfirstlane(a.Cin);
+  const int Cout = __builtin_amdgcn_readfirstlane(a.Cout);
+  const int KW = __builtin_amdgcn_readfirstlane(a.KW);
+  const int Pin = __builtin_amdgcn_readfirstlane(a.Pin);
+  const int Kp8 = __builtin_amdgcn_readfirstlane(a.Kpad);
+  const int ntw = __builtin_amdgcn_readfirstlane(MODE == 1 ? a.ntw : a.KW);
+  const int ntaps = __builtin_amdgcn_readfirstlane(
+      MODE == 1 ? a.nth * a.ntw : a.KH * a.KW);
+
+  // ---- this thread's B column (one spatial position) ----------------------
+  const int bp = t % BN, cg = t / BN;
+  int bHin = 0, bWin = 0, boff = 0, bh0 = 0, bw0 = 0;
+  {
+    const int jb = n0 + bp;
+    if (jb < a.J) {
+      const int n = jb / a.Pout, p = jb - n * a.Pout;
+      int bl, bho, bwo;
+      locate_out(a.g, p, bl, bho, bwo);
+      bHin = a.g.lv[bl].Hin;
+      bWin = a.g.lv[bl].Win;
+      boff = n * Cin * Pin + a.g.lv[bl].off_in + cg * CPT * Pin;
+      if (MODE == 1) {
+        bh0 = bho + a.ch0;
+        bw0 = bwo + a.cw0;
+      } else {
+        bh0 = bho * a.g.stride - a.g.pad;
+        bw0 = bwo * a.g.stride - a.g.pad;
+      }
+    }
+  }
+  // ---- this thread's A units: unit u -> (kb = u / BM, co = u % BM) --------
+  unsigned va[A_U];
+#pragma unroll
+  for (int i = 0; i < A_U; ++i) {
+    const int u = t + i * 256;
+    const int kb = u / BM, co = m0 + u % BM;
+    va[i] = co < Cout ? (unsigned)(kb * Cout + co) * 16u : kOOB;
+  }
+  const rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  const rsrc_t rw = make_rsrc(a.wt, a.wt_bytes);
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int csteps = Cin / BK;  // host guarantees Cin % 32 == 0
+  const int nsteps = ntaps * csteps;
+  uintx4 a_st[A_U];
+  float b_st[CPT];
+  int cur_tap = -1;
+  unsigned vb = kOOB;
+  int wtap = 0;
+  auto load_tile = [&](int step) {
+    const int tap = step / csteps;
+    const int ci0 = (step - tap * csteps) * BK;
+    if (tap != cur_tap) {  // wave-uniform
+      cur_tap = tap;
+      const int kh = tap / ntw, kw = tap - kh * ntw;
+      wtap = MODE == 1 ? (a.kh0 + 2 * kh) * KW + a.kw0 + 2 * kw : tap;
+      const int hi = bh0 + kh, wi = bw0 + kw;
+      const bool ok = hi >= 0 && hi < bHin && wi >= 0 && wi < bWin;
+      vb = ok ? (unsigned)(boff + hi * bWin + wi) * 4u : kOOB;
+    }
+    const unsigned sa = (unsigned)((wtap * Kp8 + (ci0 >> 3)) * Cout) * 16u;
+#pragma unroll
+    for (int i = 0; i < A_U; ++i) a_st[i] = buf_load16(rw, va[i], sa);
+    const unsigned prow = (unsigned)Pin * 4u;
+    unsigned so = (unsigned)ci0 * prow;
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) {
+      b_st[e] = buf_load(rx, vb, so);
+      so += prow;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_U; ++i) {
+      const int u = t + i * 256;
+      As[buf * KB * BM + u] = a_st[i];  // u = kb * BM + co: the image order
+    }
+#pragma unroll
+    for (int h = 0; h < CPT / 8; ++h) {
+      floatx8 f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = b_st[h * 8 + e];
+      const bf16x8 v = __builtin_convertvector(f, bf16x8);
+      const int kb = cg * (CPT / 8) + h;
+      Bs[buf * KB * BN + kb * BN + bp] = __builtin_bit_cast(uintx4, v);
+    }
+  };
+  auto compute = [&](int buf) {
+    const uintx4* ap = As + buf * KB * BM + wm * (BM / 2) + l31;
+    const uintx4* bq = Bs + buf * KB * BN + wn * (BN / 2) + l31;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      uintx4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = ap[(2 * s + lk) * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = bq[(2 * s + lk) * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]),
+              acc[i][j], 0, 0, 0);
+    }
+  };
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int step = 0; step < nsteps; ++step) {
+    const int cur = step & 1;
+    const bool more = step + 1 < nsteps;
+    if (more) load_tile(step + 1);   // in flight under the MFMAs below
+    compute(cur);
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: direct stores, 32 consecutive positions per accumulator row
+  const bool has_res = a.residual != nullptr;
+  const bool relu = a.relu != 0;
+  const bool has_aff = a.scale != nullptr, has_bias = a.bias != nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int rbase = m0 + wm * (BM / 2) + i * 32 + 4 * lk;
+    float sc[16], sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = min(rbase + (r & 3) + 8 * (r >> 2), Cout - 1);
+      sc[r] = has_aff ? a.scale[row] : 1.0f;
+      sh[r] = has_aff ? a.shift[row] : 0.0f;
+      if (has_bias) sh[r] += a.bias[row];
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int jc = n0 + wn * (BN / 2) + j * 32 + l31;
+      if (jc >= a.J) continue;
+      const int n = jc / a.Pout;
+      int p = jc - n * a.Pout;
+      int prow = a.Pout;
+      if (MODE == 1) {
+        int l, hc, wc;
+        locate_out(a.g, p, l, hc, wc);
+        p = a.foff[l] + (2 * hc + a.ph) * a.fW[l] + 2 * wc + a.pw;
+        prow = a.Pfull;
+      }
+      const size_t colbase = (size_t)n * Cout * prow + p;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        if (row >= Cout) continue;
+        float v = acc[i][j][r] * sc[r] + sh[r];
+        if (has_res) v += a.residual[colbase + (size_t)row * prow];
+        if (relu) v = fmaxf(v, 0.0f);
+        a.y[colbase + (size_t)row * prow] = v;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------- wgrad, wave-private --
 // One wavefront per workgroup, a 64(co) x 64(ci) tile of one tap and one
 // j-split, 32 positions per step.  Both operand tiles are loaded coalesced
@@ -519,15 +724,34 @@ struct StreamCfg {
   X(1, 1, 2, 4, 1) X(1, 1, 1, 4, 1) X(1, 1, 4, 4, 1) X(2, 1, 4, 4, 1)              \
   X(1, 1, 1, 4, 4) X(2, 1, 1, 4, 4) X(1, 2, 1, 2, 4) X(2, 2, 1, 2, 4)              \
   X(2, 2, 2, 1, 1) X(1, 1, 2, 1, 1) X(1, 1, 1, 1, 4)
+// LDS-tiled kernel shapes, marked by wvm = 0: {BM / 32, BN / 32, 0, BK, 1}
+#define LD_BF16_TILE_SHAPES(X) X(128, 128) X(64, 128) X(128, 64)
 constexpr StreamCfg kCfgs[] = {
 #define LD_ROW(TM_, TN_, WVM_, D_, KS_) {TM_, TN_, WVM_, D_, KS_},
     LD_BF16_SHAPES(LD_ROW)
+#undef LD_ROW
+#define LD_ROW(BM_, BN_) {BM_ / 32, BN_ / 32, 0, 32, 1},
+    LD_BF16_TILE_SHAPES(LD_ROW)
 #undef LD_ROW
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 template <int MODE>
 int launch_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream) {
+  if (c.wvm == 0) {  // LDS-tiled kernel
+    const int BM = c.tm * 32, BN = c.tn * 32;
+    if (k.Cin % 32 != 0) return LD_EUNSUPPORTED;
+    const int nb = ((k.Cout + BM - 1) / BM) * ((k.J + BN - 1) / BN);
+#define LD_CASE(BM_, BN_)                                                          \
+  if (BM == BM_ && BN == BN_) {                                                    \
+    hipLaunchKernelGGL((conv_tile_bf16_kernel<BM_, BN_, MODE>), dim3(nb), dim3(256), \
+                       0, stream, k);                                              \
+    return (int)hipGetLastError();                                                 \
+  }
+    LD_BF16_TILE_SHAPES(LD_CASE)
+#undef LD_CASE
+    return LD_EUNSUPPORTED;
+  }
   const int bm = (c.ks == 4 ? 1 : c.wvm) * c.tm * 32;
   const int bn = (c.ks == 4 ? 1 : 4 / c.wvm) * c.tn * 32;
   const int nb = ((k.Cout + bm - 1) / bm) * ((k.J + bn - 1) / bn);
@@ -549,6 +773,12 @@ inline int mode_taps(const ConvK& k) {
 }
 
 inline bool cfg_fits(const ConvK& k, const StreamCfg& c) {
+  if (c.wvm == 0) {
+    if (k.Cin % 32 != 0) return false;
+    const int BM = c.tm * 32;
+    const int cout32 = (k.Cout + 31) / 32 * 32;
+    return BM <= cout32 + 32;  // at most one 32-row slab of padding
+  }
   const int steps = k.Cin / 16;
   if (steps % c.d != 0) return false;
   if (c.d == 1 && steps % 2 == 0) return false;  // a deeper ring covers it
@@ -570,6 +800,18 @@ inline int cfg_model(const ConvK& k) {
   for (int i = 0; i < kNumCfgs; ++i) {
     const StreamCfg& c = kCfgs[i];
     if (!cfg_fits(k, c)) continue;
+    if (c.wvm == 0) {  // LDS-tiled: ~2x the streaming kernel's pipe efficiency
+      const long nb = (long)((k.Cout + c.tm * 32 - 1) / (c.tm * 32)) *
+                      ((k.J + c.tn * 32 - 1) / (c.tn * 32));
+      const double rounds =
+          nb <= 512 ? (double)((nb + 255) / 256) : (double)nb / 256.0;
+      const double t = rounds * c.tm * c.tn / 1.6;
+      if (best < 0 || t < best_t) {
+        best = i;
+        best_t = t;
+      }
+      continue;
+    }
     const int bm = (c.ks == 4 ? 1 : c.wvm) * c.tm * 32;
     const int bn = (c.ks == 4 ? 1 : 4 / c.wvm) * c.tn * 32;
     const long nb = (long)((k.Cout + bm - 1) / bm) * ((k.J + bn - 1) / bn);
@@ -604,7 +846,7 @@ int launch_bf16(const ConvK& k, hipStream_t stream) {
   if (const char* env = getenv("LD_CONV_BF16_SHAPE")) {  // "2x2x2x4x1": force a shape
     StreamCfg c;
     if (sscanf(env, "%dx%dx%dx%dx%d", &c.tm, &c.tn, &c.wvm, &c.d, &c.ks) == 5 &&
-        (k.Cin / 16) % c.d == 0) {
+        (c.wvm == 0 || (k.Cin / 16) % c.d == 0)) {
       const int rc = launch_cfg<MODE>(k, c, stream);
       if (rc != LD_EUNSUPPORTED) return rc;
     }

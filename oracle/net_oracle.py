@@ -132,19 +132,33 @@ def trainable_keys(sd, frozen_stages=1):
 
 
 def ld_train_step(student_sd, teacher_sd, batch, student_depth, teacher_depth,
-                  hp=None, with_backward=True):
+                  hp=None, with_backward=True, timings=None):
     """One LD forward (+backward) on the CPU: torch autograd for the nets,
     the numpy oracle for targets + loss block.  Returns dict(losses (8,5),
-    grads {key: tensor}, feats, cls, reg)."""
+    grads {key: tensor}, feats, cls, reg).  ``timings`` (dict) receives the
+    wall seconds of the stages: student_net, teacher_net, loss_block,
+    backward."""
+    import time as _time
+    tick = [_time.perf_counter()]
+
+    def lap(name):
+        now = _time.perf_counter()
+        if timings is not None:
+            timings[name] = timings.get(name, 0.0) + now - tick[0]
+        tick[0] = now
+
     keys = trainable_keys(student_sd)
     sd = dict(student_sd)
     for k in keys:
         sd[k] = student_sd[k].detach().clone().requires_grad_(with_backward)
     img = batch['img']
+    tick[0] = _time.perf_counter()
     feats, cls, reg = detector_forward(sd, img, student_depth)
+    lap('student_net')
     with torch.no_grad():
         t_feats, t_cls, t_reg = detector_forward(teacher_sd, img,
                                                  teacher_depth)
+    lap('teacher_net')
     sizes = [tuple(f.shape[2:]) for f in cls]
     targets = O.get_targets(sizes, batch['img_metas'],
                             [b.numpy() for b in batch['gt_bboxes']],
@@ -153,6 +167,7 @@ def ld_train_step(student_sd, teacher_sd, batch, student_depth, teacher_depth,
     out = O.ld_loss_block(npy(cls), npy(reg), npy(t_cls), npy(t_reg),
                           npy(feats), npy(t_feats), targets, hp,
                           with_grad=with_backward)
+    lap('loss_block')
     res = dict(losses=out['losses'], feats=feats, cls=cls, reg=reg,
                targets=targets)
     if with_backward:
@@ -161,6 +176,7 @@ def ld_train_step(student_sd, teacher_sd, batch, student_depth, teacher_depth,
               out['grads']['reg'] + out['grads']['x']]
         torch.autograd.backward(heads, gs)
         res['grads'] = {k: sd[k].grad for k in keys}
+        lap('backward')
     return res
 
 

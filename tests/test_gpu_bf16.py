@@ -95,7 +95,9 @@ def test_bf16_conv_fwd_bwd(case, bf16_mode):
 
 BF16_SHAPES = ['2x2x2x2x1', '2x2x1x2x1', '2x1x2x4x1', '1x2x2x2x1', '1x1x2x4x1',
                '1x1x1x4x1', '1x1x4x4x1', '2x1x4x4x1', '1x1x1x4x4', '2x1x1x4x4',
-               '1x2x1x2x4', '2x2x1x2x4', '2x2x2x1x1', '1x1x2x1x1', '1x1x1x1x4']
+               '1x2x1x2x4', '2x2x1x2x4', '2x2x2x1x1', '1x1x2x1x1', '1x1x1x1x4',
+               # LDS-tiled kernel (wvm = 0): BM/32 x BN/32 x 0 x BK x 1
+               '4x4x0x32x1', '2x4x0x32x1', '4x2x0x32x1']
 
 
 @pytest.mark.parametrize('shape', BF16_SHAPES)
@@ -107,10 +109,14 @@ def test_bf16_stream_shapes(shape, monkeypatch, bf16_mode):
     monkeypatch.setenv('LD_CONV_BF16_SHAPE', shape)
     dev = _dev()
     d = int(shape.split('x')[3])
+    tiled = shape.split('x')[2] == '0'
     ran = 0
     for case in BF16_CASES:
         name, N, cin, cout, k, stride, pad, levels = case
-        if (cin // 16) % d or cout % 16 or (cout // 16) % d:
+        if tiled:
+            if cin % 32 or cout % 32:
+                continue
+        elif (cin // 16) % d or cout % 16 or (cout // 16) % d:
             continue
         ran += 1
         g = torch.Generator().manual_seed(len(name) * 7 + cin)

@@ -220,7 +220,8 @@ def bench_conv(out, with_miopen=True):
 
 BF16_CFGS = ['2x2x2x2x1', '2x2x1x2x1', '2x1x2x4x1', '1x2x2x2x1', '1x1x2x4x1',
              '1x1x1x4x1', '1x1x4x4x1', '2x1x4x4x1', '1x1x1x4x4', '2x1x1x4x4',
-             '1x2x1x2x4', '2x2x1x2x4']
+             '1x2x1x2x4', '2x2x1x2x4', '4x4x0x32x1', '2x4x0x32x1',
+             '4x2x0x32x1']
 
 
 def bench_bf16(out):
@@ -267,7 +268,10 @@ def bench_bf16(out):
             steps = cin // 16
             for cfg in BF16_CFGS:
                 dd = int(cfg.split('x')[3])
-                if steps % dd:
+                if cfg.split('x')[2] == '0':
+                    if cin % 32:
+                        continue
+                elif steps % dd:
                     continue
                 os.environ['LD_CONV_BF16_SHAPE'] = cfg
                 t = timeit(lambda: Y.conv_forward_raw(x, w, stride, pad, levels),
