@@ -49,6 +49,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-roofline', action='store_true')
     ap.add_argument('--profile-steps', type=int, default=2)
+    ap.add_argument('--no-graph', action='store_true',
+                    help='skip the hipGraph-replay leg')
     ap.add_argument('--no-bf16', action='store_true',
                     help='skip the bf16 (BASELINE config 3) leg')
     return ap.parse_args()
@@ -387,6 +389,47 @@ def main():
                 roofb['step_tflops_analytic'] = \
                     1835.7e9 * args.batch_per_gpu / (dtb / args.steps) / 1e12
                 res['roofline_bf16'] = roofb
+    # ---- graph leg: the same step replayed from one captured hipGraph (the
+    # ~750 launches of a step cost ~13 ms of Python + ctypes on the host, which
+    # binds once the kernels are faster than that).  Reported beside the eager
+    # numbers; `value` stays the eager fp32 step.
+    if not args.no_graph and world == 1:
+        from ld_amd import layers as Y
+        from ld_amd.train import GraphedStep
+        graph_res = {}
+        for mode in (['fp32'] if args.no_bf16 else ['fp32', 'bf16']):
+            Y.set_precision(mode)
+            try:
+                trainer.step(dbatch)  # images of the mode exist before capture
+                torch.cuda.synchronize()
+                gs = GraphedStep(trainer, dbatch, warmup=2)
+                for _ in range(args.warmup):
+                    gs.replay()
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    out = gs.replay()
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                dtg = time.perf_counter() - t0
+                if world > 1:
+                    tt = torch.tensor([dtg], device=dev, dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dtg = float(tt)
+                graph_res[mode] = {
+                    'value': args.batch_per_gpu * world * args.steps / dtg,
+                    'unit': 'images/sec',
+                    'ms_per_step': dtg / args.steps * 1e3,
+                    'last_loss': float(out['log_vars']['loss'])}
+                del gs
+            except Exception as e:  # report, never lose the headline line
+                graph_res[mode] = {'error': f'{type(e).__name__}: {e}'[:300]}
+        Y.set_precision('fp32')
+        if rank == 0:
+            res['hipgraph_step'] = graph_res
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

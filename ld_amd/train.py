@@ -267,3 +267,61 @@ class SGDTrainer:
         self.iter += 1
         return dict(loss=loss.detach(), log_vars=log_vars,
                     num_samples=len(data['img_metas']))
+
+
+class GraphedStep:
+    """The steady-state train step captured ONCE into a hipGraph and replayed:
+    ~750 launches per step (conv / norm / loss / optimizer kernels, the
+    teacher's side stream included) become one graph launch, which takes the
+    Python + ctypes enqueue cost (~13 ms per C2 step, profiles/
+    r01 host profile) off the critical path -- it matters once the kernels are
+    faster than the host (the bf16 mode).
+
+    Contract: ``data`` holds the STATIC input buffers; a new batch is copied
+    into them (``copy_inputs``) before ``replay()``.  The shapes of the batch
+    (image size, number of GT boxes per image) are frozen into the graph, as is
+    the precision mode.  Every launch entry point of libldhip.so only enqueues
+    (no timing, no synchronisation: include/ld_hip.h), which is what makes the
+    step capturable; shape tuning must have happened before (ld_conv_tune_*
+    refuse a capturing stream).  With world_size > 1 the bucketed RCCL
+    all-reduces are captured like any other launch.
+    """
+
+    def __init__(self, trainer, data, warmup=2):
+        self.trainer, self.data = trainer, data
+        dev = data['img'].device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            # allocator / caches / weight images reach steady state on the
+            # capture stream's own key before anything is recorded
+            for _ in range(warmup):
+                trainer.step(data)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            out = trainer.step(data)
+        self._loss = out['loss']
+        lv = out['log_vars']
+        self._log_keys, self._log_tensor = list(lv._keys), lv._tensor
+        self.num_samples = out['num_samples']
+
+    def copy_inputs(self, data):
+        """New batch of the SAME shapes into the captured input buffers."""
+        self.data['img'].copy_(data['img'], non_blocking=True)
+        for k in ('gt_bboxes', 'gt_labels'):
+            for dst, src in zip(self.data[k], data[k]):
+                if dst.shape != src.shape:
+                    raise ValueError(
+                        'GraphedStep: the number of GT boxes per image is '
+                        'frozen into the captured graph')
+                dst.copy_(src, non_blocking=True)
+
+    def replay(self):
+        from .heads import LazyScalars
+        self.graph.replay()
+        self.trainer.iter += 1
+        return dict(loss=self._loss,
+                    log_vars=LazyScalars(self._log_keys, self._log_tensor),
+                    num_samples=self.num_samples)
