@@ -1796,7 +1796,12 @@ static int wgrad_splits(const ld_conv_t* c) {
 
 extern "C" size_t ld_conv_wgrad_workspace_bytes(const ld_conv_t* c) {
   if (check_conv(c) != 0) return 0;
-  return (size_t)wgrad_splits(c) * c->KH * c->KW * c->Cout * c->Cin * sizeof(float);
+  // one size for both kernel families (the bf16 workgroup-tiled wgrad picks its
+  // own split count)
+  int sp = wgrad_splits(c);
+  if (ld_bf16_wgrad_tiled(c->Cout, c->Cin, c->Pout))
+    sp = max(sp, ld_bf16_wgrad_splits(c->Cout, c->Cin, c->KH * c->KW, c->N * c->Pout));
+  return (size_t)sp * c->KH * c->KW * c->Cout * c->Cin * sizeof(float);
 }
 
 namespace {
@@ -1815,6 +1820,8 @@ int wgrad_run(const ld_conv_t* c, const float* x, const float* dy, float* dw,
   k.g.num_levels = c->num_levels;
   k.J = c->N * c->Pout;
   k.splits = wgrad_splits(c);
+  if (family == 1 && ld_bf16_wgrad_tiled(c->Cout, c->Cin, c->Pout))
+    k.splits = ld_bf16_wgrad_splits(c->Cout, c->Cin, c->KH * c->KW, k.J);
   const int wmode = wgrad_mode();
   const int wbk = family == 1 ? 32 : (wmode ? wmode : WBK);
   int jchunk = (k.J + k.splits - 1) / k.splits;

@@ -668,6 +668,188 @@ __global__ __launch_bounds__(64, 2) void conv_wgrad_wave_bf16_kernel(WgradK a) {
   }
 }
 
+// ------------------------------------------------ wgrad, workgroup-tiled ---
+// The wave-private kernel above moves 64 + 64 rows through LDS for every 8
+// MFMAs of one wavefront: at bf16 MFMA speed it is bound by the load / convert /
+// ds_write issue rate, not by the matrix core.  Here four wavefronts (2 x 2)
+// share a 128(co) x 128(ci) tile, so each staged row feeds two waves, and two
+// consecutive positions travel together: dY as ONE 8-byte load (rows are 8-byte
+// aligned when Pout is even), X as two gathered loads, packed by
+// v_cvt_pk_bf16_f32 into ONE ds_write_b32 -- 72 instructions per 8 MFMAs
+// instead of ~208.  Same 80-byte LDS row pitch and 16-byte fragment reads,
+// double-buffered with one barrier per 32-position step.
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_tile_bf16_kernel(WgradK a) {
+  constexpr int TB = 128;
+  constexpr int RGRP = 16;           // row groups of 16 threads (j-pairs)
+  constexpr int RPER = TB / RGRP;    // rows per thread and operand (8)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TB * WB_PITCH];
+  __shared__ int s_geo[LD_MAX_LEVELS * 6];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int Cin = __builtin_amdgcn_readfirstlane(a.Cin);
+  const int Cout = __builtin_amdgcn_readfirstlane(a.Cout);
+  const int Pin = __builtin_amdgcn_readfirstlane(a.Pin);
+  const int Pout = __builtin_amdgcn_readfirstlane(a.Pout);
+  const int nlev = __builtin_amdgcn_readfirstlane(a.g.num_levels);
+  const int stride = __builtin_amdgcn_readfirstlane(a.g.stride);
+  const int pad = __builtin_amdgcn_readfirstlane(a.g.pad);
+  const int mt = (Cout + TB - 1) / TB, nt = (Cin + TB - 1) / TB;
+  const int ntaps = a.KH * a.KW;
+  int b = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int ntile = b % nt;
+  b /= nt;
+  const int mtile = b % mt;
+  b /= mt;
+  const int tap = b % ntaps;
+  const int split = b / ntaps;
+  const int m0 = mtile * TB, c0 = ntile * TB;
+  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int jbeg = split * a.jchunk;
+  const int jend = min(a.J, jbeg + a.jchunk);
+
+  if (t < LD_MAX_LEVELS) {
+    const ld_conv_level_t lv = a.g.lv[t];
+    s_geo[t * 6 + 0] = lv.Hin;
+    s_geo[t * 6 + 1] = lv.Win;
+    s_geo[t * 6 + 2] = lv.Hout;
+    s_geo[t * 6 + 3] = lv.Wout;
+    s_geo[t * 6 + 4] = lv.off_in;
+    s_geo[t * 6 + 5] = lv.off_out;
+  }
+  __syncthreads();
+
+  const int kq2 = t % 16;   // j-pair within the step: j = 2 kq2, 2 kq2 + 1
+  const int r0 = t / 16;    // first row; rows r0 + 16 i
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  const rsrc_t ry = make_rsrc(a.dy, a.dy_bytes);
+  floatx2 a_st[RPER];
+  float b_st[RPER][2];
+
+  // input offset of position j for this tap (kOOB in the padding / past jend)
+  auto x_off = [&](int j) -> unsigned {
+    if (j >= jend) return kOOB;
+    const int n = j / Pout, p = j - n * Pout;
+    int l = 0;
+    for (int i = 1; i < nlev; ++i)
+      if (p >= s_geo[i * 6 + 5]) l = i;
+    const int Hin = s_geo[l * 6 + 0], Win = s_geo[l * 6 + 1];
+    const int Wout = s_geo[l * 6 + 3];
+    const int r = p - s_geo[l * 6 + 5];
+    const int ho = r / Wout, wo = r - ho * Wout;
+    const int hi = ho * stride - pad + kh, wi = wo * stride - pad + kw;
+    if (hi < 0 || hi >= Hin || wi < 0 || wi >= Win) return kOOB;
+    return (unsigned)(n * Cin * Pin + (c0 + r0) * Pin + s_geo[l * 6 + 4] + hi * Win +
+                      wi) * 4u;
+  };
+  auto load_tile = [&](int j0) {
+    const int j = j0 + 2 * kq2;
+    // dY: both positions of the pair in one 8-byte load (host: Pout even, so a
+    // pair never straddles an image and the address is 8-byte aligned)
+    unsigned vy = kOOB;
+    if (j < jend) {
+      const int n = j / Pout, p = j - n * Pout;
+      vy = (unsigned)(n * Cout * Pout + (m0 + r0) * Pout + p) * 4u;
+    }
+    const unsigned vx0 = x_off(j), vx1 = x_off(j + 1);
+    const int na = (Cout - m0 - r0 + RGRP - 1) / RGRP;  // valid rows of this thread
+    const int nb = (Cin - c0 - r0 + RGRP - 1) / RGRP;
+    unsigned sa = 0, sb = 0;
+    const unsigned da = (unsigned)RGRP * Pout * 4u, db = (unsigned)RGRP * Pin * 4u;
+#pragma unroll
+    for (int i = 0; i < RPER; ++i) {
+      const auto v = __builtin_amdgcn_raw_buffer_load_b64(ry, i < na ? vy : kOOB, sa, 0);
+      a_st[i] = __builtin_bit_cast(floatx2, v);
+      b_st[i][0] = buf_load(rx, i < nb ? vx0 : kOOB, sb);
+      b_st[i][1] = buf_load(rx, i < nb ? vx1 : kOOB, sb);
+      sa += da;
+      sb += db;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* As = lds + buf * 2 * TB * WB_PITCH;
+    unsigned char* Bs = As + TB * WB_PITCH;
+#pragma unroll
+    for (int i = 0; i < RPER; ++i) {
+      const int row = r0 + RGRP * i;
+      const bf16x2 pa = __builtin_convertvector(a_st[i], bf16x2);
+      floatx2 fb;
+      fb[0] = b_st[i][0];
+      fb[1] = b_st[i][1];
+      const bf16x2 pb = __builtin_convertvector(fb, bf16x2);
+      *(bf16x2*)(As + row * WB_PITCH + 4 * kq2) = pa;
+      *(bf16x2*)(Bs + row * WB_PITCH + 4 * kq2) = pb;
+    }
+  };
+  const int l31 = lane & 31, lk = lane >> 5;
+  auto compute = [&](int buf) {
+    const unsigned char* As = lds + buf * 2 * TB * WB_PITCH;
+    const unsigned char* Bs = As + TB * WB_PITCH;
+    const unsigned char* ap = As + (wm * 64 + l31) * WB_PITCH + 16 * lk;
+    const unsigned char* bp = Bs + (wn * 64 + l31) * WB_PITCH + 16 * lk;
+    bf16x8 af[2][2], bfr[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        af[s][i] = *(const bf16x8*)(ap + i * 32 * WB_PITCH + s * 32);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bfr[s][j] = *(const bf16x8*)(bp + j * 32 * WB_PITCH + s * 32);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i], bfr[s][j],
+                                                              acc[i][j], 0, 0, 0);
+  };
+
+  const int nsteps = (jend - jbeg + WB_J - 1) / WB_J;
+  if (nsteps > 0) {
+    load_tile(jbeg);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int step = 0; step < nsteps; ++step) {
+    const int cur = step & 1;
+    const bool more = step + 1 < nsteps;
+    if (more) load_tile(jbeg + (step + 1) * WB_J);
+    compute(cur);
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+  // slab store: [split][tap][co][ci], ci fastest (= lane & 31)
+  float* slab = a.slabs + ((size_t)split * ntaps + tap) * Cout * Cin;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ci = c0 + wn * 64 + j * 32 + l31;
+    if (ci >= Cin) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (co < Cout) slab[(size_t)co * Cin + ci] = acc[i][j][r];
+      }
+  }
+}
+
 // ---- weight images ----------------------------------------------------------
 // (Cout, Cin, KH, KW) fp32 -> fwd [tap][Cin16/8][Cout][8] bf16 and/or
 // bwd [KH*KW-1-tap][Cout16/8][Cin][8] bf16 (k rows beyond the channel count 0).
@@ -925,8 +1107,41 @@ int ld_bf16_stream_tune(int mode, const ConvK& k, hipStream_t stream) {
   return mode == 1 ? tune_bf16<1>(k, stream) : tune_bf16<0>(k, stream);
 }
 
+// Which wgrad kernel a geometry gets: the workgroup-tiled one needs even Pout
+// (8-byte dY pairs) and at least one full 128-row tile per operand.
+bool ld_bf16_wgrad_tiled(int Cout, int Cin, int Pout) {
+  if (const char* env = getenv("LD_CONV_BF16_WGRAD"))
+    if (env[0] == 'w') return false;  // "wave": force the wave-private kernel
+  return Pout % 2 == 0 && Cout >= 128 && Cin >= 128;
+}
+
+int ld_bf16_wgrad_splits(int Cout, int Cin, int ntaps, int J) {
+  // ~3 resident workgroups per CU; at least 8 steps of 32 positions per split
+  const int tiles = ((Cout + 127) / 128) * ((Cin + 127) / 128) * ntaps;
+  int sp = (768 + tiles - 1) / tiles;
+  const int max_by_k = (J + 8 * WB_J - 1) / (8 * WB_J);
+  sp = max(1, min(min(sp, max_by_k), 256));
+  const size_t wbytes = (size_t)ntaps * Cout * Cin * sizeof(float);
+  while (sp > 1 && sp * wbytes > ((size_t)256 << 20)) --sp;  // slab budget
+  // no empty trailing split
+  for (;;) {
+    int jc = (J + sp - 1) / sp;
+    jc = (jc + WB_J - 1) / WB_J * WB_J;
+    if (sp == 1 || (long)(sp - 1) * jc < J) break;
+    --sp;
+  }
+  return sp;
+}
+
 int ld_bf16_wgrad_launch(const WgradK& k, hipStream_t stream) {
   const int ntaps = k.KH * k.KW;
+  if (ld_bf16_wgrad_tiled(k.Cout, k.Cin, k.Pout)) {
+    const int blocks =
+        ((k.Cout + 127) / 128) * ((k.Cin + 127) / 128) * ntaps * k.splits;
+    hipLaunchKernelGGL(conv_wgrad_tile_bf16_kernel, dim3(blocks), dim3(256), 0, stream,
+                       k);
+    return (int)hipGetLastError();
+  }
   const int blocks = ((k.Cout + 63) / 64) * ((k.Cin + 63) / 64) * ntaps * k.splits;
   hipLaunchKernelGGL(conv_wgrad_wave_bf16_kernel, dim3(blocks), dim3(64), 0, stream, k);
   return (int)hipGetLastError();

@@ -56,6 +56,8 @@ struct WgradK {
 int ld_bf16_stream_launch(int mode, const ConvK& k, hipStream_t stream);
 int ld_bf16_stream_tune(int mode, const ConvK& k, hipStream_t stream);
 int ld_bf16_wgrad_launch(const WgradK& k, hipStream_t stream);
+bool ld_bf16_wgrad_tiled(int Cout, int Cin, int Pout);     // which bf16 wgrad kernel
+int ld_bf16_wgrad_splits(int Cout, int Cin, int ntaps, int J);  // its j-split count
 // conv.hip: fixed-order sum of the wgrad slabs into dW (shared by both families)
 int ld_wgrad_reduce_launch(const float* slabs, int splits, int ntaps, int Cout,
                            int Cin, float* dw, int accumulate, hipStream_t stream);

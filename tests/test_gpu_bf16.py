@@ -37,6 +37,12 @@ BF16_CASES = [c for c in CONV_CASES if c[2] % 16 == 0] + [
     ('3x3_80_256_levels_dgradlike', 2, 80, 256, 3, 1, 1,
      ((12, 20), (6, 10), (3, 5), (2, 3), (1, 2))),
     ('1x1_1024_2048_s2', 1, 1024, 2048, 1, 2, 0, ((10, 14), )),
+    # even P: the workgroup-tiled wgrad (8-byte dY pairs), incl. ragged tiles
+    ('3x3_256_256_even_levels', 2, 256, 256, 3, 1, 1,
+     ((20, 28), (10, 14), (6, 8))),
+    ('3x3_s2_128_even', 2, 128, 128, 3, 2, 1, ((24, 40), )),
+    ('1x1_256_1024_even', 1, 256, 1024, 1, 1, 0, ((10, 14), )),
+    ('3x3_160_192_ragged', 1, 160, 192, 3, 1, 1, ((12, 18), )),
 ]
 
 
