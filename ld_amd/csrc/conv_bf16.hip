@@ -302,11 +302,20 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_bf16_kernel(ConvK a) {
 //   packed with v_cvt_pk_bf16_f32 and stored as ds_write_b128; a fragment is ONE
 //   ds_read_b128 whose 32 lanes x 16 B are consecutive (conflict-free, no swizzle
 //   needed because the row pitch is 16 B).
-//   Pipeline: double-buffered LDS, global loads of step s+1 issued before the
-//   MFMAs of step s (register-staged, T14), one barrier per 32-deep k-step.
+//   Pipeline: at bf16 MFMA speed one 32-deep k-step is only 256 matrix cycles
+//   per wave while a load takes ~1-2 k cycles to come back, and most layers of
+//   the step yield only ~1 workgroup per CU -- so the loads run NST - 1 steps
+//   AHEAD through a ring of NST register stages (statically indexed: the step
+//   loop is unrolled by NST), two LDS buffers, one barrier per step:
+//     issue loads(step + NST - 1) -> convert + ds_write stage(step) -> barrier
+//     -> fragments + MFMAs of step.
+//   (measured: with the loads only one step ahead the 128 x 128 tile reached
+//   261 TFLOP/s on the 100x168 stage, 12 % of the pipe, profiles/
+//   r02_kernels_s3_bf16.json.)
 //   Waves 2 x 2, wave tile (BM/2) x (BN/2) = TM x TN MFMA 32x32x16 tiles.
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int NST>
 __global__ __launch_bounds__(256, 2) void conv_tile_bf16_kernel(ConvK a) {
+  static_assert(NST % 2 == 0, "ring length must be even (static LDS parity)");
   constexpr int BK = 32, KB = BK / 8;      // k rows per step, 8-blocks per step
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_U = BM * KB / 256;       // 16-byte units of A per thread
@@ -377,44 +386,52 @@ __global__ __launch_bounds__(256, 2) void conv_tile_bf16_kernel(ConvK a) {
 
   const int csteps = Cin / BK;  // host guarantees Cin % 32 == 0
   const int nsteps = ntaps * csteps;
-  uintx4 a_st[A_U];
-  float b_st[CPT];
-  int cur_tap = -1;
-  unsigned vb = kOOB;
-  int wtap = 0;
-  auto load_tile = [&](int step) {
-    const int tap = step / csteps;
-    const int ci0 = (step - tap * csteps) * BK;
-    if (tap != cur_tap) {  // wave-uniform
-      cur_tap = tap;
-      const int kh = tap / ntw, kw = tap - kh * ntw;
-      wtap = MODE == 1 ? (a.kh0 + 2 * kh) * KW + a.kw0 + 2 * kw : tap;
-      const int hi = bh0 + kh, wi = bw0 + kw;
-      const bool ok = hi >= 0 && hi < bHin && wi >= 0 && wi < bWin;
-      vb = ok ? (unsigned)(boff + hi * bWin + wi) * 4u : kOOB;
-    }
-    const unsigned sa = (unsigned)((wtap * Kp8 + (ci0 >> 3)) * Cout) * 16u;
+  uintx4 a_st[NST][A_U];
+  float b_st[NST][CPT];
+  // Load cursor (wave-uniform scalars): tap (kh, kw) and first channel of the
+  // next step to fetch.  Everything below is branch-free so that the unrolled
+  // step loop stays ONE basic block and the compiler keeps counted vmcnt waits:
+  // steps past the end are fetched through out-of-range offsets (zeros) and
+  // multiply into nothing.
+  int c_step = 0, c_kh = 0, c_kw = 0, c_ci0 = 0;
+  auto load_next = [&](uintx4* ra, float* rb) {
+    const bool live = c_step < nsteps;
+    const int wtap = MODE == 1 ? (a.kh0 + 2 * c_kh) * KW + a.kw0 + 2 * c_kw
+                               : c_kh * ntw + c_kw;
+    const int hi = bh0 + c_kh, wi = bw0 + c_kw;
+    const bool ok = live && hi >= 0 && hi < bHin && wi >= 0 && wi < bWin;
+    const unsigned vb = ok ? (unsigned)(boff + hi * bWin + wi) * 4u : kOOB;
+    const unsigned sa = (unsigned)((wtap * Kp8 + (c_ci0 >> 3)) * Cout) * 16u;
 #pragma unroll
-    for (int i = 0; i < A_U; ++i) a_st[i] = buf_load16(rw, va[i], sa);
+    for (int i = 0; i < A_U; ++i) ra[i] = buf_load16(rw, live ? va[i] : kOOB, sa);
     const unsigned prow = (unsigned)Pin * 4u;
-    unsigned so = (unsigned)ci0 * prow;
+    unsigned so = (unsigned)c_ci0 * prow;
 #pragma unroll
     for (int e = 0; e < CPT; ++e) {
-      b_st[e] = buf_load(rx, vb, so);
+      rb[e] = buf_load(rx, vb, so);
       so += prow;
     }
+    // advance: channels fastest, then kw, then kh (scalar selects, no branch)
+    ++c_step;
+    c_ci0 += BK;
+    const bool wc = c_ci0 >= Cin;
+    c_ci0 = wc ? 0 : c_ci0;
+    c_kw += wc ? 1 : 0;
+    const bool wk = c_kw >= ntw;
+    c_kw = wk ? 0 : c_kw;
+    c_kh += wk ? 1 : 0;
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const uintx4* ra, const float* rb) {
 #pragma unroll
     for (int i = 0; i < A_U; ++i) {
       const int u = t + i * 256;
-      As[buf * KB * BM + u] = a_st[i];  // u = kb * BM + co: the image order
+      As[buf * KB * BM + u] = ra[i];  // u = kb * BM + co: the image order
     }
 #pragma unroll
     for (int h = 0; h < CPT / 8; ++h) {
       floatx8 f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = b_st[h * 8 + e];
+      for (int e = 0; e < 8; ++e) f[e] = rb[h * 8 + e];
       const bf16x8 v = __builtin_convertvector(f, bf16x8);
       const int kb = cg * (CPT / 8) + h;
       Bs[buf * KB * BN + kb * BN + bp] = __builtin_bit_cast(uintx4, v);
@@ -440,16 +457,21 @@ __global__ __launch_bounds__(256, 2) void conv_tile_bf16_kernel(ConvK a) {
     }
   };
 
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  for (int step = 0; step < nsteps; ++step) {
-    const int cur = step & 1;
-    const bool more = step + 1 < nsteps;
-    if (more) load_tile(step + 1);   // in flight under the MFMAs below
-    compute(cur);
-    if (more) store_tile(cur ^ 1);
-    __syncthreads();
+#pragma unroll
+  for (int u = 0; u < NST - 1; ++u) load_next(a_st[u], b_st[u]);
+  // the trip count is rounded up to whole rings; the padding steps are zeros
+  for (int base = 0; base < nsteps; base += NST) {
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+      constexpr int ahead = NST - 1;
+      load_next(a_st[(u + ahead) % NST], b_st[(u + ahead) % NST]);
+      // LDS buffer (u & 1) was last read by the MFMAs two steps ago, which every
+      // wave finished before it passed the previous barrier (NST is even, so the
+      // buffer parity of a stage is static)
+      store_tile(u & 1, a_st[u], b_st[u]);
+      __syncthreads();
+      compute(u & 1);
+    }
   }
 
   // ---- epilogue: direct stores, 32 consecutive positions per accumulator row
@@ -906,13 +928,15 @@ struct StreamCfg {
   X(1, 1, 2, 4, 1) X(1, 1, 1, 4, 1) X(1, 1, 4, 4, 1) X(2, 1, 4, 4, 1)              \
   X(1, 1, 1, 4, 4) X(2, 1, 1, 4, 4) X(1, 2, 1, 2, 4) X(2, 2, 1, 2, 4)              \
   X(2, 2, 2, 1, 1) X(1, 1, 2, 1, 1) X(1, 1, 1, 1, 4)
-// LDS-tiled kernel shapes, marked by wvm = 0: {BM / 32, BN / 32, 0, BK, 1}
-#define LD_BF16_TILE_SHAPES(X) X(128, 128) X(64, 128) X(128, 64)
+// LDS-tiled kernel shapes, marked by wvm = 0: {BM / 32, BN / 32, 0, BK, NST}
+// (NST = register stages of the load ring; the ks field carries it)
+#define LD_BF16_TILE_SHAPES(X)                                                     \
+  X(128, 128, 2) X(128, 128, 4) X(64, 128, 4) X(128, 64, 4) X(128, 64, 2)
 constexpr StreamCfg kCfgs[] = {
 #define LD_ROW(TM_, TN_, WVM_, D_, KS_) {TM_, TN_, WVM_, D_, KS_},
     LD_BF16_SHAPES(LD_ROW)
 #undef LD_ROW
-#define LD_ROW(BM_, BN_) {BM_ / 32, BN_ / 32, 0, 32, 1},
+#define LD_ROW(BM_, BN_, NST_) {BM_ / 32, BN_ / 32, 0, 32, NST_},
     LD_BF16_TILE_SHAPES(LD_ROW)
 #undef LD_ROW
 };
@@ -924,10 +948,10 @@ int launch_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream) {
     const int BM = c.tm * 32, BN = c.tn * 32;
     if (k.Cin % 32 != 0) return LD_EUNSUPPORTED;
     const int nb = ((k.Cout + BM - 1) / BM) * ((k.J + BN - 1) / BN);
-#define LD_CASE(BM_, BN_)                                                          \
-  if (BM == BM_ && BN == BN_) {                                                    \
-    hipLaunchKernelGGL((conv_tile_bf16_kernel<BM_, BN_, MODE>), dim3(nb), dim3(256), \
-                       0, stream, k);                                              \
+#define LD_CASE(BM_, BN_, NST_)                                                    \
+  if (BM == BM_ && BN == BN_ && c.ks == NST_) {                                    \
+    hipLaunchKernelGGL((conv_tile_bf16_kernel<BM_, BN_, MODE, NST_>), dim3(nb),    \
+                       dim3(256), 0, stream, k);                                   \
     return (int)hipGetLastError();                                                 \
   }
     LD_BF16_TILE_SHAPES(LD_CASE)
@@ -987,7 +1011,7 @@ inline int cfg_model(const ConvK& k) {
                       ((k.J + c.tn * 32 - 1) / (c.tn * 32));
       const double rounds =
           nb <= 512 ? (double)((nb + 255) / 256) : (double)nb / 256.0;
-      const double t = rounds * c.tm * c.tn / 1.6;
+      const double t = rounds * c.tm * c.tn / (c.ks >= 4 ? 1.6 : 1.2);
       if (best < 0 || t < best_t) {
         best = i;
         best_t = t;

@@ -14,6 +14,19 @@ from .registry import (DETECTORS, build_backbone, build_detector, build_head,
                        build_neck)
 
 
+_INDEX_CACHE = {}
+
+
+def _device_index(values, device):
+    """A small constant int64 index tensor on ``device``, built once."""
+    key = (str(device), values)
+    t = _INDEX_CACHE.get(key)
+    if t is None:
+        t = torch.tensor(values, dtype=torch.long, device=device)
+        _INDEX_CACHE[key] = t
+    return t
+
+
 def _allow_missing_ckpt():
     """Opt-in (bench / smoke / offline config tests) for running with a
     checkpoint that cannot be found; the default is the reference's: raise."""
@@ -120,8 +133,17 @@ class SingleStageDetector(nn.Module):
         copy (the reference does one all-reduce + .item() per key)."""
         table = getattr(losses, 'table', None)
         if table is not None:
-            key_sums = table[losses.rows].sum(1)
             names = list(losses.keys())
+            rows = list(losses.rows)
+            # row selection by slicing / a cached device index: indexing with a
+            # Python list would build the index on the host and copy it over
+            # synchronously (a host sync per step, and illegal under hipGraph
+            # capture)
+            if rows == list(range(rows[0], rows[0] + len(rows))):
+                key_sums = table[rows[0]:rows[0] + len(rows)].sum(1)
+            else:
+                key_sums = table.index_select(
+                    0, _device_index(tuple(rows), table.device)).sum(1)
         else:
             names, vals = [], []
             for name, value in losses.items():
@@ -134,7 +156,11 @@ class SingleStageDetector(nn.Module):
                 names.append(name)
             key_sums = torch.stack(vals)
         sel = [i for i, k in enumerate(names) if 'loss' in k]
-        loss = key_sums[sel].sum()
+        if len(sel) == len(names):
+            loss = key_sums.sum()
+        else:
+            loss = key_sums.index_select(
+                0, _device_index(tuple(sel), key_sums.device)).sum()
         logged = torch.cat([key_sums.detach(), loss.detach().reshape(1)])
         from .train import collectives_on
         if collectives_on():

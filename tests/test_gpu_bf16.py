@@ -103,7 +103,8 @@ BF16_SHAPES = ['2x2x2x2x1', '2x2x1x2x1', '2x1x2x4x1', '1x2x2x2x1', '1x1x2x4x1',
                '1x1x1x4x1', '1x1x4x4x1', '2x1x4x4x1', '1x1x1x4x4', '2x1x1x4x4',
                '1x2x1x2x4', '2x2x1x2x4', '2x2x2x1x1', '1x1x2x1x1', '1x1x1x1x4',
                # LDS-tiled kernel (wvm = 0): BM/32 x BN/32 x 0 x BK x 1
-               '4x4x0x32x1', '2x4x0x32x1', '4x2x0x32x1']
+               '4x4x0x32x2', '4x4x0x32x4', '2x4x0x32x4', '4x2x0x32x4',
+               '4x2x0x32x2']
 
 
 @pytest.mark.parametrize('shape', BF16_SHAPES)

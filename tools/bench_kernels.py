@@ -220,8 +220,8 @@ def bench_conv(out, with_miopen=True):
 
 BF16_CFGS = ['2x2x2x2x1', '2x2x1x2x1', '2x1x2x4x1', '1x2x2x2x1', '1x1x2x4x1',
              '1x1x1x4x1', '1x1x4x4x1', '2x1x4x4x1', '1x1x1x4x4', '2x1x1x4x4',
-             '1x2x1x2x4', '2x2x1x2x4', '4x4x0x32x1', '2x4x0x32x1',
-             '4x2x0x32x1']
+             '1x2x1x2x4', '2x2x1x2x4', '4x4x0x32x2', '4x4x0x32x4',
+             '2x4x0x32x4', '4x2x0x32x4', '4x2x0x32x2']
 
 
 def bench_bf16(out):
