@@ -91,6 +91,10 @@ typedef struct {
   int32_t flags;
 } ld_loss_hp_t;
 #define LD_LOSS_PROB_CLS 1
+/* target assignment: the imitation region is "anchor centre strictly inside a
+ * GT box" (get_im_region modes 'fitnet' / 'decouple' / 'gibox',
+ * ld_head.py:597-611) instead of the 'finegrained' IoU rule (:594-596) */
+#define LD_IM_CENTER_INSIDE 2
 
 /* ---- library ------------------------------------------------------------ */
 /* ABI version of this header; bump on any signature change. */

@@ -229,7 +229,8 @@ __global__ __launch_bounds__(kBlock) void atss_select_kernel(
 constexpr int kGtChunk = 128;
 
 __global__ __launch_bounds__(kBlock) void atss_dense_kernel(
-    ld_geom_t geom, int num_classes, const float* __restrict__ anchors,
+    ld_geom_t geom, int num_classes, int im_center_inside,
+    const float* __restrict__ anchors,
     const float* __restrict__ gt_bboxes, const int64_t* __restrict__ gt_labels,
     const int32_t* __restrict__ num_gt, int max_gt,
     const int32_t* __restrict__ valid_hw,
@@ -281,8 +282,14 @@ __global__ __launch_bounds__(kBlock) void atss_dense_kernel(
         const float t = s_thr[j];
         // atss_assigner.py:271-272
         if ((di < t) && (di >= 0.25f * t)) vmax = fmaxf(vmax, iou);
-        // ld_head.py:594-596
-        if (iou > 0.5f * s_cm[j]) is_im = true;
+        if (im_center_inside) {
+          // 'fitnet' / 'decouple' / 'gibox' region: anchor centre strictly
+          // inside a GT box (ld_head.py:598-606)
+          const float cx = (ab.x2 + ab.x1) / 2, cy = (ab.y2 + ab.y1) / 2;
+          if (cx > gt.x1 && cx < gt.x2 && cy > gt.y1 && cy < gt.y2) is_im = true;
+        } else if (iou > 0.5f * s_cm[j]) {  // 'finegrained', ld_head.py:594-596
+          is_im = true;
+        }
       }
     }
   }
@@ -422,7 +429,8 @@ extern "C" int ld_atss_targets_ex(const ld_geom_t* geom, const ld_loss_hp_t* hp,
   }
   dim3 gridb((A + kBlock - 1) / kBlock, N);
   hipLaunchKernelGGL(atss_dense_kernel, gridb, dim3(kBlock), 0, stream, *geom,
-                     hp->num_classes, anchors, gt_bboxes, gt_labels, num_gt,
+                     hp->num_classes, (hp->flags & LD_IM_CENTER_INSIDE) ? 1 : 0, anchors,
+                     gt_bboxes, gt_labels, num_gt,
                      max_gt > 0 ? max_gt : 1, valid_hw, keys, thr, colmax,
                      labels, label_weights, bbox_targets, vlr, im, counts, gt_inds,
                      max_overlaps);

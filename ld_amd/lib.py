@@ -51,6 +51,7 @@ class LossHpT(C.Structure):
 
 
 LD_LOSS_PROB_CLS = 1
+LD_IM_CENTER_INSIDE = 2
 
 
 class ConvLevelT(C.Structure):

@@ -1,0 +1,53 @@
+"""The benchmark train step alone, for rocprofv3 (--kernel-trace --stats / --pmc):
+    rocprofv3 --kernel-trace --stats --output-format csv -d out -o step -- \
+        python tools/profile_step.py --mode bf16 --steps 5
+Same model, batch and shipped conv shape table as bench.py; `--graph` replays the
+captured hipGraph instead of enqueueing eagerly."""
+import argparse
+import os
+import sys
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--mode', default='fp32', choices=['fp32', 'bf16'])
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--graph', action='store_true')
+    args = ap.parse_args()
+    from ld_amd import layers as Y
+    from ld_amd import model_zoo, synthetic
+    from ld_amd.train import GraphedStep, SGDTrainer
+    dev = torch.device('cuda:0')
+    Y.set_precision(args.mode)
+    det = model_zoo.build_seeded_ld_detector(50, 101, dev)
+    tr = SGDTrainer(det, lr=model_zoo.OPTIMIZER['lr'])
+    b = synthetic.synthetic_batch(2, (800, 1333), (800, 1344), 7, 1234)
+    d = dict(img=b['img'].to(dev), img_metas=b['img_metas'],
+             gt_bboxes=[x.to(dev) for x in b['gt_bboxes']],
+             gt_labels=[x.to(dev) for x in b['gt_labels']])
+    for _ in range(args.warmup):
+        tr.step(d)
+    torch.cuda.synchronize()
+    if args.graph:
+        g = GraphedStep(tr, d)
+        run = g.replay
+    else:
+        run = lambda: tr.step(d)  # noqa: E731
+    import time
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    print(f'{args.mode} graph={args.graph}: {dt * 1e3:.2f} ms/step, '
+          f'{2 / dt:.1f} img/s')
+
+
+if __name__ == '__main__':
+    main()
