@@ -224,6 +224,21 @@ int ld_loss_main_parts(const ld_geom_t* geom, const ld_loss_hp_t* hp,
                        void* workspace, size_t workspace_bytes, int parts,
                        ld_stream_t stream);
 
+/* The 'gibox' imitation region (LDHead.get_gi_region, ld_head.py:613-637;
+ * LDv2Head: ld_gflv2.py:619-644 with hp->flags & LD_LOSS_PROB_CLS): per level,
+ * over all cells of all images, the General-Instance score max_c |teacher -
+ * student| and box (the winner's decoded distribution), then the first `topn`
+ * (10) survivors of a greedy NMS at `iou_thr` (0.3) -- torchvision.ops.nms's
+ * published semantics: descending score, IoU > thr suppresses.  Writes the
+ * (N, A) 0/1 mask `im` and the per-level selected counts into
+ * counts[N + L + l] (the slots ld_loss_main reads for loss_im); run it between
+ * ld_atss_targets and ld_loss_main.  Equal scores: lower cell index first. */
+size_t ld_gi_region_workspace_bytes(const ld_geom_t* geom);
+int ld_gi_region(const ld_geom_t* geom, const ld_loss_hp_t* hp, const ld_maps_t* cls,
+                 const ld_maps_t* reg, const ld_maps_t* t_cls, const ld_maps_t* t_reg,
+                 int topn, float iou_thr, float* im, int32_t* counts, void* workspace,
+                 size_t workspace_bytes, ld_stream_t stream);
+
 /* losses: device float[8 * num_levels], key-major (loss_cls[0..L), ...). */
 int ld_loss_finalize(const ld_geom_t* geom, const ld_loss_hp_t* hp,
                      const int32_t* counts, const float* norm,

@@ -511,6 +511,122 @@ __global__ __launch_bounds__(kBlk) void loss_im_dense_kernel(
   if (threadIdx.x == 0) partial[part_idx(S_IM, blockIdx.z, bm, c.n)] = s_im;
 }
 
+// ------------------------------------- 'gibox' imitation region (GI boxes) ---
+// LDHead.get_gi_region (ld_head.py:613-637; LDv2Head: ld_gflv2.py:619-644
+// without the sigmoids): per level, over ALL cells of all images,
+//   z = teacher_score - student_score, giscore = max_c |z|, the GI box is the
+//   teacher's decoded box where the teacher wins (z >= 0 at the arg-max class)
+//   and the student's otherwise; keep the first `topn` boxes of a greedy NMS
+//   (IoU > thr suppresses, descending giscore) -- torchvision.ops.nms(...)[:10].
+// Two launches: a dense scoring sweep (thread = cell) and one 1024-thread
+// workgroup per level that extracts the topn survivors by repeated
+// arg-max + suppression (O(topn * cells), never the sort or the O(M^2) mask).
+__global__ __launch_bounds__(kBlk) void gi_score_kernel(
+    ld_geom_t geom, ld_loss_hp_t hp, BlockMap bm, ld_maps_t cls, ld_maps_t t_cls,
+    ld_maps_t reg, ld_maps_t t_reg, float* __restrict__ giscore,
+    float* __restrict__ gibox) {
+  const Cell c = locate256(geom, bm);
+  if (!c.active) return;
+  const int C = hp.cls_channels > 0 ? hp.cls_channels : hp.num_classes;
+  const bool prob = (hp.flags & LD_LOSS_PROB_CLS) != 0;
+  float best = -1.0f, zbest = 0.0f;
+  for (int ch = 0; ch < C; ++ch) {
+    const float xs = *chan_ptr(cls, c, ch), xt = *chan_ptr(t_cls, c, ch);
+    const float z = prob ? xt - xs : ld::sigmoidf_(xt) - ld::sigmoidf_(xs);
+    const float az = fabsf(z);
+    if (az > best) {  // first maximal class
+      best = az;
+      zbest = z;
+    }
+  }
+  const ld_maps_t& src = zbest >= 0.0f ? t_reg : reg;  // who is bigger
+  float e[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float v[K17], p[K17];
+    load_side(src, c, s, v);
+    e[s] = ld::softmax_expect<K17>(v, p);
+  }
+  const float cx = (float)c.x, cy = (float)c.y;  // anchor centre / stride
+  giscore[c.o] = best;
+  reinterpret_cast<float4*>(gibox)[c.o] =
+      make_float4(cx - e[0], cy - e[1], cx + e[2], cy + e[3]);
+}
+
+__global__ __launch_bounds__(1024) void gi_select_kernel(
+    ld_geom_t geom, int topn, float iou_thr, float* __restrict__ giscore,
+    const float* __restrict__ gibox, float* __restrict__ im,
+    int32_t* __restrict__ counts) {
+  __shared__ float s_val[1024];
+  __shared__ int s_idx[1024];
+  __shared__ float4 s_keep;
+  __shared__ int s_pick;
+  const int l = blockIdx.x, t = threadIdx.x;
+  const ld_level_t lv = geom.lv[l];
+  const int Al = lv.H * lv.W, N = geom.num_imgs, A = geom.num_anchors;
+  const int M = N * Al;
+  auto flat = [&](int m) -> size_t {  // candidate m = n * A_l + r -> (n, anchor)
+    const int n = m / Al, r = m - n * Al;
+    return (size_t)n * A + lv.offset + r;
+  };
+  for (int m = t; m < M; m += 1024) im[flat(m)] = 0.0f;
+  int kept = 0;
+  for (int round = 0; round < topn; ++round) {
+    float bv = -1.0f;
+    int bi = 0x7fffffff;
+    for (int m = t; m < M; m += 1024) {
+      const float v = giscore[flat(m)];
+      if (v > bv) {  // ascending m per thread: first maximum
+        bv = v;
+        bi = m;
+      }
+    }
+    s_val[t] = bv;
+    s_idx[t] = bi;
+    __syncthreads();
+    for (int w = 512; w >= 1; w >>= 1) {
+      if (t < w) {
+        const float ov = s_val[t + w];
+        const int oi = s_idx[t + w];
+        if (ov > s_val[t] || (ov == s_val[t] && oi < s_idx[t])) {
+          s_val[t] = ov;
+          s_idx[t] = oi;
+        }
+      }
+      __syncthreads();
+    }
+    if (t == 0) {
+      s_pick = s_val[0] >= 0.0f ? s_idx[0] : -1;
+      if (s_pick >= 0) {
+        const size_t o = flat(s_pick);
+        s_keep = reinterpret_cast<const float4*>(gibox)[o];
+        im[o] = 1.0f;
+      }
+    }
+    __syncthreads();
+    if (s_pick < 0) break;  // uniform
+    ++kept;
+    const float4 k = s_keep;
+    const float ka = (k.z - k.x) * (k.w - k.y);
+    for (int m = t; m < M; m += 1024) {
+      const size_t o = flat(m);
+      if (giscore[o] < 0.0f) continue;
+      if (m == s_pick) {
+        giscore[o] = -1.0f;
+        continue;
+      }
+      const float4 b = reinterpret_cast<const float4*>(gibox)[o];
+      const float iw = fmaxf(fminf(k.z, b.z) - fmaxf(k.x, b.x), 0.0f);
+      const float ih = fmaxf(fminf(k.w, b.w) - fmaxf(k.y, b.y), 0.0f);
+      const float inter = iw * ih;
+      const float iou = inter / (ka + (b.z - b.x) * (b.w - b.y) - inter);
+      if (iou > iou_thr) giscore[o] = -1.0f;
+    }
+    __syncthreads();
+  }
+  if (t == 0) counts[N + geom.num_levels + l] = kept;
+}
+
 // ------------------------------------------------------------ finalise ------
 // Fixed-order sum of the per-block partials of level l: [slot][z][n][b].
 __global__ __launch_bounds__(kWave) void loss_finalize_kernel(
@@ -816,6 +932,36 @@ extern "C" int ld_loss_finalize(const ld_geom_t* geom, const ld_loss_hp_t* hp,
                       kClsChunk - 1) / kClsChunk,
                      (hp->feat_channels + chunk - 1) / chunk, counts, norm,
                      (const float*)workspace + w.pre_floats, losses);
+  return (int)hipGetLastError();
+}
+
+extern "C" size_t ld_gi_region_workspace_bytes(const ld_geom_t* geom) {
+  if (check_geom(geom) != 0) return 0;
+  return (size_t)geom->num_imgs * geom->num_anchors * 5 * sizeof(float);
+}
+
+extern "C" int ld_gi_region(const ld_geom_t* geom, const ld_loss_hp_t* hp,
+                            const ld_maps_t* cls, const ld_maps_t* reg,
+                            const ld_maps_t* t_cls, const ld_maps_t* t_reg, int topn,
+                            float iou_thr, float* im, int32_t* counts,
+                            void* workspace, size_t workspace_bytes,
+                            ld_stream_t stream_) {
+  if (int e = check_geom(geom)) return e;
+  if (int e = check_hp(hp)) return e;
+  if (!cls || !reg || !t_cls || !t_reg || !im || !counts || topn < 1 ||
+      !(iou_thr >= 0.0f))
+    return LD_EINVAL;
+  if (!workspace || workspace_bytes < ld_gi_region_workspace_bytes(geom))
+    return LD_ENOSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const BlockMap bm = make_block_map(*geom, kBlk);
+  float* giscore = (float*)workspace;
+  float* gibox = giscore + (size_t)geom->num_imgs * geom->num_anchors;
+  hipLaunchKernelGGL(gi_score_kernel, dim3(bm.blocks_per_img, geom->num_imgs),
+                     dim3(kBlk), 0, stream, *geom, *hp, bm, *cls, *t_cls, *reg, *t_reg,
+                     giscore, gibox);
+  hipLaunchKernelGGL(gi_select_kernel, dim3(geom->num_levels), dim3(1024), 0, stream,
+                     *geom, topn, iou_thr, giscore, gibox, im, counts);
   return (int)hipGetLastError();
 }
 

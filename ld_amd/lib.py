@@ -175,6 +175,9 @@ SIGNATURES = {
     'ld_quality_backward': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _vp, _i32, _vp, _sz, _vp]),
+    'ld_gi_region_workspace_bytes': (_sz, [_G]),
+    'ld_gi_region': (C.c_int, [_G, _H, _M, _M, _M, _M, _i32, _f32, _vp, _vp,
+                               _vp, _sz, _vp]),
     'ld_loss_finalize': (C.c_int, [_G, _H, _vp, _vp, _vp, _vp, _vp]),
     'ld_kl_integral_dense': (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _vp,
                                        _vp, _vp, _vp]),
