@@ -75,6 +75,23 @@ class LossDict(dict):
     rows = None
 
 
+def _imitation_flags(method, lw_im):
+    """hp flags of the imitation region (ld_head.py:170-191,580-611).
+    'finegrained': IoU > 0.5 max IoU per GT.  'fitnet': anchor centre strictly
+    inside a GT.  'gibox': the GI boxes (selected after the forward; the region
+    flag only matters for its weight-0 evaluation).  'decouple' adds
+    ``2 * mse(x[outside], teacher_x[inside])`` -- two row sets of different
+    sizes, which F.mse_loss cannot broadcast: the reference itself raises on
+    that branch, so there is nothing to reproduce."""
+    if method == 'decouple' and lw_im != 0.0:
+        raise NotImplementedError(
+            "imitation_method='decouple': ld_head.py:176-183 evaluates "
+            'mse_loss(x[ng_inds], teacher_x[fg_inds]) on row sets of different '
+            'sizes, which raises in the reference as well')
+    return L.LD_IM_CENTER_INSIDE if method in ('fitnet', 'decouple',
+                                               'gibox') else 0
+
+
 class LazyScalars(dict):
     """dict of python floats backed by one device tensor; the single D2H copy
     happens on first access (the reference syncs 9 times per step).
@@ -434,6 +451,9 @@ class LDHead(GFLHead):
         # fused forward launch already produced
         self.unit_upstream = False
 
+    def _imitation_flags(self, lw_im):
+        return _imitation_flags(self.imitation_method, lw_im)
+
     def forward_train(self, x, out_teacher, teacher_x, img_metas, gt_bboxes,
                       gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None,
                       **kwargs):
@@ -454,12 +474,7 @@ class LDHead(GFLHead):
         """ld_head.py:284-375 -> dict of 8 lists of per-level scalars."""
         self._check_loss_cfg()
         lw_im = float(self.loss_im.loss_weight)
-        if self.imitation_method != 'finegrained' and lw_im != 0.0:
-            raise NotImplementedError(
-                f"imitation_method='{self.imitation_method}' with a non-zero "
-                'loss_im weight (gibox needs torchvision NMS and is CUDA-only '
-                'in the reference, SURVEY.md quirk Q3); with weight 0 the '
-                'term is exactly 0 and is evaluated as such')
+        im_flags = self._imitation_flags(lw_im)
         if x[0].shape[1] != 256:
             raise ValueError('LDHead hard-codes 256 feature channels '
                              '(ld_head.py:153-154)')
@@ -471,12 +486,17 @@ class LDHead(GFLHead):
                       lw_ld_vlr=self.loss_ld_vlr.loss_weight,
                       T_ld_vlr=self.loss_ld_vlr.T,
                       lw_kd=self.loss_kd.loss_weight, T_kd=self.loss_kd.T,
-                      lw_im=lw_im)
+                      lw_im=lw_im, flags=im_flags)
         targets = self.get_targets_batched(sizes, img_metas, gt_bboxes,
                                            gt_labels, hp, device)
         teacher = ([t.detach() for t in soft_label],
                    [t.detach() for t in soft_target],
                    [t.detach() for t in teacher_x])
+        if self.imitation_method == 'gibox' and lw_im != 0.0:
+            targets = LB.gi_region(hp, targets,
+                                   [c.detach() for c in cls_scores],
+                                   [b.detach() for b in bbox_preds],
+                                   teacher[0], teacher[1])
         table, _ = LB.LDLossBlock.apply(hp, targets, teacher,
                                         self._norm_reducer(),
                                         self.unit_upstream, *cls_scores,
@@ -655,12 +675,7 @@ class LDv2Head(GFocalHead):
         """ld_gflv2.py:286-380 -> dict of 8 lists of per-level scalars."""
         self._check_loss_cfg()
         lw_im = float(self.loss_im.loss_weight)
-        if self.imitation_method != 'finegrained' and lw_im != 0.0:
-            raise NotImplementedError(
-                f"imitation_method='{self.imitation_method}' with a non-zero "
-                'loss_im weight: SURVEY.md section 8(f)-4 (gibox is CUDA-only '
-                'in the reference, quirk Q3); use imitation_method='
-                "'finegrained'")
+        im_flags = _imitation_flags(self.imitation_method, lw_im)
         if x[0].shape[1] != 256:
             raise ValueError('LDv2Head hard-codes 256 feature channels '
                              '(ld_gflv2.py:155-156)')
@@ -673,11 +688,19 @@ class LDv2Head(GFocalHead):
                       T_ld_vlr=self.loss_ld_vlr.T,
                       lw_kd=self.loss_kd.loss_weight, T_kd=self.loss_kd.T,
                       lw_im=lw_im)
+        hp.flags |= im_flags
         targets = self.get_targets_batched(sizes, img_metas, gt_bboxes,
                                            gt_labels, hp, device)
         t_kd = [t.detach() for t in soft_label]
         teacher = (t_kd, [t.detach() for t in soft_target],
                    [t.detach() for t in teacher_x], t_kd)
+        if self.imitation_method == 'gibox' and lw_im != 0.0:
+            # ld_gflv2.py:619-644: raw teacher cls_feat vs the student's
+            # probabilities, no sigmoids
+            targets = LB.gi_region(hp, targets,
+                                   [c.detach() for c in cls_scores],
+                                   [b.detach() for b in bbox_preds], t_kd,
+                                   teacher[1])
         table, _ = LB.LDLossBlock.apply(hp, targets, teacher,
                                         self._norm_reducer(),
                                         self.unit_upstream, *cls_scores,

@@ -129,6 +129,29 @@ def grid_anchors(featmap_sizes, strides, device, anchor_scale=8):
     return out
 
 
+def gi_region(hp, targets, cls, reg, t_cls, t_reg, topn=10, iou_thr=0.3):
+    """The 'gibox' imitation region (ld_gi_region): replaces targets['im'] and
+    the per-level IM counts in targets['counts'] by the (<= topn per level)
+    General-Instance boxes' cells.  Returns the updated targets dict (a shallow
+    copy: the assignment results themselves are shared)."""
+    lib = L.get_lib()
+    geom = targets['geom']
+    device = cls[0].device
+    im = torch.empty_like(targets['im'])
+    counts = targets['counts'].clone()
+    ws = workspace(device, lib.ld_gi_region_workspace_bytes(C.byref(geom)),
+                   'gi_region')
+    L.check(lib.ld_gi_region(
+        C.byref(geom), C.byref(hp), C.byref(L.make_maps(cls)),
+        C.byref(L.make_maps(reg)), C.byref(L.make_maps(t_cls)),
+        C.byref(L.make_maps(t_reg)), int(topn), float(iou_thr), L.ptr(im),
+        L.ptr(counts), L.ptr(ws), ws.numel(), L.stream_ptr(device)),
+        'ld_gi_region')
+    out = dict(targets)
+    out['im'], out['counts'] = im, counts
+    return out
+
+
 class _LossState:
     pass
 

@@ -679,6 +679,115 @@ def gen_e2e_v2():
     print('e2e_v2.npz')
 
 
+# ------------------------------------------- other imitation regions (8f-4) --
+def _patch_for_gibox():
+    """get_gi_region is CUDA-only in the reference (quirk Q3): it calls
+    ``torch.arange(...).cuda()`` (ld_head.py:631) and
+    ``torch.ops.torchvision.nms`` (:637).  To execute it here, ``.cuda()``
+    becomes the identity and the torchvision op is registered with its
+    published semantics (greedy, descending score, IoU > thr suppresses;
+    restated -- the compiled op is absent), so everything around the NMS core
+    is the reference's own arithmetic."""
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+    def nms(dets, scores, iou_threshold):
+        order = torch.argsort(scores, descending=True, stable=True)
+        b = dets[order]
+        area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        keep, alive = [], torch.ones(len(order), dtype=torch.bool)
+        for i in range(len(order)):
+            if not alive[i]:
+                continue
+            keep.append(int(order[i]))
+            if len(keep) >= 64:  # callers take [:10]
+                break
+            w = (torch.minimum(b[i, 2], b[i + 1:, 2]) -
+                 torch.maximum(b[i, 0], b[i + 1:, 0])).clamp(min=0)
+            h = (torch.minimum(b[i, 3], b[i + 1:, 3]) -
+                 torch.maximum(b[i, 1], b[i + 1:, 1])).clamp(min=0)
+            inter = w * h
+            iou = inter / (area[i] + area[i + 1:] - inter)
+            alive[i + 1:] &= ~(iou > iou_threshold)
+        return torch.tensor(keep, dtype=torch.long)
+
+    try:
+        torch.library.define('torchvision::nms',
+                             '(Tensor dets, Tensor scores, float iou_threshold) '
+                             '-> Tensor')
+        torch.library.impl('torchvision::nms', 'cpu')(nms)
+    except RuntimeError:
+        pass  # already registered in this process
+
+
+IMITATION_CASES = [
+    # name, head kind, method, pad, img_shape, num_gt, batch seed, input seed
+    ('fitnet_small', 'v1', 'fitnet', (160, 224), (150, 200), [20, 7], 12, 301),
+    ('fitnet_c2', 'v1', 'fitnet', (800, 1344), (800, 1333), [7, 7], 1234, 302),
+    ('gibox_small', 'v1', 'gibox', (160, 224), (160, 224), [3, 1], 11, 303),
+    ('gibox_c2', 'v1', 'gibox', (800, 1344), (800, 1333), [7, 7], 1234, 304),
+    ('gibox_v2_small', 'v2', 'gibox', (160, 224), (150, 200), [20, 7], 12, 305),
+]
+
+
+def gen_imitation():
+    _patch_for_gibox()
+    d = {}
+    for name, kind, method, pad, img_shape, num_gt, bseed, hseed in \
+            IMITATION_CASES:
+        head = _ld_head(method) if kind == 'v1' else _ldv2_head(method)
+        if kind == 'v2':
+            head.load_state_dict(
+                synthetic.seeded_state_dict(head.state_dict(), seed=5))
+        picked = []
+        if method == 'gibox':
+            orig = head.get_gi_region
+
+            def rec(*a, _o=orig, **k):
+                out = _o(*a, **k)
+                picked.append(_np(out).astype(np.int64))
+                return out
+
+            head.get_gi_region = rec
+        batch = synthetic.synthetic_batch(
+            num_imgs=len(num_gt), img_shape=img_shape, pad_shape=pad,
+            num_gt=num_gt, seed=bseed)
+        sizes = synthetic.level_shapes(pad)
+        hi = synthetic.synthetic_head_inputs(
+            len(num_gt), sizes, seed=hseed,
+            num_classes=80 if kind == 'v1' else 81)
+        for k in ('cls', 'reg', 'x'):
+            for t in hi[k]:
+                t.requires_grad_(True)
+        if kind == 'v1':
+            losses = head.loss(hi['cls'], hi['reg'], batch['gt_bboxes'],
+                               batch['gt_labels'], (hi['t_cls'], hi['t_reg']),
+                               hi['x'], hi['t_x'], batch['img_metas'])
+        else:
+            scores = [_v2_quality_tail(head, c, r)[0]
+                      for c, r in zip(hi['cls'], hi['reg'])]
+            losses = head.loss(scores, hi['reg'], hi['cls'],
+                               batch['gt_bboxes'], batch['gt_labels'],
+                               (None, hi['t_reg'], hi['t_cls']), hi['x'],
+                               hi['t_x'], batch['img_metas'])
+        table = np.stack(
+            [np.array([float(v.detach()) for v in losses[k]]) for k in LOSS_KEYS])
+        sum(sum(v) for v in losses.values()).backward()
+        d[name + '_cfg'] = np.array(list(pad) + list(img_shape) + [bseed, hseed])
+        d[name + '_num_gt'] = np.array(num_gt)
+        d[name + '_losses'] = table.astype(np.float64)
+        for l, idx in enumerate(picked):
+            d[f'{name}_gi_idx_{l}'] = idx
+        gx = [t.grad if t.grad is not None else torch.zeros_like(t)
+              for t in hi['x']]
+        d[name + '_gx_abs_sum'] = np.array(
+            [float(g.double().abs().sum()) for g in gx])
+        d[name + '_gx_nonzero_rows'] = np.array(
+            [int((g.abs().sum(1) > 0).sum()) for g in gx])
+        print(f'  imitation {name}: loss_im', table[7])
+    np.savez_compressed(os.path.join(OUT, 'imitation.npz'), **d)
+    print('imitation.npz')
+
+
 # ------------------------------------------------------------ inference ----
 # GFLHead.get_bboxes (anchor_head.py:497-589 -> gfl_head.py:354-451 ->
 # post_processing/bbox_nms.py:70-195 multiclass_nms -> mmcv.ops.batched_nms,
@@ -737,7 +846,7 @@ def gen_infer():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='kat,anchors,targets,lossblock,e2e,infer,'
-                    'lossblock_v2,e2e_v2')
+                    'lossblock_v2,e2e_v2,imitation')
     ap.add_argument('--e2e-cases', default='')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
@@ -755,6 +864,8 @@ def main():
         gen_e2e([c for c in args.e2e_cases.split(',') if c])
     if 'infer' in only:
         gen_infer()
+    if 'imitation' in only:
+        gen_imitation()
     if 'lossblock_v2' in only:
         gen_lossblock_v2()
     if 'e2e_v2' in only:

@@ -201,8 +201,21 @@ def im_region_finegrained(anchors, gts):
     return (iou > F32(0.5) * iou.max(0)[None, :]).any(1).astype(F32)
 
 
+def im_region_center_inside(anchors, gts):
+    """ld_head.py:597-611, modes 'fitnet' / 'decouple' / 'gibox': 1 where the
+    anchor centre lies strictly inside some GT box."""
+    anchors = np.asarray(anchors, dtype=F32)
+    gts = np.asarray(gts, dtype=F32).reshape(-1, 4)
+    cx = (anchors[:, 2] + anchors[:, 0]) / F32(2)
+    cy = (anchors[:, 3] + anchors[:, 1]) / F32(2)
+    flag = np.zeros(anchors.shape[0], dtype=bool)
+    for g in gts:
+        flag |= (cx > g[0]) & (cx < g[2]) & (cy > g[1]) & (cy < g[3])
+    return flag.astype(F32)
+
+
 def get_targets_single(anchors, flags, num_level, gts, gt_labels,
-                       num_classes=80, topk=9):
+                       num_classes=80, topk=9, im_mode='finegrained'):
     """ld_head.py:449-577 for one image (allowed_border=-1 so
     inside_flags == valid_flags, core/anchor/utils.py:44-45; pos_weight=-1).
     Returns dense (A,) arrays after `unmap`."""
@@ -218,7 +231,8 @@ def get_targets_single(anchors, flags, num_level, gts, gt_labels,
         s += n
     gt_inds, _ = atss_assign(anc, nl_inside, gts, topk)
     vlr = vlr_region(anc, nl_inside, gts, topk)
-    im = im_region_finegrained(anc, gts)
+    im = im_region_finegrained(anc, gts) if im_mode == 'finegrained' \
+        else im_region_center_inside(anc, gts)
     pos = np.nonzero(gt_inds > 0)[0]
     labels_i = np.full(anc.shape[0], num_classes, dtype=np.int64)
     lw_i = np.zeros(anc.shape[0], dtype=F32)
@@ -246,7 +260,8 @@ def get_targets_single(anchors, flags, num_level, gts, gt_labels,
 
 
 def get_targets(featmap_sizes, img_metas, gt_bboxes, gt_labels,
-                strides=(8, 16, 32, 64, 128), num_classes=80, topk=9):
+                strides=(8, 16, 32, 64, 128), num_classes=80, topk=9,
+                im_mode='finegrained'):
     """ld_head.py:377-447 (+ anchor_head.py:145-173): dense (N, A) targets in
     level-major anchor order; num_total_pos = sum_i max(P_i, 1)."""
     anchors = np.concatenate(grid_anchors(featmap_sizes, strides))
@@ -256,7 +271,7 @@ def get_targets(featmap_sizes, img_metas, gt_bboxes, gt_labels,
         flags = np.concatenate(
             valid_flags(featmap_sizes, meta['pad_shape'], strides))
         t = get_targets_single(anchors, flags, num_level, np.asarray(gb),
-                               np.asarray(gl), num_classes, topk)
+                               np.asarray(gl), num_classes, topk, im_mode)
         if t is None:
             return None
         per_img.append(t)
@@ -633,6 +648,46 @@ def ld_loss_block(cls, reg, t_cls, t_reg, x, t_x, targets, hp=None,
 
 
 # --------------------------------------------------------------------------
+# the 'gibox' imitation region
+# --------------------------------------------------------------------------
+def gi_region(cls, reg, t_cls, t_reg, prob=False, topn=10, iou_thr=0.3):
+    """LDHead.get_gi_region (ld_head.py:613-637; LDv2Head ld_gflv2.py:619-644
+    with ``prob``: no sigmoids) on per-level NCHW arrays: per level the first
+    ``topn`` survivors of torchvision.ops.nms(gibox, giscore, iou_thr) over all
+    cells of all images.  torchvision's op is compiled code outside the
+    reference checkout; its published algorithm (greedy, descending score, IoU >
+    thr suppresses) is restated by nms_greedy below (equal scores: lower index
+    first).  Returns (per-level index arrays into the (N*H*W) rows, dense
+    (N, A) 0/1 mask in level-major anchor order)."""
+    N = cls[0].shape[0]
+    idxs, masks = [], []
+    for l in range(len(cls)):
+        n, _, h, w = cls[l].shape
+        s_r, t_r = _nchw_to_rows(cls[l]), _nchw_to_rows(t_cls[l])
+        if prob:
+            z = t_r.astype(F32) - s_r.astype(F32)
+        else:
+            z = _sigmoid(t_r) - _sigmoid(s_r)
+        az = np.abs(z)
+        index = az.argmax(1)
+        giscore = az[np.arange(az.shape[0]), index]
+        teacher_wins = z[np.arange(z.shape[0]), index] >= 0
+        ys, xs = np.meshgrid(np.arange(h, dtype=F32), np.arange(w, dtype=F32),
+                             indexing='ij')
+        ctr = np.tile(np.stack([xs.reshape(-1), ys.reshape(-1)], -1), (n, 1))
+        sd, _ = integral(_nchw_to_rows(reg[l]))
+        td, _ = integral(_nchw_to_rows(t_reg[l]))
+        box = np.where(teacher_wins[:, None], distance2bbox(ctr, td),
+                       distance2bbox(ctr, sd)).astype(F32)
+        keep = nms_greedy(box, giscore, iou_thr, max_keep=topn)[:topn]
+        idxs.append(np.asarray(keep, dtype=np.int64))
+        m = np.zeros(n * h * w, dtype=F32)
+        m[keep] = 1
+        masks.append(m.reshape(n, h * w))
+    return idxs, np.concatenate(masks, 1)
+
+
+# --------------------------------------------------------------------------
 # inference: GFLHead.get_bboxes  (SURVEY.md section 8f rank 1; the checker of
 # ld_amd/csrc/infer.hip)
 #   anchor_head.py:497-589 -> gfl_head.py:354-451 (_get_bboxes)
@@ -644,8 +699,8 @@ def ld_loss_block(cls, reg, t_cls, t_reg, x, t_x, targets, hp=None,
 # shim).  Equal scores are ordered lower-index-first (the compiled op's order
 # for ties is an artefact of its unstable sort).
 # --------------------------------------------------------------------------
-def nms_greedy(boxes, scores, iou_thr):
-    """Indices kept, in descending-score order."""
+def nms_greedy(boxes, scores, iou_thr, max_keep=None):
+    """Indices kept, in descending-score order (the first ``max_keep``)."""
     order = np.argsort(-scores, kind='stable')
     b = boxes[order].astype(F32)
     areas = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
@@ -656,7 +711,7 @@ def nms_greedy(boxes, scores, iou_thr):
         if removed[i]:
             continue
         keep.append(i)
-        if i + 1 == n:
+        if i + 1 == n or (max_keep is not None and len(keep) >= max_keep):
             break
         r = b[i + 1:]
         w = np.maximum(np.minimum(b[i, 2], r[:, 2]) - np.maximum(b[i, 0], r[:, 0]),
