@@ -1134,8 +1134,14 @@ int ld_bf16_stream_tune(int mode, const ConvK& k, hipStream_t stream) {
 // Which wgrad kernel a geometry gets: the workgroup-tiled one needs even Pout
 // (8-byte dY pairs) and at least one full 128-row tile per operand.
 bool ld_bf16_wgrad_tiled(int Cout, int Cin, int Pout) {
-  if (const char* env = getenv("LD_CONV_BF16_WGRAD"))
-    if (env[0] == 'w') return false;  // "wave": force the wave-private kernel
+  // Measured on the C2 step (profiles/r02_bench_s1.json vs r02_bench_s4.json):
+  // the wave-private kernel runs the step's weight gradients at 154-160
+  // TFLOP/s, the workgroup-tiled one at 128 -- its barrier per 32 positions
+  // costs more than the halved staging work saves while the kernel is
+  // issue-bound.  The tiled kernel therefore is opt-in
+  // (LD_CONV_BF16_WGRAD=tile) until the activations are stored in bf16.
+  const char* env = getenv("LD_CONV_BF16_WGRAD");
+  if (!env || env[0] != 't') return false;
   return Pout % 2 == 0 && Cout >= 128 && Cin >= 128;
 }
 

@@ -64,9 +64,12 @@ def test_bf16_layout_identity(bf16_mode):
     assert torch.equal(y.reshape(ref.shape).cpu(), ref)
 
 
+@pytest.mark.parametrize('wgrad', ['wave', 'tile'])
 @pytest.mark.parametrize('case', BF16_CASES, ids=[c[0] for c in BF16_CASES])
-def test_bf16_conv_fwd_bwd(case, bf16_mode):
+def test_bf16_conv_fwd_bwd(case, wgrad, bf16_mode, monkeypatch):
     from ld_amd import layers as Y
+    # both weight-gradient kernels (the workgroup-tiled one is opt-in)
+    monkeypatch.setenv('LD_CONV_BF16_WGRAD', wgrad)
     dev = _dev()
     name, N, cin, cout, k, stride, pad, levels = case
     import zlib
