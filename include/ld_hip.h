@@ -552,6 +552,26 @@ int ld_deform_im2col(const float* x, const float* offset, int N, int Cin, int Hi
                      int Win, int KH, int KW, int stride, int pad, int dilation,
                      float* col, ld_stream_t stream);
 
+/* ---- device input pipeline ---------------------
+ * Resize(keep_ratio) -> flip -> Normalize(to_rgb) -> Pad -> collate of the
+ * reference's train_pipeline (configs/ld/ld_r18_gflv1_r101_fpn_coco_1x.py:66-77,
+ * datasets/pipelines/transforms.py:203-233,416-450,524-580) for a whole batch in
+ * one launch.  `imgs` is a DEVICE array of N descriptors; `data` points to a
+ * decoded uint8 HWC image (3 channels, BGR as cv2.imread delivers) in device
+ * memory; (new_h, new_w) is the resized size (mmcv.imrescale's rounding is host
+ * logic: ld_amd/pipeline.py); `flip` = horizontal flip of the resized image.
+ * out (N, 3, Hpad, Wpad) fp32, zeros beyond (new_h, new_w); mean / std_inv are
+ * HOST float[3] in output-channel order (RGB when to_rgb).  Bilinear =
+ * cv2 INTER_LINEAR on 8-bit data (11-bit fixed-point coefficients, rounded
+ * uint8 result before normalisation). */
+typedef struct {
+  const unsigned char* data;
+  int32_t src_h, src_w, new_h, new_w, flip, reserved;
+} ld_image_t;
+int ld_preprocess_batch(const ld_image_t* imgs, int N, int Hpad, int Wpad,
+                        const float* mean, const float* std_inv, int to_rgb,
+                        float* out, ld_stream_t stream);
+
 /* ---- inference post-processing ---------------
  * GFLHead.get_bboxes for a whole batch (gfl_head.py:354-451 ->
  * post_processing/bbox_nms.py:70-195 -> mmcv.ops.batched_nms): sigmoid scores,

@@ -31,6 +31,7 @@ PER_FILE = {
     'rows.hip': ['-ffp-contract=off'],
     'infer.hip': ['-ffp-contract=off'],
     'quality.hip': ['-ffp-contract=off'],
+    'pipeline.hip': ['-ffp-contract=off'],
 }
 
 

@@ -83,6 +83,13 @@ class BnJobT(C.Structure):  # ld_bn_job_t
                 ('first_block', C.c_int32), ('reserved', C.c_int32)]
 
 
+class ImageT(C.Structure):  # ld_image_t
+    _fields_ = [('data', C.c_void_p), ('src_h', C.c_int32),
+                ('src_w', C.c_int32), ('new_h', C.c_int32),
+                ('new_w', C.c_int32), ('flip', C.c_int32),
+                ('reserved', C.c_int32)]
+
+
 class ConvEpilogueT(C.Structure):
     _fields_ = [('bias', C.c_void_p), ('scale', C.c_void_p),
                 ('shift', C.c_void_p), ('residual', C.c_void_p),
@@ -167,6 +174,9 @@ SIGNATURES = {
                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _M, _M, _M, _M, _M, _M, _vp, _sz, _i32,
                                      _vp]),
+    'ld_preprocess_batch': (C.c_int, [_vp, _i32, _i32, _i32,
+                                      C.POINTER(C.c_float),
+                                      C.POINTER(C.c_float), _i32, _vp, _vp]),
     'ld_deform_im2col': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                    _i32, _i32, _i32, _i32, _vp, _vp]),
     'ld_quality_forward': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp,

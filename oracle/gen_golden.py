@@ -843,10 +843,93 @@ def gen_infer():
     np.savez_compressed(os.path.join(OUT, 'infer.npz'), **d)
 
 
+def gen_pipeline():
+    """Input pipeline: the reference's OWN samplers,
+    box transforms and random draws (pure numpy / torch code under
+    /root/reference; the image arithmetic itself lives in mmcv / cv2, absent,
+    see oracle/pipeline_oracle.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        'ref_group_sampler',
+        os.path.join(ref_shim.REFERENCE_ROOT,
+                     'mmdet/datasets/samplers/group_sampler.py'))
+    gs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gs)
+    from mmdet.datasets.pipelines import transforms as T
+
+    class DS:
+        pass
+
+    out = {}
+    rs = np.random.RandomState(5)
+    cases = {'mixed103': (rs.rand(103) < 0.7).astype(np.uint8),
+             'one_group17': np.ones(17, np.uint8),
+             'tiny3': np.array([0, 1, 1], np.uint8)}
+    for name, flag in cases.items():
+        ds = DS()
+        ds.flag = flag
+        out[f'sampler_{name}_flag'] = flag
+        for spg in (1, 2):
+            for world in (1, 2, 8):
+                for seed, epoch in ((0, 0), (0, 3), (7, 1)):
+                    rows = []
+                    for rank in range(world):
+                        s = gs.DistributedGroupSampler(ds, spg, world, rank,
+                                                       seed=seed)
+                        s.set_epoch(epoch)
+                        rows.append(np.array(list(iter(s)), np.int64))
+                        assert len(rows[-1]) == len(s)
+                    out[f'sampler_{name}_spg{spg}_w{world}_s{seed}_e{epoch}'] = \
+                        np.stack(rows)
+        for spg in (1, 2, 4):
+            np.random.seed(11 + spg)
+            s = gs.GroupSampler(ds, spg)
+            out[f'gsampler_{name}_spg{spg}'] = np.array(list(iter(s)), np.int64)
+    # box transforms
+    resize = T.Resize(img_scale=(1333, 800), keep_ratio=True)
+    flipper = T.RandomFlip(flip_ratio=0.5)
+    rs = np.random.RandomState(9)
+    for i, (h, w, nh, nw) in enumerate(((480, 640, 800, 1067),
+                                        (640, 427, 1199, 800),
+                                        (375, 500, 800, 1067),
+                                        (333, 1000, 444, 1333))):
+        xy = rs.rand(23, 2) * [w, h]
+        wh = rs.rand(23, 2) * [w, h] * 0.6
+        boxes = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        sf = np.array([nw / w, nh / h, nw / w, nh / h], np.float32)
+        res = dict(gt_bboxes=boxes.copy(), bbox_fields=['gt_bboxes'],
+                   scale_factor=sf, img_shape=(nh, nw, 3))
+        resize._resize_bboxes(res)
+        out[f'box{i}_in'] = boxes
+        out[f'box{i}_geom'] = np.array([h, w, nh, nw])
+        out[f'box{i}_resized'] = res['gt_bboxes']
+        out[f'box{i}_flipped'] = flipper.bbox_flip(res['gt_bboxes'],
+                                                   (nh, nw, 3), 'horizontal')
+    # random draws: multi-scale modes and the flip decision
+    scales = [(1333, 640), (1333, 800)]
+    np.random.seed(21)
+    out['draw_range'] = np.array(
+        [T.Resize.random_sample(scales)[0] for _ in range(16)])
+    np.random.seed(22)
+    out['draw_value'] = np.array(
+        [T.Resize.random_select([(1333, 640), (1333, 672), (1333, 800)])[0]
+         for _ in range(16)])
+    np.random.seed(23)
+    flips = []
+    for _ in range(32):
+        res = dict(img=np.zeros((4, 4, 3), np.uint8), img_shape=(4, 4, 3),
+                   img_fields=['img'], bbox_fields=[], mask_fields=[],
+                   seg_fields=[])
+        flips.append(bool(flipper(res)['flip']))
+    out['draw_flip'] = np.array(flips)
+    np.savez_compressed(os.path.join(OUT, 'pipeline.npz'), **out)
+    print('pipeline.npz', len(out), 'arrays')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='kat,anchors,targets,lossblock,e2e,infer,'
-                    'lossblock_v2,e2e_v2,imitation')
+                    'lossblock_v2,e2e_v2,imitation,pipeline')
     ap.add_argument('--e2e-cases', default='')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
@@ -870,6 +953,8 @@ def main():
         gen_lossblock_v2()
     if 'e2e_v2' in only:
         gen_e2e_v2()
+    if 'pipeline' in only:
+        gen_pipeline()
 
 
 if __name__ == '__main__':

@@ -409,7 +409,11 @@ _REAL = {
     'mmcv.runner': dict(
         force_fp32=_identity_decorator_factory,
         auto_fp16=_identity_decorator_factory,
-        load_checkpoint=_load_checkpoint),
+        load_checkpoint=_load_checkpoint,
+        HOOKS=Registry('hook'), Hook=type('Hook', (), {}),
+        get_dist_info=lambda: (0, 1)),
+    'mmcv.runner.hooks': dict(HOOKS=Registry('hook'),
+                              Hook=type('Hook', (), {})),
     'mmcv.cnn': dict(
         ConvModule=ConvModule, Scale=Scale, build_conv_layer=build_conv_layer,
         build_norm_layer=build_norm_layer, normal_init=normal_init,
@@ -431,6 +435,8 @@ def _dummy_callable(*args, **kwargs):
 class _FakeModule(types.ModuleType):
 
     def __getattr__(self, name):
+        if name == '__version__':  # mmdet/datasets/coco.py:21 compares it
+            return '99.0.0'
         if name.startswith('__') and name.endswith('__'):
             raise AttributeError(name)
         if name[:1].isupper():

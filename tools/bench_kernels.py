@@ -13,6 +13,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -284,6 +285,49 @@ def bench_bf16(out):
     out['conv_bf16'] = res
 
 
+def bench_pipeline(out):
+    """Device input pipeline at the C2 batch geometry (2 COCO-sized images ->
+    2 x 3 x 800 x 1088 fp32): whole call (pinned staging + H2D + kernel) and
+    the kernel alone on device-resident raw images, against its HBM bytes
+    (3 B read per source pixel touched + 12 B written per padded pixel)."""
+    import ctypes as C
+    from ld_amd import lib as L
+    from ld_amd.pipeline import DevicePipeline
+    rs = np.random.RandomState(0)
+    imgs = [rs.randint(0, 256, (480, 640, 3)).astype(np.uint8),
+            rs.randint(0, 256, (427, 640, 3)).astype(np.uint8)]
+    pipe = DevicePipeline(device='cuda:0')
+    np.random.seed(0)
+    plans = pipe.plan([im.shape[:2] for im in imgs])
+    t_call = timeit(lambda: pipe(imgs, plans=plans))
+    res = pipe(imgs, plans=plans)
+    N, _, Hp, Wp = res['img'].shape
+    lib = L.get_lib()
+    raw = [torch.from_numpy(im).cuda() for im in imgs]
+    desc = (L.ImageT * N)()
+    for i, (p, im) in enumerate(zip(plans, imgs)):
+        desc[i].data = raw[i].data_ptr()
+        desc[i].src_h, desc[i].src_w = im.shape[:2]
+        desc[i].new_h, desc[i].new_w = p['img_shape'][:2]
+        desc[i].flip = int(p['flip'])
+    dd = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8).cuda()
+    o = torch.empty_like(res['img'])
+    mean = (C.c_float * 3)(*pipe.mean.tolist())
+    sinv = (C.c_float * 3)(*pipe.std_inv.tolist())
+    st = torch.cuda.current_stream().cuda_stream
+
+    def k():
+        L.check(lib.ld_preprocess_batch(dd.data_ptr(), N, Hp, Wp, mean, sinv, 1,
+                                        o.data_ptr(), st), 'pre')
+    t_k = timeit(k, iters=50)
+    nbytes = sum(im.size for im in imgs) + o.numel() * 4
+    out['pipeline'] = dict(batch=[list(im.shape) for im in imgs],
+                           out=list(o.shape), call_ms=t_call * 1e3,
+                           kernel_us=t_k * 1e6, bytes=nbytes,
+                           kernel_GBps=nbytes / t_k / 1e9)
+    print('pipeline', out['pipeline'])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--tag', default='r01')
@@ -301,6 +345,8 @@ def main():
         bench_stream_sweep(out)
     if 'bf16' in args.only.split(','):
         bench_bf16(out)
+    if 'pipeline' in args.only.split(','):
+        bench_pipeline(out)
     os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
     path = os.path.join(REPO, 'gpurun_out', f'kernels_{args.tag}.json')
     with open(path, 'w') as f:
