@@ -461,6 +461,7 @@ __global__ __launch_bounds__(64 * WVM * WVN * KG) void conv_igemm_kernel(ConvK a
 template <int TM, int TN, int WVM, int MODE, int D, int OCC, int KS>
 __global__ __launch_bounds__(256, OCC) void conv_stream_kernel(ConvK a) {
   static_assert(KS == 1 || (KS == 4 && WVM == 1), "KS is 1 or 4");
+  static_assert(D * (TM + TN) < 64, "ring exceeds the 6-bit vmcnt counter");
   constexpr int WVN = 4 / WVM;
   constexpr int WM = TM * 32, WN = TN * 32;
   constexpr int BM = KS == 4 ? WM : WVM * WM, BNT = KS == 4 ? WN : WVN * WN;
@@ -1037,8 +1038,17 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, int sp
   const int ci = (int)(i % Cin);
   const size_t q = i / Cin;
   const int co = (int)(q % Cout), tap = (int)(q / Cout);
+  // eight slab reads in flight per thread, summed in split order
   float s = 0.0f;
-  for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * per + i];
+  int k = 0;
+  for (; k + 8 <= splits; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = slabs[(size_t)(k + u) * per + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < splits; ++k) s += slabs[(size_t)k * per + i];
   const size_t o = ((size_t)co * Cin + ci) * ntaps + tap;
   dw[o] = accumulate ? dw[o] + s : s;
 }
@@ -1158,7 +1168,10 @@ struct StreamCfg {
   X(1, 1, 4, 8, 1) X(3, 1, 1, 8, 1) X(3, 2, 1, 8, 1) X(2, 2, 2, 4, 1)              \
   X(2, 2, 1, 4, 1) X(1, 2, 2, 4, 1) X(1, 1, 2, 4, 1) X(1, 1, 1, 4, 1)              \
   X(3, 1, 1, 4, 1) X(3, 2, 1, 4, 1) X(1, 1, 1, 8, 4) X(1, 2, 1, 8, 4)              \
-  X(2, 1, 1, 8, 4) X(2, 2, 1, 8, 4)
+  X(2, 1, 1, 8, 4) X(2, 2, 1, 8, 4)                                                \
+  X(1, 1, 1, 16, 1) X(1, 1, 2, 16, 1) X(1, 1, 4, 16, 1) X(2, 1, 2, 16, 1)          \
+  X(1, 2, 2, 16, 1) X(2, 1, 1, 16, 1) X(1, 1, 1, 16, 4) X(2, 1, 1, 16, 4)          \
+  X(1, 2, 1, 16, 4)
 constexpr StreamCfg kStreamCfgs[] = {
 #define LD_STREAM_ROW(TM_, TN_, WVM_, D_, KS_) {TM_, TN_, WVM_, D_, KS_},
     LD_STREAM_SHAPES(LD_STREAM_ROW)
@@ -1184,6 +1197,7 @@ int launch_stream_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream) {
 
 #define MODE1_TAPS(k) ((k).nth > 0 ? (k).nth * (k).ntw : (k).KH * (k).KW)
 inline bool stream_cfg_fits(const ConvK& k, const StreamCfg& c) {
+  if (c.wvm < 1) return false;
   if (k.Cin % (2 * c.d) != 0) return false;
   if (c.d == 4 && k.Cin % 16 == 0) return false;  // the 8-deep ring covers it
   const int bm = c.wvm * c.tm * 32;
@@ -1247,7 +1261,7 @@ int pick_stream_cfg(const ConvK& k, StreamCfg* forced) {
     StreamCfg c;
     c.ks = 1;
     if (sscanf(env, "%dx%dx%dx%dx%d", &c.tm, &c.tn, &c.wvm, &c.d, &c.ks) >= 4) {
-      if (k.Cin % (2 * c.d) != 0) c.d = 4;
+      while (c.d > 4 && k.Cin % (2 * c.d) != 0) c.d /= 2;
       *forced = c;
       return -2;
     }
@@ -1269,7 +1283,10 @@ int launch_stream(const ConvK& k, hipStream_t stream) {
     const int rc = launch_stream_cfg<MODE>(k, forced, stream);
     if (rc != LD_EUNSUPPORTED) return rc;
     forced.ks = 1;  // no split-K instance at this ring depth
-    return launch_stream_cfg<MODE>(k, forced, stream);
+    const int rc1 = launch_stream_cfg<MODE>(k, forced, stream);
+    if (rc1 != LD_EUNSUPPORTED) return rc1;
+    const int m = stream_cfg_model(k);  // no such instance for this layer
+    return m < 0 ? LD_EUNSUPPORTED : launch_stream_cfg<MODE>(k, kStreamCfgs[m], stream);
   }
   return launch_stream_cfg<MODE>(k, kStreamCfgs[pick], stream);
 }

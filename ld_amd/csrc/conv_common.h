@@ -64,6 +64,7 @@ int ld_wgrad_reduce_launch(const float* slabs, int splits, int ntaps, int Cout,
 
 namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
 constexpr int WBK = 32;   // wgrad k-slice (spatial positions) per step

@@ -22,7 +22,7 @@ class KernelProfile:
     active = None
 
     def __init__(self):
-        self.records = []  # (tag, flops, start_event, end_event)
+        self.records = []  # (tag, flops, start_event, end_event, shape key)
 
     def __enter__(self):
         KernelProfile.active = self
@@ -34,16 +34,26 @@ class KernelProfile:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for tag, flops, a, b in self.records:
+        for tag, flops, a, b, _ in self.records:
             t, f, n = agg.get(tag, (0.0, 0.0, 0))
             agg[tag] = (t + a.elapsed_time(b) * 1e-3, f + flops, n + 1)
+        return agg
+
+    def by_shape(self):
+        """{(tag, shape key): (seconds, flops, launches)} -- the per-layer
+        table tools/profile_step.py prints."""
+        torch.cuda.synchronize()
+        agg = {}
+        for tag, flops, a, b, key in self.records:
+            t, f, n = agg.get((tag, key), (0.0, 0.0, 0))
+            agg[(tag, key)] = (t + a.elapsed_time(b) * 1e-3, f + flops, n + 1)
         return agg
 
 
 class _timed:
 
-    def __init__(self, tag, flops):
-        self.tag, self.flops = tag, flops
+    def __init__(self, tag, d):
+        self.tag, self.d = tag, d
         self.prof = KernelProfile.active
 
     def __enter__(self):
@@ -55,7 +65,11 @@ class _timed:
     def __exit__(self, *exc):
         if self.prof is not None:
             self.b.record()
-            self.prof.records.append((self.tag, self.flops, self.a, self.b))
+            d = self.d
+            key = (f'{d.Cin}>{d.Cout} k{d.KH} s{d.stride} N{d.N} '
+                   f'P{d.Pout} L{d.num_levels}')
+            self.prof.records.append((self.tag, _conv_flops(d), self.a, self.b,
+                                      key))
 
 
 def _conv_flops(d):
@@ -401,7 +415,7 @@ def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
                    lambda: tune(C.byref(d), L.ptr(x3), L.ptr(wt_fwd),
                                 C.byref(ep), L.ptr(y3),
                                 L.stream_ptr(x3.device)))
-    with _timed('conv_fwd_bf16' if bf16 else 'conv_fwd', _conv_flops(d)):
+    with _timed('conv_fwd_bf16' if bf16 else 'conv_fwd', d):
         L.check(fn(C.byref(d), L.ptr(x3), L.ptr(wt_fwd), C.byref(ep),
                    L.ptr(y3), L.stream_ptr(x3.device)), 'ld_conv_forward')
     return y3, out_levels
@@ -477,8 +491,7 @@ class ConvFn(torch.autograd.Function):
             _tune_once('bf16_dgrad' if bf16 else 'dgrad', d, (),
                        lambda: tune(C.byref(d), L.ptr(dy), L.ptr(wt_bwd),
                                     L.ptr(dx), st))
-            with _timed('conv_dgrad_bf16' if bf16 else 'conv_dgrad',
-                        _conv_flops(d)):
+            with _timed('conv_dgrad_bf16' if bf16 else 'conv_dgrad', d):
                 L.check(dgrad(C.byref(d), L.ptr(dy), L.ptr(wt_bwd),
                               L.ptr(dx), st), 'ld_conv_dgrad')
         pw, pb = ctx.params
@@ -489,8 +502,7 @@ class ConvFn(torch.autograd.Function):
             ws = workspace(x3.device, need, 'wgrad')
             bf16 = _PRECISION[0] == 'bf16' and cin >= 16
             wgrad = lib.ld_conv_bf16_wgrad if bf16 else lib.ld_conv_wgrad
-            with _timed('conv_wgrad_bf16' if bf16 else 'conv_wgrad',
-                        _conv_flops(d)):
+            with _timed('conv_wgrad_bf16' if bf16 else 'conv_wgrad', d):
                 L.check(wgrad(C.byref(d), L.ptr(x3), L.ptr(dy), L.ptr(dw),
                               0 if sink is None else 1, L.ptr(ws),
                               ws.numel(), st), 'ld_conv_wgrad')

@@ -104,7 +104,9 @@ def test_conv_fwd_bwd(case):
 
 STREAM_SHAPES = ['2x2x2x8', '2x2x1x8', '2x1x2x8', '1x2x2x8', '1x2x4x8', '1x2x1x8',
                  '1x1x2x8', '1x1x1x8', '1x1x4x8', '3x1x1x8', '3x2x1x8', '0',
-                 '1x1x1x8x4', '1x2x1x8x4', '2x1x1x8x4', '2x2x1x8x4']
+                 '1x1x1x8x4', '1x2x1x8x4', '2x1x1x8x4', '2x2x1x8x4',
+                 '1x1x1x16', '1x1x2x16', '1x1x4x16', '2x1x2x16', '1x2x2x16',
+                 '2x1x1x16', '1x1x1x16x4', '2x1x1x16x4', '1x2x1x16x4']
 
 
 @pytest.mark.parametrize('shape', STREAM_SHAPES)

@@ -82,6 +82,8 @@ CONV_SHAPES = [
     ('r101.l3.conv3 1x1 256-1024', 2, 256, 1024, 1, 1, 0, ((50, 84), )),
     ('r50.l4.conv1 1x1 2048-512', 2, 2048, 512, 1, 1, 0, ((25, 42), )),
     ('r50.l4.conv3 1x1 512-2048', 2, 512, 2048, 1, 1, 0, ((25, 42), )),
+    ('r50.l2.conv1 1x1 512-128', 2, 512, 128, 1, 1, 0, ((100, 168), )),
+    ('r50.l1.conv1 1x1 256-64', 2, 256, 64, 1, 1, 0, ((200, 336), )),
 ]
 
 TILES = ['128x128x16', '128x64x16', '64x128x16', '64x64x32', '64x64x16',
@@ -124,7 +126,11 @@ def bench_conv_tiles(out):
 
 STREAM_CFGS = ['2x2x2x8x1', '2x2x1x8x1', '2x1x2x8x1', '1x2x2x8x1', '1x2x1x8x1',
                '1x1x2x8x1', '1x1x1x8x1', '1x1x4x8x1', '3x1x1x8x1', '3x2x1x8x1',
-               '1x1x1x8x4', '1x2x1x8x4', '2x1x1x8x4', '2x2x1x8x4']
+               '1x1x1x8x4', '1x2x1x8x4', '2x1x1x8x4', '2x2x1x8x4',
+               # 16-deep ring
+               '1x1x1x16x1', '1x1x2x16x1', '1x1x4x16x1', '2x1x2x16x1',
+               '1x2x2x16x1', '2x1x1x16x1', '1x1x1x16x4', '2x1x1x16x4',
+               '1x2x1x16x4']
 
 
 def bench_stream_sweep(out):
@@ -146,6 +152,8 @@ def bench_stream_sweep(out):
             tm, tn, wvm = (int(v) for v in cfg.split('x')[:3])
             if wvm * tm * 32 >= 2 * cout and wvm > 1 and not cfg.endswith('x4'):
                 continue  # more than half the workgroup's rows would be padding
+            if int(cfg.split('x')[3]) == 16 and wvm and cin % 32:
+                continue
             os.environ['LD_CONV_STREAM'] = cfg
             t = timeit(lambda: Y.conv_forward_raw(x, w, stride, pad, levels), 2, 5)
             r[cfg] = round(flops / t / 1e12, 1)
@@ -285,6 +293,42 @@ def bench_bf16(out):
     out['conv_bf16'] = res
 
 
+def bench_wgrad(out):
+    """Weight gradient per C2 layer shape under each kernel (LD_CONV_WGRAD:
+    32 / 16 positions per step of the wave-private kernel); the
+    slab reduce pass is included in every number."""
+    import ctypes as C
+    from ld_amd import lib as L
+    dev = torch.device('cuda:0')
+    lib = L.get_lib()
+    res = []
+    for name, N, cin, cout, k, stride, pad, levels in CONV_SHAPES + [
+            ('head gfl_reg 3x3 256-68', 2, 256, 68, 3, 1, 1,
+             ((100, 168), (50, 84), (25, 42), (13, 21), (7, 11))),
+            ('r50.l2.0.conv1 1x1 256-128', 2, 256, 128, 1, 1, 0, ((200, 336), )),
+            ('r50.l3.0.ds 1x1 s2 512-1024', 2, 512, 1024, 1, 2, 0, ((100, 168), ))]:
+        P = sum(h * w for h, w in levels)
+        x = torch.randn(N, cin, P, device=dev)
+        d, _ = Y.conv_desc(N, cin, cout, k, k, stride, pad, levels)
+        go = torch.randn(N, cout, d.Pout, device=dev)
+        dw = torch.empty(cout, cin, k, k, device=dev)
+        flops = 2.0 * N * d.Pout * cout * cin * k * k
+        st = L.stream_ptr(dev)
+        r = dict(name=name)
+        for mode in ('32', '16'):
+            os.environ['LD_CONV_WGRAD'] = mode
+            need = lib.ld_conv_wgrad_workspace_bytes(C.byref(d))
+            ws = LB.workspace(dev, need, 'wgrad')
+            t = timeit(lambda: lib.ld_conv_wgrad(C.byref(d), L.ptr(x), L.ptr(go),
+                                                 L.ptr(dw), 0, L.ptr(ws),
+                                                 ws.numel(), st), 2, 7)
+            r['wgrad' + mode] = round(flops / t / 1e12, 1)
+        os.environ.pop('LD_CONV_WGRAD', None)
+        res.append(r)
+        print(r, flush=True)
+    out['conv_wgrad'] = res
+
+
 def bench_pipeline(out):
     """Device input pipeline at the C2 batch geometry (2 COCO-sized images ->
     2 x 3 x 800 x 1088 fp32): whole call (pinned staging + H2D + kernel) and
@@ -347,6 +391,8 @@ def main():
         bench_bf16(out)
     if 'pipeline' in args.only.split(','):
         bench_pipeline(out)
+    if 'wgrad' in args.only.split(','):
+        bench_wgrad(out)
     os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
     path = os.path.join(REPO, 'gpurun_out', f'kernels_{args.tag}.json')
     with open(path, 'w') as f:

@@ -19,6 +19,9 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--graph', action='store_true')
+    ap.add_argument('--layers', default='',
+                    help='write the per-layer conv table (HIP events around '
+                         'every conv launch, teacher on the main stream) here')
     args = ap.parse_args()
     from ld_amd import layers as Y
     from ld_amd import model_zoo, synthetic
@@ -47,6 +50,25 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     print(f'{args.mode} graph={args.graph}: {dt * 1e3:.2f} ms/step, '
           f'{2 / dt:.1f} img/s')
+    if args.layers:
+        det.use_teacher_stream = False
+        tr.step(d)
+        with Y.KernelProfile() as prof:
+            for _ in range(args.steps):
+                tr.step(d)
+        rows = sorted(prof.by_shape().items(), key=lambda kv: -kv[1][0])
+        tot = sum(v[0] for _, v in rows)
+        with open(args.layers, 'w') as f:
+            f.write(f'# per-layer conv table, {args.mode}, {args.steps} steps; '
+                    'ms = per step over all launches of that shape\n')
+            f.write('kind,shape,launches_per_step,ms_per_step,tflops,'
+                    'pct_of_conv\n')
+            for (tag, key), (t, fl, n) in rows:
+                f.write(f'{tag},{key},{n / args.steps:g},'
+                        f'{t / args.steps * 1e3:.4f},{fl / t / 1e12:.1f},'
+                        f'{100 * t / tot:.2f}\n')
+        print('conv total %.2f ms/step; wrote %s' %
+              (tot / args.steps * 1e3, args.layers))
 
 
 if __name__ == '__main__':
