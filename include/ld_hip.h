@@ -416,6 +416,28 @@ int ld_conv_bf16_tune_dgrad(const ld_conv_t* c, const float* dy, const void* wt_
 int ld_conv_bf16_wgrad(const ld_conv_t* c, const float* x, const float* dy, float* dw,
                        int accumulate, void* workspace, size_t workspace_bytes,
                        ld_stream_t stream);
+/* bf16 channel-blocked ("C8") activation operand.  ld_conv_to_c8 rewrites an
+ * fp32 (N, C, P) tensor as bf16 (N, C/8, P, 8) (round to nearest even; C a
+ * multiple of 8; `out` holds N*C*P bf16).  The *_c8 entry points take that
+ * image as the activation operand of the forward conv (x_c8, Cin % 32 == 0) or
+ * of the data gradient (dy_c8, Cout % 32 == 0) -- one 16-byte load per
+ * (position, 8 channels), no conversion inside the GEMM loop; weights, the
+ * fused epilogue and the fp32 (N, C, P) output are those of
+ * ld_conv_bf16_forward / ld_conv_bf16_dgrad, and so are the results bit for
+ * bit (the same bf16 operands enter the same fp32 accumulation order as the
+ * LDS-tiled kernel of the fp32-input path).  LD_EUNSUPPORTED when the channel
+ * count does not fit: use the fp32-input entry point. */
+int ld_conv_to_c8(const float* x, int N, int C, int P, void* out, ld_stream_t stream);
+int ld_conv_bf16_forward_c8(const ld_conv_t* c, const void* x_c8, const void* wt_fwd,
+                            const ld_conv_epilogue_t* ep, float* y,
+                            ld_stream_t stream);
+int ld_conv_bf16_tune_forward_c8(const ld_conv_t* c, const void* x_c8,
+                                 const void* wt_fwd, const ld_conv_epilogue_t* ep,
+                                 float* y, ld_stream_t stream);
+int ld_conv_bf16_dgrad_c8(const ld_conv_t* c, const void* dy_c8, const void* wt_bwd,
+                          float* dx, ld_stream_t stream);
+int ld_conv_bf16_tune_dgrad_c8(const ld_conv_t* c, const void* dy_c8,
+                               const void* wt_bwd, float* dx, ld_stream_t stream);
 
 /* Small-Cin variant (the 7x7 stride-2 stem, resnet.py:558-570): flat
  * (ci,kh,kw) reduction; wt = [pad32(Cin*KH*KW)][Cout] image obtained with

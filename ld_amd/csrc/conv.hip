@@ -1549,9 +1549,15 @@ int build_forward(const ld_conv_t* c, const float* x, const void* wt_fwd,
   k.g.num_levels = c->num_levels;
   k.J = c->N * c->Pout;
   for (int l = 0; l < LD_MAX_LEVELS; ++l) k.g.lv[l] = c->lv[l];
-  if (family == 1) {
+  if (family >= 1) {
     // bf16 image: [tap][Cin16 / 8][Cout][8] bf16 = 4 floats per (8-block, co)
     k.Kpad = (c->Cin + 15) / 16 * 2;
+    if (family == 2) {  // x is the bf16 C8 image: half the bytes per element
+      if (c->Cin % 32 != 0) return LD_EUNSUPPORTED;
+      k.x_c8 = 1;
+      return set_extents(k, ((size_t)c->N * c->Cin * c->Pin + 1) / 2,
+                         (size_t)c->KH * c->KW * k.Kpad * c->Cout * 4);
+    }
     return set_extents(k, (size_t)c->N * c->Cin * c->Pin,
                        (size_t)c->KH * c->KW * k.Kpad * c->Cout * 4);
   }
@@ -1571,6 +1577,26 @@ extern "C" int ld_conv_bf16_forward(const ld_conv_t* c, const float* x,
   ConvK k;
   if (int e = build_forward(c, x, wt_fwd, ep, y, k, 1)) return e;
   return ld_bf16_stream_launch(0, k, (hipStream_t)stream);
+}
+
+// Same with the activation operand as the bf16 channel-blocked image of
+// ld_conv_to_c8 (Cin a multiple of 32).
+extern "C" int ld_conv_bf16_forward_c8(const ld_conv_t* c, const void* x_c8,
+                                       const void* wt_fwd,
+                                       const ld_conv_epilogue_t* ep, float* y,
+                                       ld_stream_t stream) {
+  ConvK k;
+  if (int e = build_forward(c, (const float*)x_c8, wt_fwd, ep, y, k, 2)) return e;
+  return ld_bf16_stream_launch(0, k, (hipStream_t)stream);
+}
+
+extern "C" int ld_conv_bf16_tune_forward_c8(const ld_conv_t* c, const void* x_c8,
+                                            const void* wt_fwd,
+                                            const ld_conv_epilogue_t* ep, float* y,
+                                            ld_stream_t stream) {
+  ConvK k;
+  if (int e = build_forward(c, (const float*)x_c8, wt_fwd, ep, y, k, 2)) return e;
+  return ld_bf16_stream_tune(0, k, (hipStream_t)stream);
 }
 
 extern "C" int ld_conv_bf16_tune_forward(const ld_conv_t* c, const float* x,
@@ -1665,13 +1691,19 @@ int dgrad_walk(const ld_conv_t* c, const float* dy, const void* wt_bwd, float* d
     k.fW[l] = c->lv[l].Win;
     k.foff[l] = c->lv[l].off_in;
   }
-  k.Kpad = family == 1 ? (c->Cout + 15) / 16 * 2 : kpad_rows(c->Cout);
-  if (int e = set_extents(k, (size_t)c->N * c->Cout * c->Pout,
-                          (size_t)c->KH * c->KW * k.Kpad * c->Cin * (family == 1 ? 4 : 1)))
+  k.Kpad = family >= 1 ? (c->Cout + 15) / 16 * 2 : kpad_rows(c->Cout);
+  if (family == 2) {  // dy is the bf16 C8 image
+    if (c->Cout % 32 != 0) return LD_EUNSUPPORTED;
+    k.x_c8 = 1;
+  }
+  if (int e = set_extents(
+          k, family == 2 ? ((size_t)c->N * c->Cout * c->Pout + 1) / 2
+                         : (size_t)c->N * c->Cout * c->Pout,
+          (size_t)c->KH * c->KW * k.Kpad * c->Cin * (family >= 1 ? 4 : 1)))
     return e;
-  if (family == 1 && c->Cout % 16 != 0) return LD_EUNSUPPORTED;
+  if (family >= 1 && c->Cout % 16 != 0) return LD_EUNSUPPORTED;
   auto run = [&](int mode, const ConvK& q) -> int {
-    if (family == 1)
+    if (family >= 1)
       return tune ? ld_bf16_stream_tune(mode, q, stream)
                   : ld_bf16_stream_launch(mode, q, stream);
     if (mode == 1) return tune ? tune_stream<1>(q, stream) : launch_igemm<1>(q, stream);
@@ -1752,6 +1784,19 @@ extern "C" int ld_conv_bf16_tune_dgrad(const ld_conv_t* c, const float* dy,
                                        const void* wt_bwd, float* dx,
                                        ld_stream_t stream) {
   return dgrad_walk(c, dy, wt_bwd, dx, stream, true, 1);
+}
+
+// data gradient with dy as the bf16 C8 image (Cout a multiple of 32)
+extern "C" int ld_conv_bf16_dgrad_c8(const ld_conv_t* c, const void* dy_c8,
+                                     const void* wt_bwd, float* dx,
+                                     ld_stream_t stream) {
+  return dgrad_walk(c, (const float*)dy_c8, wt_bwd, dx, stream, false, 2);
+}
+
+extern "C" int ld_conv_bf16_tune_dgrad_c8(const ld_conv_t* c, const void* dy_c8,
+                                          const void* wt_bwd, float* dx,
+                                          ld_stream_t stream) {
+  return dgrad_walk(c, (const float*)dy_c8, wt_bwd, dx, stream, true, 2);
 }
 
 // which wgrad kernel: 0 = 128x128 workgroup tiles (LDS shared by 4 waves),

@@ -516,6 +516,218 @@ __global__ __launch_bounds__(256, 2) void conv_tile_bf16_kernel(ConvK a) {
   }
 }
 
+// ------------------------------- forward/dgrad, LDS-tiled, bf16 C8 input --
+// PMC of the kernel above (profiles/r02_pmc_tile_bf16/): with fp32 activations
+// every B element costs a 4-byte gather plus a share of a conversion -- 11
+// non-MFMA instructions per MFMA, the matrix pipe 8.5 % busy, INSTRUCTION-ISSUE
+// bound.  Here the activation operand arrives as the bf16 channel-blocked image
+// (N, C/8, P, 8) written by ld_conv_to_c8: the eight channels of one position
+// are 16 contiguous bytes, i.e. exactly one row of the LDS image
+// [BK/8][BN][8] -- one 16-byte load + one ds_write_b128 per (position, 8
+// channels), no conversion, tap shifts stay 16-byte aligned and padding is
+// still the buffer descriptor's out-of-range zero.  Per 32-deep k-step and
+// wave: 4 loads, 4 ds_write_b128, 8 fragment reads, 8 MFMAs.
+// Everything else (A image, pipeline, epilogue, MODE 1 parity classes) is the
+// kernel above.
+template <int BM, int BN, int MODE, int NST>
+__global__ __launch_bounds__(256, 2) void conv_tile_c8_kernel(ConvK a) {
+  static_assert(NST % 2 == 0, "ring length must be even (static LDS parity)");
+  constexpr int BK = 32, KB = BK / 8;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int A_U = BM * KB / 256;  // 16-byte units of A per thread
+  constexpr int CG = 256 / BN;        // k-block groups across the block
+  constexpr int B_U = KB / CG;        // 16-byte units of B per thread
+  static_assert(A_U >= 1 && B_U >= 1, "tile shape");
+  __shared__ __attribute__((aligned(16))) uintx4 lds[2 * KB * (BM + BN)];
+  uintx4* As = lds;                   // [2][KB][BM]
+  uintx4* Bs = lds + 2 * KB * BM;     // [2][KB][BN]
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lk = lane >> 5;
+  const int mtiles = (a.Cout + BM - 1) / BM;
+  const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int m0 = (tile % mtiles) * BM;
+  const int n0 = (tile / mtiles) * BN;
+
+  const int Cin = __builtin_amdgcn_readfirstlane(a.Cin);
+  const int Cout = __builtin_amdgcn_readfirstlane(a.Cout);
+  const int KW = __builtin_amdgcn_readfirstlane(a.KW);
+  const int Pin = __builtin_amdgcn_readfirstlane(a.Pin);
+  const int Kp8 = __builtin_amdgcn_readfirstlane(a.Kpad);
+  const int ntw = __builtin_amdgcn_readfirstlane(MODE == 1 ? a.ntw : a.KW);
+  const int ntaps = __builtin_amdgcn_readfirstlane(
+      MODE == 1 ? a.nth * a.ntw : a.KH * a.KW);
+
+  // ---- this thread's B column (one spatial position), in 16-byte units -----
+  const int bp = t % BN;
+  const int cg = __builtin_amdgcn_readfirstlane(t / BN);
+  int bHin = 0, bWin = 0, boff = 0, bh0 = 0, bw0 = 0;
+  {
+    const int jb = n0 + bp;
+    if (jb < a.J) {
+      const int n = jb / a.Pout, p = jb - n * a.Pout;
+      int bl, bho, bwo;
+      locate_out(a.g, p, bl, bho, bwo);
+      bHin = a.g.lv[bl].Hin;
+      bWin = a.g.lv[bl].Win;
+      boff = n * (Cin >> 3) * Pin + a.g.lv[bl].off_in;
+      if (MODE == 1) {
+        bh0 = bho + a.ch0;
+        bw0 = bwo + a.cw0;
+      } else {
+        bh0 = bho * a.g.stride - a.g.pad;
+        bw0 = bwo * a.g.stride - a.g.pad;
+      }
+    }
+  }
+  unsigned va[A_U];
+#pragma unroll
+  for (int i = 0; i < A_U; ++i) {
+    const int u = t + i * 256;
+    const int kb = u / BM, co = m0 + u % BM;
+    va[i] = co < Cout ? (unsigned)(kb * Cout + co) * 16u : kOOB;
+  }
+  const rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  const rsrc_t rw = make_rsrc(a.wt, a.wt_bytes);
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int csteps = Cin / BK;  // host guarantees Cin % 32 == 0
+  const int nsteps = ntaps * csteps;
+  uintx4 a_st[NST][A_U], b_st[NST][B_U];
+  int c_step = 0, c_kh = 0, c_kw = 0, c_ci0 = 0;
+  auto load_next = [&](uintx4* ra, uintx4* rb) {
+    const bool live = c_step < nsteps;
+    const int wtap = MODE == 1 ? (a.kh0 + 2 * c_kh) * KW + a.kw0 + 2 * c_kw
+                               : c_kh * ntw + c_kw;
+    const int hi = bh0 + c_kh, wi = bw0 + c_kw;
+    const bool ok = live && hi >= 0 && hi < bHin && wi >= 0 && wi < bWin;
+    const unsigned vb = ok ? (unsigned)(boff + hi * bWin + wi) * 16u : kOOB;
+    const unsigned sa = (unsigned)((wtap * Kp8 + (c_ci0 >> 3)) * Cout) * 16u;
+#pragma unroll
+    for (int i = 0; i < A_U; ++i) ra[i] = buf_load16(rw, live ? va[i] : kOOB, sa);
+    const unsigned prow = (unsigned)Pin * 16u;
+    unsigned so = (unsigned)((c_ci0 >> 3) + cg * B_U) * prow;
+#pragma unroll
+    for (int q = 0; q < B_U; ++q) {
+      rb[q] = buf_load16(rx, vb, so);
+      so += prow;
+    }
+    ++c_step;
+    c_ci0 += BK;
+    const bool wc = c_ci0 >= Cin;
+    c_ci0 = wc ? 0 : c_ci0;
+    c_kw += wc ? 1 : 0;
+    const bool wk = c_kw >= ntw;
+    c_kw = wk ? 0 : c_kw;
+    c_kh += wk ? 1 : 0;
+  };
+  auto store_tile = [&](int buf, const uintx4* ra, const uintx4* rb) {
+#pragma unroll
+    for (int i = 0; i < A_U; ++i) As[buf * KB * BM + t + i * 256] = ra[i];
+#pragma unroll
+    for (int q = 0; q < B_U; ++q)
+      Bs[buf * KB * BN + (cg * B_U + q) * BN + bp] = rb[q];
+  };
+  auto compute = [&](int buf) {
+    const uintx4* ap = As + buf * KB * BM + wm * (BM / 2) + l31;
+    const uintx4* bq = Bs + buf * KB * BN + wn * (BN / 2) + l31;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      uintx4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = ap[(2 * s + lk) * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = bq[(2 * s + lk) * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]),
+              acc[i][j], 0, 0, 0);
+    }
+  };
+
+#pragma unroll
+  for (int u = 0; u < NST - 1; ++u) load_next(a_st[u], b_st[u]);
+  for (int base = 0; base < nsteps; base += NST) {
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+      constexpr int ahead = NST - 1;
+      load_next(a_st[(u + ahead) % NST], b_st[(u + ahead) % NST]);
+      store_tile(u & 1, a_st[u], b_st[u]);
+      __syncthreads();
+      compute(u & 1);
+    }
+  }
+
+  // ---- epilogue: direct stores, 32 consecutive positions per accumulator row
+  const bool has_res = a.residual != nullptr;
+  const bool relu = a.relu != 0;
+  const bool has_aff = a.scale != nullptr, has_bias = a.bias != nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int rbase = m0 + wm * (BM / 2) + i * 32 + 4 * lk;
+    float sc[16], sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = min(rbase + (r & 3) + 8 * (r >> 2), Cout - 1);
+      sc[r] = has_aff ? a.scale[row] : 1.0f;
+      sh[r] = has_aff ? a.shift[row] : 0.0f;
+      if (has_bias) sh[r] += a.bias[row];
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int jc = n0 + wn * (BN / 2) + j * 32 + l31;
+      if (jc >= a.J) continue;
+      const int n = jc / a.Pout;
+      int p = jc - n * a.Pout;
+      int prow = a.Pout;
+      if (MODE == 1) {
+        int l, hc, wc;
+        locate_out(a.g, p, l, hc, wc);
+        p = a.foff[l] + (2 * hc + a.ph) * a.fW[l] + 2 * wc + a.pw;
+        prow = a.Pfull;
+      }
+      const size_t colbase = (size_t)n * Cout * prow + p;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        if (row >= Cout) continue;
+        float v = acc[i][j][r] * sc[r] + sh[r];
+        if (has_res) v += a.residual[colbase + (size_t)row * prow];
+        if (relu) v = fmaxf(v, 0.0f);
+        a.y[colbase + (size_t)row * prow] = v;
+      }
+    }
+  }
+}
+
+// fp32 (N, C, P) -> bf16 channel-blocked (N, C/8, P, 8), round to nearest even.
+// A thread converts one (n, 8-channel block, position): eight row reads that are
+// each coalesced across the wave, one 16-byte write.
+__global__ __launch_bounds__(256) void to_c8_kernel(const float* __restrict__ x, int C8,
+                                                    int P, uintx4* __restrict__ out) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const size_t blk = (size_t)blockIdx.z * C8 + blockIdx.y;  // (n, c8)
+  const float* src = x + blk * 8 * P + p;
+  floatx8 f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = src[(size_t)e * P];
+  const bf16x8 v = __builtin_convertvector(f, bf16x8);
+  out[blk * P + p] = __builtin_bit_cast(uintx4, v);
+}
+
 // ---------------------------------------------------- wgrad, wave-private --
 // One wavefront per workgroup, a 64(co) x 64(ci) tile of one tap and one
 // j-split, 32 positions per step.  Both operand tiles are loaded coalesced
@@ -932,6 +1144,16 @@ struct StreamCfg {
 // (NST = register stages of the load ring; the ks field carries it)
 #define LD_BF16_TILE_SHAPES(X)                                                     \
   X(128, 128, 2) X(128, 128, 4) X(64, 128, 4) X(128, 64, 4) X(128, 64, 2)
+// C8-input tiled kernel shapes (family 2): (BM, BN, NST)
+#define LD_C8_TILE_SHAPES(X)                                                       \
+  X(128, 128, 2) X(128, 128, 4) X(64, 128, 4) X(128, 64, 4) X(64, 64, 4)           \
+  X(64, 128, 2) X(128, 64, 2) X(64, 64, 2) X(128, 256, 2) X(64, 256, 2)
+constexpr StreamCfg kC8Cfgs[] = {
+#define LD_ROW(BM_, BN_, NST_) {BM_ / 32, BN_ / 32, 0, 32, NST_},
+    LD_C8_TILE_SHAPES(LD_ROW)
+#undef LD_ROW
+};
+constexpr int kNumC8Cfgs = sizeof(kC8Cfgs) / sizeof(kC8Cfgs[0]);
 constexpr StreamCfg kCfgs[] = {
 #define LD_ROW(TM_, TN_, WVM_, D_, KS_) {TM_, TN_, WVM_, D_, KS_},
     LD_BF16_SHAPES(LD_ROW)
@@ -941,6 +1163,55 @@ constexpr StreamCfg kCfgs[] = {
 #undef LD_ROW
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+inline int mode_taps(const ConvK& k) {
+  return k.nth > 0 ? k.nth * k.ntw : k.KH * k.KW;
+}
+
+template <int MODE>
+int launch_c8_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream) {
+  const int BM = c.tm * 32, BN = c.tn * 32;
+  if (k.Cin % 32 != 0) return LD_EUNSUPPORTED;
+  const int nb = ((k.Cout + BM - 1) / BM) * ((k.J + BN - 1) / BN);
+#define LD_CASE(BM_, BN_, NST_)                                                    \
+  if (BM == BM_ && BN == BN_ && c.ks == NST_) {                                    \
+    hipLaunchKernelGGL((conv_tile_c8_kernel<BM_, BN_, MODE, NST_>), dim3(nb),      \
+                       dim3(256), 0, stream, k);                                   \
+    return (int)hipGetLastError();                                                 \
+  }
+  LD_C8_TILE_SHAPES(LD_CASE)
+#undef LD_CASE
+  return LD_EUNSUPPORTED;
+}
+
+inline bool c8_cfg_fits(const ConvK& k, const StreamCfg& c) {
+  if (k.Cin % 32 != 0) return false;
+  const int BM = c.tm * 32;
+  const int cout32 = (k.Cout + 31) / 32 * 32;
+  return BM <= cout32 + 32;
+}
+
+// model pick: rounds over the 256 CUs (2 resident workgroups each), larger
+// tiles re-use operands better
+inline int c8_cfg_model(const ConvK& k) {
+  int best = -1;
+  double best_t = 0;
+  for (int i = 0; i < kNumC8Cfgs; ++i) {
+    const StreamCfg& c = kC8Cfgs[i];
+    if (!c8_cfg_fits(k, c)) continue;
+    const long nb = (long)((k.Cout + c.tm * 32 - 1) / (c.tm * 32)) *
+                    ((k.J + c.tn * 32 - 1) / (c.tn * 32));
+    const double rounds = nb <= 512 ? (double)((nb + 255) / 256) : (double)nb / 256.0;
+    const int area = c.tm * c.tn;
+    const double eff = area >= 16 ? 1.0 : area >= 8 ? 0.8 : 0.6;
+    const double t = rounds * area / eff / (c.ks >= 4 ? 1.05 : 1.0);
+    if (best < 0 || t < best_t) {
+      best = i;
+      best_t = t;
+    }
+  }
+  return best;
+}
 
 template <int MODE>
 int launch_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream) {
@@ -972,10 +1243,6 @@ int launch_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream) {
   LD_BF16_SHAPES(LD_CASE)
 #undef LD_CASE
   return LD_EUNSUPPORTED;
-}
-
-inline int mode_taps(const ConvK& k) {
-  return k.nth > 0 ? k.nth * k.ntw : k.KH * k.KW;
 }
 
 inline bool cfg_fits(const ConvK& k, const StreamCfg& c) {
@@ -1046,8 +1313,91 @@ inline int cfg_index(const LdTuneCfg& c) {
   return -1;
 }
 
+inline int c8_cfg_index(const LdTuneCfg& c) {
+  for (int i = 0; i < kNumC8Cfgs; ++i)
+    if (kC8Cfgs[i].tm == c.tm && kC8Cfgs[i].tn == c.tn && kC8Cfgs[i].ks == c.ks &&
+        c.wvm == 0)
+      return i;
+  return -1;
+}
+
+template <int MODE>
+int launch_c8(const ConvK& k, hipStream_t stream) {
+  if (k.Cin % 32 != 0) return LD_EUNSUPPORTED;
+  if (const char* env = getenv("LD_CONV_C8_SHAPE")) {  // "4x4x2": BM/32 x BN/32 x NST
+    StreamCfg c{0, 0, 0, 32, 0};
+    if (sscanf(env, "%dx%dx%d", &c.tm, &c.tn, &c.ks) == 3 && c8_cfg_fits(k, c)) {
+      const int rc = launch_c8_cfg<MODE>(k, c, stream);
+      if (rc != LD_EUNSUPPORTED) return rc;
+    }
+  }
+  int pick = -1;
+  LdTuneCfg t;
+  if (ld_tune_lookup(make_tune_key(MODE, 2, k), &t)) {
+    pick = c8_cfg_index(t);
+    if (pick >= 0 && !c8_cfg_fits(k, kC8Cfgs[pick])) pick = -1;
+  }
+  if (pick < 0) pick = c8_cfg_model(k);
+  if (pick < 0) return LD_EUNSUPPORTED;
+  return launch_c8_cfg<MODE>(k, kC8Cfgs[pick], stream);
+}
+
+template <int MODE>
+int tune_c8(const ConvK& k, hipStream_t stream) {
+  if (k.Cin % 32 != 0) return 1;
+  const LdTuneKey key = make_tune_key(MODE, 2, k);
+  LdTuneCfg have;
+  if (ld_tune_lookup(key, &have)) return 1;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(stream, &cap);
+  if (cap != hipStreamCaptureStatusNone) return LD_EUNSUPPORTED;
+  int pick = c8_cfg_model(k);
+  if (pick < 0) return 1;
+  (void)hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  constexpr int kReps = 3;
+  float best_ms = -1.0f;
+  for (int i = 0; i < kNumC8Cfgs; ++i) {
+    if (!c8_cfg_fits(k, kC8Cfgs[i])) continue;
+    if (launch_c8_cfg<MODE>(k, kC8Cfgs[i], stream) != 0) continue;
+    float ms = -1.0f;
+    for (int trial = 0; trial < 2; ++trial) {
+      (void)hipEventRecord(e0, stream);
+      for (int rep = 0; rep < kReps; ++rep) launch_c8_cfg<MODE>(k, kC8Cfgs[i], stream);
+      (void)hipEventRecord(e1, stream);
+      if (hipEventSynchronize(e1) != hipSuccess) break;
+      float t = 0.0f;
+      (void)hipEventElapsedTime(&t, e0, e1);
+      if (ms < 0.0f || t < ms) ms = t;
+    }
+    if (ms < 0.0f) continue;
+    if (best_ms < 0.0f || ms < best_ms) {
+      best_ms = ms;
+      pick = i;
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  const StreamCfg& c = kC8Cfgs[pick];
+  if (const char* lg = getenv("LD_CONV_TUNE_LOG"))
+    if (lg[0] == '1') {
+      const double fl = 2.0 * k.J * k.Cout * k.Cin * mode_taps(k);
+      fprintf(stderr,
+              "[ld_conv c8] mode %d Cin %d Cout %d k %dx%d s%d J %d lv %d -> "
+              "%dx%dx%d  %.1f TFLOP/s\n",
+              MODE, k.Cin, k.Cout, k.KH, k.KW, k.g.stride, k.J, k.g.num_levels,
+              c.tm * 32, c.tn * 32, c.ks,
+              best_ms > 0 ? fl / (best_ms * 1e-3 / kReps) / 1e12 : 0.0);
+    }
+  if (best_ms > 0.0f) ld_tune_store(key, LdTuneCfg{c.tm, c.tn, 0, c.d, c.ks});
+  return 0;
+}
+
 template <int MODE>
 int launch_bf16(const ConvK& k, hipStream_t stream) {
+  if (k.x_c8) return launch_c8<MODE>(k, stream);
   if (k.Cin % 16 != 0) return LD_EUNSUPPORTED;
   if (const char* env = getenv("LD_CONV_BF16_SHAPE")) {  // "2x2x2x4x1": force a shape
     StreamCfg c;
@@ -1070,6 +1420,7 @@ int launch_bf16(const ConvK& k, hipStream_t stream) {
 
 template <int MODE>
 int tune_bf16(const ConvK& k, hipStream_t stream) {
+  if (k.x_c8) return tune_c8<MODE>(k, stream);
   if (k.Cin % 16 != 0) return 1;
   const LdTuneKey key = make_tune_key(MODE, 1, k);
   LdTuneCfg have;
@@ -1174,6 +1525,14 @@ int ld_bf16_wgrad_launch(const WgradK& k, hipStream_t stream) {
   }
   const int blocks = ((k.Cout + 63) / 64) * ((k.Cin + 63) / 64) * ntaps * k.splits;
   hipLaunchKernelGGL(conv_wgrad_wave_bf16_kernel, dim3(blocks), dim3(64), 0, stream, k);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_conv_to_c8(const float* x, int N, int C, int P, void* out,
+                             ld_stream_t stream) {
+  if (!x || !out || N < 1 || C < 8 || C % 8 != 0 || P < 1) return LD_EINVAL;
+  hipLaunchKernelGGL(to_c8_kernel, dim3((P + 255) / 256, C / 8, N), dim3(256), 0,
+                     (hipStream_t)stream, x, C / 8, P, (uintx4*)out);
   return (int)hipGetLastError();
 }
 

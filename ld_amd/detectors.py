@@ -231,6 +231,39 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
             out_teacher = self.teacher_model.bbox_head(teacher_x)
         return teacher_x, out_teacher
 
+    @staticmethod
+    def _img_key(img):
+        return (img.data_ptr(), img._version, tuple(img.shape))
+
+    def prefetch_teacher(self, img):
+        """Software pipelining across steps.  The frozen teacher depends on the
+        batch only (kd_one_stage.py:70-72: no_grad, eval), so its forward for
+        the NEXT batch can be enqueued on the teacher stream now and run under
+        this step's student forward AND backward, filling the CUs the
+        under-filled student launches (50x84 / 25x42 stages, wgrad at 2 waves
+        per SIMD) leave idle.  The forward_train call that later receives this
+        same ``img`` tensor (same storage, same version) consumes the result;
+        any other image falls back to the in-step teacher forward.  Numerically
+        identical: the same kernels on the same inputs."""
+        if not (self.use_teacher_stream and img.is_cuda and self.eval_teacher):
+            return False
+        if self.teacher_stream is None:
+            self.teacher_stream = torch.cuda.Stream(device=img.device)
+        main = torch.cuda.current_stream(img.device)
+        side = self.teacher_stream
+        side.wait_stream(main)  # the batch (and all earlier work) is ready
+        with torch.cuda.stream(side):
+            teacher_x, out_teacher = self._teacher_forward(img)
+            done = torch.cuda.Event()
+            done.record(side)
+        # FIFO: the prefetch for step i + 1 is enqueued before step i consumes
+        # its own
+        if not hasattr(self, '_prefetched') or self._prefetched is None:
+            self._prefetched = []
+        self._prefetched.append((self._img_key(img), teacher_x, out_teacher,
+                                 done))
+        return True
+
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels,
                       gt_bboxes_ignore=None):
         """kd_one_stage.py:46-81."""
@@ -240,6 +273,24 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
                 'few to LDHead.forward_train on that branch '
                 '(kd_one_stage.py:74-76 vs ld_head.py:73-82)')
         side = None
+        queue = getattr(self, '_prefetched', None) or []
+        pre = None
+        if queue and queue[0][0] == self._img_key(img):
+            pre = queue.pop(0)
+        else:
+            queue.clear()  # a different batch arrived: drop stale prefetches
+        if pre is not None:
+            main = torch.cuda.current_stream(img.device)
+            teacher_x, out_teacher = pre[1], pre[2]
+            x = self.extract_feat(img)
+            # wait for THAT forward only: the stream may already hold the
+            # prefetch of the following batch
+            main.wait_event(pre[3])
+            for t in list(teacher_x) + [t for lvl in out_teacher for t in lvl]:
+                t.record_stream(main)
+            return self.bbox_head.forward_train(x, out_teacher, teacher_x,
+                                                img_metas, gt_bboxes,
+                                                gt_labels, gt_bboxes_ignore)
         if self.use_teacher_stream and img.is_cuda:
             if self.teacher_stream is None:
                 self.teacher_stream = torch.cuda.Stream(device=img.device)

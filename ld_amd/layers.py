@@ -164,6 +164,66 @@ def _use_bf16(reduction_channels):
     return _PRECISION[0] == 'bf16' and reduction_channels % 16 == 0
 
 
+# bf16 mode: hand the MFMA kernels their activation operand as the bf16
+# channel-blocked image (N, C/8, P, 8) instead of fp32 (N, C, P).  One HBM-bound
+# conversion launch per distinct tensor (cached on the tensor: a block input
+# feeds conv1 and the downsample conv, an FPN level feeds both head towers),
+# then 16-byte operand loads and no conversion inside the GEMM loop
+# (conv_bf16.hip conv_tile_c8_kernel).  LD_CONV_C8=0 keeps the fp32-input
+# kernels.
+_C8 = [os.environ.get('LD_CONV_C8', '1') == '1']
+
+
+def set_c8(flag):
+    _C8[0] = bool(flag)
+
+
+def _use_c8(reduction_channels, ksize=3, stride=1, J=1 << 30, x=None):
+    """Whether a conv takes the C8 image of its activation operand.  The GEMM
+    itself is faster with it everywhere (profiles/r02_kernels_c8.json: head
+    tower 709 vs 495 TFLOP/s, 50x84 stages 205 vs 178), but a SEPARATE
+    conversion launch only pays where the image is re-read by several taps of
+    a large layer: 3x3 convs from the 100x168 stage up, and stride-2 3x3 convs.
+    An image that already exists (a producer wrote it, or another conv of the
+    same tensor asked for it) is always used.  LD_CONV_C8=all forces it."""
+    if not (_C8[0] and _PRECISION[0] == 'bf16' and
+            reduction_channels % 32 == 0):
+        return False
+    if _C8_ALL or (x is not None and _c8_cached(x) is not None):
+        return True
+    return ksize >= 3 and (J >= 33600 or stride == 2)
+
+
+_C8_ALL = os.environ.get('LD_CONV_C8', '1') == 'all'
+if _C8_ALL:
+    _C8[0] = True
+
+
+def _c8_cached(x3):
+    hit = getattr(x3, '_ld_c8', None)
+    if hit is not None and hit[0] == (x3._version, x3.data_ptr()):
+        return hit[1]
+    return None
+
+
+def to_c8(x3):
+    """bf16 (N, C/8, P, 8) image of an fp32 (N, C, P) tensor (cached)."""
+    key = (x3._version, x3.data_ptr())
+    hit = getattr(x3, '_ld_c8', None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    N, Cc, P = x3.shape
+    out = torch.empty(N * Cc * P, dtype=torch.bfloat16, device=x3.device)
+    L.check(L.get_lib().ld_conv_to_c8(L.ptr(x3), N, Cc, P, L.ptr(out),
+                                      L.stream_ptr(x3.device)),
+            'ld_conv_to_c8')
+    try:
+        x3._ld_c8 = (key, out)
+    except AttributeError:
+        pass
+    return out
+
+
 def _register(reg, t):
     if id(t) not in reg:
         reg[id(t)] = weakref.ref(t)
@@ -404,19 +464,25 @@ def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
         _dev_f32(residual, 'residual')
         assert residual.shape == y3.shape
     ep = _epilogue(bias, scale, shift, residual, relu)
+    c8 = bf16 and _use_c8(cin, kh, stride, N * d.Pout, x3)
     fn = lib.ld_conv_forward_smallc if smallc else (
+        lib.ld_conv_bf16_forward_c8 if c8 else
         lib.ld_conv_bf16_forward if bf16 else lib.ld_conv_forward)
-    if not smallc:
-        tune = lib.ld_conv_bf16_tune_forward if bf16 else \
-            lib.ld_conv_tune_forward
-        _tune_once('bf16_forward' if bf16 else 'forward', d,
-                   (bias is not None, scale is not None,
-                    residual is not None, bool(relu)),
-                   lambda: tune(C.byref(d), L.ptr(x3), L.ptr(wt_fwd),
-                                C.byref(ep), L.ptr(y3),
-                                L.stream_ptr(x3.device)))
     with _timed('conv_fwd_bf16' if bf16 else 'conv_fwd', d):
-        L.check(fn(C.byref(d), L.ptr(x3), L.ptr(wt_fwd), C.byref(ep),
+        # the conversion launch is part of the conv's measured time
+        xin = to_c8(x3) if c8 else x3
+        if not smallc:
+            tune = lib.ld_conv_bf16_tune_forward_c8 if c8 else \
+                lib.ld_conv_bf16_tune_forward if bf16 else \
+                lib.ld_conv_tune_forward
+            _tune_once('c8_forward' if c8 else
+                       'bf16_forward' if bf16 else 'forward', d,
+                       (bias is not None, scale is not None,
+                        residual is not None, bool(relu)),
+                       lambda: tune(C.byref(d), L.ptr(xin), L.ptr(wt_fwd),
+                                    C.byref(ep), L.ptr(y3),
+                                    L.stream_ptr(x3.device)))
+        L.check(fn(C.byref(d), L.ptr(xin), L.ptr(wt_fwd), C.byref(ep),
                    L.ptr(y3), L.stream_ptr(x3.device)), 'ld_conv_forward')
     return y3, out_levels
 
@@ -485,14 +551,19 @@ class ConvFn(torch.autograd.Function):
             bf16 = _use_bf16(cout)  # the data gradient reduces over Cout
             _, wt_bwd = weight_images(w, True, bf16=bf16, need_fwd=False)
             dx = torch.empty_like(x3)
-            tune = lib.ld_conv_bf16_tune_dgrad if bf16 else \
+            c8 = bf16 and _use_c8(cout, kh, stride, N * d.Pin, dy)
+            tune = lib.ld_conv_bf16_tune_dgrad_c8 if c8 else \
+                lib.ld_conv_bf16_tune_dgrad if bf16 else \
                 lib.ld_conv_tune_dgrad
-            dgrad = lib.ld_conv_bf16_dgrad if bf16 else lib.ld_conv_dgrad
-            _tune_once('bf16_dgrad' if bf16 else 'dgrad', d, (),
-                       lambda: tune(C.byref(d), L.ptr(dy), L.ptr(wt_bwd),
-                                    L.ptr(dx), st))
+            dgrad = lib.ld_conv_bf16_dgrad_c8 if c8 else \
+                lib.ld_conv_bf16_dgrad if bf16 else lib.ld_conv_dgrad
             with _timed('conv_dgrad_bf16' if bf16 else 'conv_dgrad', d):
-                L.check(dgrad(C.byref(d), L.ptr(dy), L.ptr(wt_bwd),
+                dyin = to_c8(dy) if c8 else dy
+                _tune_once('c8_dgrad' if c8 else
+                           'bf16_dgrad' if bf16 else 'dgrad', d, (),
+                           lambda: tune(C.byref(d), L.ptr(dyin),
+                                        L.ptr(wt_bwd), L.ptr(dx), st))
+                L.check(dgrad(C.byref(d), L.ptr(dyin), L.ptr(wt_bwd),
                               L.ptr(dx), st), 'ld_conv_dgrad')
         pw, pb = ctx.params
         if ctx.needs_input_grad[1]:

@@ -231,7 +231,13 @@ class SGDTrainer:
             self.flat_momentum[o:o + p.numel()].copy_(
                 buf.reshape(-1).to(self.flat_momentum.device))
 
-    def step(self, data):
+    def step(self, data, next_data=None):
+        """One iteration on ``data``.  ``next_data`` (optional): the batch of
+        the FOLLOWING step, already on the device -- a distillation detector
+        then runs its frozen teacher on it concurrently with this step
+        (KnowledgeDistillationSingleStageDetector.prefetch_teacher)."""
+        if next_data is not None and hasattr(self.model, 'prefetch_teacher'):
+            self.model.prefetch_teacher(next_data['img'])
         self.arena.zero_grad()
         # _parse_losses sums the loss keys with unit coefficients, so the fused
         # loss block may hand back the gradient its forward launch already

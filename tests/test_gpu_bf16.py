@@ -200,3 +200,64 @@ def test_bf16_train_step_vs_fp32_golden(golden, bf16_mode):
     assert np.quantile(rels, 0.9) < 3e-2
     assert rels.max() < 6e-2
     assert np.isfinite(float(loss))
+
+
+C8_SHAPES = ['4x4x2', '4x4x4', '2x4x4', '4x2x4', '2x2x4', '2x4x2', '4x2x2',
+             '2x2x2', '4x8x2', '2x8x2']
+
+
+def test_to_c8_layout():
+    """ld_conv_to_c8: (N, C, P) fp32 -> (N, C/8, P, 8) bf16, RNE."""
+    from ld_amd import layers as Y
+    dev = _dev()
+    x = torch.randn(2, 48, 77, device=dev) * 3
+    got = Y.to_c8(x).reshape(2, 6, 77, 8)
+    want = x.to(torch.bfloat16).reshape(2, 6, 8, 77).permute(0, 1, 3, 2)
+    assert torch.equal(got, want)
+    assert Y.to_c8(x) is Y.to_c8(x)  # cached on the tensor
+    x.add_(1.0)                       # ... until it changes
+    want = x.to(torch.bfloat16).reshape(2, 6, 8, 77).permute(0, 1, 3, 2)
+    assert torch.equal(Y.to_c8(x).reshape(2, 6, 77, 8), want)
+
+
+@pytest.mark.parametrize('shape', C8_SHAPES)
+def test_c8_kernel_bit_identical_to_fp32_input_tile_kernel(shape, monkeypatch,
+                                                           bf16_mode):
+    """The C8-input kernel feeds the SAME bf16 operands to the same MFMA
+    sequence as the LDS-tiled kernel that reads fp32 activations: forward with
+    the fused epilogue and both data-gradient modes agree bit for bit, for
+    every tile shape."""
+    from ld_amd import layers as Y
+    dev = _dev()
+    ran = 0
+    for case in BF16_CASES:
+        name, N, cin, cout, k, stride, pad, levels = case
+        if cin % 32 or cout % 32:
+            continue
+        ran += 1
+        g = torch.Generator().manual_seed(len(name) * 3 + cout)
+        P = sum(h * w for h, w in levels)
+        x = torch.randn(N, cin, P, generator=g).to(dev)
+        w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k)**0.5
+             ).to(dev)
+        scale = (torch.rand(cout, generator=g) + 0.5).to(dev)
+        shift = torch.randn(cout, generator=g).to(dev)
+        outs = []
+        monkeypatch.setattr(Y, '_C8_ALL', True)  # every layer, not only the
+        for c8 in (False, True):                  # ones the policy picks
+            Y.set_c8(c8)
+            monkeypatch.setenv('LD_CONV_BF16_SHAPE', '4x4x0x32x2')
+            monkeypatch.setenv('LD_CONV_C8_SHAPE', shape)
+            try:
+                y, _ = Y.conv_forward_raw(x, w, stride, pad, levels,
+                                          scale=scale, shift=shift, relu=True)
+                xd = x.clone().requires_grad_(True)
+                yd, _ = Y.conv2d(xd, w, None, stride, pad, levels)
+                go = torch.Generator().manual_seed(7)
+                yd.backward(torch.randn(yd.shape, generator=go).to(dev))
+            finally:
+                Y.set_c8(True)
+            outs.append((y, xd.grad))
+        assert torch.equal(outs[0][0], outs[1][0]), f'{name} fwd [{shape}]'
+        assert torch.equal(outs[0][1], outs[1][1]), f'{name} dgrad [{shape}]'
+    assert ran >= 4

@@ -51,3 +51,41 @@ def test_graphed_step_equals_eager(mode):
         assert np.isfinite(float(out_g['loss']))
     finally:
         Y.set_precision('fp32')
+
+
+def test_teacher_prefetch_bit_identical():
+    """SGDTrainer.step(data, next_data=...) runs the frozen teacher of the next
+    batch under this step (KnowledgeDistillationSingleStageDetector.
+    prefetch_teacher); three pipelined steps give exactly the parameters and
+    losses of three plain steps, also when a DIFFERENT batch arrives than the
+    one that was prefetched (the stale result is dropped)."""
+    import torch
+    from ld_amd import model_zoo, synthetic
+    from ld_amd.train import SGDTrainer
+    dev = torch.device('cuda:0')
+
+    def batch(seed):
+        b = synthetic.synthetic_batch(2, (160, 200), (160, 224), 3, seed)
+        return dict(img=b['img'].to(dev), img_metas=b['img_metas'],
+                    gt_bboxes=[x.to(dev) for x in b['gt_bboxes']],
+                    gt_labels=[x.to(dev) for x in b['gt_labels']])
+
+    batches = [batch(s) for s in (5, 6, 7)]
+    results = []
+    for mode in ('plain', 'pipelined', 'stale'):
+        det = model_zoo.build_seeded_ld_detector(18, 18, dev)
+        tr = SGDTrainer(det, lr=0.01)
+        losses = []
+        for i, b in enumerate(batches):
+            if mode == 'plain':
+                out = tr.step(b)
+            elif mode == 'pipelined':
+                out = tr.step(b, next_data=batches[(i + 1) % 3])
+            else:  # announces a batch that never comes
+                out = tr.step(b, next_data=batches[(i + 2) % 3])
+            losses.append(out['loss'].clone())
+        torch.cuda.synchronize()
+        results.append((torch.stack(losses), tr.arena.flat_param.clone()))
+    for other in results[1:]:
+        assert torch.equal(results[0][0], other[0])
+        assert torch.equal(results[0][1], other[1])

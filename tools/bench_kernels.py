@@ -293,6 +293,55 @@ def bench_bf16(out):
     out['conv_bf16'] = res
 
 
+def bench_c8(out):
+    """bf16 forward / dgrad per C2 layer shape: fp32-input kernels (shape table
+    / model pick) vs the C8-input tiled kernel under every tile shape, with and
+    without the conversion launch."""
+    from ld_amd import lib as L
+    import ctypes as C
+    dev = torch.device('cuda:0')
+    lib = L.get_lib()
+    Y.set_precision('bf16')
+    Y._C8_ALL = True
+    shapes = ['4x4x2', '4x4x4', '2x4x4', '4x2x4', '2x2x4', '2x4x2', '4x2x2',
+              '2x2x2', '4x8x2', '2x8x2']
+    res = []
+    for name, N, cin, cout, k, stride, pad, levels in CONV_SHAPES:
+        if cin % 32 or cout % 32:
+            continue
+        P = sum(h * w for h, w in levels)
+        x = torch.randn(N, cin, P, device=dev)
+        w = torch.randn(cout, cin, k, k, device=dev) * 0.05
+        d, _ = Y.conv_desc(N, cin, cout, k, k, stride, pad, levels)
+        flops = 2.0 * N * d.Pout * cout * cin * k * k
+        r = dict(name=name)
+        Y.set_c8(False)
+        t = timeit(lambda: Y.conv_forward_raw(x, w, stride, pad, levels), 2, 7)
+        r['fp32in'] = round(flops / t / 1e12, 1)
+        Y.set_c8(True)
+        xc = Y.to_c8(x)
+        t = timeit(lambda: lib.ld_conv_to_c8(L.ptr(x), N, cin, P, L.ptr(xc),
+                                             L.stream_ptr(dev)), 2, 7)
+        r['to_c8_us'] = round(t * 1e6, 1)
+        r['to_c8_GBps'] = round(x.numel() * 6 / t / 1e9)
+        best = 0
+        for sh in shapes:
+            os.environ['LD_CONV_C8_SHAPE'] = sh
+            t = timeit(lambda: Y.conv_forward_raw(x, w, stride, pad, levels),
+                       2, 7)  # cached image: the GEMM alone
+            r[sh] = round(flops / t / 1e12, 1)
+            best = max(best, r[sh])
+        os.environ.pop('LD_CONV_C8_SHAPE', None)
+        r['best_c8'] = best
+        tb = flops / (best * 1e12)
+        r['best_c8_incl_convert'] = round(
+            flops / (tb + r['to_c8_us'] * 1e-6) / 1e12, 1)
+        res.append(r)
+        print(r, flush=True)
+    Y.set_precision('fp32')
+    out['conv_c8'] = res
+
+
 def bench_wgrad(out):
     """Weight gradient per C2 layer shape under each kernel (LD_CONV_WGRAD:
     32 / 16 positions per step of the wave-private kernel); the
@@ -393,6 +442,8 @@ def main():
         bench_pipeline(out)
     if 'wgrad' in args.only.split(','):
         bench_wgrad(out)
+    if 'c8' in args.only.split(','):
+        bench_c8(out)
     os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
     path = os.path.join(REPO, 'gpurun_out', f'kernels_{args.tag}.json')
     with open(path, 'w') as f:

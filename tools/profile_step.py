@@ -19,6 +19,8 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--graph', action='store_true')
+    ap.add_argument('--pipeline', action='store_true',
+                    help='teacher of the next batch under this step')
     ap.add_argument('--layers', default='',
                     help='write the per-layer conv table (HIP events around '
                          'every conv launch, teacher on the main stream) here')
@@ -41,14 +43,16 @@ def main():
         g = GraphedStep(tr, d)
         run = g.replay
     else:
-        run = lambda: tr.step(d)  # noqa: E731
+        run = (lambda: tr.step(d, next_data=d)) if args.pipeline else \
+            (lambda: tr.step(d))  # noqa: E731
     import time
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print(f'{args.mode} graph={args.graph}: {dt * 1e3:.2f} ms/step, '
+    print(f'{args.mode} graph={args.graph} pipeline={args.pipeline}: '
+          f'{dt * 1e3:.2f} ms/step, '
           f'{2 / dt:.1f} img/s')
     if args.layers:
         det.use_teacher_stream = False
