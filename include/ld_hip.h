@@ -506,6 +506,20 @@ int ld_gn_backward(const ld_levels_t* lv, const float* dy, const float* y,
                    const float* rstd, int N, int C, int G, int relu, float* dx,
                    float* dgamma, float* dbeta, int accumulate, void* workspace,
                    size_t workspace_bytes, ld_stream_t stream);
+/* The same with a bf16 channel-blocked side output (see ld_conv_to_c8): y_c8 /
+ * dx_c8 receive the (N, C/8, P, 8) bf16 image of the fp32 tensor written in the
+ * same launch, for the bf16 conv that consumes it next.  The fp32 results are
+ * bit-identical to ld_gn_forward / ld_gn_backward.  Needs C % 8 == 0, P % 4 == 0
+ * and 16-byte aligned tensors (LD_EUNSUPPORTED otherwise). */
+int ld_gn_forward_c8(const ld_levels_t* lv, const float* x, const float* gamma,
+                     const float* beta, int N, int C, int G, float eps, int relu,
+                     float* y, void* y_c8, float* mean, float* rstd, void* workspace,
+                     size_t workspace_bytes, ld_stream_t stream);
+int ld_gn_backward_c8(const ld_levels_t* lv, const float* dy, const float* y,
+                      const float* x, const float* gamma, const float* mean,
+                      const float* rstd, int N, int C, int G, int relu, float* dx,
+                      void* dx_c8, float* dgamma, float* dbeta, int accumulate,
+                      void* workspace, size_t workspace_bytes, ld_stream_t stream);
 /* MaxPool2d(kernel 3, stride 2, pad 1) on rows = N*C planes (resnet.py:570);
  * forward only (the stem is frozen, frozen_stages=1). */
 int ld_maxpool3x3s2(const float* x, int rows, int H, int W, float* y,

@@ -333,6 +333,112 @@ __global__ __launch_bounds__(256) void gn_apply4_kernel(
   *reinterpret_cast<float4*>(y + idx) = make_float4(out[0], out[1], out[2], out[3]);
 }
 
+// ---- bf16 channel-blocked side output ("C8", conv_bf16.hip) ------------------
+// In bf16 mode the conv that consumes y (forward) or dx (data gradient) wants
+// its activation operand as (N, C/8, P, 8) bf16.  These variants own 8 channels
+// x 4 positions per thread, write the SAME fp32 tensor as the kernels above
+// (identical expressions) and, from the values already in registers, the C8
+// image: no separate conversion launch, no re-read.
+typedef float gn_floatx8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned gn_uintx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void store_c8x4(gn_uintx4* __restrict__ dst,
+                                           const float (&v)[8][4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    gn_floatx8 f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = v[e][k];
+    dst[k] = __builtin_bit_cast(gn_uintx4, __builtin_convertvector(f, gn_bf16x8));
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_c8_kernel(
+    const float* __restrict__ x, Levels lv, int C, int G,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+    float* __restrict__ y, gn_uintx4* __restrict__ y_c8) {
+  const int C8 = C >> 3;
+  const int blk = blockIdx.y;  // n * C8 + c8
+  const int c8 = blk % C8, n = blk / C8;
+  const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (p >= lv.P) return;
+  const int l0 = level_of_pos(lv, p), l3 = level_of_pos(lv, p + 3);
+  float out[8][4];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c8 * 8 + e;
+    const size_t ob = ((size_t)n * G + c / (C / G)) * lv.num_levels;
+    const size_t idx = ((size_t)n * C + c) * lv.P + p;
+    const float4 v = *reinterpret_cast<const float4*>(x + idx);
+    const float ga = gamma[c], be = beta[c];
+    const float in[4] = {v.x, v.y, v.z, v.w};
+    if (l0 == l3) {
+      const float mu = mean[ob + l0], rs = rstd[ob + l0];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out[e][k] = (in[k] - mu) * rs * ga + be;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int l = level_of_pos(lv, p + k);
+        out[e][k] = (in[k] - mean[ob + l]) * rstd[ob + l] * ga + be;
+      }
+    }
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out[e][k] = fmaxf(out[e][k], 0.f);
+    }
+    *reinterpret_cast<float4*>(y + idx) =
+        make_float4(out[e][0], out[e][1], out[e][2], out[e][3]);
+  }
+  store_c8x4(y_c8 + (size_t)blk * lv.P + p, out);
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_c8_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y,
+    const float* __restrict__ x, Levels lv, int C, int G,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ gm, int relu,
+    float* __restrict__ dx, gn_uintx4* __restrict__ dx_c8) {
+  const int C8 = C >> 3;
+  const int blk = blockIdx.y;
+  const int c8 = blk % C8, n = blk / C8;
+  const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (p >= lv.P) return;
+  const int L = lv.num_levels;
+  float out[8][4];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c8 * 8 + e;
+    const size_t ob = ((size_t)n * G + c / (C / G)) * L;
+    const size_t idx = ((size_t)n * C + c) * lv.P + p;
+    const float ga = gamma[c];
+    const float4 t0 = *reinterpret_cast<const float4*>(dy + idx);
+    const float4 t2 = *reinterpret_cast<const float4*>(x + idx);
+    const float a_dy[4] = {t0.x, t0.y, t0.z, t0.w};
+    const float a_x[4] = {t2.x, t2.y, t2.z, t2.w};
+    float a_y[4] = {1.f, 1.f, 1.f, 1.f};
+    if (relu) {
+      const float4 t1 = *reinterpret_cast<const float4*>(y + idx);
+      a_y[0] = t1.x; a_y[1] = t1.y; a_y[2] = t1.z; a_y[3] = t1.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int l = level_of_pos(lv, p + k);
+      const float mu = mean[ob + l], rs = rstd[ob + l];
+      const float fm1 = gm[(ob + l) * 2 + 0], fm2 = gm[(ob + l) * 2 + 1];
+      float dz = a_dy[k];
+      if (relu && !(a_y[k] > 0.f)) dz = 0.f;
+      const float xh = (a_x[k] - mu) * rs;
+      out[e][k] = rs * (ga * dz - fm1 - xh * fm2);
+    }
+    *reinterpret_cast<float4*>(dx + idx) =
+        make_float4(out[e][0], out[e][1], out[e][2], out[e][3]);
+  }
+  store_c8x4(dx_c8 + (size_t)blk * lv.P + p, out);
+}
+
 // backward pass A: per (n, c, level): s1 = sum dz, s2 = sum dz * xhat, each
 // level cut into kGnBwdSplit slices (the 16800-cell level would otherwise sit
 // on two workgroups per CU)
@@ -755,11 +861,11 @@ extern "C" size_t ld_gn_forward_workspace_bytes(const ld_levels_t* lv, int N,
   return (size_t)N * G * lv->num_levels * kGnSplit * 2 * sizeof(double);
 }
 
-extern "C" int ld_gn_forward(const ld_levels_t* lv, const float* x,
-                             const float* gamma, const float* beta, int N, int C,
-                             int G, float eps, int relu, float* y, float* mean,
-                             float* rstd, void* workspace, size_t workspace_bytes,
-                             ld_stream_t stream) {
+static int gn_forward_impl(const ld_levels_t* lv, const float* x, const float* gamma,
+                           const float* beta, int N, int C, int G, float eps,
+                           int relu, float* y, void* y_c8, float* mean, float* rstd,
+                           void* workspace, size_t workspace_bytes,
+                           ld_stream_t stream) {
   if (int e = check_levels(lv)) return e;
   if (!x || !gamma || !beta || !y || !mean || !rstd || N < 1 || C < 1 || G < 1 ||
       C % G)
@@ -773,7 +879,13 @@ extern "C" int ld_gn_forward(const ld_levels_t* lv, const float* x,
   hipLaunchKernelGGL(gn_stats_final_kernel, dim3((ngl + 255) / 256), dim3(256), 0,
                      LD_STREAM, (const double*)workspace, k, N, C, G, eps, mean,
                      rstd);
-  if (k.P % 4 == 0 && ((uintptr_t)x | (uintptr_t)y) % 16 == 0)
+  if (y_c8) {
+    if (k.P % 4 != 0 || C % 8 != 0 || ((uintptr_t)x | (uintptr_t)y) % 16 != 0)
+      return LD_EUNSUPPORTED;
+    hipLaunchKernelGGL(gn_apply_c8_kernel, dim3((k.P / 4 + 255) / 256, N * (C / 8)),
+                       dim3(256), 0, LD_STREAM, x, k, C, G, mean, rstd, gamma, beta,
+                       relu, y, (gn_uintx4*)y_c8);
+  } else if (k.P % 4 == 0 && ((uintptr_t)x | (uintptr_t)y) % 16 == 0)
     hipLaunchKernelGGL(gn_apply4_kernel, dim3((k.P / 4 + 255) / 256, N * C),
                        dim3(256), 0, LD_STREAM, x, k, C, G, mean, rstd, gamma, beta,
                        relu, y);
@@ -781,6 +893,25 @@ extern "C" int ld_gn_forward(const ld_levels_t* lv, const float* x,
     hipLaunchKernelGGL(gn_apply_kernel, dim3((k.P + 255) / 256, N * C), dim3(256), 0,
                        LD_STREAM, x, k, C, G, mean, rstd, gamma, beta, relu, y);
   return (int)hipGetLastError();
+}
+
+extern "C" int ld_gn_forward(const ld_levels_t* lv, const float* x,
+                             const float* gamma, const float* beta, int N, int C,
+                             int G, float eps, int relu, float* y, float* mean,
+                             float* rstd, void* workspace, size_t workspace_bytes,
+                             ld_stream_t stream) {
+  return gn_forward_impl(lv, x, gamma, beta, N, C, G, eps, relu, y, nullptr, mean,
+                         rstd, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ld_gn_forward_c8(const ld_levels_t* lv, const float* x,
+                                const float* gamma, const float* beta, int N, int C,
+                                int G, float eps, int relu, float* y, void* y_c8,
+                                float* mean, float* rstd, void* workspace,
+                                size_t workspace_bytes, ld_stream_t stream) {
+  if (!y_c8) return LD_EINVAL;
+  return gn_forward_impl(lv, x, gamma, beta, N, C, G, eps, relu, y, y_c8, mean, rstd,
+                         workspace, workspace_bytes, stream);
 }
 
 static size_t gn_bwd_sums_bytes(int L, int N, int C) {
@@ -795,12 +926,12 @@ extern "C" size_t ld_gn_backward_workspace_bytes(const ld_levels_t* lv, int N,
          (size_t)N * C * lv->num_levels * 2 * sizeof(float);
 }
 
-extern "C" int ld_gn_backward(const ld_levels_t* lv, const float* dy, const float* y,
-                              const float* x, const float* gamma, const float* mean,
-                              const float* rstd, int N, int C, int G, int relu,
-                              float* dx, float* dgamma, float* dbeta, int accumulate,
-                              void* workspace, size_t workspace_bytes,
-                              ld_stream_t stream) {
+static int gn_backward_impl(const ld_levels_t* lv, const float* dy, const float* y,
+                            const float* x, const float* gamma, const float* mean,
+                            const float* rstd, int N, int C, int G, int relu,
+                            float* dx, void* dx_c8, float* dgamma, float* dbeta,
+                            int accumulate, void* workspace, size_t workspace_bytes,
+                            ld_stream_t stream) {
   if (int e = check_levels(lv)) return e;
   if (!dy || !x || !gamma || !mean || !rstd || !dx || N < 1 || C < 1 || G < 1 ||
       C % G)
@@ -821,7 +952,13 @@ extern "C" int ld_gn_backward(const ld_levels_t* lv, const float* dy, const floa
   const bool vec = k.P % 4 == 0 &&
                    ((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx |
                     (uintptr_t)(relu ? y : x)) % 16 == 0;
-  if (vec)
+  if (dx_c8) {
+    if (!vec || C % 8 != 0) return LD_EUNSUPPORTED;
+    hipLaunchKernelGGL(gn_bwd_apply_c8_kernel,
+                       dim3((k.P / 4 + 255) / 256, N * (C / 8)), dim3(256), 0,
+                       LD_STREAM, dy, y, x, k, C, G, mean, rstd, gamma, gm, relu, dx,
+                       (gn_uintx4*)dx_c8);
+  } else if (vec)
     hipLaunchKernelGGL(gn_bwd_apply_kernel<4>, dim3((k.P / 4 + 255) / 256, N * C),
                        dim3(256), 0, LD_STREAM, dy, y, x, k, C, G, mean, rstd, gamma,
                        gm, relu, dx);
@@ -834,6 +971,30 @@ extern "C" int ld_gn_backward(const ld_levels_t* lv, const float* dy, const floa
                        LD_STREAM, sums, N, C, k.num_levels, dgamma, dbeta,
                        accumulate);
   return (int)hipGetLastError();
+}
+
+extern "C" int ld_gn_backward(const ld_levels_t* lv, const float* dy, const float* y,
+                              const float* x, const float* gamma, const float* mean,
+                              const float* rstd, int N, int C, int G, int relu,
+                              float* dx, float* dgamma, float* dbeta, int accumulate,
+                              void* workspace, size_t workspace_bytes,
+                              ld_stream_t stream) {
+  return gn_backward_impl(lv, dy, y, x, gamma, mean, rstd, N, C, G, relu, dx, nullptr,
+                          dgamma, dbeta, accumulate, workspace, workspace_bytes,
+                          stream);
+}
+
+extern "C" int ld_gn_backward_c8(const ld_levels_t* lv, const float* dy,
+                                 const float* y, const float* x, const float* gamma,
+                                 const float* mean, const float* rstd, int N, int C,
+                                 int G, int relu, float* dx, void* dx_c8,
+                                 float* dgamma, float* dbeta, int accumulate,
+                                 void* workspace, size_t workspace_bytes,
+                                 ld_stream_t stream) {
+  if (!dx_c8) return LD_EINVAL;
+  return gn_backward_impl(lv, dy, y, x, gamma, mean, rstd, N, C, G, relu, dx, dx_c8,
+                          dgamma, dbeta, accumulate, workspace, workspace_bytes,
+                          stream);
 }
 
 extern "C" int ld_maxpool3x3s2(const float* x, int rows, int H, int W, float* y,

@@ -206,12 +206,17 @@ def _c8_cached(x3):
     return None
 
 
+C8_STATS = dict(converted=0, reused=0)
+
+
 def to_c8(x3):
     """bf16 (N, C/8, P, 8) image of an fp32 (N, C, P) tensor (cached)."""
     key = (x3._version, x3.data_ptr())
     hit = getattr(x3, '_ld_c8', None)
     if hit is not None and hit[0] == key:
+        C8_STATS['reused'] += 1
         return hit[1]
+    C8_STATS['converted'] += 1
     N, Cc, P = x3.shape
     out = torch.empty(N * Cc * P, dtype=torch.bfloat16, device=x3.device)
     L.check(L.get_lib().ld_conv_to_c8(L.ptr(x3), N, Cc, P, L.ptr(out),
@@ -730,10 +735,37 @@ def conv_bn_act_infer(x3, w, gamma, beta, mean, var, eps, stride, pad, levels,
 # ---------------------------------------------------------------------------
 # GroupNorm + ReLU on level-concatenated tensors
 # ---------------------------------------------------------------------------
+def _c8_side_output(t):
+    """bf16 mode: a producer kernel may write the C8 image of its fp32 output in
+    the same launch (the next conv then finds it cached on the tensor).  Returns
+    the buffer to fill, or None when the geometry does not allow it."""
+    N, c, P = t.shape
+    if not (_C8[0] and _PRECISION[0] == 'bf16' and c % 32 == 0 and P % 4 == 0
+            and t.data_ptr() % 16 == 0):
+        return None
+    return torch.empty(N * c * P, dtype=torch.bfloat16, device=t.device)
+
+
+def _attach_c8(t, buf):
+    try:
+        t._ld_c8 = ((t._version, t.data_ptr()), buf)
+    except AttributeError:
+        pass
+
+
 def _gn_forward_launch(lv, x3, gamma, beta, N, c, groups, eps, relu, y, stats):
     lib = L.get_lib()
     need = lib.ld_gn_forward_workspace_bytes(C.byref(lv), N, groups)
     ws = workspace(x3.device, need, 'gn_fwd')
+    y_c8 = _c8_side_output(y) if x3.data_ptr() % 16 == 0 else None
+    if y_c8 is not None:
+        L.check(lib.ld_gn_forward_c8(
+            C.byref(lv), L.ptr(x3), L.ptr(gamma), L.ptr(beta), N, c, groups,
+            eps, 1 if relu else 0, L.ptr(y), L.ptr(y_c8), L.ptr(stats[0]),
+            L.ptr(stats[1]), L.ptr(ws), ws.numel(),
+            L.stream_ptr(x3.device)), 'ld_gn_forward_c8')
+        _attach_c8(y, y_c8)
+        return
     L.check(lib.ld_gn_forward(C.byref(lv), L.ptr(x3), L.ptr(gamma),
                               L.ptr(beta), N, c, groups, eps,
                               1 if relu else 0, L.ptr(y), L.ptr(stats[0]),
@@ -780,11 +812,23 @@ class GnActFn(torch.autograd.Function):
             dbeta = torch.empty(c, dtype=torch.float32, device=x3.device)
         need = lib.ld_gn_backward_workspace_bytes(C.byref(lv), N, c)
         ws = workspace(x3.device, need, 'gn')
-        L.check(lib.ld_gn_backward(
-            C.byref(lv), L.ptr(dy), L.ptr(y), L.ptr(x3), L.ptr(gamma),
-            L.ptr(stats[0]), L.ptr(stats[1]), N, c, groups, 1 if relu else 0,
-            L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), 1 if direct else 0,
-            L.ptr(ws), ws.numel(), L.stream_ptr(x3.device)), 'ld_gn_backward')
+        aligned = all(t.data_ptr() % 16 == 0 for t in (dy, y, x3))
+        dx_c8 = _c8_side_output(dx) if aligned else None
+        if dx_c8 is not None:
+            L.check(lib.ld_gn_backward_c8(
+                C.byref(lv), L.ptr(dy), L.ptr(y), L.ptr(x3), L.ptr(gamma),
+                L.ptr(stats[0]), L.ptr(stats[1]), N, c, groups,
+                1 if relu else 0, L.ptr(dx), L.ptr(dx_c8), L.ptr(dgamma),
+                L.ptr(dbeta), 1 if direct else 0, L.ptr(ws), ws.numel(),
+                L.stream_ptr(x3.device)), 'ld_gn_backward_c8')
+            _attach_c8(dx, dx_c8)
+        else:
+            L.check(lib.ld_gn_backward(
+                C.byref(lv), L.ptr(dy), L.ptr(y), L.ptr(x3), L.ptr(gamma),
+                L.ptr(stats[0]), L.ptr(stats[1]), N, c, groups,
+                1 if relu else 0, L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta),
+                1 if direct else 0, L.ptr(ws), ws.numel(),
+                L.stream_ptr(x3.device)), 'ld_gn_backward')
         if direct:
             dgamma = dbeta = None
             _emit(pg)

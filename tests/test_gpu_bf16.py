@@ -261,3 +261,46 @@ def test_c8_kernel_bit_identical_to_fp32_input_tile_kernel(shape, monkeypatch,
         assert torch.equal(outs[0][0], outs[1][0]), f'{name} fwd [{shape}]'
         assert torch.equal(outs[0][1], outs[1][1]), f'{name} dgrad [{shape}]'
     assert ran >= 4
+
+
+def test_gn_c8_side_output(bf16_mode):
+    """GroupNorm(+ReLU) forward and backward write the C8 image of their fp32
+    output in the same launch: the fp32 tensors equal the plain kernels' bit for
+    bit, the image equals a from-scratch conversion, and the conv that follows
+    finds it cached (no conversion launch)."""
+    from ld_amd import layers as Y
+    dev = _dev()
+    levels = ((12, 20), (6, 10), (3, 4))
+    P = sum(h * w for h, w in levels)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, P, generator=g).to(dev)
+    gamma = (torch.rand(64, generator=g) + 0.5).to(dev)
+    beta = torch.randn(64, generator=g).to(dev)
+    go = torch.randn(2, 64, P, generator=g).to(dev)
+    outs = []
+    for c8 in (False, True):
+        Y.set_c8(c8)
+        try:
+            xr = x.clone().requires_grad_(True)
+            gr, br = gamma.clone().requires_grad_(True), \
+                beta.clone().requires_grad_(True)
+            y = Y.gn_act(xr, gr, br, 32, 1e-5, levels, relu=True)
+            img = Y._c8_cached(y)
+            if c8:
+                assert img is not None
+                want = y.detach().to(torch.bfloat16).reshape(
+                    2, 8, 8, P).permute(0, 1, 3, 2).reshape(-1)
+                assert torch.equal(img, want)
+                before = dict(Y.C8_STATS)
+                w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
+                Y.conv_forward_raw(y.detach(), w, 1, 1, levels)  # other object
+                Y.conv_forward_raw(y, w, 1, 1, levels)
+                assert Y.C8_STATS['reused'] == before['reused'] + 1
+            else:
+                assert img is None
+            y.backward(go)
+            outs.append((y.detach(), xr.grad, gr.grad, br.grad))
+        finally:
+            Y.set_c8(True)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

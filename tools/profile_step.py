@@ -54,6 +54,10 @@ def main():
     print(f'{args.mode} graph={args.graph} pipeline={args.pipeline}: '
           f'{dt * 1e3:.2f} ms/step, '
           f'{2 / dt:.1f} img/s')
+    if args.mode == 'bf16':
+        Y.C8_STATS.update(converted=0, reused=0)
+        run()
+        print('C8 operand images per step:', Y.C8_STATS)
     if args.layers:
         det.use_teacher_stream = False
         tr.step(d)
