@@ -183,7 +183,8 @@ def _use_c8(reduction_channels, ksize=3, stride=1, J=1 << 30, x=None):
     itself is faster with it everywhere (profiles/r02_kernels_c8.json: head
     tower 709 vs 495 TFLOP/s, 50x84 stages 205 vs 178), but a SEPARATE
     conversion launch only pays where the image is re-read by several taps of
-    a large layer: 3x3 convs from the 100x168 stage up, and stride-2 3x3 convs.
+    a large layer: 3x3 convs from the 100x168 stage up, and the stride-2 3x3
+    convs of the backbone.
     An image that already exists (a producer wrote it, or another conv of the
     same tensor asked for it) is always used.  LD_CONV_C8=all forces it."""
     if not (_C8[0] and _PRECISION[0] == 'bf16' and
@@ -191,7 +192,7 @@ def _use_c8(reduction_channels, ksize=3, stride=1, J=1 << 30, x=None):
         return False
     if _C8_ALL or (x is not None and _c8_cached(x) is not None):
         return True
-    return ksize >= 3 and (J >= 33600 or stride == 2)
+    return ksize >= 3 and (J >= 33600 or (stride == 2 and J >= 2048))
 
 
 _C8_ALL = os.environ.get('LD_CONV_C8', '1') == 'all'

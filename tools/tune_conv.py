@@ -22,6 +22,8 @@ def main():
                                                   'tune_table.txt'))
     ap.add_argument('--modes', default='fp32,bf16')
     ap.add_argument('--student', type=int, default=50)
+    ap.add_argument('--fresh', action='store_true',
+                    help='forget the shipped table first (retune everything)')
     args = ap.parse_args()
     os.environ.setdefault('LD_CONV_TUNE_LOG', '1')
     from ld_amd import layers as Y
@@ -36,12 +38,20 @@ def main():
              gt_bboxes=[x.to(dev) for x in b['gt_bboxes']],
              gt_labels=[x.to(dev) for x in b['gt_labels']])
     Y.autotune(True)
+    if args.fresh:
+        L.get_lib().ld_conv_tune_clear()
     # the teacher must not run concurrently while candidates are being timed
     det.use_teacher_stream = False
     for mode in args.modes.split(','):
         Y.set_precision(mode)
-        tr.step(d)
-        torch.cuda.synchronize()
+        # bf16: once with the C8 operand policy (family 2 keys for the layers
+        # that use it), once without (family 1 keys for every layer)
+        for c8 in ((True, False) if mode == 'bf16' else (True, )):
+            Y.set_c8(c8)
+            Y._TUNED.clear()
+            tr.step(d)
+            torch.cuda.synchronize()
+        Y.set_c8(True)
     n = L.save_tune_table(args.out)
     print(f'wrote {n} records to {args.out}')
 
