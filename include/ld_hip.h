@@ -326,6 +326,12 @@ typedef struct {
   const float* shift;
   const float* residual; /* same shape as y */
   int32_t relu;
+  int32_t reserved;
+  /* bf16 forward entry points only (NULL elsewhere): also write the final values
+   * as the bf16 channel-blocked image (N, Cout/8, Pout, 8) of ld_conv_to_c8 --
+   * bit-identical to converting y afterwards -- for the conv that consumes y
+   * next.  Needs Cout % 8 == 0. */
+  void* y_c8;
 } ld_conv_epilogue_t;
 
 /* (Cout,Cin,KH,KW) parameter -> GEMM images: wt_fwd [tap][Cin_pad][Cout]

@@ -1543,6 +1543,8 @@ int build_forward(const ld_conv_t* c, const float* x, const void* wt_fwd,
   k.shift = ep ? ep->shift : nullptr;
   k.residual = ep ? ep->residual : nullptr;
   k.relu = ep ? ep->relu : 0;
+  k.y_c8 = ep ? ep->y_c8 : nullptr;
+  if (k.y_c8 && (family == 0 || c->Cout % 8 != 0)) return LD_EINVAL;
   if ((k.scale == nullptr) != (k.shift == nullptr)) return LD_EINVAL;
   k.N = c->N; k.Cin = c->Cin; k.Cout = c->Cout; k.KH = c->KH; k.KW = c->KW;
   k.g.stride = c->stride; k.g.pad = c->pad; k.Pin = c->Pin; k.Pout = c->Pout;
@@ -1642,6 +1644,7 @@ extern "C" int ld_conv_forward_smallc(const ld_conv_t* c, const float* x,
   k.shift = ep ? ep->shift : nullptr;
   k.residual = ep ? ep->residual : nullptr;
   k.relu = ep ? ep->relu : 0;
+  if (ep && ep->y_c8) return LD_EINVAL;  // bf16 entry points only
   if ((k.scale == nullptr) != (k.shift == nullptr)) return LD_EINVAL;
   k.N = c->N; k.Cin = c->Cin; k.Cout = c->Cout; k.KH = c->KH; k.KW = c->KW;
   k.g.stride = c->stride; k.g.pad = c->pad; k.Pin = c->Pin; k.Pout = c->Pout;

@@ -41,6 +41,15 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx8 __attribute__((ext_vector_type(8)));
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
+
+// Epilogue side output (a.y_c8): the bf16 channel-blocked (C8) image of y, for
+// the conv that consumes y next.  A lane holds rows rbase + 8g + {0..3} (g =
+// 0..3) of one position: four consecutive channels = one half of a 16-byte C8
+// row -> one 8-byte store; the two lane halves of a wave fill the row,
+// consecutive lanes consecutive positions (fully coalesced).
 
 inline int k8_blocks(int k) { return (k + 15) / 16 * 2; }  // 8-blocks per tap
 
@@ -249,6 +258,7 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_bf16_kernel(ConvK a) {
 
   // ---- epilogue: direct stores, 32 consecutive positions per accumulator row
   const bool has_res = a.residual != nullptr;
+  const bool c8out = a.y_c8 != nullptr;
   const bool relu = a.relu != 0;
   const bool has_aff = a.scale != nullptr, has_bias = a.bias != nullptr;
 #pragma unroll
@@ -277,13 +287,30 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_bf16_kernel(ConvK a) {
       }
       const size_t colbase = (size_t)n * Cout * prow + p;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rbase + (r & 3) + 8 * (r >> 2);
-        if (row >= Cout) continue;
-        float v = acc[i][j][r] * sc[r] + sh[r];
-        if (has_res) v += a.residual[colbase + (size_t)row * prow];
-        if (relu) v = fmaxf(v, 0.0f);
-        a.y[colbase + (size_t)row * prow] = v;
+      for (int g = 0; g < 4; ++g) {
+        floatx4_t q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const int row = rbase + e + 8 * g;
+          float v = 0.0f;
+          if (row < Cout) {
+            v = acc[i][j][r] * sc[r] + sh[r];
+            if (has_res) v += a.residual[colbase + (size_t)row * prow];
+            if (relu) v = fmaxf(v, 0.0f);
+            a.y[colbase + (size_t)row * prow] = v;
+          }
+          q[e] = v;
+        }
+        // side output: this lane's four channels = half of a 16-byte C8 row
+        if (MODE == 0 && c8out && rbase + 8 * g < Cout) {
+          const int row0 = rbase + 8 * g;
+          const size_t o =
+              (((size_t)n * (Cout >> 3) + (row0 >> 3)) * a.Pout + p) * 16 +
+              (row0 & 4) * 2;
+          *(uintx2*)((char*)a.y_c8 + o) =
+              __builtin_bit_cast(uintx2, __builtin_convertvector(q, bf16x4));
+        }
       }
     }
   }
@@ -476,6 +503,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile_bf16_kernel(ConvK a) {
 
   // ---- epilogue: direct stores, 32 consecutive positions per accumulator row
   const bool has_res = a.residual != nullptr;
+  const bool c8out = a.y_c8 != nullptr;
   const bool relu = a.relu != 0;
   const bool has_aff = a.scale != nullptr, has_bias = a.bias != nullptr;
 #pragma unroll
@@ -504,13 +532,30 @@ __global__ __launch_bounds__(256, 2) void conv_tile_bf16_kernel(ConvK a) {
       }
       const size_t colbase = (size_t)n * Cout * prow + p;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rbase + (r & 3) + 8 * (r >> 2);
-        if (row >= Cout) continue;
-        float v = acc[i][j][r] * sc[r] + sh[r];
-        if (has_res) v += a.residual[colbase + (size_t)row * prow];
-        if (relu) v = fmaxf(v, 0.0f);
-        a.y[colbase + (size_t)row * prow] = v;
+      for (int g = 0; g < 4; ++g) {
+        floatx4_t q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const int row = rbase + e + 8 * g;
+          float v = 0.0f;
+          if (row < Cout) {
+            v = acc[i][j][r] * sc[r] + sh[r];
+            if (has_res) v += a.residual[colbase + (size_t)row * prow];
+            if (relu) v = fmaxf(v, 0.0f);
+            a.y[colbase + (size_t)row * prow] = v;
+          }
+          q[e] = v;
+        }
+        // side output: this lane's four channels = half of a 16-byte C8 row
+        if (MODE == 0 && c8out && rbase + 8 * g < Cout) {
+          const int row0 = rbase + 8 * g;
+          const size_t o =
+              (((size_t)n * (Cout >> 3) + (row0 >> 3)) * a.Pout + p) * 16 +
+              (row0 & 4) * 2;
+          *(uintx2*)((char*)a.y_c8 + o) =
+              __builtin_bit_cast(uintx2, __builtin_convertvector(q, bf16x4));
+        }
       }
     }
   }
@@ -672,6 +717,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile_c8_kernel(ConvK a) {
 
   // ---- epilogue: direct stores, 32 consecutive positions per accumulator row
   const bool has_res = a.residual != nullptr;
+  const bool c8out = a.y_c8 != nullptr;
   const bool relu = a.relu != 0;
   const bool has_aff = a.scale != nullptr, has_bias = a.bias != nullptr;
 #pragma unroll
@@ -700,13 +746,30 @@ __global__ __launch_bounds__(256, 2) void conv_tile_c8_kernel(ConvK a) {
       }
       const size_t colbase = (size_t)n * Cout * prow + p;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rbase + (r & 3) + 8 * (r >> 2);
-        if (row >= Cout) continue;
-        float v = acc[i][j][r] * sc[r] + sh[r];
-        if (has_res) v += a.residual[colbase + (size_t)row * prow];
-        if (relu) v = fmaxf(v, 0.0f);
-        a.y[colbase + (size_t)row * prow] = v;
+      for (int g = 0; g < 4; ++g) {
+        floatx4_t q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const int row = rbase + e + 8 * g;
+          float v = 0.0f;
+          if (row < Cout) {
+            v = acc[i][j][r] * sc[r] + sh[r];
+            if (has_res) v += a.residual[colbase + (size_t)row * prow];
+            if (relu) v = fmaxf(v, 0.0f);
+            a.y[colbase + (size_t)row * prow] = v;
+          }
+          q[e] = v;
+        }
+        // side output: this lane's four channels = half of a 16-byte C8 row
+        if (MODE == 0 && c8out && rbase + 8 * g < Cout) {
+          const int row0 = rbase + 8 * g;
+          const size_t o =
+              (((size_t)n * (Cout >> 3) + (row0 >> 3)) * a.Pout + p) * 16 +
+              (row0 & 4) * 2;
+          *(uintx2*)((char*)a.y_c8 + o) =
+              __builtin_bit_cast(uintx2, __builtin_convertvector(q, bf16x4));
+        }
       }
     }
   }

@@ -440,8 +440,10 @@ def _tune_once(kind, d, ep_flags, call):
         L.check(rc, 'ld_conv_tune_' + kind)
 
 
-def _epilogue(bias=None, scale=None, shift=None, residual=None, relu=False):
+def _epilogue(bias=None, scale=None, shift=None, residual=None, relu=False,
+              y_c8=None):
     ep = L.ConvEpilogueT()
+    ep.y_c8 = y_c8.data_ptr() if y_c8 is not None else None
     ep.bias = bias.data_ptr() if bias is not None else None
     ep.scale = scale.data_ptr() if scale is not None else None
     ep.shift = shift.data_ptr() if shift is not None else None
@@ -451,8 +453,10 @@ def _epilogue(bias=None, scale=None, shift=None, residual=None, relu=False):
 
 
 def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
-                     shift=None, residual=None, relu=False):
-    """One implicit-GEMM launch.  Returns (y3, out_levels)."""
+                     shift=None, residual=None, relu=False, emit_c8=False):
+    """One implicit-GEMM launch.  Returns (y3, out_levels).  ``emit_c8``: in
+    bf16 mode also write the C8 image of y from the epilogue (for a y that goes
+    straight into another conv: the frozen conv+BN+ReLU chains)."""
     lib = L.get_lib()
     _dev_f32(x3, 'conv input')
     N, cin, P = x3.shape
@@ -469,7 +473,11 @@ def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
     if residual is not None:
         _dev_f32(residual, 'residual')
         assert residual.shape == y3.shape
-    ep = _epilogue(bias, scale, shift, residual, relu)
+    y_c8 = None
+    if emit_c8 and bf16 and _C8[0] and cout % 32 == 0:
+        y_c8 = torch.empty(N * cout * d.Pout, dtype=torch.bfloat16,
+                           device=x3.device)
+    ep = _epilogue(bias, scale, shift, residual, relu, y_c8)
     c8 = bf16 and _use_c8(cin, kh, stride, N * d.Pout, x3)
     fn = lib.ld_conv_forward_smallc if smallc else (
         lib.ld_conv_bf16_forward_c8 if c8 else
@@ -490,6 +498,8 @@ def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
                                     L.stream_ptr(x3.device)))
         L.check(fn(C.byref(d), L.ptr(xin), L.ptr(wt_fwd), C.byref(ep),
                    L.ptr(y3), L.stream_ptr(x3.device)), 'ld_conv_forward')
+    if y_c8 is not None:
+        _attach_c8(y3, y_c8)
     return y3, out_levels
 
 
@@ -607,7 +617,9 @@ def conv2d(x3, w, bias, stride, pad, levels):
     if torch.is_grad_enabled() and (x3.requires_grad or w.requires_grad or
                                     (bias is not None and bias.requires_grad)):
         return ConvFn.apply(x3, w, bias, stride, pad, levels), out_levels
-    y3, _ = conv_forward_raw(x3, w, stride, pad, levels, bias=bias)
+    # no autograd: a frozen conv (teacher FPN / head) whose output feeds convs
+    y3, _ = conv_forward_raw(x3, w, stride, pad, levels, bias=bias,
+                             emit_c8=True)
     return y3, out_levels
 
 
@@ -730,7 +742,8 @@ def conv_bn_act_infer(x3, w, gamma, beta, mean, var, eps, stride, pad, levels,
     layer1 and the whole teacher."""
     scale, shift, _ = bn_prepare(gamma, beta, mean, var, eps)
     return conv_forward_raw(x3, w, stride, pad, levels, scale=scale,
-                            shift=shift, residual=residual, relu=relu)
+                            shift=shift, residual=residual, relu=relu,
+                            emit_c8=True)
 
 
 # ---------------------------------------------------------------------------

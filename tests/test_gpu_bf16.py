@@ -304,3 +304,50 @@ def test_gn_c8_side_output(bf16_mode):
             Y.set_c8(True)
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_conv_epilogue_c8_output(bf16_mode, monkeypatch):
+    """emit_c8: the bf16 forward kernels (streaming, LDS-tiled, C8-input) write
+    the C8 image of y from the epilogue; it equals a conversion of y, y itself
+    is unchanged, and a chain conv -> conv runs without a conversion launch."""
+    from ld_amd import layers as Y
+    dev = _dev()
+    monkeypatch.setattr(Y, '_C8_ALL', True)
+    g = torch.Generator().manual_seed(11)
+    levels = ((12, 20), (6, 10))
+    P = sum(h * w for h, w in levels)
+    x = torch.randn(2, 64, P, generator=g).to(dev)
+    w1 = (torch.randn(96, 64, 3, 3, generator=g) * 0.05).to(dev)
+    w2 = (torch.randn(64, 96, 1, 1, generator=g) * 0.1).to(dev)
+    scale = (torch.rand(96, generator=g) + 0.5).to(dev)
+    shift = torch.randn(96, generator=g).to(dev)
+    res = torch.randn(2, 96, P, generator=g).to(dev)
+    for env, val in (('LD_CONV_BF16_SHAPE', '1x1x2x4x1'),
+                     ('LD_CONV_BF16_SHAPE', '2x1x1x4x4'),
+                     ('LD_CONV_BF16_SHAPE', '4x2x0x32x2'),
+                     ('LD_CONV_C8_SHAPE', '2x2x2')):
+        monkeypatch.setenv(env, val)
+        Y.set_c8(env == 'LD_CONV_C8_SHAPE')
+        try:
+            ref, _ = Y.conv_forward_raw(x, w1, 1, 1, levels, scale=scale,
+                                        shift=shift, residual=res, relu=True)
+            Y.set_c8(True)
+            if env != 'LD_CONV_C8_SHAPE':
+                monkeypatch.setattr(Y, '_use_c8', lambda *a, **k: False)
+            y, _ = Y.conv_forward_raw(x, w1, 1, 1, levels, scale=scale,
+                                      shift=shift, residual=res, relu=True,
+                                      emit_c8=True)
+            monkeypatch.undo()
+            monkeypatch.setattr(Y, '_C8_ALL', True)
+        finally:
+            Y.set_c8(True)
+        assert torch.equal(y, ref), val
+        img = Y._c8_cached(y)
+        assert img is not None, val
+        want = y.to(torch.bfloat16).reshape(2, 12, 8, P).permute(
+            0, 1, 3, 2).reshape(-1)
+        assert torch.equal(img, want), val
+        before = dict(Y.C8_STATS)
+        Y.conv_forward_raw(y, w2, 1, 0, levels)
+        assert Y.C8_STATS['converted'] == before['converted'], val
+        assert Y.C8_STATS['reused'] == before['reused'] + 1, val
