@@ -486,6 +486,11 @@ int ld_bn_prepare_batch(const ld_bn_job_t* jobs, const int32_t* block_job,
 int ld_bn_act_forward(const float* x, const float* residual, const float* scale,
                       const float* shift, int N, int C, int P, int relu, float* y,
                       ld_stream_t stream);
+/* The same with the bf16 channel-blocked image of y as a side output (see
+ * ld_gn_forward_c8); C % 8 == 0, P % 4 == 0, 16-byte aligned tensors. */
+int ld_bn_act_forward_c8(const float* x, const float* residual, const float* scale,
+                         const float* shift, int N, int C, int P, int relu,
+                         float* y, void* y_c8, ld_stream_t stream);
 size_t ld_bn_act_backward_workspace_bytes(int N, int C, int P);
 /* dz = relu ? dy*(y>0) : dy; dx = dz*scale (may be NULL); dres = dz (may be
  * NULL); dgamma = sum dz*(x-mean)*rstd, dbeta = sum dz (either may be NULL). */

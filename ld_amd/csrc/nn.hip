@@ -354,6 +354,38 @@ __device__ __forceinline__ void store_c8x4(gn_uintx4* __restrict__ dst,
   }
 }
 
+// y = act(x * scale[c] + shift[c] (+ residual)) with the C8 side output
+__global__ __launch_bounds__(256) void bn_act_fwd_c8_kernel(
+    const float* __restrict__ x, const float* __restrict__ residual,
+    const float* __restrict__ scale, const float* __restrict__ shift, int C, int P,
+    int relu, float* __restrict__ y, gn_uintx4* __restrict__ y_c8) {
+  const int C8 = C >> 3;
+  const int blk = blockIdx.y;  // n * C8 + c8
+  const int c8 = blk % C8, n = blk / C8;
+  const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (p >= P) return;
+  float out[8][4];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c8 * 8 + e;
+    const float s = scale[c], b = shift[c];
+    const size_t idx = ((size_t)n * C + c) * P + p;
+    float4 v = *reinterpret_cast<const float4*>(x + idx);
+    v.x = v.x * s + b; v.y = v.y * s + b; v.z = v.z * s + b; v.w = v.w * s + b;
+    if (residual) {
+      const float4 r = *reinterpret_cast<const float4*>(residual + idx);
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+      v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(y + idx) = v;
+    out[e][0] = v.x; out[e][1] = v.y; out[e][2] = v.z; out[e][3] = v.w;
+  }
+  store_c8x4(y_c8 + (size_t)blk * P + p, out);
+}
+
 __global__ __launch_bounds__(256) void gn_apply_c8_kernel(
     const float* __restrict__ x, Levels lv, int C, int G,
     const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -788,6 +820,21 @@ extern "C" int ld_bn_prepare_batch(const ld_bn_job_t* jobs, const int32_t* block
   if (!jobs || !block_job || nblocks < 1) return LD_EINVAL;
   hipLaunchKernelGGL(bn_prepare_batch_kernel, dim3(nblocks), dim3(256), 0, LD_STREAM,
                      jobs, block_job);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_bn_act_forward_c8(const float* x, const float* residual,
+                                    const float* scale, const float* shift, int N,
+                                    int C, int P, int relu, float* y, void* y_c8,
+                                    ld_stream_t stream) {
+  if (!x || !scale || !shift || !y || !y_c8 || N < 1 || C < 1 || P < 1)
+    return LD_EINVAL;
+  if (P % 4 != 0 || C % 8 != 0 || (uintptr_t)x % 16 != 0 || (uintptr_t)y % 16 != 0 ||
+      (residual && (uintptr_t)residual % 16 != 0))
+    return LD_EUNSUPPORTED;
+  hipLaunchKernelGGL(bn_act_fwd_c8_kernel, dim3((P / 4 + 255) / 256, N * (C / 8)),
+                     dim3(256), 0, LD_STREAM, x, residual, scale, shift, C, P, relu, y,
+                     (gn_uintx4*)y_c8);
   return (int)hipGetLastError();
 }
 

@@ -661,6 +661,24 @@ def _bn_prepare(gamma, beta, mean, var, eps):
     return buf[0], buf[1], buf[2]
 
 
+def _bn_act_forward_launch(x3, residual, scale, shift, N, c, P, relu, y):
+    lib = L.get_lib()
+    aligned = x3.data_ptr() % 16 == 0 and (
+        residual is None or residual.data_ptr() % 16 == 0)
+    y_c8 = _c8_side_output(y) if aligned else None
+    if y_c8 is not None:
+        L.check(lib.ld_bn_act_forward_c8(
+            L.ptr(x3), L.ptr(residual), L.ptr(scale), L.ptr(shift), N, c, P,
+            1 if relu else 0, L.ptr(y), L.ptr(y_c8),
+            L.stream_ptr(x3.device)), 'ld_bn_act_forward_c8')
+        _attach_c8(y, y_c8)
+        return
+    L.check(lib.ld_bn_act_forward(L.ptr(x3), L.ptr(residual), L.ptr(scale),
+                                  L.ptr(shift), N, c, P, 1 if relu else 0,
+                                  L.ptr(y), L.stream_ptr(x3.device)),
+            'ld_bn_act_forward')
+
+
 class BnActFn(torch.autograd.Function):
 
     @staticmethod
@@ -672,10 +690,7 @@ class BnActFn(torch.autograd.Function):
         y = torch.empty_like(x3)
         if residual is not None:
             _dev_f32(residual, 'bn residual')
-        L.check(lib.ld_bn_act_forward(L.ptr(x3), L.ptr(residual), L.ptr(scale),
-                                      L.ptr(shift), N, c, P, 1 if relu else 0,
-                                      L.ptr(y), L.stream_ptr(x3.device)),
-                'ld_bn_act_forward')
+        _bn_act_forward_launch(x3, residual, scale, shift, N, c, P, relu, y)
         ctx.save_for_backward(x3, y, scale, mean, rstd)
         ctx.relu = relu
         ctx.has_res = residual is not None
@@ -728,10 +743,7 @@ def bn_act(x3, gamma, beta, mean, var, eps, residual=None, relu=True):
     N, c, P = x3.shape
     scale, shift, _ = bn_prepare(gamma, beta, mean, var, eps)
     y = torch.empty_like(x3)
-    L.check(lib.ld_bn_act_forward(L.ptr(x3), L.ptr(residual), L.ptr(scale),
-                                  L.ptr(shift), N, c, P, 1 if relu else 0,
-                                  L.ptr(y), L.stream_ptr(x3.device)),
-            'ld_bn_act_forward')
+    _bn_act_forward_launch(x3, residual, scale, shift, N, c, P, relu, y)
     return y
 
 

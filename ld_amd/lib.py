@@ -240,6 +240,8 @@ SIGNATURES = {
     'ld_conv_wgrad': (C.c_int, [_CV, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     'ld_bn_prepare': (C.c_int, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp,
                                 _vp]),
+    'ld_bn_act_forward_c8': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32,
+                                       _i32, _vp, _vp, _vp]),
     'ld_bn_act_forward': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                     _i32, _vp, _vp]),
     'ld_bn_act_backward_workspace_bytes': (_sz, [_i32, _i32, _i32]),

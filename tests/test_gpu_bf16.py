@@ -351,3 +351,33 @@ def test_conv_epilogue_c8_output(bf16_mode, monkeypatch):
         Y.conv_forward_raw(y, w2, 1, 0, levels)
         assert Y.C8_STATS['converted'] == before['converted'], val
         assert Y.C8_STATS['reused'] == before['reused'] + 1, val
+
+
+def test_bn_act_c8_side_output(bf16_mode):
+    """Eval-BN + residual + ReLU forward: fp32 y identical with and without the
+    C8 side output; the image equals a conversion of y."""
+    from ld_amd import layers as Y
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    N, c, P = 2, 64, 13 * 20
+    x = torch.randn(N, c, P, generator=g).to(dev)
+    res = torch.randn(N, c, P, generator=g).to(dev)
+    gamma = (torch.rand(c, generator=g) + 0.5).to(dev)
+    beta = torch.randn(c, generator=g).to(dev)
+    mean = torch.randn(c, generator=g).to(dev)
+    var = (torch.rand(c, generator=g) + 0.5).to(dev)
+    outs = []
+    for c8 in (False, True):
+        Y.set_c8(c8)
+        try:
+            y = Y.bn_act(x, gamma, beta, mean, var, 1e-5, residual=res,
+                         relu=True)
+        finally:
+            Y.set_c8(True)
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    assert Y._c8_cached(outs[0]) is None
+    img = Y._c8_cached(outs[1])
+    want = outs[1].to(torch.bfloat16).reshape(N, c // 8, 8, P).permute(
+        0, 1, 3, 2).reshape(-1)
+    assert torch.equal(img, want)
