@@ -643,6 +643,22 @@ int ld_get_bboxes(const ld_geom_t* g, const ld_maps_t* cls, const ld_maps_t* reg
                   float iou_thr, int max_per_img, float* dets, int64_t* labels,
                   int32_t* counts, void* workspace, size_t workspace_bytes,
                   ld_stream_t stream);
+/* The reference's optional nms type 'voting_cluster_diounms'
+ * (post_processing/bbox_nms.py:141-176): same pipeline, but (1) the overlap
+ * measure of the suppression is DIoU with the centre-distance term raised to
+ * 0.8, evaluated on boxes shifted by 4000 * label as the reference shifts them
+ * (Cluster-NMS iterated to its fixed point keeps exactly the boxes of the greedy
+ * pass used here), and (2) score voting: every kept box is replaced by the
+ * exp(-(1 - DIoU)^2 / 0.025) * score weighted mean of the candidates at or
+ * below it in score order whose DIoU with it exceeds 0.7 (all other candidates
+ * enter with the factor exp(-40), as in the reference's dense product).
+ * Same arguments, workspace and outputs as ld_get_bboxes. */
+int ld_get_bboxes_voting(const ld_geom_t* g, const ld_maps_t* cls, const ld_maps_t* reg,
+                  int num_classes, int reg_max, const float* img_hw,
+                  const float* scale_factors, int nms_pre, float score_thr,
+                  float iou_thr, int max_per_img, float* dets, int64_t* labels,
+                  int32_t* counts, void* workspace, size_t workspace_bytes,
+                  ld_stream_t stream);
 
 #ifdef __cplusplus
 }

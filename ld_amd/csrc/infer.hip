@@ -305,11 +305,33 @@ __global__ __launch_bounds__(kSortThreads) void infer_cand_sort_kernel(
 // `cand` holds, per image (stride `cand_stride`), the best min(count, limit)
 // candidates in descending order.  exhausted[n] = the list ran out before
 // max_keep detections although more candidates exist (fast path only).
+// DIOU = the reference's 'voting_cluster_diounms' branch (bbox_nms.py:141-176):
+// overlap measure IoU - D^0.8 (D = squared centre distance / squared diagonal
+// of the enclosing box, bbox_nms.py:35-67 with beta = 0.8) on boxes shifted by
+// 4000 * label exactly as the reference shifts them (the fp32 rounding of the
+// shifted coordinates is part of its decisions).  Cluster-NMS iterated to
+// convergence keeps exactly the boxes of the greedy pass below; keep_rank[q] =
+// position of kept box q in the sorted candidate list, for the voting pass.
+__device__ __forceinline__ float diou_measure(const float (&a)[4], float area_a,
+                                              const float (&b)[4], float area_b) {
+  const float w = fmaxf(fminf(a[2], b[2]) - fmaxf(a[0], b[0]), 0.f);
+  const float h = fmaxf(fminf(a[3], b[3]) - fmaxf(a[1], b[1]), 0.f);
+  const float inter = w * h;
+  const float uni = area_a + area_b - inter;
+  const float dx = (b[2] + b[0]) / 2 - (a[2] + a[0]) / 2;
+  const float dy = (b[3] + b[1]) / 2 - (a[3] + a[1]) / 2;
+  const float cw = fmaxf(a[2], b[2]) - fminf(a[0], b[0]);
+  const float ch = fmaxf(a[3], b[3]) - fminf(a[1], b[1]);
+  const float D = (dx * dx + dy * dy) / (cw * cw + ch * ch + 1e-7f);
+  return inter / uni - powf(D, 0.8f);
+}
+
+template <bool DIOU>
 __global__ __launch_bounds__(kNmsThreads) void infer_nms_kernel(
     Plan p, const unsigned long long* cand, size_t cand_stride, int limit,
     const int* cand_count, const unsigned* max_coord, const float* boxes,
     float iou_thr, int max_keep, float* dets, long long* labels, int* counts,
-    int* exhausted) {
+    int* exhausted, int* keep_rank) {
   __shared__ float k_box[kMaxKeep][4];  // class-shifted coordinates
   __shared__ float k_area[kMaxKeep];
   __shared__ int k_label[kMaxKeep];
@@ -319,7 +341,7 @@ __global__ __launch_bounds__(kNmsThreads) void infer_nms_kernel(
   const int Mall = min(cand_count[n], p.cand_cap);
   const int M = min(Mall, limit);
   const unsigned long long* keys = cand + (size_t)n * cand_stride;
-  const float shift_unit = __uint_as_float(max_coord[n]) + 1.0f;
+  const float shift_unit = DIOU ? 4000.0f : __uint_as_float(max_coord[n]) + 1.0f;
   if (t == 0) s_nkept = 0;
   __syncthreads();
   for (int base = 0; base < M; base += kNmsThreads) {
@@ -347,10 +369,17 @@ __global__ __launch_bounds__(kNmsThreads) void infer_nms_kernel(
       const int nk = s_nkept;
       for (int q = 0; q < nk && alive; ++q) {
         if (k_label[q] != label) continue;
-        const float w = fmaxf(fminf(sb[2], k_box[q][2]) - fmaxf(sb[0], k_box[q][0]), 0.f);
-        const float h = fmaxf(fminf(sb[3], k_box[q][3]) - fmaxf(sb[1], k_box[q][1]), 0.f);
-        const float inter = w * h;
-        const float ovr = inter / (k_area[q] + area - inter);
+        float ovr;
+        if (DIOU) {
+          ovr = diou_measure(k_box[q], k_area[q], sb, area);
+        } else {
+          const float w =
+              fmaxf(fminf(sb[2], k_box[q][2]) - fmaxf(sb[0], k_box[q][0]), 0.f);
+          const float h =
+              fmaxf(fminf(sb[3], k_box[q][3]) - fmaxf(sb[1], k_box[q][1]), 0.f);
+          const float inter = w * h;
+          ovr = inter / (k_area[q] + area - inter);
+        }
         if (ovr > iou_thr) alive = false;
       }
     }
@@ -372,14 +401,22 @@ __global__ __launch_bounds__(kNmsThreads) void infer_nms_kernel(
         for (int k = 0; k < 4; ++k) d[k] = ob[k];
         d[4] = sc;
         labels[(size_t)n * max_keep + q] = label;
+        if (DIOU) keep_rank[(size_t)n * max_keep + q] = i;
       }
       __syncthreads();
       if (t == 0) s_nkept = q + 1;
       if (t > u && s_alive[t] && label == k_label[q]) {
-        const float w = fmaxf(fminf(sb[2], k_box[q][2]) - fmaxf(sb[0], k_box[q][0]), 0.f);
-        const float h = fmaxf(fminf(sb[3], k_box[q][3]) - fmaxf(sb[1], k_box[q][1]), 0.f);
-        const float inter = w * h;
-        const float ovr = inter / (k_area[q] + area - inter);
+        float ovr;
+        if (DIOU) {
+          ovr = diou_measure(k_box[q], k_area[q], sb, area);
+        } else {
+          const float w =
+              fmaxf(fminf(sb[2], k_box[q][2]) - fmaxf(sb[0], k_box[q][0]), 0.f);
+          const float h =
+              fmaxf(fminf(sb[3], k_box[q][3]) - fmaxf(sb[1], k_box[q][1]), 0.f);
+          const float inter = w * h;
+          ovr = inter / (k_area[q] + area - inter);
+        }
         if (ovr > iou_thr) s_alive[t] = 0;
       }
       __syncthreads();
@@ -391,6 +428,73 @@ __global__ __launch_bounds__(kNmsThreads) void infer_nms_kernel(
     counts[n] = s_nkept;
     if (exhausted) exhausted[n] = (s_nkept < max_keep && Mall > M) ? 1 : 0;
   }
+}
+
+// ---- 6. score voting (bbox_nms.py:160-163) ----------------------------------
+// For kept box i (rank r_i in the sorted list):
+//   new_box = sum_j w_ij * box_j / sum_j w_ij over ALL candidates j,
+//   w_ij = exp(-(1 - B_ij)^2 / 0.025) * score_j,
+//   B_ij = DIoU(i, j) if j >= r_i (upper triangle incl. the diagonal), same
+//          class-shifted geometry, and DIoU > 0.7; else 0  -- so every other
+//          candidate still enters with the factor exp(-40), as in the
+//          reference's dense matrix product.
+// One workgroup per (kept box, image); fp32 sums like torch.mm / sum.
+__global__ __launch_bounds__(256) void infer_vote_kernel(
+    Plan p, const unsigned long long* cand, const int* cand_count, const float* boxes,
+    int max_keep, const int* counts, const int* keep_rank, float* dets) {
+  __shared__ float red[5][256];
+  const int n = blockIdx.y, q = blockIdx.x, t = threadIdx.x;
+  if (q >= counts[n]) return;
+  const int M = min(cand_count[n], p.cand_cap);
+  const unsigned long long* keys = cand + (size_t)n * p.cand_cap;
+  auto fetch = [&](int j, float (&ob)[4], float (&sb)[4], float& sc, int& label) {
+    const unsigned long long key = keys[j];
+    sc = __uint_as_float((unsigned)(key >> 32));
+    const unsigned pidx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+    const int slot = (int)(pidx / (unsigned)p.C);
+    label = (int)(pidx - (unsigned)slot * (unsigned)p.C);
+    const float* bo = boxes + ((size_t)n * p.Ktot + slot) * 4;
+    const float off = (float)label * 4000.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ob[k] = bo[k];
+      sb[k] = ob[k] + off;
+    }
+  };
+  const int ri = keep_rank[(size_t)n * max_keep + q];
+  float iob[4], isb[4], isc;
+  int ilabel;
+  fetch(ri, iob, isb, isc, ilabel);
+  const float iarea = (isb[2] - isb[0]) * (isb[3] - isb[1]);
+  float sw = 0.f, sx[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int j = t; j < M; j += 256) {
+    float ob[4], sb[4], sc;
+    int label;
+    fetch(j, ob, sb, sc, label);
+    float B = 0.f;
+    if (j >= ri && label == ilabel) {
+      const float area = (sb[2] - sb[0]) * (sb[3] - sb[1]);
+      const float d = diou_measure(isb, iarea, sb, area);
+      if (d > 0.7f) B = d;
+    }
+    const float om = 1.0f - B;
+    const float w = expf(-(om * om) / 0.025f) * sc;
+    sw += w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sx[k] += w * ob[k];
+  }
+  red[4][t] = sw;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[k][t] = sx[k];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) red[k][t] += red[k][t + s];
+    }
+    __syncthreads();
+  }
+  if (t < 4) dets[((size_t)n * max_keep + q) * 5 + t] = red[t][0] / red[4][0];
 }
 
 int make_plan(const ld_geom_t* g, int num_classes, int nms_pre, Plan* p) {
@@ -429,7 +533,7 @@ int make_plan(const ld_geom_t* g, int num_classes, int nms_pre, Plan* p) {
 }
 
 struct Offsets {
-  size_t keys, boxes, scores, cand, cand_top, count, maxc, flags, total;
+  size_t keys, boxes, scores, cand, cand_top, count, maxc, flags, rank, total;
 };
 
 Offsets layout(const Plan& p) {
@@ -448,6 +552,7 @@ Offsets layout(const Plan& p) {
   o.count = take((size_t)p.N * sizeof(int));
   o.maxc = take((size_t)p.N * sizeof(unsigned));
   o.flags = take((size_t)p.N * sizeof(int));
+  o.rank = take((size_t)p.N * kMaxKeep * sizeof(int));
   o.total = at;
   return o;
 }
@@ -461,13 +566,13 @@ extern "C" size_t ld_get_bboxes_workspace_bytes(const ld_geom_t* g, int num_clas
   return layout(p).total;
 }
 
-extern "C" int ld_get_bboxes(const ld_geom_t* g, const ld_maps_t* cls,
-                             const ld_maps_t* reg, int num_classes, int reg_max,
-                             const float* img_hw, const float* scale_factors,
-                             int nms_pre, float score_thr, float iou_thr,
-                             int max_per_img, float* dets, int64_t* labels,
-                             int32_t* counts, void* workspace, size_t workspace_bytes,
-                             ld_stream_t stream_) {
+static int get_bboxes_impl(const ld_geom_t* g, const ld_maps_t* cls,
+                           const ld_maps_t* reg, int num_classes, int reg_max,
+                           const float* img_hw, const float* scale_factors,
+                           int nms_pre, float score_thr, float iou_thr,
+                           int max_per_img, float* dets, int64_t* labels,
+                           int32_t* counts, void* workspace, size_t workspace_bytes,
+                           ld_stream_t stream_, bool voting) {
   Plan p;
   if (int e = make_plan(g, num_classes, nms_pre, &p)) return e;
   if (!cls || !reg || !img_hw || !dets || !labels || !counts) return LD_EINVAL;
@@ -501,7 +606,7 @@ extern "C" int ld_get_bboxes(const ld_geom_t* g, const ld_maps_t* cls,
     }
   // LD_INFER_SORT=global: the plain global-memory bitonic sorts everywhere
   const char* env = getenv("LD_INFER_SORT");
-  const bool force_global = env && env[0] == 'g';
+  const bool force_global = voting || (env && env[0] == 'g');
   const bool fast_topk = !force_global && nms_pre <= kSelN;
   if (nsorted > 0) {
     hipLaunchKernelGGL(infer_keys_kernel, dim3((maxpad + 255) / 256, p.L, p.N),
@@ -526,9 +631,10 @@ extern "C" int ld_get_bboxes(const ld_geom_t* g, const ld_maps_t* cls,
       const int v = atoi(lim);
       if (v >= 1 && v <= kSelN) limit = v;
     }
-    hipLaunchKernelGGL(infer_nms_kernel, dim3(p.N), dim3(kNmsThreads), 0, stream, p,
-                       cand_top, (size_t)kSelN, limit, count, maxc, boxes, iou_thr,
-                       max_per_img, dets, (long long*)labels, counts, flags);
+    hipLaunchKernelGGL(infer_nms_kernel<false>, dim3(p.N), dim3(kNmsThreads), 0, stream,
+                       p, cand_top, (size_t)kSelN, limit, count, maxc, boxes, iou_thr,
+                       max_per_img, dets, (long long*)labels, counts, flags,
+                       (int*)nullptr);
     // rare: the best kSelN ran out before max_per_img detections -> redo the
     // NMS over the fully sorted list (the caller reads `counts` next anyway)
     int host_flags[64];
@@ -546,10 +652,45 @@ extern "C" int ld_get_bboxes(const ld_geom_t* g, const ld_maps_t* cls,
   if (need_global) {
     hipLaunchKernelGGL(infer_cand_sort_kernel, dim3(p.N), dim3(kSortThreads), 0, stream,
                        p, cand, count);
-    hipLaunchKernelGGL(infer_nms_kernel, dim3(p.N), dim3(kNmsThreads), 0, stream, p,
-                       cand, (size_t)p.cand_cap, p.cand_cap, count, maxc, boxes,
-                       iou_thr, max_per_img, dets, (long long*)labels, counts,
-                       (int*)nullptr);
+    if (voting) {
+      int* rank = (int*)(ws + o.rank);
+      hipLaunchKernelGGL(infer_nms_kernel<true>, dim3(p.N), dim3(kNmsThreads), 0, stream,
+                         p, cand, (size_t)p.cand_cap, p.cand_cap, count, maxc, boxes,
+                         iou_thr, max_per_img, dets, (long long*)labels, counts,
+                         (int*)nullptr, rank);
+      hipLaunchKernelGGL(infer_vote_kernel, dim3(max_per_img, p.N), dim3(256), 0, stream,
+                         p, cand, count, boxes, max_per_img, counts, rank, dets);
+    } else {
+      hipLaunchKernelGGL(infer_nms_kernel<false>, dim3(p.N), dim3(kNmsThreads), 0,
+                         stream, p, cand, (size_t)p.cand_cap, p.cand_cap, count, maxc,
+                         boxes, iou_thr, max_per_img, dets, (long long*)labels, counts,
+                         (int*)nullptr, (int*)nullptr);
+    }
   }
   return (int)hipGetLastError();
+}
+
+extern "C" int ld_get_bboxes(const ld_geom_t* g, const ld_maps_t* cls,
+                             const ld_maps_t* reg, int num_classes, int reg_max,
+                             const float* img_hw, const float* scale_factors,
+                             int nms_pre, float score_thr, float iou_thr,
+                             int max_per_img, float* dets, int64_t* labels,
+                             int32_t* counts, void* workspace, size_t workspace_bytes,
+                             ld_stream_t stream) {
+  return get_bboxes_impl(g, cls, reg, num_classes, reg_max, img_hw, scale_factors,
+                         nms_pre, score_thr, iou_thr, max_per_img, dets, labels,
+                         counts, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int ld_get_bboxes_voting(const ld_geom_t* g, const ld_maps_t* cls,
+                                    const ld_maps_t* reg, int num_classes,
+                                    int reg_max, const float* img_hw,
+                                    const float* scale_factors, int nms_pre,
+                                    float score_thr, float iou_thr, int max_per_img,
+                                    float* dets, int64_t* labels, int32_t* counts,
+                                    void* workspace, size_t workspace_bytes,
+                                    ld_stream_t stream) {
+  return get_bboxes_impl(g, cls, reg, num_classes, reg_max, img_hw, scale_factors,
+                         nms_pre, score_thr, iou_thr, max_per_img, dets, labels,
+                         counts, workspace, workspace_bytes, stream, true);
 }

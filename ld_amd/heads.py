@@ -403,10 +403,11 @@ class GFLHead(nn.Module):
             raise NotImplementedError('with_nms=False (raw per-level boxes) is '
                                       'not wired; SURVEY.md section 8f')
         nms = cfg['nms'] if isinstance(cfg, dict) else cfg.nms
-        if nms.get('type', 'nms') != 'nms':
+        nms_type = nms.get('type', 'nms')
+        if nms_type not in ('nms', 'voting_cluster_diounms'):
             raise NotImplementedError(
-                f"nms type {nms.get('type')!r}: only 'nms' is built (the "
-                'score-voting Cluster-DIoU-NMS of bbox_nms.py:141-176 is not)')
+                f"nms type {nms_type!r}: the reference's multiclass_nms knows "
+                "'nms' and 'voting_cluster_diounms' (bbox_nms.py:141-188)")
         get = cfg.get if hasattr(cfg, 'get') else lambda k, d=None: cfg[k]
         if get('min_bbox_size', 0) not in (0, -1):
             raise NotImplementedError('min_bbox_size > 0')
@@ -421,7 +422,7 @@ class GFLHead(nn.Module):
             strides, shapes, sfs, nms_pre=get('nms_pre', -1),
             score_thr=get('score_thr'), iou_thr=nms['iou_threshold'],
             max_per_img=get('max_per_img'), num_classes=self.cls_out_channels,
-            reg_max=self.reg_max)
+            reg_max=self.reg_max, voting=nms_type == 'voting_cluster_diounms')
 
 
 @HEADS.register_module()

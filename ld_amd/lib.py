@@ -211,6 +211,8 @@ SIGNATURES = {
     'ld_get_bboxes_workspace_bytes': (_sz, [_G, _i32, _i32]),
     'ld_get_bboxes': (C.c_int, [_G, _M, _M, _i32, _i32, _vp, _vp, _i32, _f32,
                                 _f32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'ld_get_bboxes_voting': (C.c_int, [_G, _M, _M, _i32, _i32, _vp, _vp, _i32, _f32,
+                                _f32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     'ld_conv_weight_transform_batch': (C.c_int, [_vp, _vp, _i32, _vp]),
     'ld_bn_prepare_batch': (C.c_int, [_vp, _vp, _i32, _vp]),
     'ld_conv_forward': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),

@@ -233,6 +233,55 @@ INFER_CASES = [
 ]
 
 
+def infer_inputs_clustered(pad, num_imgs, seed, device='cpu'):
+    """Head outputs whose neighbouring anchors predict nearly the same box (one
+    sharp distribution per side shared by all positions of a level plus small
+    noise), so that score voting has clusters to average: the case the
+    'voting_cluster_diounms' branch exists for.  IEEE-exact ops only."""
+    sizes = level_shapes(pad)
+    gen = _gen(seed)
+    bins = torch.arange(17, dtype=torch.float32)
+    cls, reg = [], []
+    for li, (h, w) in enumerate(sizes):
+        c = _normal((num_imgs, 80, h, w), gen) * 1.25 - 6.0
+        c[:, 3] += 5.0   # two classes fire on every anchor: dense clusters of
+        c[:, 17] += 5.0  # near-identical same-class boxes
+        cls.append(c)
+        centre = torch.tensor([5.0, 4.0, 6.0, 5.0]) + float(li % 2)
+        peak = -((bins[None, :] - centre[:, None]) ** 2) * 2.0  # (4, 17)
+        base = peak.reshape(1, 68, 1, 1).expand(num_imgs, 68, h, w)
+        reg.append((base + _normal((num_imgs, 68, h, w), gen) * 0.3)
+                   .contiguous())
+    return [c.to(device) for c in cls], [r.to(device) for r in reg]
+
+
+VOTING_CASES = [
+    # name, pad, img_shapes, scale factors, seed, nms_pre, clustered
+    ('v_small', (128, 160), [(128, 160, 3), (120, 150, 3)],
+     [[1.0, 1.0, 1.0, 1.0], [1.25, 1.25, 1.25, 1.25]], 61, 1000, False),
+    ('v_clustered', (128, 160), [(128, 160, 3), (128, 150, 3)],
+     [[1.0, 1.0, 1.0, 1.0], [2.0, 2.0, 2.0, 2.0]], 62, 1000, True),
+    ('v_clustered_topk', (256, 320), [(256, 320, 3), (250, 300, 3)],
+     [[1.0, 1.0, 1.0, 1.0], [0.5, 0.5, 0.5, 0.5]], 63, 60, True),
+]
+
+
+def voting_inputs(case, device='cpu'):
+    import numpy as np
+    name, pad, img_shapes, sfs, seed, nms_pre, clustered = case
+    if clustered:
+        cls, reg = infer_inputs_clustered(pad, len(img_shapes), seed, device)
+    else:
+        hi = synthetic_head_inputs(len(img_shapes), level_shapes(pad),
+                                   seed=seed)
+        cls = [(c * 1.25 - 1.0).to(device) for c in hi['cls']]
+        reg = [r.to(device) for r in hi['reg']]
+    metas = [dict(img_shape=s_, pad_shape=tuple(pad) + (3, ),
+                  scale_factor=np.array(f, dtype=np.float32))
+             for s_, f in zip(img_shapes, sfs)]
+    return cls, reg, metas
+
+
 def infer_inputs(case, device='cpu'):
     """(cls_scores, bbox_preds, img_metas) of an INFER_CASES row."""
     import numpy as np

@@ -843,6 +843,41 @@ def gen_infer():
     np.savez_compressed(os.path.join(OUT, 'infer.npz'), **d)
 
 
+def gen_infer_voting():
+    """Score-voting Cluster-DIoU-NMS: the reference's own multiclass_nms branch
+    (bbox_nms.py:141-176, pure torch -> PINNED, unlike the mmcv batched_nms of
+    the default branch)."""
+    import mmcv
+    head = _ld_head()
+    d = {}
+    for case in synthetic.VOTING_CASES:
+        name, pad, img_shapes, sfs, seed, nms_pre, clustered = case
+        cls, reg, metas = synthetic.voting_inputs(case)
+        for thr in (0.6, 0.85):
+            cfg = mmcv.ConfigDict(dict(
+                nms_pre=nms_pre, min_bbox_size=0, score_thr=0.05,
+                nms=dict(type='voting_cluster_diounms', iou_threshold=thr),
+                max_per_img=100))
+            for rescale in (False, True):
+                res = head.get_bboxes(cls, reg, metas, cfg=cfg,
+                                      rescale=rescale)
+                tag = f'{name}_t{int(thr * 100)}_r{int(rescale)}'
+                for i, (db, dl) in enumerate(res):
+                    d[f'{tag}_bboxes_{i}'] = _np(db).astype(np.float32)
+                    d[f'{tag}_labels_{i}'] = _np(dl).astype(np.int64)
+        # how much the voting moved the boxes (vs plain nms): fingerprint
+        cfg0 = mmcv.ConfigDict(dict(nms_pre=nms_pre, min_bbox_size=0,
+                                    score_thr=0.05,
+                                    nms=dict(type='nms', iou_threshold=0.6),
+                                    max_per_img=100))
+        plain = head.get_bboxes(cls, reg, metas, cfg=cfg0, rescale=False)
+        print(f'[voting] {name}: dets',
+              [int(d[f"{name}_t60_r0_labels_{i}"].shape[0])
+               for i in range(len(img_shapes))], 'plain nms dets',
+              [int(p[1].shape[0]) for p in plain])
+    np.savez_compressed(os.path.join(OUT, 'infer_voting.npz'), **d)
+
+
 def gen_pipeline():
     """Input pipeline: the reference's OWN samplers,
     box transforms and random draws (pure numpy / torch code under
@@ -929,7 +964,7 @@ def gen_pipeline():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='kat,anchors,targets,lossblock,e2e,infer,'
-                    'lossblock_v2,e2e_v2,imitation,pipeline')
+                    'lossblock_v2,e2e_v2,imitation,pipeline,infer_voting')
     ap.add_argument('--e2e-cases', default='')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
@@ -955,6 +990,8 @@ def main():
         gen_e2e_v2()
     if 'pipeline' in only:
         gen_pipeline()
+    if 'infer_voting' in only:
+        gen_infer_voting()
 
 
 if __name__ == '__main__':

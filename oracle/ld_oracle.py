@@ -760,6 +760,66 @@ def multiclass_nms(bboxes, scores, score_thr, iou_thr, max_num):
     return dets, labels[keep].astype(np.int64)
 
 
+def diou_matrix(box, beta=0.8):
+    """bbox_nms.py:35-67 diou(box, box, beta) in fp32: IoU - D^beta, D = squared
+    centre distance / (squared diagonal of the enclosing box + 1e-7)."""
+    b = box.astype(F32)
+    x1, y1, x2, y2 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    w = np.clip(np.minimum(x2[:, None], x2[None]) -
+                np.maximum(x1[:, None], x1[None]), 0, None)
+    h = np.clip(np.minimum(y2[:, None], y2[None]) -
+                np.maximum(y1[:, None], y1[None]), 0, None)
+    inter = (w * h).astype(F32)
+    area = ((x2 - x1) * (y2 - y1)).astype(F32)
+    union = (area[:, None] + area[None] - inter).astype(F32)
+    cx, cy = (x2 + x1) / F32(2), (y2 + y1) / F32(2)
+    cw = np.maximum(x2[:, None], x2[None]) - np.minimum(x1[:, None], x1[None])
+    ch = np.maximum(y2[:, None], y2[None]) - np.minimum(y1[:, None], y1[None])
+    D = (((cx[None] - cx[:, None]) ** 2 + (cy[None] - cy[:, None]) ** 2) /
+         (cw ** 2 + ch ** 2 + F32(1e-7))).astype(F32)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        return (inter / union - D ** F32(beta)).astype(F32)
+
+
+def multiclass_nms_voting(bboxes, scores, score_thr, iou_thr, max_num):
+    """bbox_nms.py:141-176, nms_cfg type 'voting_cluster_diounms': sort all
+    (anchor, class) candidates by score, Cluster-NMS on DIoU^0.8 of the
+    4000 * label shifted boxes iterated to its fixed point, then score voting:
+    every kept box becomes the exp(-(1 - DIoU)^2 / 0.025) * score weighted mean
+    of the boxes below it in the list with DIoU > 0.7 (and, with weight e^-40,
+    of everything else: the reference multiplies the dense matrix)."""
+    n, C = scores.shape
+    flat_s = scores.reshape(-1)
+    valid = np.nonzero(flat_s > F32(score_thr))[0]
+    if valid.size == 0:
+        return np.zeros((0, 5), F32), np.zeros(0, np.int64)
+    a_idx, labels = valid // C, valid % C
+    b, s = bboxes[a_idx].astype(F32), flat_s[valid].astype(F32)
+    order = np.argsort(-s, kind='stable')
+    b, s, labels = b[order], s[order], labels[order]
+    box = (b + (labels.astype(F32) * F32(4000))[:, None]).astype(F32)
+    iouu = diou_matrix(box, 0.8)
+    iou = np.triu(iouu, 1)
+    B = iou
+    for _ in range(999):
+        A = B
+        maxA = A.max(0)
+        E = (maxA <= F32(iou_thr)).astype(F32)[:, None]
+        B = iou * E
+        if np.array_equal(A, B):
+            break
+    B = np.triu(iouu) * E
+    keep = maxA <= F32(iou_thr)
+    wts = (np.exp(-(F32(1) - B * (B > F32(0.7))) ** 2 / F32(0.025)).astype(F32)
+           * s[None, :]).astype(F32)
+    voted = ((wts @ b).astype(F32) / wts.sum(1, keepdims=True)).astype(F32)
+    kk = np.nonzero(keep)[0]
+    if max_num > 0:
+        kk = kk[:max_num]
+    dets = np.concatenate([voted[kk], s[kk][:, None]], 1).astype(F32)
+    return dets, labels[kk].astype(np.int64)
+
+
 def get_bboxes_pre_nms(cls_scores, bbox_preds, img_shapes, nms_pre,
                        strides=(8, 16, 32, 64, 128), reg_max=16):
     """gfl_head.py:391-424: per level sigmoid scores, Integral * stride, top
@@ -795,12 +855,14 @@ def get_bboxes_pre_nms(cls_scores, bbox_preds, img_shapes, nms_pre,
 
 
 def get_bboxes(cls_scores, bbox_preds, img_shapes, scale_factors, nms_pre=1000,
-               score_thr=0.05, iou_thr=0.6, max_per_img=100, rescale=False):
+               score_thr=0.05, iou_thr=0.6, max_per_img=100, rescale=False,
+               voting=False):
     """GFLHead.get_bboxes.  -> per image (dets (k, 5), labels (k))."""
     out = []
     pre = get_bboxes_pre_nms(cls_scores, bbox_preds, img_shapes, nms_pre)
     for n, (bb, sc) in enumerate(pre):
         if rescale:
             bb = (bb / np.asarray(scale_factors[n], F32)[None]).astype(F32)
-        out.append(multiclass_nms(bb, sc, score_thr, iou_thr, max_per_img))
+        fn = multiclass_nms_voting if voting else multiclass_nms
+        out.append(fn(bb, sc, score_thr, iou_thr, max_per_img))
     return out

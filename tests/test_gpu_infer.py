@@ -110,7 +110,7 @@ def test_head_api_and_edge_cases(golden):
         assert tuple(d.shape) == (0, 5) and tuple(l.shape) == (0, )
     with pytest.raises(NotImplementedError):
         head.get_bboxes(cls, reg, metas, cfg=dict(
-            cfg, nms=dict(type='voting_cluster_diounms', iou_threshold=0.6)))
+            cfg, nms=dict(type='soft_nms', iou_threshold=0.6)))
 
 
 def test_detector_simple_test():
@@ -181,3 +181,58 @@ def test_fallback_when_best_candidates_run_out(monkeypatch):
     with pytest.raises(Exception):  # negative thresholds are rejected
         LB.get_bboxes([c.to(dev) for c in cls], [r.to(dev) for r in reg],
                       STRIDES, shapes, None, nms_pre=case[5], iou_thr=-1.0)
+
+
+VCASES = {c[0]: c for c in synthetic.VOTING_CASES}
+
+
+@pytest.mark.parametrize('rescale', [False, True], ids=['r0', 'r1'])
+@pytest.mark.parametrize('thr', [0.6, 0.85])
+@pytest.mark.parametrize('name', list(VCASES))
+def test_voting_nms_vs_reference_golden(golden, name, thr, rescale):
+    """ld_get_bboxes_voting against the REFERENCE's own
+    multiclass_nms(type='voting_cluster_diounms') outputs (pure torch in the
+    reference: this NMS variant is parity-pinned end to end)."""
+    from ld_amd import lossblock as LB
+    dev = torch.device('cuda:0')
+    g = golden['infer_voting']
+    case = VCASES[name]
+    cls, reg, metas = synthetic.voting_inputs(case, device=dev)
+    shapes = [m['img_shape'] for m in metas]
+    sfs = [m['scale_factor'] for m in metas] if rescale else None
+    res = LB.get_bboxes(cls, reg, STRIDES, shapes, sfs, nms_pre=case[5],
+                        score_thr=0.05, iou_thr=thr, max_per_img=100,
+                        voting=True)
+    for i, (d, l) in enumerate(res):
+        tag = f'{name}_t{int(thr * 100)}_r{int(rescale)}'
+        dets, labels = d.cpu().numpy(), l.cpu().numpy()
+        gd, gl = g[f'{tag}_bboxes_{i}'], g[f'{tag}_labels_{i}']
+        assert dets.shape == gd.shape
+        assert np.array_equal(labels, gl), tag
+        np.testing.assert_allclose(dets[:, :4], gd[:, :4], atol=2e-3, rtol=0,
+                                   err_msg=tag)
+        np.testing.assert_allclose(dets[:, 4], gd[:, 4], atol=1e-6, rtol=0)
+
+
+def test_voting_head_api():
+    """cfg.nms.type = 'voting_cluster_diounms' through GFLHead.get_bboxes."""
+    from ld_amd import model_zoo
+    from ld_amd.registry import build_head
+    dev = torch.device('cuda:0')
+    case = synthetic.VOTING_CASES[1]
+    cls, reg, metas = synthetic.voting_inputs(case, device=dev)
+    cfg = dict(model_zoo.gfl_detector(50)['bbox_head'])
+    head = build_head(cfg).to(dev)
+    tc = dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05,
+              nms=dict(type='voting_cluster_diounms', iou_threshold=0.6),
+              max_per_img=100)
+    voted = head.get_bboxes(cls, reg, metas, cfg=tc)
+    tc['nms'] = dict(type='nms', iou_threshold=0.6)
+    plain = head.get_bboxes(cls, reg, metas, cfg=tc)
+    assert voted[0][0].shape == (100, 5)
+    # same top-scoring class, different (averaged) coordinates
+    assert int(voted[0][1][0]) == int(plain[0][1][0])
+    assert float((voted[0][0][0, :4] - plain[0][0][0, :4]).abs().max()) > 1e-2
+    with pytest.raises(NotImplementedError):
+        tc['nms'] = dict(type='soft_nms', iou_threshold=0.6)
+        head.get_bboxes(cls, reg, metas, cfg=tc)

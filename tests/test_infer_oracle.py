@@ -109,3 +109,41 @@ def test_nms_known_answers():
     # max_num truncation keeps the best
     d, l = O.multiclass_nms(b, s, 0.05, 0.6, 2)
     assert l.tolist() == [0, 1] and d.shape == (2, 5)
+
+
+VCASES = {c[0]: c for c in synthetic.VOTING_CASES}
+
+
+@pytest.mark.parametrize('thr', [0.6, 0.85])
+@pytest.mark.parametrize('name', list(VCASES))
+def test_voting_nms_vs_reference(golden, name, thr):
+    """Score-voting Cluster-DIoU-NMS (nms type 'voting_cluster_diounms'): the
+    reference branch is pure torch (bbox_nms.py:141-176), so these goldens PIN
+    it end to end."""
+    g = golden['infer_voting']
+    case = VCASES[name]
+    cls, reg, metas = synthetic.voting_inputs(case)
+    cls, reg = [c.numpy() for c in cls], [r.numpy() for r in reg]
+    shapes = [m['img_shape'] for m in metas]
+    sfs = [m['scale_factor'] for m in metas]
+    moved = 0.0
+    for rs in (0, 1):
+        res = O.get_bboxes(cls, reg, shapes, sfs, nms_pre=case[5], iou_thr=thr,
+                           rescale=bool(rs), voting=True)
+        plain = O.get_bboxes(cls, reg, shapes, sfs, nms_pre=case[5],
+                             iou_thr=thr, rescale=bool(rs))
+        for i, (dets, labels) in enumerate(res):
+            tag = f'{name}_t{int(thr * 100)}_r{rs}'
+            gd, gl = g[f'{tag}_bboxes_{i}'], g[f'{tag}_labels_{i}']
+            assert dets.shape == gd.shape
+            assert np.array_equal(labels, gl)
+            np.testing.assert_allclose(dets[:, :4], gd[:, :4], atol=2e-3,
+                                       rtol=0)
+            np.testing.assert_allclose(dets[:, 4], gd[:, 4], atol=1e-6, rtol=0)
+            # the voted box differs from the un-voted candidate it came from
+            same = min(len(dets), len(plain[i][0]))
+            if same and np.array_equal(labels[:1], plain[i][1][:1]):
+                moved = max(moved, float(np.abs(
+                    dets[0, :4] - plain[i][0][0, :4]).max()))
+    if case[6]:
+        assert moved > 1e-2, 'clustered case: voting must move the top box'
