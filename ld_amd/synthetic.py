@@ -255,6 +255,19 @@ def infer_inputs_clustered(pad, num_imgs, seed, device='cpu'):
     return [c.to(device) for c in cls], [r.to(device) for r in reg]
 
 
+def grad_probe(n, seed):
+    """Deterministic pseudo-random direction in [-0.5, 0.5)^n (integer hash,
+    exact on every platform): gradient fingerprints dot(grad, probe) that --
+    unlike a norm -- see sign flips, permutations and transposed layouts."""
+    import numpy as np
+    i = np.arange(n, dtype=np.uint64)
+    h = (i * np.uint64(2654435761) + np.uint64(seed * 40503 + 12345)) & \
+        np.uint64(0xFFFFFFFF)
+    h = (h ^ (h >> np.uint64(15))) * np.uint64(2246822519) & np.uint64(0xFFFFFFFF)
+    h = h ^ (h >> np.uint64(13))
+    return h.astype(np.float64) / 4294967296.0 - 0.5
+
+
 VOTING_CASES = [
     # name, pad, img_shapes, scale factors, seed, nms_pre, clustered
     ('v_small', (128, 160), [(128, 160, 3), (120, 150, 3)],

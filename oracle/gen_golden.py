@@ -473,6 +473,15 @@ def gen_e2e(cases=None):
                 norms.append(float(p.grad.double().norm()))
         d[name + '_grad_names'] = np.array(names)
         d[name + '_grad_norms'] = np.array(norms)
+        # two random projections per gradient (synthetic.grad_probe): sensitive
+        # to sign, order and layout, which a norm is not
+        params = dict(det.named_parameters())
+        proj = []
+        for k in names:
+            gflat = params[k].grad.double().reshape(-1).numpy()
+            proj.append([float(gflat @ synthetic.grad_probe(gflat.size, sd))
+                         for sd in (0, 1)])
+        d[name + '_grad_proj'] = np.array(proj)
         d[name + '_num_trainable'] = np.array(
             sum(p.numel() for p in det.parameters() if p.requires_grad))
         # state_dict contract: key names + shapes, student and teacher

@@ -68,6 +68,24 @@ def test_train_step_vs_reference_golden(golden, name, sdepth, lw_im):
         if not np.isclose(got_n, r, rtol=5e-3, atol=1e-6):
             bad.append((k, got_n, r))
     assert not bad, f'{len(bad)} grad norms off, first: {bad[:5]}'
+    # ... and two pseudo-random projections of every gradient (sign / order /
+    # layout sensitive).  A gradient with relative L2 error e moves a random
+    # projection by ~ e * |g| * |probe| / sqrt(n); e <= 5e-3 is the element-wise
+    # bound of test_features_vs_cpu_oracle, asserted here at 4 sigma.
+    if name + '_grad_proj' in g.files:
+        from ld_amd import synthetic
+        proj = g[name + '_grad_proj']
+        off = []
+        for k, rn, pr in zip(names, norms, proj):
+            gflat = params[k].grad.double().reshape(-1).cpu().numpy()
+            for sd in (0, 1):
+                probe = synthetic.grad_probe(gflat.size, sd)
+                got_p = float(gflat @ probe)
+                tol = 4 * 5e-3 * rn * np.linalg.norm(probe) / \
+                    np.sqrt(gflat.size) + 1e-7
+                if abs(got_p - pr[sd]) > tol:
+                    off.append((k, sd, got_p, float(pr[sd]), tol))
+        assert not off, f'{len(off)} gradient projections off: {off[:5]}'
     # frozen parameters received nothing
     for k, p in params.items():
         if not p.requires_grad:
