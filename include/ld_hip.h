@@ -89,12 +89,21 @@ typedef struct {
    * cls_channels = 0 means num_classes. */
   int32_t cls_channels;
   int32_t flags;
+  /* LD_LOSS_ATSS (LDATSSHead over ATSSGFLHead, ld_atss.py:44-250): loss_cls is
+   * the sigmoid FocalLoss (gamma = qfl_beta = 2, focal_alpha) instead of QFL;
+   * the GIoU term is weighted by the ATSS centerness target and normalised by
+   * the sum of those targets (1 if that sum is < 1e-12); a centerness BCE term
+   * (lw_ctr, ld_loss_centerness) is added and reported in the loss_kd_neg row;
+   * there is no DFL term (set lw_dfl = 0) and loss_ld_neg = 0.15 * loss_ld's
+   * module on the VLR region (set lw_ld_vlr = 0.6 * lw_ld, T_ld_vlr = T_ld). */
+  float lw_ctr, focal_alpha;
 } ld_loss_hp_t;
 #define LD_LOSS_PROB_CLS 1
 /* target assignment: the imitation region is "anchor centre strictly inside a
  * GT box" (get_im_region modes 'fitnet' / 'decouple' / 'gibox',
  * ld_head.py:597-611) instead of the 'finegrained' IoU rule (:594-596) */
 #define LD_IM_CENTER_INSIDE 2
+#define LD_LOSS_ATSS 4
 
 /* ---- library ------------------------------------------------------------ */
 /* ABI version of this header; bump on any signature change. */
@@ -210,6 +219,14 @@ int ld_loss_main(const ld_geom_t* geom, const ld_loss_hp_t* hp,
 #define LD_LOSS_PART_CLS 4
 #define LD_LOSS_PART_IM 8
 #define LD_LOSS_PART_ALL 15
+/* LD_LOSS_ATSS only: the centerness term.  ctr / grad_ctr: (N, 1, H_l, W_l)
+ * maps; score = the centerness targets ld_loss_prepass wrote; call between
+ * ld_loss_main_parts and ld_loss_finalize (same workspace). */
+int ld_loss_centerness(const ld_geom_t* geom, const ld_loss_hp_t* hp,
+                       const ld_maps_t* ctr, const int64_t* labels,
+                       const float* score, const float* norm, const float* upstream,
+                       const ld_maps_t* grad_ctr, void* workspace,
+                       size_t workspace_bytes, ld_stream_t stream);
 int ld_loss_main_parts(const ld_geom_t* geom, const ld_loss_hp_t* hp,
                        const ld_maps_t* cls, const ld_maps_t* reg,
                        const ld_maps_t* t_cls, const ld_maps_t* t_reg,

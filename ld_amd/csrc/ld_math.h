@@ -104,6 +104,31 @@ LD_HD float qfl_pos(float x, float score, float* dq) {
   return bce * d * d;
 }
 
+// Sigmoid focal loss, gamma = 2 (losses/focal_loss.py:12-47, the pure-torch
+// py_sigmoid_focal_loss the reference runs on CPU; the compiled mmcv op computes
+// the same function):  bce_with_logits(x, t) * (alpha t + (1 - alpha)(1 - t)) *
+// pt^2,  pt = (1 - p) t + p (1 - t).
+//   t = 1 : f = alpha (1 - p)^2 softplus(-x),  df/dx = alpha (1 - p)^2 (2 p log p - (1 - p))
+//   t = 0 : f = (1 - alpha) p^2 softplus(x),   df/dx = (1 - alpha) p^2 (p - 2 (1 - p) log(1 - p))
+// (-log p = softplus(-x), -log(1 - p) = softplus(x))
+LD_HD float focal_pos(float x, float alpha, float* df) {
+  float p = sigmoidf_(x), spn = softplusf_(-x);
+  float q = 1.0f - p;
+  *df = alpha * q * q * (-2.0f * p * spn - q);
+  return alpha * q * q * spn;
+}
+LD_HD float focal_neg(float x, float alpha, float* df) {
+  float p = sigmoidf_(x), sp = softplusf_(x);
+  *df = (1.0f - alpha) * p * p * (p + 2.0f * (1.0f - p) * sp);
+  return (1.0f - alpha) * p * p * sp;
+}
+// binary_cross_entropy_with_logits(x, t) and d/dx (centerness,
+// losses/cross_entropy_loss.py:52-90)
+LD_HD float bce_logits(float x, float t, float* d) {
+  *d = sigmoidf_(x) - t;
+  return softplusf_(x) - t * x;
+}
+
 // Quality focal loss on PROBABILITIES (use_sigmoid=False: GFLv2, where the
 // prediction is sigmoid(cls_feat) * quality; gfocal_loss.py:27-46 with
 // F.binary_cross_entropy).  torch clamps the two logs at -100 in the forward

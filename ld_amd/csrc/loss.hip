@@ -67,6 +67,14 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// divisor of loss_bbox / loss_dfl: LDHead sum(weight_targets) + 1e-6
+// (ld_head.py:362-365); LDATSSHead sum(centerness targets), 1 if < EPS
+// (ld_atss.py:245-249)
+__device__ __forceinline__ float avg_divisor(const ld_loss_hp_t& hp, const float* norm) {
+  if (hp.flags & LD_LOSS_ATSS) return norm[1] < 1e-12f ? 1.0f : norm[1];
+  return norm[1] + 1e-6f;
+}
+
 struct Cell {  // where this thread sits
   int n, l, r, a, x, y;
   bool active;
@@ -133,11 +141,18 @@ __global__ __launch_bounds__(kWave) void loss_prepass_kernel(
       const float4 t = reinterpret_cast<const float4*>(bbox_targets)[c.o];
       const Box tgt{t.x / stride, t.y / stride, t.z / stride, t.w / stride};
       sc = ld::iou_pair(box, tgt);
+      if (hp.flags & LD_LOSS_ATSS) {
+        // centerness target (atss_gfl_head.py:312-331), image pixels; the
+        // anchor centre is (x, y) * stride exactly
+        const float ax = cx * stride, ay = cy * stride;
+        const float l_ = ax - t.x, t_ = ay - t.y, r_ = t.z - ax, b_ = t.w - ay;
+        sc = sqrtf((fminf(l_, r_) / fmaxf(l_, r_)) * (fminf(t_, b_) / fmaxf(t_, b_)));
+      }
     }
     weight_targets[c.o] = wt;
     score[c.o] = sc;
   }
-  const float s = wave_sum(wt);
+  const float s = wave_sum((hp.flags & LD_LOSS_ATSS) ? sc : wt);
   if (threadIdx.x == 0)
     partial[(size_t)S_WSUM * gridDim.y * bm.blocks_per_img +
             (size_t)c.n * bm.blocks_per_img + blockIdx.x] = s;
@@ -219,8 +234,9 @@ __global__ __launch_bounds__(kBlk) void loss_pos_kernel(
     ld_geom_t geom, ld_loss_hp_t hp, BlockMap bm, ld_maps_t cls, ld_maps_t t_cls,
     ld_maps_t reg, const int64_t* __restrict__ labels,
     const float* __restrict__ bbox_targets, const float* __restrict__ weight_targets,
-    const float* __restrict__ norm, const float* __restrict__ upstream,
-    float* __restrict__ posrec, float* __restrict__ partial) {
+    const float* __restrict__ score, const float* __restrict__ norm,
+    const float* __restrict__ upstream, float* __restrict__ posrec,
+    float* __restrict__ partial) {
   // cls / t_cls here are the maps of the KD term (LDHead: the class logits;
   // LDv2Head: the raw cls_feat of student and teacher)
   __shared__ float lds4[4];
@@ -231,8 +247,9 @@ __global__ __launch_bounds__(kBlk) void loss_pos_kernel(
     if (lab >= 0 && lab < hp.num_classes) {
       const int L = geom.num_levels;
       const float up_bbox = upstream ? upstream[1 * L + c.l] : 1.0f;
-      const float inv_avg = 1.0f / (norm[1] + 1e-6f);
-      const float wt = weight_targets[c.o];
+      const float inv_avg = 1.0f / avg_divisor(hp, norm);
+      // GIoU weight: max class score (LDHead) / centerness target (LDATSSHead)
+      const float wt = (hp.flags & LD_LOSS_ATSS) ? score[c.o] : weight_targets[c.o];
       const float c_bbox = up_bbox * hp.lw_bbox * wt * inv_avg;
       float e[4];
 #pragma unroll
@@ -334,7 +351,7 @@ __global__ __launch_bounds__(kBlk) void loss_reg_dense_kernel(
         }
       }
       if (pos) {
-        const float inv_avg = 1.0f / (norm[1] + 1e-6f);
+        const float inv_avg = 1.0f / avg_divisor(hp, norm);
         const float c_dfl = up_dfl * hp.lw_dfl * wt * 0.25f * inv_avg;
         const float stride = (float)geom.lv[c.l].stride;
         const float cx = (float)c.x, cy = (float)c.y;
@@ -397,6 +414,7 @@ __global__ __launch_bounds__(kBlk) void loss_cls_dense_kernel(
   const int NC = hp.num_classes;  // foreground classes: labels in [0, NC)
   const int C = hp.cls_channels > 0 ? hp.cls_channels : NC;
   const bool prob = (hp.flags & LD_LOSS_PROB_CLS) != 0;
+  const bool focal = (hp.flags & LD_LOSS_ATSS) != 0;
   const int ch0 = blockIdx.z * kClsChunk;
   const int ch1 = min(C, ch0 + kClsChunk);
   float s_cls = 0.0f, s_kd = 0.0f;
@@ -433,7 +451,10 @@ __global__ __launch_bounds__(kBlk) void loss_cls_dense_kernel(
       for (int ch = ch0; ch < ch1; ++ch) {
         const float x = *chan_ptr(cls, c, ch);
         float dq, q;
-        if (prob) {
+        if (focal) {
+          q = (pos && ch == (int)lab) ? ld::focal_pos(x, hp.focal_alpha, &dq)
+                                      : ld::focal_neg(x, hp.focal_alpha, &dq);
+        } else if (prob) {
           // gfocal_loss.py:41 takes every label < pred.size(1) as "positive",
           // background (label = num_classes, score 0) included; for it the
           // positive formula bce(p, 0) |0 - p|^2 IS the negative one
@@ -627,6 +648,31 @@ __global__ __launch_bounds__(1024) void gi_select_kernel(
   if (t == 0) counts[N + geom.num_levels + l] = kept;
 }
 
+// ------------------------------- centerness BCE on the positives (ATSS) -----
+__global__ __launch_bounds__(kBlk) void loss_ctr_dense_kernel(
+    ld_geom_t geom, ld_loss_hp_t hp, BlockMap bm, ld_maps_t ctr,
+    const int64_t* __restrict__ labels, const float* __restrict__ score,
+    const float* __restrict__ norm, const float* __restrict__ upstream,
+    ld_maps_t grad_ctr, float* __restrict__ partial) {
+  __shared__ float lds4[4];
+  const Cell c = locate256(geom, bm);
+  float s_ctr = 0.0f;
+  if (c.active) {
+    const int64_t lab = labels[c.o];
+    float g = 0.0f;
+    if (lab >= 0 && lab < hp.num_classes) {
+      const float up = upstream ? upstream[6 * geom.num_levels + c.l] : 1.0f;
+      const float nts = fmaxf(norm[0], 1.0f);
+      float d;
+      s_ctr = ld::bce_logits(*chan_ptr(ctr, c, 0), score[c.o], &d);
+      g = up * hp.lw_ctr * d / nts;
+    }
+    *chan_ptr_w(grad_ctr, c, 0) = g;
+  }
+  s_ctr = block_sum(s_ctr, lds4);
+  if (threadIdx.x == 0) partial[part_idx(S_WSUM, 0, bm, c.n)] = s_ctr;
+}
+
 // ------------------------------------------------------------ finalise ------
 // Fixed-order sum of the per-block partials of level l: [slot][z][n][b].
 __global__ __launch_bounds__(kWave) void loss_finalize_kernel(
@@ -638,10 +684,18 @@ __global__ __launch_bounds__(kWave) void loss_finalize_kernel(
   const size_t nb = (size_t)N * bm.blocks_per_img;
   const int b0 = bm.blk_start[l], b1 = bm.blk_start[l + 1];
   const int per = b1 - b0;
-  float acc[7];
+  float acc[8];
 #pragma unroll
-  for (int k = 0; k < 7; ++k) {
-    const int Z = k == S_BBOX ? 1 : (k == S_CLS || k == S_KD) ? zcls : k == S_IM ? zim : 4;
+  for (int k = 0; k < 8; ++k) {
+    // S_WSUM of the MAIN partials = the centerness term (LD_LOSS_ATSS)
+    const int Z = (k == S_BBOX || k == S_WSUM) ? 1
+                  : (k == S_CLS || k == S_KD)  ? zcls
+                  : k == S_IM                  ? zim
+                                               : 4;
+    if (k == S_WSUM && !(hp.flags & LD_LOSS_ATSS)) {
+      acc[k] = 0.0f;
+      continue;
+    }
     float a = 0.0f;
     for (int i = threadIdx.x; i < per * N * Z; i += kWave) {
       const int z = i / (per * N), r = i - z * per * N;
@@ -652,7 +706,7 @@ __global__ __launch_bounds__(kWave) void loss_finalize_kernel(
   }
   if (threadIdx.x == 0) {
     const float nts = fmaxf(norm[0], 1.0f);
-    const float avg = norm[1] + 1e-6f;
+    const float avg = avg_divisor(hp, norm);
     const int P_l = counts[N + l], F_l = counts[N + L + l];
     losses[0 * L + l] = hp.lw_cls * acc[S_CLS] / nts;
     losses[1 * L + l] = hp.lw_bbox * acc[S_BBOX] / avg;
@@ -660,7 +714,9 @@ __global__ __launch_bounds__(kWave) void loss_finalize_kernel(
     losses[3 * L + l] = hp.lw_ld * acc[S_LD] / 4.0f;
     losses[4 * L + l] = hp.lw_ld_vlr * acc[S_VLR] / 16.0f;
     losses[5 * L + l] = P_l > 0 ? hp.lw_kd * acc[S_KD] / (float)P_l : 0.0f;
-    losses[6 * L + l] = 0.0f;  // loss_kd_neg = 0 * KD (ld_head.py:267-271)
+    // LDHead: loss_kd_neg = 0 * KD (ld_head.py:267-271); LDATSSHead: this row
+    // carries loss_centerness (ld_atss.py:136-140)
+    losses[6 * L + l] = (hp.flags & LD_LOSS_ATSS) ? hp.lw_ctr * acc[S_WSUM] / nts : 0.0f;
     losses[7 * L + l] = (P_l > 0 && F_l > 0)
                             ? hp.lw_im * acc[S_IM] / ((float)F_l * (float)hp.feat_channels)
                             : 0.0f;
@@ -851,6 +907,7 @@ extern "C" int ld_loss_main_parts(
   if (split != (kd_t != nullptr) || split != (grad_kd != nullptr)) return LD_EINVAL;
   if (((hp->flags & LD_LOSS_PROB_CLS) != 0) != split)
     return LD_EINVAL;  // probabilities cannot carry the KD logits, and vice versa
+  if ((hp->flags & LD_LOSS_ATSS) && (hp->flags & LD_LOSS_PROB_CLS)) return LD_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   const LossWs w = loss_ws(*geom);
   const BlockMap& bm = w.bm256;
@@ -860,7 +917,8 @@ extern "C" int ld_loss_main_parts(
   if (parts & LD_LOSS_PART_POS)
     hipLaunchKernelGGL(loss_pos_kernel, dim3(bx, by), dim3(kBlk), 0, stream, *geom, *hp,
                        bm, split ? *kd_s : *cls, split ? *kd_t : *t_cls, *reg, labels,
-                       bbox_targets, weight_targets, norm, upstream, posrec, partial);
+                       bbox_targets, weight_targets, score, norm, upstream, posrec,
+                       partial);
   if (parts & LD_LOSS_PART_REG) {
     // streaming (non-temporal) access once the three 68-channel maps exceed what
     // the 256 MiB Infinity Cache can hold; at train-step sizes the gradient is
@@ -895,6 +953,26 @@ extern "C" int ld_loss_main_parts(
                        *geom, *hp, bm, *x, *t_x, im, counts, upstream, *grad_x, chunk,
                        partial);
   }
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_loss_centerness(const ld_geom_t* geom, const ld_loss_hp_t* hp,
+                                  const ld_maps_t* ctr, const int64_t* labels,
+                                  const float* score, const float* norm,
+                                  const float* upstream, const ld_maps_t* grad_ctr,
+                                  void* workspace, size_t workspace_bytes,
+                                  ld_stream_t stream_) {
+  if (int e = check_geom(geom)) return e;
+  if (int e = check_hp(hp)) return e;
+  if (!(hp->flags & LD_LOSS_ATSS)) return LD_EINVAL;
+  if (!ctr || !labels || !score || !norm || !grad_ctr) return LD_EINVAL;
+  if (!workspace || workspace_bytes < ld_loss_workspace_bytes(geom))
+    return LD_ENOSPACE;
+  const LossWs w = loss_ws(*geom);
+  float* partial = (float*)workspace + w.pre_floats;
+  hipLaunchKernelGGL(loss_ctr_dense_kernel, dim3(w.bm256.blocks_per_img, geom->num_imgs),
+                     dim3(kBlk), 0, (hipStream_t)stream_, *geom, *hp, w.bm256, *ctr,
+                     labels, score, norm, upstream, *grad_ctr, partial);
   return (int)hipGetLastError();
 }
 

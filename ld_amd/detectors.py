@@ -183,6 +183,11 @@ class GFL(SingleStageDetector):
 
 
 @DETECTORS.register_module()
+class ATSS(SingleStageDetector):
+    """atss.py:6-16 (the detector type of configs/gfl/atss_gfl_*.py)."""
+
+
+@DETECTORS.register_module()
 class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
     """kd_one_stage.py:12-108: student + frozen teacher (hidden from
     ``parameters()`` / ``state_dict()``), dual forward, LD loss."""
@@ -267,7 +272,8 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels,
                       gt_bboxes_ignore=None):
         """kd_one_stage.py:46-81."""
-        if not self.output_feature:
+        if not self.output_feature and \
+                type(self.bbox_head).__name__ in ('LDHead', 'LDv2Head'):
             raise NotImplementedError(
                 'output_feature=False: the reference passes one argument too '
                 'few to LDHead.forward_train on that branch '
@@ -288,9 +294,8 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
             main.wait_event(pre[3])
             for t in list(teacher_x) + [t for lvl in out_teacher for t in lvl]:
                 t.record_stream(main)
-            return self.bbox_head.forward_train(x, out_teacher, teacher_x,
-                                                img_metas, gt_bboxes,
-                                                gt_labels, gt_bboxes_ignore)
+            return self._head_train(x, out_teacher, teacher_x, img_metas,
+                                    gt_bboxes, gt_labels, gt_bboxes_ignore)
         if self.use_teacher_stream and img.is_cuda:
             if self.teacher_stream is None:
                 self.teacher_stream = torch.cuda.Stream(device=img.device)
@@ -307,6 +312,17 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
                 t.record_stream(main)
         else:
             teacher_x, out_teacher = self._teacher_forward(img)
+        return self._head_train(x, out_teacher, teacher_x, img_metas,
+                                gt_bboxes, gt_labels, gt_bboxes_ignore)
+
+    def _head_train(self, x, out_teacher, teacher_x, img_metas, gt_bboxes,
+                    gt_labels, gt_bboxes_ignore):
+        """kd_one_stage.py:73-80: the feature-imitation heads take teacher_x,
+        the others (LDATSSHead, ...) do not."""
+        if not self.output_feature:
+            return self.bbox_head.forward_train(x, out_teacher, img_metas,
+                                                gt_bboxes, gt_labels,
+                                                gt_bboxes_ignore)
         return self.bbox_head.forward_train(x, out_teacher, teacher_x,
                                             img_metas, gt_bboxes, gt_labels,
                                             gt_bboxes_ignore)

@@ -506,6 +506,202 @@ class LDHead(GFLHead):
         return self._loss_dict(table)
 
 
+ATSS_LOSS_KEYS = ['loss_cls', 'loss_bbox', 'loss_ld', 'loss_ld_neg',
+                  'loss_cls_kd', 'loss_centerness']
+# rows of the fused block's (8, L) table that carry them (LD_LOSS_ATSS)
+_ATSS_ROWS = [0, 1, 3, 4, 5, 6]
+
+
+@HEADS.register_module()
+class ATSSGFLHead(GFLHead):
+    """atss_gfl_head.py:52-185: the ATSS head with a general-distribution box
+    branch -- GFLHead's two towers, ``atss_cls`` / ``atss_reg`` /
+    ``atss_centerness`` output convs (state_dict names of the reference),
+    FocalLoss + centerness-weighted GIoU + centerness BCE.  forward returns
+    (cls_scores, bbox_preds, centernesses)."""
+
+    def __init__(self, num_classes, in_channels, stacked_convs=4,
+                 conv_cfg=None,
+                 norm_cfg=dict(type='GN', num_groups=32, requires_grad=True),
+                 loss_centerness=dict(type='CrossEntropyLoss',
+                                      use_sigmoid=True, loss_weight=1.0),
+                 reg_max=16, **kwargs):
+        kwargs.setdefault('loss_cls', dict(type='FocalLoss', use_sigmoid=True,
+                                           gamma=2.0, alpha=0.25,
+                                           loss_weight=1.0))
+        kwargs.setdefault('bbox_coder', dict(
+            type='DeltaXYWHBBoxCoder', target_means=(.0, .0, .0, .0),
+            target_stds=(1.0, 1.0, 1.0, 1.0)))
+        super().__init__(num_classes, in_channels, stacked_convs=stacked_convs,
+                         conv_cfg=conv_cfg, norm_cfg=norm_cfg,
+                         loss_dfl=dict(type='DistributionFocalLoss',
+                                       loss_weight=0.0),
+                         reg_max=reg_max, **kwargs)
+        self.loss_centerness = build_loss(loss_centerness)
+
+    def _init_layers(self):
+        """atss_gfl_head.py:90-125."""
+        self.relu = nn.ReLU(inplace=True)
+        self.cls_convs = nn.ModuleList()
+        self.reg_convs = nn.ModuleList()
+        for i in range(self.stacked_convs):
+            chn = self.in_channels if i == 0 else self.feat_channels
+            self.cls_convs.append(
+                ConvModule(chn, self.feat_channels, 3, stride=1, padding=1,
+                           conv_cfg=self.conv_cfg, norm_cfg=self.norm_cfg))
+            self.reg_convs.append(
+                ConvModule(chn, self.feat_channels, 3, stride=1, padding=1,
+                           conv_cfg=self.conv_cfg, norm_cfg=self.norm_cfg))
+        assert self.num_anchors == 1, 'one square anchor per position'
+        self.atss_cls = Conv2d(self.feat_channels,
+                               self.num_anchors * self.cls_out_channels, 3,
+                               padding=1)
+        self.atss_reg = Conv2d(self.feat_channels, 4 * (self.reg_max + 1), 3,
+                               padding=1)
+        self.atss_centerness = Conv2d(self.feat_channels, self.num_anchors, 3,
+                                      padding=1)
+        self.scales = nn.ModuleList(
+            [Scale(1.0) for _ in self.anchor_generator.strides])
+
+    def init_weights(self):
+        """atss_gfl_head.py:127-137."""
+        for m in self.cls_convs:
+            normal_init(m.conv, std=0.01)
+        for m in self.reg_convs:
+            normal_init(m.conv, std=0.01)
+        normal_init(self.atss_cls, std=0.01, bias=bias_init_with_prob(0.01))
+        normal_init(self.atss_reg, std=0.01)
+        normal_init(self.atss_centerness, std=0.01)
+
+    def forward(self, feats):
+        """atss_gfl_head.py:139-183, all levels in one launch per layer."""
+        assert len(feats) == len(self.scales)
+        x3, levels = Y.pack_levels(feats)
+        cls_feat = reg_feat = x3
+        for m in self.cls_convs:
+            cls_feat, _ = m.forward3(cls_feat, levels)
+        for m in self.reg_convs:
+            reg_feat, _ = m.forward3(reg_feat, levels)
+        cls3, _ = self.atss_cls.forward3(cls_feat, levels)
+        reg3, _ = self.atss_reg.forward3(reg_feat, levels)
+        ctr3, _ = self.atss_centerness.forward3(reg_feat, levels)
+        scales = torch.stack([s.scale for s in self.scales])
+        reg3 = Y.scale_levels(reg3, scales, levels)
+        return (Y.split_levels(cls3, levels), Y.split_levels(reg3, levels),
+                Y.split_levels(ctr3, levels))
+
+    def _check_loss_cfg(self):
+        from .losses import CrossEntropyLoss, FocalLoss, GIoULoss
+        if not isinstance(self.loss_cls, FocalLoss) or \
+                not isinstance(self.loss_bbox, GIoULoss) or \
+                not isinstance(self.loss_centerness, CrossEntropyLoss) or \
+                not self.loss_centerness.use_sigmoid:
+            raise NotImplementedError(
+                'the fused ATSS loss block implements FocalLoss + GIoULoss + '
+                'sigmoid CrossEntropyLoss centerness')
+        if self.loss_cls.gamma != 2.0:
+            raise NotImplementedError('FocalLoss gamma != 2')
+        if self.train_cfg.get('allowed_border', -1) >= 0:
+            raise NotImplementedError('allowed_border >= 0')
+        if self.train_cfg.get('pos_weight', -1) > 0:
+            raise NotImplementedError('pos_weight > 0')
+
+    def _hp(self, **over):
+        kw = dict(lw_dfl=0.0, lw_ctr=self.loss_centerness.loss_weight,
+                  focal_alpha=self.loss_cls.alpha, qfl_beta=2.0,
+                  flags=L.LD_LOSS_ATSS)
+        kw.update(over)
+        return super()._hp(**kw)
+
+    def _atss_loss_dict(self, table, keys):
+        d = LossDict((k, [table[r, l] for l in range(table.shape[1])])
+                     for k, r in zip(ATSS_LOSS_KEYS, _ATSS_ROWS) if k in keys)
+        d.table = table
+        d.rows = [r for k, r in zip(ATSS_LOSS_KEYS, _ATSS_ROWS) if k in keys]
+        return d
+
+    def loss(self, cls_scores, bbox_preds, centernesses, gt_bboxes, gt_labels,
+             img_metas, gt_bboxes_ignore=None):
+        """atss_gfl_head.py:187-310: loss_cls, loss_bbox, loss_centerness."""
+        self._check_loss_cfg()
+        sizes = [tuple(int(v) for v in f.shape[-2:]) for f in cls_scores]
+        device = cls_scores[0].device
+        hp = self._hp()
+        targets = self.get_targets_batched(sizes, img_metas, gt_bboxes,
+                                           gt_labels, hp, device)
+        dummy_x = [c.detach() for c in cls_scores]
+        hp.feat_channels = cls_scores[0].shape[1]
+        teacher = ([c.detach() for c in cls_scores],
+                   [b.detach() for b in bbox_preds], dummy_x)
+        table, _ = LB.LDLossBlock.apply(hp, targets, teacher,
+                                        self._norm_reducer(),
+                                        self.unit_upstream, *cls_scores,
+                                        *bbox_preds, *dummy_x, *centernesses)
+        return self._atss_loss_dict(table, ('loss_cls', 'loss_bbox',
+                                            'loss_centerness'))
+
+    def get_bboxes(self, *args, **kwargs):
+        raise NotImplementedError(
+            'ATSSGFLHead.get_bboxes (centerness-weighted scores, '
+            'atss_gfl_head.py:420-560) is not wired to ld_get_bboxes')
+
+
+@HEADS.register_module()
+class LDATSSHead(ATSSGFLHead):
+    """ld_atss.py:13-250: localization distillation on the ATSS-GFL head --
+    LD on the positives weighted by the max class score, 0.15 x LD on the
+    valuable localisation region, KD on the positives' class logits.  The
+    detector calls it with output_feature=False:
+    forward_train(x, out_teacher, img_metas, ...)."""
+
+    def __init__(self, num_classes, in_channels,
+                 loss_ld=dict(type='LocalizationDistillationLoss',
+                              loss_weight=0.25, T=10),
+                 loss_kd=None, **kwargs):
+        super().__init__(num_classes, in_channels, **kwargs)
+        self.loss_ld = build_loss(loss_ld)
+        self.loss_kd = build_loss(loss_kd)
+
+    def forward_train(self, x, out_teacher, img_metas, gt_bboxes,
+                      gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None,
+                      **kwargs):
+        """ld_atss.py:252-290."""
+        outs = self(x)
+        if gt_labels is None:
+            raise NotImplementedError('LDATSSHead needs gt_labels')
+        if proposal_cfg is not None:
+            raise NotImplementedError('proposal_cfg')
+        return self.loss(*outs, gt_bboxes, gt_labels, out_teacher, img_metas,
+                         gt_bboxes_ignore=gt_bboxes_ignore)
+
+    def loss(self, cls_scores, bbox_preds, centernesses, gt_bboxes, gt_labels,
+             soft_target, img_metas, gt_bboxes_ignore=None):
+        """ld_atss.py:168-250 -> the six keys of ATSS_LOSS_KEYS."""
+        self._check_loss_cfg()
+        soft_labels, soft_corners = soft_target[0], soft_target[1]
+        sizes = [tuple(int(v) for v in f.shape[-2:]) for f in cls_scores]
+        assert len(sizes) == self.anchor_generator.num_levels
+        device = cls_scores[0].device
+        # loss_ld_neg = 0.15 * loss_ld(..., avg_factor=4) on the VLR region
+        # (ld_atss.py:148-159); the block's VLR term is lw_ld_vlr * sum / 16
+        hp = self._hp(lw_ld=self.loss_ld.loss_weight, T_ld=self.loss_ld.T,
+                      lw_ld_vlr=0.15 * 4.0 * self.loss_ld.loss_weight,
+                      T_ld_vlr=self.loss_ld.T,
+                      lw_kd=self.loss_kd.loss_weight, T_kd=self.loss_kd.T)
+        targets = self.get_targets_batched(sizes, img_metas, gt_bboxes,
+                                           gt_labels, hp, device)
+        dummy_x = [c.detach() for c in cls_scores]
+        hp.feat_channels = cls_scores[0].shape[1]
+        teacher = ([t.detach() for t in soft_labels],
+                   [t.detach() for t in soft_corners], dummy_x)
+        table, _ = LB.LDLossBlock.apply(hp, targets, teacher,
+                                        self._norm_reducer(),
+                                        self.unit_upstream, *cls_scores,
+                                        *bbox_preds, *dummy_x, *centernesses)
+        self.last_targets = targets
+        return self._atss_loss_dict(table, ATSS_LOSS_KEYS)
+
+
 class _Marker(nn.Module):
     """Parameter-free placeholder that keeps nn.Sequential's indices (and with
     them the state_dict keys ``reg_conf.0.*`` / ``reg_conf.2.*``) identical to

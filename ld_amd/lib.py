@@ -47,11 +47,13 @@ class LossHpT(C.Structure):
                 ('T_ld', C.c_float), ('lw_ld_vlr', C.c_float),
                 ('T_ld_vlr', C.c_float), ('lw_kd', C.c_float),
                 ('T_kd', C.c_float), ('lw_im', C.c_float),
-                ('cls_channels', C.c_int32), ('flags', C.c_int32)]
+                ('cls_channels', C.c_int32), ('flags', C.c_int32),
+                ('lw_ctr', C.c_float), ('focal_alpha', C.c_float)]
 
 
 LD_LOSS_PROB_CLS = 1
 LD_IM_CENTER_INSIDE = 2
+LD_LOSS_ATSS = 4
 
 
 class ConvLevelT(C.Structure):
@@ -190,6 +192,8 @@ SIGNATURES = {
     'ld_gi_region': (C.c_int, [_G, _H, _M, _M, _M, _M, _i32, _f32, _vp, _vp,
                                _vp, _sz, _vp]),
     'ld_loss_finalize': (C.c_int, [_G, _H, _vp, _vp, _vp, _vp, _vp]),
+    'ld_loss_centerness': (C.c_int, [_G, _H, _M, _vp, _vp, _vp, _vp, _M, _vp,
+                                     _sz, _vp]),
     'ld_kl_integral_dense': (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _vp,
                                        _vp, _vp, _vp]),
     'ld_kd_kl_rows': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp,

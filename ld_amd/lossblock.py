@@ -29,9 +29,10 @@ def workspace(device, nbytes, tag='ws'):
 def make_hp(num_classes=80, reg_max=16, topk=9, feat_channels=256, lw_cls=1.0,
             qfl_beta=2.0, lw_bbox=2.0, giou_eps=1e-6, lw_dfl=0.25, lw_ld=0.25,
             T_ld=10.0, lw_ld_vlr=0.25, T_ld_vlr=10.0, lw_kd=10.0, T_kd=2.0,
-            lw_im=2.0, cls_channels=0, flags=0):
+            lw_im=2.0, cls_channels=0, flags=0, lw_ctr=0.0, focal_alpha=0.25):
     hp = L.LossHpT()
     hp.cls_channels, hp.flags = cls_channels, flags
+    hp.lw_ctr, hp.focal_alpha = lw_ctr, focal_alpha
     hp.num_classes, hp.reg_max, hp.topk = num_classes, reg_max, topk
     hp.feat_channels = feat_channels
     hp.lw_cls, hp.qfl_beta, hp.lw_bbox, hp.giou_eps = (lw_cls, qfl_beta,
@@ -157,13 +158,16 @@ class _LossState:
 
 
 def loss_block_forward(hp, targets, cls, reg, t_cls, t_reg, x, t_x,
-                       reduce_norm=None, upstream=None, kd_s=None, kd_t=None):
+                       reduce_norm=None, upstream=None, kd_s=None, kd_t=None,
+                       ctr=None):
     """Run prepass -> (normaliser reduction) -> main -> finalise.
 
     cls/reg/x: student per-level NCHW tensors; t_*: teacher's.
     kd_s / kd_t (LDv2): student / teacher maps of the KD term when it does not
     run on ``cls`` itself (raw cls_feat, ld_gflv2.py:243); ``cls`` then holds
     probabilities and ``t_cls`` is unused.
+    ctr (LDATSSHead, hp.flags & LD_LOSS_ATSS): the student's centerness maps;
+    their gradient comes back as grads['ctr'] and the centerness loss in row 6.
     reduce_norm: optional callable(norm_tensor[2]) doing the cross-rank MEAN
     in place (core/utils/dist_utils.py:63-69) -- device side, no host sync.
     Returns (losses (8, L) tensor, grads dict of lists, norm tensor).
@@ -220,11 +224,22 @@ def loss_block_forward(hp, targets, cls, reg, t_cls, t_reg, x, t_x,
         C.byref(m_kds) if split else None, C.byref(m_kdt) if split else None,
         C.byref(mg_kd) if split else None, L.ptr(ws), ws.numel(), 15, st),
         'ld_loss_main')
+    g_ctr = None
+    if hp.flags & L.LD_LOSS_ATSS:
+        if ctr is None:
+            raise L.LdError('LD_LOSS_ATSS needs the centerness maps')
+        g_ctr = [torch.empty_like(t, memory_format=torch.contiguous_format)
+                 for t in ctr]
+        L.check(lib.ld_loss_centerness(
+            C.byref(geom), C.byref(hp), C.byref(L.make_maps(ctr)),
+            L.ptr(targets['labels']), L.ptr(score), L.ptr(norm), L.ptr(up),
+            C.byref(L.make_maps(g_ctr)), L.ptr(ws), ws.numel(), st),
+            'ld_loss_centerness')
     L.check(lib.ld_loss_finalize(
         C.byref(geom), C.byref(hp), L.ptr(targets['counts']), L.ptr(norm),
         L.ptr(ws), L.ptr(losses), st), 'ld_loss_finalize')
-    return losses, dict(cls=g_cls, reg=g_reg, x=g_x, kd=g_kd), norm, dict(
-        weight_targets=wt, score=score)
+    return losses, dict(cls=g_cls, reg=g_reg, x=g_x, kd=g_kd, ctr=g_ctr), \
+        norm, dict(weight_targets=wt, score=score)
 
 
 class LDLossBlock(torch.autograd.Function):
@@ -239,12 +254,15 @@ class LDLossBlock(torch.autograd.Function):
         nl = targets['geom'].num_levels
         cls, reg, x = (student[:nl], student[nl:2 * nl],
                        student[2 * nl:3 * nl])
-        kd_s = student[3 * nl:] or None  # LDv2: raw cls_feat
+        # 4th student group: LDv2 = raw cls_feat, LDATSS = centerness maps
+        extra = student[3 * nl:] or None
+        atss = bool(hp.flags & L.LD_LOSS_ATSS)
+        kd_s, ctr = (None, extra) if atss else (extra, None)
         t_cls, t_reg, t_x = teacher[:3]
         kd_t = teacher[3] if len(teacher) > 3 else None
         losses, grads, norm, aux = loss_block_forward(
             hp, targets, cls, reg, t_cls, t_reg, x, t_x, reduce_norm,
-            kd_s=kd_s, kd_t=kd_t)
+            kd_s=kd_s, kd_t=kd_t, ctr=ctr)
         ctx.unit_upstream = unit_upstream
         ctx.pack = (hp, targets, teacher, norm)
         ctx.nl = nl
@@ -262,19 +280,24 @@ class LDLossBlock(torch.autograd.Function):
             nl = ctx.nl
             cls, reg, x = (student[:nl], student[nl:2 * nl],
                            student[2 * nl:3 * nl])
-            kd_s = student[3 * nl:] or None
+            extra = student[3 * nl:] or None
+            atss = bool(hp.flags & L.LD_LOSS_ATSS)
+            kd_s, ctr = (None, extra) if atss else (extra, None)
             # the normalisers are constants of the graph (the reference takes
             # them through .item(), ld_head.py:340-341,363): reuse them
             _, grads, _, _ = _rerun_with_upstream(hp, targets, teacher, norm,
-                                                  cls, reg, x, g_losses, kd_s)
+                                                  cls, reg, x, g_losses, kd_s,
+                                                  ctr)
         out = tuple(grads['cls']) + tuple(grads['reg']) + tuple(grads['x'])
         if grads.get('kd') is not None:
             out = out + tuple(grads['kd'])
+        if grads.get('ctr') is not None:
+            out = out + tuple(grads['ctr'])
         return (None, None, None, None, None) + out
 
 
 def _rerun_with_upstream(hp, targets, teacher, norm, cls, reg, x, upstream,
-                         kd_s=None):
+                         kd_s=None, ctr=None):
     t_cls, t_reg, t_x = teacher[:3]
     kd_t = teacher[3] if len(teacher) > 3 else None
     fixed = norm.clone()
@@ -284,7 +307,7 @@ def _rerun_with_upstream(hp, targets, teacher, norm, cls, reg, x, upstream,
 
     return loss_block_forward(hp, targets, cls, reg, t_cls, t_reg, x, t_x,
                               reduce_norm=_restore, upstream=upstream,
-                              kd_s=kd_s, kd_t=kd_t)
+                              kd_s=kd_s, kd_t=kd_t, ctr=ctr)
 
 
 # ---------------------------------------------------------------------------

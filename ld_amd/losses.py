@@ -207,8 +207,10 @@ class GIoULoss(nn.Module):
 
     def forward(self, pred, target, weight=None, avg_factor=None,
                 reduction_override=None, **kwargs):
-        if weight is not None and not torch.any(weight > 0):
-            return (pred * weight).sum()  # 0
+        # The reference returns (pred * weight).sum() = 0 early when no weight is
+        # positive (iou_loss.py:346-348), which costs a host sync per call; the
+        # row kernel yields the same zero (rows are multiplied by the weight)
+        # without looking at the weights on the host.
         assert reduction_override in (None, 'none', 'mean', 'sum')
         reduction = reduction_override if reduction_override else self.reduction
         if weight is not None and weight.dim() > 1:
@@ -216,6 +218,44 @@ class GIoULoss(nn.Module):
             weight = weight.mean(-1)
         rows = _RowLoss.apply(_launch_giou, pred, weight, target, self.eps)
         return self.loss_weight * _reduce_weighted(rows, reduction, avg_factor)
+
+
+@LOSSES.register_module()
+class FocalLoss(nn.Module):
+    """losses/focal_loss.py:111-181 (sigmoid focal loss).  Evaluated inside the
+    fused loss block of LDATSSHead (hp flag LD_LOSS_ATSS, gamma = 2); the
+    module carries the hyper-parameters and is registrable for the configs."""
+
+    def __init__(self, use_sigmoid=True, gamma=2.0, alpha=0.25,
+                 reduction='mean', loss_weight=1.0):
+        super().__init__()
+        assert use_sigmoid is True, 'Only sigmoid focal loss supported now.'
+        self.use_sigmoid, self.gamma, self.alpha = use_sigmoid, gamma, alpha
+        self.reduction, self.loss_weight = reduction, loss_weight
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError(
+            'FocalLoss runs inside the fused LDATSSHead loss block '
+            '(ld_loss_main_parts with LD_LOSS_ATSS); a stand-alone launch is '
+            'not built')
+
+
+@LOSSES.register_module()
+class CrossEntropyLoss(nn.Module):
+    """losses/cross_entropy_loss.py:93-214; only the use_sigmoid=True form the
+    ATSS centerness branch uses, evaluated by ld_loss_centerness."""
+
+    def __init__(self, use_sigmoid=False, use_mask=False, reduction='mean',
+                 class_weight=None, loss_weight=1.0):
+        super().__init__()
+        self.use_sigmoid, self.use_mask = use_sigmoid, use_mask
+        self.reduction, self.class_weight = reduction, class_weight
+        self.loss_weight = loss_weight
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError(
+            'CrossEntropyLoss (centerness) runs inside the fused LDATSSHead '
+            'loss block (ld_loss_centerness)')
 
 
 @LOSSES.register_module()

@@ -127,6 +127,52 @@ def ldv2_detector(student_depth=50, teacher_depth=101,
                 test_cfg=copy.deepcopy(_TEST_CFG))
 
 
+def _atss_head_common():
+    """configs/gfl/atss_gfl_r50_1x.py:26-47 / configs/ld/ld_r50_atss_r101_1x.py:
+    29-58."""
+    return dict(
+        num_classes=80, in_channels=256, stacked_convs=4, feat_channels=256,
+        anchor_generator=dict(type='AnchorGenerator', ratios=[1.0],
+                              octave_base_scale=8, scales_per_octave=1,
+                              strides=[8, 16, 32, 64, 128]),
+        bbox_coder=dict(type='DeltaXYWHBBoxCoder',
+                        target_means=[.0, .0, .0, .0],
+                        target_stds=[0.1, 0.1, 0.2, 0.2]),
+        loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0,
+                      alpha=0.25, loss_weight=1.0),
+        loss_bbox=dict(type='GIoULoss', loss_weight=2.0),
+        loss_centerness=dict(type='CrossEntropyLoss', use_sigmoid=True,
+                             loss_weight=1.0))
+
+
+def atss_gfl_detector(depth=101):
+    """An ATSS-GFL teacher (configs/gfl/atss_gfl_r{50,101}_*.py)."""
+    return dict(type='ATSS', pretrained=None, backbone=_backbone(depth),
+                neck=_neck(depth),
+                bbox_head=dict(type='ATSSGFLHead', **_atss_head_common()),
+                train_cfg=copy.deepcopy(_TRAIN_CFG),
+                test_cfg=copy.deepcopy(_TEST_CFG))
+
+
+def ld_atss_detector(student_depth=50, teacher_depth=101):
+    """configs/ld/ld_r50_atss_r101_1x.py: LDATSSHead student <- ATSS-GFL
+    teacher; output_feature is the detector's default (False): the head takes
+    no teacher features."""
+    head = dict(type='LDATSSHead',
+                loss_ld=dict(type='KnowledgeDistillationKLDivLoss',
+                             loss_weight=0.25, T=10),
+                loss_kd=dict(type='KnowledgeDistillationKLDivLoss',
+                             loss_weight=10, T=2),
+                **_atss_head_common())
+    return dict(type='KnowledgeDistillationSingleStageDetector',
+                pretrained=None,
+                teacher_config=dict(model=atss_gfl_detector(teacher_depth)),
+                teacher_ckpt=None, backbone=_backbone(student_depth),
+                neck=_neck(student_depth), bbox_head=head,
+                train_cfg=copy.deepcopy(_TRAIN_CFG),
+                test_cfg=copy.deepcopy(_TEST_CFG))
+
+
 OPTIMIZER = dict(type='SGD', lr=0.0025, momentum=0.9, weight_decay=0.0001)
 
 

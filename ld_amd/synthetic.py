@@ -255,6 +255,14 @@ def infer_inputs_clustered(pad, num_imgs, seed, device='cpu'):
     return [c.to(device) for c in cls], [r.to(device) for r in reg]
 
 
+def synthetic_centerness(num_imgs, featmap_sizes, seed=0, device='cpu'):
+    """Centerness logits ~ 1.5 * randn for the ATSS heads (a separate stream:
+    the draw order of synthetic_head_inputs is part of the older goldens)."""
+    gen = _gen(seed + 7919)
+    return [(_normal((num_imgs, 1, h, w), gen) * 1.5).to(device)
+            for (h, w) in featmap_sizes]
+
+
 def grad_probe(n, seed):
     """Deterministic pseudo-random direction in [-0.5, 0.5)^n (integer hash,
     exact on every platform): gradient fingerprints dot(grad, probe) that --

@@ -852,6 +852,139 @@ def gen_infer():
     np.savez_compressed(os.path.join(OUT, 'infer.npz'), **d)
 
 
+def _ld_atss_head():
+    """LDATSSHead as configs/ld/ld_r50_atss_r101_1x.py:29-58 builds it."""
+    from mmdet.models import build_head
+    cfg = dict(
+        type='LDATSSHead', num_classes=80, in_channels=256, stacked_convs=4,
+        feat_channels=256,
+        anchor_generator=dict(type='AnchorGenerator', ratios=[1.0],
+                              octave_base_scale=8, scales_per_octave=1,
+                              strides=[8, 16, 32, 64, 128]),
+        bbox_coder=dict(type='DeltaXYWHBBoxCoder',
+                        target_means=[.0, .0, .0, .0],
+                        target_stds=[0.1, 0.1, 0.2, 0.2]),
+        loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0,
+                      alpha=0.25, loss_weight=1.0),
+        loss_bbox=dict(type='GIoULoss', loss_weight=2.0),
+        loss_ld=dict(type='KnowledgeDistillationKLDivLoss', loss_weight=0.25,
+                     T=10),
+        loss_kd=dict(type='KnowledgeDistillationKLDivLoss', loss_weight=10,
+                     T=2),
+        loss_centerness=dict(type='CrossEntropyLoss', use_sigmoid=True,
+                             loss_weight=1.0),
+        train_cfg=ref_shim.ConfigDict(
+            assigner=dict(type='ATSSAssigner', topk=9), allowed_border=-1,
+            pos_weight=-1, debug=False),
+        test_cfg=ref_shim.ConfigDict(
+            nms_pre=1000, min_bbox_size=0, score_thr=0.05,
+            nms=dict(type='nms', iou_threshold=0.6), max_per_img=100))
+    return build_head(cfg)
+
+
+ATSS_KEYS = ['loss_cls', 'loss_bbox', 'loss_ld', 'loss_ld_neg', 'loss_cls_kd',
+             'loss_centerness']
+
+
+def gen_lossblock_atss():
+    """LDATSSHead.loss (ld_atss.py:168-250) executed by the reference on the
+    LOSSBLOCK_CASES inputs + synthetic centerness maps: loss table (6 keys x 5
+    levels) and the gradients of the sum of all entries wrt cls / reg /
+    centerness."""
+    head = _ld_atss_head()
+    d = {}
+    for name, pad, img_shape, num_gt, bseed, hseed, store in LOSSBLOCK_CASES:
+        batch = synthetic.synthetic_batch(
+            num_imgs=len(num_gt), img_shape=img_shape, pad_shape=pad,
+            num_gt=num_gt, seed=bseed)
+        sizes = synthetic.level_shapes(pad)
+        hi = synthetic.synthetic_head_inputs(len(num_gt), sizes, seed=hseed)
+        hi['ctr'] = synthetic.synthetic_centerness(len(num_gt), sizes,
+                                                   seed=hseed)
+        for k in ('cls', 'reg', 'ctr'):
+            for t in hi[k]:
+                t.requires_grad_(True)
+        t0 = time.time()
+        losses = head.loss(hi['cls'], hi['reg'], hi['ctr'],
+                           batch['gt_bboxes'], batch['gt_labels'],
+                           (hi['t_cls'], hi['t_reg'], None),
+                           batch['img_metas'])
+        table = np.stack([np.array([float(v.detach()) for v in losses[k]])
+                          for k in ATSS_KEYS])
+        total = sum(sum(v) for v in losses.values())
+        total.backward()
+        d[name + '_cfg'] = np.array(
+            list(pad) + list(img_shape) + [bseed, hseed])
+        d[name + '_num_gt'] = np.array(num_gt)
+        d[name + '_losses'] = table.astype(np.float64)
+        for k in ('cls', 'reg', 'ctr'):
+            gs = [t.grad if t.grad is not None else torch.zeros_like(t)
+                  for t in hi[k]]
+            d[f'{name}_g{k}_abs_sum'] = np.array(
+                [float(g.double().abs().sum()) for g in gs])
+            d[f'{name}_g{k}_sum'] = np.array(
+                [float(g.double().sum()) for g in gs])
+            for l, g in enumerate(gs):
+                if store:
+                    d[f'{name}_g{k}_{l}'] = _np(g)
+                else:
+                    flat = _np(g).reshape(-1)
+                    d[f'{name}_g{k}_{l}_sample'] = flat[
+                        np.arange(0, flat.size, 1009)]
+        print(f'  lossblock_atss {name}: {time.time() - t0:.2f}s  total='
+              f'{float(total):.6f}', table.sum(1))
+    np.savez_compressed(os.path.join(OUT, 'lossblock_atss.npz'), **d)
+    print('lossblock_atss.npz')
+
+
+def gen_e2e_atss():
+    """One LD train step of configs/ld/ld_r50_atss_r101_1x.py (LDATSSHead
+    student <- ATSS-GFL R101 teacher) executed by the reference: loss table,
+    gradient norms and projections."""
+    d = {}
+    for name, pad, img_shape, num_gt, bseed in (
+            ('tiny', (128, 160), (128, 150), [3, 2], 41),
+            ('small', (256, 320), (256, 320), [5, 2], 42)):
+        torch.manual_seed(0)
+        det = build_reference_detector('configs/ld/ld_r50_atss_r101_1x.py')
+        det.load_state_dict(
+            synthetic.seeded_state_dict(det.state_dict(), seed=1))
+        det.teacher_model.load_state_dict(
+            synthetic.seeded_state_dict(det.teacher_model.state_dict(),
+                                        seed=2))
+        det.train()
+        batch = synthetic.synthetic_batch(
+            num_imgs=len(num_gt), img_shape=img_shape, pad_shape=pad,
+            num_gt=num_gt, seed=bseed)
+        losses = det.forward_train(batch['img'], batch['img_metas'],
+                                   batch['gt_bboxes'], batch['gt_labels'])
+        table = np.stack([np.array([float(v.detach()) for v in losses[k]])
+                          for k in ATSS_KEYS])
+        loss, log_vars = det._parse_losses(losses)
+        loss.backward()
+        d[name + '_cfg'] = np.array(list(pad) + list(img_shape) + [bseed])
+        d[name + '_num_gt'] = np.array(num_gt)
+        d[name + '_losses'] = table.astype(np.float64)
+        names, norms, proj = [], [], []
+        for k, p in det.named_parameters():
+            if p.grad is not None:
+                names.append(k)
+                norms.append(float(p.grad.double().norm()))
+                gflat = p.grad.double().reshape(-1).numpy()
+                proj.append([float(gflat @ synthetic.grad_probe(gflat.size,
+                                                                sd))
+                             for sd in (0, 1)])
+        d[name + '_grad_names'] = np.array(names)
+        d[name + '_grad_norms'] = np.array(norms)
+        d[name + '_grad_proj'] = np.array(proj)
+        d[name + '_student_keys'] = np.array(list(det.state_dict().keys()))
+        d[name + '_teacher_keys'] = np.array(
+            list(det.teacher_model.state_dict().keys()))
+        print(f'  e2e_atss {name}:',
+              {k: round(v, 6) for k, v in log_vars.items()})
+    np.savez_compressed(os.path.join(OUT, 'e2e_atss.npz'), **d)
+
+
 def gen_infer_voting():
     """Score-voting Cluster-DIoU-NMS: the reference's own multiclass_nms branch
     (bbox_nms.py:141-176, pure torch -> PINNED, unlike the mmcv batched_nms of
@@ -973,7 +1106,8 @@ def gen_pipeline():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='kat,anchors,targets,lossblock,e2e,infer,'
-                    'lossblock_v2,e2e_v2,imitation,pipeline,infer_voting')
+                    'lossblock_v2,e2e_v2,imitation,pipeline,infer_voting,'
+                    'lossblock_atss,e2e_atss')
     ap.add_argument('--e2e-cases', default='')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
@@ -1001,6 +1135,10 @@ def main():
         gen_pipeline()
     if 'infer_voting' in only:
         gen_infer_voting()
+    if 'lossblock_atss' in only:
+        gen_lossblock_atss()
+    if 'e2e_atss' in only:
+        gen_e2e_atss()
 
 
 if __name__ == '__main__':

@@ -648,6 +648,153 @@ def ld_loss_block(cls, reg, t_cls, t_reg, x, t_x, targets, hp=None,
 
 
 # --------------------------------------------------------------------------
+# LDATSSHead (ld_atss.py:44-250 over atss_gfl_head.py)
+# --------------------------------------------------------------------------
+def focal_elements(x, target, alpha=0.25):
+    """py_sigmoid_focal_loss (losses/focal_loss.py:12-47), gamma = 2:
+    bce_with_logits(x, t) * (alpha t + (1 - alpha)(1 - t)) * pt^2 with
+    pt = (1 - p) t + p (1 - t).  Returns (loss, dloss/dx) element-wise."""
+    x = x.astype(F32)
+    p = _sigmoid(x)
+    t = target.astype(F32)
+    a = F32(alpha)
+    spn, sp = _softplus(-x), _softplus(x)  # -log p, -log(1 - p)
+    q = F32(1) - p
+    fpos = a * q * q * spn
+    dpos = a * q * q * (-F32(2) * p * spn - q)
+    fneg = (F32(1) - a) * p * p * sp
+    dneg = (F32(1) - a) * p * p * (p + F32(2) * q * sp)
+    return (np.where(t > 0, fpos, fneg).astype(F32),
+            np.where(t > 0, dpos, dneg).astype(F32))
+
+
+def centerness_target(anchors, gts):
+    """atss_gfl_head.py:312-331."""
+    cx = (anchors[:, 2] + anchors[:, 0]) / F32(2)
+    cy = (anchors[:, 3] + anchors[:, 1]) / F32(2)
+    l_, t_ = cx - gts[:, 0], cy - gts[:, 1]
+    r_, b_ = gts[:, 2] - cx, gts[:, 3] - cy
+    lr = np.stack([l_, r_], 1)
+    tb = np.stack([t_, b_], 1)
+    return np.sqrt((lr.min(1) / lr.max(1)) * (tb.min(1) / tb.max(1))).astype(
+        F32)
+
+
+def ld_atss_loss_block(cls, reg, ctr, t_cls, t_reg, targets, hp=None,
+                       reduce_mean=None):
+    """LDATSSHead.loss on per-level NCHW numpy arrays.  Returns
+    dict(losses=(6, L) [loss_cls, loss_bbox, loss_ld, loss_ld_neg,
+    loss_cls_kd, loss_centerness], grads=dict(cls, reg, ctr) of the sum of all
+    entries, num_total_samples, avg_factor)."""
+    H = dict(DEFAULT_HP)
+    H.update(dict(lw_ctr=1.0, focal_alpha=0.25))
+    if hp:
+        H.update(hp)
+    rm = reduce_mean or (lambda v: v)
+    C, R = H['num_classes'], H['reg_max'] + 1
+    L = len(cls)
+    nts = max(float(rm(float(targets['num_total_pos']))), 1.0)
+    losses = np.zeros((6, L), dtype=F32)
+    state = []
+    csum = np.float32(0)
+    start = 0
+    for l in range(L):
+        n, _, h, w = cls[l].shape
+        A_l = h * w
+        stride = F32(H['strides'][l])
+        sl = slice(start, start + A_l)
+        start += A_l
+        anchors = np.tile(targets['anchors'][sl], (n, 1))
+        labels = targets['labels'][:, sl].reshape(-1)
+        lw = targets['label_weights'][:, sl].reshape(-1)
+        bt = targets['bbox_targets'][:, sl].reshape(-1, 4)
+        vlr = targets['vlr'][:, sl].reshape(-1)
+        c_r, r_r = _nchw_to_rows(cls[l]), _nchw_to_rows(reg[l])
+        k_r = _nchw_to_rows(ctr[l]).reshape(-1)
+        tc_r, tr_r = _nchw_to_rows(t_cls[l]), _nchw_to_rows(t_reg[l])
+        g_c, g_r = np.zeros_like(c_r), np.zeros_like(r_r)
+        g_k = np.zeros_like(k_r)
+        pos = np.nonzero((labels >= 0) & (labels < C))[0]
+        rem = np.nonzero(vlr > 0)[0]
+        st = dict(g_c=g_c, g_r=g_r, g_k=g_k,
+                  shapes=(cls[l].shape, reg[l].shape, ctr[l].shape))
+        # ---- FocalLoss on every anchor (ld_atss.py:80-82)
+        onehot = np.zeros_like(c_r)
+        if pos.size:
+            onehot[pos, labels[pos]] = 1
+        f, df = focal_elements(c_r, onehot, H['focal_alpha'])
+        loss_cls = F32(H['lw_cls']) * (f.sum(1, dtype=F32) * lw).sum(
+            dtype=F32) / F32(nts)
+        g_c += df * (lw * F32(H['lw_cls']) / F32(nts))[:, None]
+        loss_bbox = loss_ld = loss_kd = loss_ctr = F32(0)
+        if pos.size:
+            actr = np.stack([(anchors[pos, 0] + anchors[pos, 2]) / F32(2),
+                             (anchors[pos, 1] + anchors[pos, 3]) / F32(2)],
+                            -1) / stride
+            ct = centerness_target(anchors[pos], bt[pos])
+            wt = _sigmoid(c_r).max(1)[pos]
+            dist, p_soft = integral(r_r[pos], H['reg_max'])
+            box = distance2bbox(actr, dist)
+            tgt = bt[pos] / stride
+            # GIoU weighted by the centerness target (ld_atss.py:124-129)
+            gl, gbox = giou_loss_rows(box, tgt, H['giou_eps'])
+            loss_bbox = F32(H['lw_bbox']) * (gl * ct).sum(dtype=F32)
+            gdist = np.stack([-gbox[:, 0], -gbox[:, 1], gbox[:, 2],
+                              gbox[:, 3]], -1) * (F32(H['lw_bbox']) *
+                                                  ct)[:, None]
+            proj = np.arange(R, dtype=F32)
+            g_int = p_soft * (proj[None, None, :] - dist[:, :, None])
+            st['bbox_grad'] = (gdist[:, :, None] * g_int).reshape(-1, 4 * R)
+            # LD (ld_atss.py:118-122, avg_factor=4.0)
+            w4 = np.repeat(wt, 4)
+            kl, kg = kd_kl_rows(r_r[pos].reshape(-1, R),
+                                tr_r[pos].reshape(-1, R), H['T_ld'])
+            loss_ld = F32(H['lw_ld']) * (kl * w4).sum(dtype=F32) / F32(4)
+            g_r[pos] += (kg * (w4 * F32(H['lw_ld']) /
+                               F32(4))[:, None]).reshape(-1, 4 * R)
+            # KD on the class logits (ld_atss.py:130-134)
+            kl, kg = kd_kl_rows(c_r[pos], tc_r[pos], H['T_kd'])
+            loss_kd = F32(H['lw_kd']) * (kl * lw[pos]).sum(
+                dtype=F32) / F32(pos.size)
+            g_c[pos] += kg * (lw[pos] * F32(H['lw_kd']) /
+                              F32(pos.size))[:, None]
+            # centerness BCE (ld_atss.py:136-140)
+            xk = k_r[pos]
+            bce = _softplus(xk) - ct * xk
+            loss_ctr = F32(H['lw_ctr']) * bce.sum(dtype=F32) / F32(nts)
+            g_k[pos] = (_sigmoid(xk) - ct) * F32(H['lw_ctr']) / F32(nts)
+            st['pos'] = pos
+            csum = csum + ct.sum(dtype=F32)
+        # ---- 0.15 * LD on the VLR region (ld_atss.py:148-159)
+        loss_neg = F32(0)
+        if rem.size:
+            w4 = np.repeat(vlr[rem], 4)
+            kl, kg = kd_kl_rows(r_r[rem].reshape(-1, R),
+                                tr_r[rem].reshape(-1, R), H['T_ld'])
+            coef = F32(0.15) * F32(H['lw_ld']) / F32(4)
+            loss_neg = coef * (kl * w4).sum(dtype=F32)
+            g_r[rem] += (kg * (w4 * coef)[:, None]).reshape(-1, 4 * R)
+        losses[:, l] = [loss_cls, loss_bbox, loss_ld, loss_neg, loss_kd,
+                        loss_ctr]
+        state.append(st)
+    avg = float(rm(float(csum)))
+    if avg < 1e-12:
+        avg = 1.0
+    losses[1] /= F32(avg)
+    grads = dict(cls=[], reg=[], ctr=[])
+    for st in state:
+        if 'pos' in st:
+            st['g_r'][st['pos']] += st['bbox_grad'] / F32(avg)
+        grads['cls'].append(_rows_to_nchw(st['g_c'], st['shapes'][0]))
+        grads['reg'].append(_rows_to_nchw(st['g_r'], st['shapes'][1]))
+        grads['ctr'].append(st['g_k'].reshape(
+            st['shapes'][2][0], st['shapes'][2][2], st['shapes'][2][3])[
+                :, None])
+    return dict(losses=losses, grads=grads, num_total_samples=nts,
+                avg_factor=avg)
+
+
+# --------------------------------------------------------------------------
 # the 'gibox' imitation region
 # --------------------------------------------------------------------------
 def gi_region(cls, reg, t_cls, t_reg, prob=False, topn=10, iou_thr=0.3):

@@ -1,0 +1,213 @@
+"""GPU tests (-m gpu) of the ATSS-GFL / LDATSS head:
+the fused loss block with LD_LOSS_ATSS (FocalLoss, centerness-weighted GIoU,
+centerness BCE, LD + 0.15 x VLR-LD + KD) against the REFERENCE's
+LDATSSHead.loss outputs (tests/golden/lossblock_atss.npz): loss table within
+1e-4, gradients of the summed table wrt cls / reg / centerness element-wise;
+then the registry-level head and a whole detector step."""
+import numpy as np
+import pytest
+import torch
+
+from test_oracle_atss import CASES, check_grads, inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _head(dev, ld=True):
+    from ld_amd.config import ConfigDict
+    from ld_amd.registry import build_head
+    cfg = dict(
+        type='LDATSSHead' if ld else 'ATSSGFLHead', num_classes=80,
+        in_channels=256, stacked_convs=4, feat_channels=256,
+        anchor_generator=dict(type='AnchorGenerator', ratios=[1.0],
+                              octave_base_scale=8, scales_per_octave=1,
+                              strides=[8, 16, 32, 64, 128]),
+        bbox_coder=dict(type='DeltaXYWHBBoxCoder',
+                        target_means=[.0, .0, .0, .0],
+                        target_stds=[0.1, 0.1, 0.2, 0.2]),
+        loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0,
+                      alpha=0.25, loss_weight=1.0),
+        loss_bbox=dict(type='GIoULoss', loss_weight=2.0),
+        loss_centerness=dict(type='CrossEntropyLoss', use_sigmoid=True,
+                             loss_weight=1.0),
+        train_cfg=ConfigDict.wrap(dict(
+            assigner=dict(type='ATSSAssigner', topk=9), allowed_border=-1,
+            pos_weight=-1, debug=False)))
+    if ld:
+        cfg.update(
+            loss_ld=dict(type='KnowledgeDistillationKLDivLoss',
+                         loss_weight=0.25, T=10),
+            loss_kd=dict(type='KnowledgeDistillationKLDivLoss',
+                         loss_weight=10, T=2))
+    return build_head(cfg).to(dev)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_ldatss_loss_vs_reference(golden, name):
+    from ld_amd.heads import ATSS_LOSS_KEYS
+    dev = torch.device('cuda:0')
+    g = golden['lossblock_atss']
+    batch, sizes, hi = inputs(g, name)
+    head = _head(dev)
+    dv = {k: [t.to(dev).requires_grad_(k in ('cls', 'reg', 'ctr'))
+              for t in v] for k, v in hi.items()}
+    losses = head.loss(dv['cls'], dv['reg'], dv['ctr'],
+                       [b.to(dev) for b in batch['gt_bboxes']],
+                       [l.to(dev) for l in batch['gt_labels']],
+                       (dv['t_cls'], dv['t_reg'], None), batch['img_metas'])
+    assert list(losses.keys()) == ATSS_LOSS_KEYS
+    table = torch.stack([torch.stack(losses[k]) for k in ATSS_LOSS_KEYS])
+    total = table.sum()
+    total.backward()
+    got = table.detach().cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(got, g[name + '_losses'], rtol=1e-4, atol=1e-4)
+    grads = {k: [t.grad.cpu().numpy() for t in dv[k]]
+             for k in ('cls', 'reg', 'ctr')}
+    check_grads(g, name, grads, 5e-4, 5e-8)
+
+
+def test_ldatss_nonunit_upstream_and_oracle():
+    """Weighted sum of the loss entries (the rerun-with-upstream path) against
+    the oracle's analytic gradients scaled per key."""
+    import ld_oracle as O
+    from ld_amd import synthetic
+    dev = torch.device('cuda:0')
+    pad = (160, 224)
+    num_gt = [4, 2]
+    batch = synthetic.synthetic_batch(2, pad, pad, num_gt, 31)
+    sizes = synthetic.level_shapes(pad)
+    hi = synthetic.synthetic_head_inputs(2, sizes, seed=131)
+    hi['ctr'] = synthetic.synthetic_centerness(2, sizes, seed=131)
+    head = _head(dev)
+    dv = {k: [t.to(dev).requires_grad_(k in ('cls', 'reg', 'ctr'))
+              for t in v] for k, v in hi.items()}
+    losses = head.loss(dv['cls'], dv['reg'], dv['ctr'],
+                       [b.to(dev) for b in batch['gt_bboxes']],
+                       [l.to(dev) for l in batch['gt_labels']],
+                       (dv['t_cls'], dv['t_reg'], None), batch['img_metas'])
+    (3.0 * sum(losses['loss_centerness'])).backward()
+    t = O.get_targets(sizes, batch['img_metas'],
+                      [b.numpy() for b in batch['gt_bboxes']],
+                      [l.numpy() for l in batch['gt_labels']])
+    hn = {k: [t_.numpy() for t_ in v] for k, v in hi.items()}
+    ref = O.ld_atss_loss_block(hn['cls'], hn['reg'], hn['ctr'], hn['t_cls'],
+                               hn['t_reg'], t,
+                               hp=dict(lw_cls=0, lw_bbox=0, lw_ld=0, lw_kd=0,
+                                       lw_ctr=3.0))
+    for l in range(5):
+        np.testing.assert_allclose(dv['ctr'][l].grad.cpu().numpy(),
+                                   ref['grads']['ctr'][l], rtol=5e-4,
+                                   atol=1e-8)
+        assert float(dv['cls'][l].grad.abs().max()) == 0.0
+        assert float(dv['reg'][l].grad.abs().max()) == 0.0
+
+
+def test_atss_gfl_head_forward_and_plain_loss():
+    """ATSSGFLHead: three outputs per level from the reference's parameter
+    names; its own loss (no teacher) = the LDATSS table's cls / bbox /
+    centerness rows."""
+    dev = torch.device('cuda:0')
+    head = _head(dev, ld=False)
+    keys = set(head.state_dict())
+    assert {'atss_cls.weight', 'atss_reg.weight', 'atss_centerness.weight',
+            'cls_convs.0.conv.weight', 'reg_convs.3.gn.weight',
+            'scales.4.scale'} <= keys
+    from ld_amd import synthetic
+    pad = (128, 160)
+    sizes = synthetic.level_shapes(pad)
+    feats = [torch.randn(2, 256, h, w, device=dev) for h, w in sizes]
+    cls, reg, ctr = head(feats)
+    assert [tuple(c.shape) for c in ctr] == [(2, 1, h, w) for h, w in sizes]
+    assert cls[0].shape[1] == 80 and reg[0].shape[1] == 68
+    batch = synthetic.synthetic_batch(2, pad, pad, [3, 2], 5)
+    losses = head.forward_train(
+        feats, batch['img_metas'], [b.to(dev) for b in batch['gt_bboxes']],
+        [l.to(dev) for l in batch['gt_labels']])
+    assert list(losses.keys()) == ['loss_cls', 'loss_bbox', 'loss_centerness']
+    tot = sum(sum(v) for v in losses.values())
+    tot.backward()
+    assert torch.isfinite(tot)
+    assert head.atss_centerness.weight.grad is not None
+
+
+@pytest.mark.parametrize('name', ['tiny', 'small'])
+def test_ld_atss_train_step_vs_reference(golden, name):
+    """Whole detector step of configs/ld/ld_r50_atss_r101_1x.py (LDATSSHead
+    R50 student <- ATSS-GFL R101 teacher, output_feature=False) against the
+    reference's loss table, gradient norms and gradient projections."""
+    from ld_amd import model_zoo, synthetic
+    from ld_amd.heads import ATSS_LOSS_KEYS
+    from ld_amd.registry import build_detector
+    dev = torch.device('cuda:0')
+    g = golden['e2e_atss']
+    cfg = g[name + '_cfg']
+    pad, img_shape, bseed = tuple(cfg[:2]), tuple(cfg[2:4]), int(cfg[4])
+    num_gt = [int(x) for x in g[name + '_num_gt']]
+    det = build_detector(model_zoo.ld_atss_detector(50, 101))
+    assert list(det.state_dict().keys()) == \
+        [str(k) for k in g[name + '_student_keys']]
+    assert list(det.teacher_model.state_dict().keys()) == \
+        [str(k) for k in g[name + '_teacher_keys']]
+    det.load_state_dict(synthetic.seeded_state_dict(det.state_dict(), seed=1))
+    det.teacher_model.load_state_dict(synthetic.seeded_state_dict(
+        det.teacher_model.state_dict(), seed=2))
+    det.to(dev)
+    det.train()
+    batch = synthetic.synthetic_batch(len(num_gt), img_shape, pad, num_gt,
+                                      bseed)
+    losses = det(img=batch['img'].to(dev), img_metas=batch['img_metas'],
+                 gt_bboxes=[b.to(dev) for b in batch['gt_bboxes']],
+                 gt_labels=[l.to(dev) for l in batch['gt_labels']])
+    assert list(losses.keys()) == ATSS_LOSS_KEYS
+    table = torch.stack([torch.stack(losses[k]) for k in ATSS_LOSS_KEYS])
+    loss, log_vars = det._parse_losses(losses)
+    loss.backward()
+    got = table.detach().cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(got, g[name + '_losses'], rtol=1e-4, atol=1e-4)
+    names = [str(k) for k in g[name + '_grad_names']]
+    params = dict(det.named_parameters())
+    bad, off = [], []
+    for k, rn, pr in zip(names, g[name + '_grad_norms'],
+                         g[name + '_grad_proj']):
+        gflat = params[k].grad.double().reshape(-1).cpu().numpy()
+        if not np.isclose(np.linalg.norm(gflat), rn, rtol=5e-3, atol=1e-6):
+            bad.append((k, float(np.linalg.norm(gflat)), float(rn)))
+        for sd in (0, 1):
+            probe = synthetic.grad_probe(gflat.size, sd)
+            tol = 4 * 5e-3 * rn * np.linalg.norm(probe) / \
+                np.sqrt(gflat.size) + 1e-7
+            if abs(float(gflat @ probe) - pr[sd]) > tol:
+                off.append((k, sd))
+    assert not bad, f'{len(bad)} grad norms off: {bad[:4]}'
+    assert not off, f'{len(off)} grad projections off: {off[:4]}'
+    for k, p in params.items():
+        if not p.requires_grad:
+            assert p.grad is None, k
+
+
+def test_ld_atss_sgd_steps():
+    """Two SGDTrainer steps (fused unit-upstream backward, arena, SGD) on the
+    LD-ATSS detector: every trainable parameter receives a gradient."""
+    import os
+    from ld_amd import model_zoo, synthetic
+    from ld_amd.registry import build_detector
+    from ld_amd.train import SGDTrainer
+    dev = torch.device('cuda:0')
+    det = build_detector(model_zoo.ld_atss_detector(18, 18))
+    det.load_state_dict(synthetic.seeded_state_dict(det.state_dict(), seed=1))
+    det.teacher_model.load_state_dict(synthetic.seeded_state_dict(
+        det.teacher_model.state_dict(), seed=2))
+    det.to(dev)
+    det.train()
+    os.environ['LD_CHECK_GRADS'] = '1'
+    try:
+        tr = SGDTrainer(det, lr=0.001)
+        b = synthetic.synthetic_batch(2, (128, 160), (128, 160), [3, 2], 9)
+        d = dict(img=b['img'].to(dev), img_metas=b['img_metas'],
+                 gt_bboxes=[x.to(dev) for x in b['gt_bboxes']],
+                 gt_labels=[x.to(dev) for x in b['gt_labels']])
+        l0 = float(tr.step(d)['loss'])
+        l1 = float(tr.step(d)['loss'])
+    finally:
+        os.environ.pop('LD_CHECK_GRADS', None)
+    assert np.isfinite(l0) and np.isfinite(l1)
