@@ -801,10 +801,20 @@ __global__ __launch_bounds__(256) void to_c8_kernel(const float* __restrict__ x,
 // of one wave execute in order: no s_barrier anywhere.
 constexpr int WB_J = 32;             // positions per step
 constexpr int WB_PITCH = 2 * WB_J + 16;  // bytes per LDS row
+// VY / VX: the dY / X tile is fetched four positions per lane (one 16-byte load,
+// two v_cvt_pk, one 8-byte LDS write: 8 load instructions per operand and step
+// instead of 32 + 32 conversions + 32 two-byte LDS writes).  Four consecutive
+// positions of one channel row are contiguous whenever Pout % 4 == 0 (VY) and,
+// for X, when input position == output position (1x1, stride 1, no padding:
+// VX).  A 3x3 conv keeps the per-element X path (tap shifts, padding).  The LDS
+// image and the MFMA order are those of the per-element kernel: same bits.
+template <bool VY, bool VX>
 __global__ __launch_bounds__(64, 2) void conv_wgrad_wave_bf16_kernel(WgradK a) {
   constexpr int TB = 64;
   constexpr int RG = 64 / WB_J;   // rows covered by one load instruction (2)
   constexpr int RPER = TB / RG;   // rows per lane and operand (32)
+  constexpr int RG4 = 64 / (WB_J / 4);  // rows per 16-byte load instruction (8)
+  constexpr int RPER4 = TB / RG4;       // 16-byte loads per lane and operand (8)
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TB * WB_PITCH];
   __shared__ int s_geo[LD_MAX_LEVELS * 6];
   unsigned char* As = lds;                  // [TB][WB_PITCH]  dY rows (co)
@@ -845,8 +855,10 @@ __global__ __launch_bounds__(64, 2) void conv_wgrad_wave_bf16_kernel(WgradK a) {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  const int kq = lane % WB_J;  // this lane's j offset within a step
-  const int r0 = lane / WB_J;  // first row; rows r0 + RG*i
+  const int kq = lane % WB_J;  // per-element path: this lane's j within a step
+  const int r0 = lane / WB_J;  // ... and its first row; rows r0 + RG*i
+  const int kq4 = lane % (WB_J / 4);  // 16-byte path: group of four positions
+  const int r4 = lane / (WB_J / 4);   // ... first row; rows r4 + RG4*i
 
   floatx16 acc[2][2];
 #pragma unroll
@@ -858,58 +870,100 @@ __global__ __launch_bounds__(64, 2) void conv_wgrad_wave_bf16_kernel(WgradK a) {
 
   const rsrc_t rx = make_rsrc(a.x, a.x_bytes);
   const rsrc_t ry = make_rsrc(a.dy, a.dy_bytes);
-  float a_st[RPER], b_st[RPER];
+  float a_st[VY ? 1 : RPER], b_st[VX ? 1 : RPER];
+  floatx4_t a_v4[VY ? RPER4 : 1], b_v4[VX ? RPER4 : 1];
   const bool rows_full = (m0 + TB <= Cout) && (c0 + TB <= Cin);
 
   auto load_tile = [&](int j0) {
-    const int j = j0 + kq;
     unsigned vy = kOOB, vx = kOOB;
-    if (j < jend) {
-      const int n = j / Pout, p = j - n * Pout;
-      int l = 0;
-      for (int i = 1; i < nlev; ++i)
-        if (p >= s_geo[i * 6 + 5]) l = i;
-      const int Hin = s_geo[l * 6 + 0], Win = s_geo[l * 6 + 1];
-      const int Wout = s_geo[l * 6 + 3];
-      const int r = p - s_geo[l * 6 + 5];
-      const int ho = r / Wout, wo = r - ho * Wout;
-      const int hi = ho * stride - pad + kh, wi = wo * stride - pad + kw;
-      vy = (unsigned)(n * Cout * Pout + (m0 + r0) * Pout + p) * 4u;
-      if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win)
-        vx = (unsigned)(n * Cin * Pin + (c0 + r0) * Pin + s_geo[l * 6 + 4] +
-                        hi * Win + wi) * 4u;
+    if (!VY || !VX) {  // per-element geometry
+      const int j = j0 + kq;
+      if (j < jend) {
+        const int n = j / Pout, p = j - n * Pout;
+        int l = 0;
+        for (int i = 1; i < nlev; ++i)
+          if (p >= s_geo[i * 6 + 5]) l = i;
+        const int Hin = s_geo[l * 6 + 0], Win = s_geo[l * 6 + 1];
+        const int Wout = s_geo[l * 6 + 3];
+        const int r = p - s_geo[l * 6 + 5];
+        const int ho = r / Wout, wo = r - ho * Wout;
+        const int hi = ho * stride - pad + kh, wi = wo * stride - pad + kw;
+        vy = (unsigned)(n * Cout * Pout + (m0 + r0) * Pout + p) * 4u;
+        if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win)
+          vx = (unsigned)(n * Cin * Pin + (c0 + r0) * Pin + s_geo[l * 6 + 4] +
+                          hi * Win + wi) * 4u;
+      }
+    }
+    unsigned vy4 = kOOB, vx4 = kOOB;
+    if (VY || VX) {  // four consecutive positions of one image (Pout % 4 == 0)
+      const int j = j0 + 4 * kq4;
+      if (j < jend) {
+        const int n = j / Pout, p = j - n * Pout;
+        vy4 = (unsigned)(n * Cout * Pout + (m0 + r4) * Pout + p) * 4u;
+        vx4 = (unsigned)(n * Cin * Pin + (c0 + r4) * Pin + p) * 4u;  // VX: Pin == Pout
+      }
     }
     // row offsets advance in SGPRs inside the step (see conv_wgrad_wave_kernel)
     unsigned da = (unsigned)RG * Pout * 4u, db = (unsigned)RG * Pin * 4u;
-    asm volatile("" : "+s"(da), "+s"(db));
-    unsigned sa = 0, sb = 0;
-    if (rows_full) {
+    unsigned da4 = (unsigned)RG4 * Pout * 4u, db4 = (unsigned)RG4 * Pin * 4u;
+    asm volatile("" : "+s"(da), "+s"(db), "+s"(da4), "+s"(db4));
+    int na = (Cout - m0 - r0 + RG - 1) / RG, nb = (Cin - c0 - r0 + RG - 1) / RG;
+    int na4 = (Cout - m0 - r4 + RG4 - 1) / RG4, nb4 = (Cin - c0 - r4 + RG4 - 1) / RG4;
+    if (rows_full) na = nb = na4 = nb4 = 1 << 20;
+    asm volatile("" : "+v"(na), "+v"(nb), "+v"(na4), "+v"(nb4));
+    if (VY) {
+      unsigned so = 0;
 #pragma unroll
-      for (int i = 0; i < RPER; ++i) {
-        a_st[i] = buf_load(ry, vy, sa);
-        b_st[i] = buf_load(rx, vx, sb);
-        sa += da;
-        sb += db;
+      for (int i = 0; i < RPER4; ++i) {
+        a_v4[i] = __builtin_bit_cast(floatx4_t, buf_load16(ry, i < na4 ? vy4 : kOOB, so));
+        so += da4;
       }
     } else {
-      int na = (Cout - m0 - r0 + RG - 1) / RG, nb = (Cin - c0 - r0 + RG - 1) / RG;
-      asm volatile("" : "+v"(na), "+v"(nb));
+      unsigned so = 0;
 #pragma unroll
       for (int i = 0; i < RPER; ++i) {
-        a_st[i] = buf_load(ry, i < na ? vy : kOOB, sa);
-        b_st[i] = buf_load(rx, i < nb ? vx : kOOB, sb);
-        sa += da;
-        sb += db;
+        a_st[i] = buf_load(ry, i < na ? vy : kOOB, so);
+        so += da;
+      }
+    }
+    if (VX) {
+      unsigned so = 0;
+#pragma unroll
+      for (int i = 0; i < RPER4; ++i) {
+        b_v4[i] = __builtin_bit_cast(floatx4_t, buf_load16(rx, i < nb4 ? vx4 : kOOB, so));
+        so += db4;
+      }
+    } else {
+      unsigned so = 0;
+#pragma unroll
+      for (int i = 0; i < RPER; ++i) {
+        b_st[i] = buf_load(rx, i < nb ? vx : kOOB, so);
+        so += db;
       }
     }
   };
   auto store_tile = [&]() {
-    __bf16* ap = (__bf16*)(As + r0 * WB_PITCH) + kq;
-    __bf16* bp = (__bf16*)(Bs + r0 * WB_PITCH) + kq;
+    if (VY) {
+      unsigned char* ap = As + r4 * WB_PITCH + kq4 * 8;
 #pragma unroll
-    for (int i = 0; i < RPER; ++i) {
-      ap[RG * i * (WB_PITCH / 2)] = (__bf16)a_st[i];
-      bp[RG * i * (WB_PITCH / 2)] = (__bf16)b_st[i];
+      for (int i = 0; i < RPER4; ++i)
+        *(uintx2*)(ap + RG4 * i * WB_PITCH) =
+            __builtin_bit_cast(uintx2, __builtin_convertvector(a_v4[i], bf16x4));
+    } else {
+      __bf16* ap = (__bf16*)(As + r0 * WB_PITCH) + kq;
+#pragma unroll
+      for (int i = 0; i < RPER; ++i) ap[RG * i * (WB_PITCH / 2)] = (__bf16)a_st[i];
+    }
+    if (VX) {
+      unsigned char* bp = Bs + r4 * WB_PITCH + kq4 * 8;
+#pragma unroll
+      for (int i = 0; i < RPER4; ++i)
+        *(uintx2*)(bp + RG4 * i * WB_PITCH) =
+            __builtin_bit_cast(uintx2, __builtin_convertvector(b_v4[i], bf16x4));
+    } else {
+      __bf16* bp = (__bf16*)(Bs + r0 * WB_PITCH) + kq;
+#pragma unroll
+      for (int i = 0; i < RPER; ++i) bp[RG * i * (WB_PITCH / 2)] = (__bf16)b_st[i];
     }
   };
 
@@ -1587,7 +1641,26 @@ int ld_bf16_wgrad_launch(const WgradK& k, hipStream_t stream) {
     return (int)hipGetLastError();
   }
   const int blocks = ((k.Cout + 63) / 64) * ((k.Cin + 63) / 64) * ntaps * k.splits;
-  hipLaunchKernelGGL(conv_wgrad_wave_bf16_kernel, dim3(blocks), dim3(64), 0, stream, k);
+  // 16-byte operand loads where four consecutive positions are contiguous
+  const char* env = getenv("LD_CONV_BF16_WGRAD_VEC");
+  const bool allow = !(env && env[0] == '0');
+  const bool vy = allow && k.Pout % 4 == 0 && ((uintptr_t)k.dy % 16) == 0;
+  const bool vx = vy && k.KH == 1 && k.KW == 1 && k.g.stride == 1 && k.g.pad == 0 &&
+                  k.Pin == k.Pout && ((uintptr_t)k.x % 16) == 0;
+  // measured (profiles/r02_layers_bf16_c8.csv vs the VY-only run): both
+  // operands vectorised (+3-5 % on the 1x1 layers) pays, dY alone next to a
+  // per-element X (3x3: two geometries per lane) is 10 % SLOWER -- the kernel is
+  // bound by the latency of its one-step-ahead loads, not by instruction count
+  const bool vy_only = vy && !vx && env && env[0] == 'y';  // test hook
+  if (vx)
+    hipLaunchKernelGGL((conv_wgrad_wave_bf16_kernel<true, true>), dim3(blocks), dim3(64),
+                       0, stream, k);
+  else if (vy_only)
+    hipLaunchKernelGGL((conv_wgrad_wave_bf16_kernel<true, false>), dim3(blocks), dim3(64),
+                       0, stream, k);
+  else
+    hipLaunchKernelGGL((conv_wgrad_wave_bf16_kernel<false, false>), dim3(blocks),
+                       dim3(64), 0, stream, k);
   return (int)hipGetLastError();
 }
 

@@ -381,3 +381,30 @@ def test_bn_act_c8_side_output(bf16_mode):
     want = outs[1].to(torch.bfloat16).reshape(N, c // 8, 8, P).permute(
         0, 1, 3, 2).reshape(-1)
     assert torch.equal(img, want)
+
+
+def test_bf16_wgrad_vectorised_loads_same_bits(bf16_mode, monkeypatch):
+    """The 16-byte-load variants of the wave-private bf16 weight gradient (dY
+    always when Pout % 4 == 0, X too for 1x1 stride-1 convs) build the same LDS
+    image as the per-element kernel: identical weight gradients."""
+    from ld_amd import layers as Y
+    dev = _dev()
+    ran = 0
+    for case in BF16_CASES:
+        name, N, cin, cout, k, stride, pad, levels = case
+        P = sum(h * w for h, w in levels)
+        g = torch.Generator().manual_seed(len(name) + cout)
+        x = torch.randn(N, cin, P, generator=g).to(dev)
+        w = (torch.randn(cout, cin, k, k, generator=g) * 0.05).to(dev)
+        outs = []
+        for vec in ('0', '1', 'y'):  # per-element, default, dY-only vectorised
+            monkeypatch.setenv('LD_CONV_BF16_WGRAD_VEC', vec)
+            wd = w.clone().requires_grad_(True)
+            y, _ = Y.conv2d(x, wd, None, stride, pad, levels)
+            go = torch.Generator().manual_seed(3)
+            y.backward(torch.randn(y.shape, generator=go).to(dev))
+            outs.append(wd.grad)
+        assert torch.equal(outs[0], outs[1]), name
+        assert torch.equal(outs[0], outs[2]), name
+        ran += 1
+    assert ran >= 8
