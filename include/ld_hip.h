@@ -104,6 +104,13 @@ typedef struct {
  * ld_head.py:597-611) instead of the 'finegrained' IoU rule (:594-596) */
 #define LD_IM_CENTER_INSIDE 2
 #define LD_LOSS_ATSS 4
+/* with LD_LOSS_ATSS: LDFCOSHead over FCOSGFLHead (ld_fcos_head.py:46-217).
+ * Points instead of anchors: the cell centre is (x + 0.5, y + 0.5) strides,
+ * bbox_targets hold (left, top, right, bottom) distances in pixels
+ * (ld_fcos_targets), the centerness target comes from those distances, and the
+ * VLR term is weighted by vlr * max_c sigmoid(cls) (the "remain" points,
+ * ld_fcos_head.py:117-131; set lw_ld_vlr = lw_ld for its 0.25 factor). */
+#define LD_LOSS_FCOS 8
 
 /* ---- library ------------------------------------------------------------ */
 /* ABI version of this header; bump on any signature change. */
@@ -159,6 +166,18 @@ int ld_atss_targets_ex(const ld_geom_t* geom, const ld_loss_hp_t* hp,
 /* Materialise the anchors (A, 4) -- only for API compatibility
  * (AnchorGenerator.grid_anchors, anchor_generator.py:207-270); the kernels
  * never read them. */
+/* FCOS point targets for the whole batch (LDFCOSHead.get_targets,
+ * ld_fcos_head.py:261-414): same output arrays as ld_atss_targets; bbox_targets
+ * = (l, t, r, b) distances of the assigned object, vlr = 1 on the points that
+ * lie inside some gt box but are assigned to none ("remain"), label_weights = 1,
+ * im = 0.  regress_ranges: HOST float[2 * num_levels] (lo, hi per level).
+ * counts[N + 2L] = total number of positives (no per-image floor). */
+int ld_fcos_targets(const ld_geom_t* geom, int num_classes,
+                    const float* regress_ranges, int center_sampling,
+                    float center_sample_radius, const float* gt_bboxes,
+                    const int64_t* gt_labels, const int32_t* num_gt, int max_gt,
+                    int64_t* labels, float* label_weights, float* bbox_targets,
+                    float* vlr, float* im, int32_t* counts, ld_stream_t stream);
 int ld_grid_anchors(const ld_geom_t* geom, float* anchors, ld_stream_t stream);
 
 /* ---- fused loss block ----------------------------------------------------
@@ -187,6 +206,15 @@ int ld_loss_prepass(const ld_geom_t* geom, const ld_loss_hp_t* hp,
                     const int32_t* counts, float* weight_targets, float* score,
                     float* norm, void* workspace, size_t workspace_bytes,
                     ld_stream_t stream);
+
+/* The same with the VLR array: needed by LD_LOSS_FCOS (weight_targets are also
+ * produced where vlr > 0); vlr may be NULL otherwise. */
+int ld_loss_prepass_ex(const ld_geom_t* geom, const ld_loss_hp_t* hp,
+                       const ld_maps_t* cls, const ld_maps_t* reg,
+                       const int64_t* labels, const float* bbox_targets,
+                       const float* vlr, const int32_t* counts,
+                       float* weight_targets, float* score, float* norm,
+                       void* workspace, size_t workspace_bytes, ld_stream_t stream);
 
 /* Forward + gradient of every loss term.  grad_* have the same descriptors
  * as their inputs and are fully overwritten.  `upstream` (device,

@@ -111,22 +111,38 @@ __device__ __forceinline__ void load_side(const ld_maps_t& m, const Cell& c,
 }
 
 // ------------------------------------------------------------- prepass ----
+// target box in stride units: xyxy / stride (anchor heads) or the point +-
+// (l, t, r, b) / stride (FCOS: distance2bbox(points / stride, targets / stride),
+// ld_fcos_head.py:82-87)
+__device__ __forceinline__ Box target_box(bool fcos, float cx, float cy, const float4& t,
+                                          float stride) {
+  if (fcos)
+    return Box{cx - t.x / stride, cy - t.y / stride, cx + t.z / stride,
+               cy + t.w / stride};
+  return Box{t.x / stride, t.y / stride, t.z / stride, t.w / stride};
+}
+
 __global__ __launch_bounds__(kWave) void loss_prepass_kernel(
     ld_geom_t geom, ld_loss_hp_t hp, BlockMap bm, ld_maps_t cls, ld_maps_t reg,
     const int64_t* __restrict__ labels, const float* __restrict__ bbox_targets,
-    float* __restrict__ weight_targets, float* __restrict__ score,
+    const float* __restrict__ vlr, float* __restrict__ weight_targets, float* __restrict__ score,
     float* __restrict__ partial) {
   const Cell c = locate(geom, bm);
+  const bool fcos = (hp.flags & LD_LOSS_FCOS) != 0;
   float wt = 0.0f, sc = 0.0f;
   if (c.active) {
     const int64_t lab = labels[c.o];
-    if (lab >= 0 && lab < hp.num_classes) {
+    const bool is_pos = lab >= 0 && lab < hp.num_classes;
+    if (is_pos || (fcos && vlr != nullptr && vlr[c.o] > 0.0f)) {
       const int CC = hp.cls_channels > 0 ? hp.cls_channels : hp.num_classes;
       float m = *chan_ptr(cls, c, 0);
       for (int ch = 1; ch < CC; ++ch) m = fmaxf(m, *chan_ptr(cls, c, ch));
       // LDHead: max_c sigmoid(x_c) == sigmoid(max_c x_c) (ld_head.py:198-199);
-      // LDv2Head: the map already holds probabilities (ld_gflv2.py:200)
+      // LDv2Head: the map already holds probabilities (ld_gflv2.py:200);
+      // LDFCOSHead also needs it on the "remain" points (ld_fcos_head.py:122)
       wt = (hp.flags & LD_LOSS_PROB_CLS) ? m : ld::sigmoidf_(m);
+    }
+    if (is_pos) {
       float e[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -135,13 +151,19 @@ __global__ __launch_bounds__(kWave) void loss_prepass_kernel(
         e[s] = ld::softmax_expect<K17>(v, p);
       }
       const float stride = (float)geom.lv[c.l].stride;
-      // anchor centre / stride == (x, y) exactly (ld_head.py:196)
-      const float cx = (float)c.x, cy = (float)c.y;
+      // anchor centre / stride == (x, y) exactly (ld_head.py:196); FCOS points
+      // sit at (x + 0.5, y + 0.5) strides (stride // 2 / stride, even strides)
+      const float cx = (float)c.x + (fcos ? 0.5f : 0.0f);
+      const float cy = (float)c.y + (fcos ? 0.5f : 0.0f);
       const Box box{cx - e[0], cy - e[1], cx + e[2], cy + e[3]};
       const float4 t = reinterpret_cast<const float4*>(bbox_targets)[c.o];
-      const Box tgt{t.x / stride, t.y / stride, t.z / stride, t.w / stride};
+      const Box tgt = target_box(fcos, cx, cy, t, stride);
       sc = ld::iou_pair(box, tgt);
-      if (hp.flags & LD_LOSS_ATSS) {
+      if (fcos) {
+        // fcos_gfl_head.py:705-721 on the (l, t, r, b) targets
+        sc = sqrtf((fminf(t.x, t.z) / fmaxf(t.x, t.z)) *
+                   (fminf(t.y, t.w) / fmaxf(t.y, t.w)));
+      } else if (hp.flags & LD_LOSS_ATSS) {
         // centerness target (atss_gfl_head.py:312-331), image pixels; the
         // anchor centre is (x, y) * stride exactly
         const float ax = cx * stride, ay = cy * stride;
@@ -259,10 +281,12 @@ __global__ __launch_bounds__(kBlk) void loss_pos_kernel(
         e[s] = ld::softmax_expect<K17>(sv, p);
       }
       const float stride = (float)geom.lv[c.l].stride;
-      const float cx = (float)c.x, cy = (float)c.y;
+      const bool fcos = (hp.flags & LD_LOSS_FCOS) != 0;
+      const float cx = (float)c.x + (fcos ? 0.5f : 0.0f);
+      const float cy = (float)c.y + (fcos ? 0.5f : 0.0f);
       const Box box{cx - e[0], cy - e[1], cx + e[2], cy + e[3]};
       const float4 t = reinterpret_cast<const float4*>(bbox_targets)[c.o];
-      const Box tgt{t.x / stride, t.y / stride, t.z / stride, t.w / stride};
+      const Box tgt = target_box(fcos, cx, cy, t, stride);
       float iou, g[4];
       const float gl = ld::giou_loss_grad(box, tgt, hp.giou_eps, &iou, g);
       s_bbox = wt * gl;
@@ -303,7 +327,10 @@ __global__ __launch_bounds__(kBlk) void loss_reg_dense_kernel(
   if (c.active) {
     const int64_t lab = labels[c.o];
     const bool pos = lab >= 0 && lab < hp.num_classes;
-    const float v = vlr[c.o];
+    // VLR weight: the region value itself (LDHead / LDATSSHead); for LDFCOSHead
+    // the "remain" flag times max_c sigmoid(cls) (ld_fcos_head.py:122-123)
+    float v = vlr[c.o];
+    if ((hp.flags & LD_LOSS_FCOS) && v > 0.0f) v *= weight_targets[c.o];
     const bool rem = v > 0.0f;
     float gr[K17];
 #pragma unroll
@@ -354,13 +381,16 @@ __global__ __launch_bounds__(kBlk) void loss_reg_dense_kernel(
         const float inv_avg = 1.0f / avg_divisor(hp, norm);
         const float c_dfl = up_dfl * hp.lw_dfl * wt * 0.25f * inv_avg;
         const float stride = (float)geom.lv[c.l].stride;
-        const float cx = (float)c.x, cy = (float)c.y;
+        const bool fcos = (hp.flags & LD_LOSS_FCOS) != 0;
+        const float cx = (float)c.x + (fcos ? 0.5f : 0.0f);
+        const float cy = (float)c.y + (fcos ? 0.5f : 0.0f);
         const float4 t = reinterpret_cast<const float4*>(bbox_targets)[c.o];
+        const Box tb = target_box(fcos, cx, cy, t, stride);
         const float rm = (float)hp.reg_max;
-        const float dist = side == 0   ? cx - t.x / stride
-                           : side == 1 ? cy - t.y / stride
-                           : side == 2 ? t.z / stride - cx
-                                       : t.w / stride - cy;
+        const float dist = side == 0   ? cx - tb.x1
+                           : side == 1 ? cy - tb.y1
+                           : side == 2 ? tb.x2 - cx
+                                       : tb.y2 - cy;
         const float ytgt = ld::clamp_dist(dist, rm);
         float p[K17];
         const float e = ld::softmax_expect<K17>(sv, p);
@@ -861,9 +891,23 @@ extern "C" int ld_loss_prepass(const ld_geom_t* geom, const ld_loss_hp_t* hp,
                                const int64_t* labels, const float* bbox_targets,
                                const int32_t* counts, float* weight_targets,
                                float* score, float* norm, void* workspace,
-                               size_t workspace_bytes, ld_stream_t stream_) {
+                               size_t workspace_bytes, ld_stream_t stream) {
+  return ld_loss_prepass_ex(geom, hp, cls, reg, labels, bbox_targets, nullptr, counts,
+                            weight_targets, score, norm, workspace, workspace_bytes,
+                            stream);
+}
+
+extern "C" int ld_loss_prepass_ex(const ld_geom_t* geom, const ld_loss_hp_t* hp,
+                                  const ld_maps_t* cls, const ld_maps_t* reg,
+                                  const int64_t* labels, const float* bbox_targets,
+                                  const float* vlr, const int32_t* counts,
+                                  float* weight_targets, float* score, float* norm,
+                                  void* workspace, size_t workspace_bytes,
+                                  ld_stream_t stream_) {
   if (int e = check_geom(geom)) return e;
   if (int e = check_hp(hp)) return e;
+  if ((hp->flags & LD_LOSS_FCOS) && (!vlr || !(hp->flags & LD_LOSS_ATSS)))
+    return LD_EINVAL;
   if (!cls || !reg || !labels || !bbox_targets || !counts || !weight_targets ||
       !score || !norm)
     return LD_EINVAL;
@@ -874,7 +918,7 @@ extern "C" int ld_loss_prepass(const ld_geom_t* geom, const ld_loss_hp_t* hp,
   float* partial = (float*)workspace;
   dim3 grid(bm.blocks_per_img, geom->num_imgs);
   hipLaunchKernelGGL(loss_prepass_kernel, grid, dim3(kWave), 0, stream, *geom,
-                     *hp, bm, *cls, *reg, labels, bbox_targets, weight_targets,
+                     *hp, bm, *cls, *reg, labels, bbox_targets, vlr, weight_targets,
                      score, partial);
   const int nparts = geom->num_imgs * bm.blocks_per_img;
   hipLaunchKernelGGL(loss_norm_kernel, dim3(1), dim3(256), 0, stream, nparts,

@@ -336,6 +336,100 @@ __global__ void atss_counts_finalize(int N, int L, int32_t* counts) {
   }
 }
 
+// ------------------------------------------------------ FCOS point targets ---
+// LDFCOSHead._get_target_single (ld_fcos_head.py:261-353) for every point of
+// every image: the object with the smallest area among those whose (centre-
+// sampled) box contains the point and whose largest side distance falls in the
+// level's regress range; ties keep the lower gt index (torch.min's first
+// minimum).  Points inside some gt box but assigned to none are the head's
+// "remain" set (label num_classes + 1 in the reference): reported as background
+// with vlr = 1.  bbox_targets = (left, top, right, bottom) distances in pixels.
+struct FcosCfg {
+  float lo[LD_MAX_LEVELS], hi[LD_MAX_LEVELS];
+  float radius;
+  int center_sampling;
+};
+
+__global__ __launch_bounds__(kBlock) void fcos_dense_kernel(
+    ld_geom_t geom, int num_classes, FcosCfg cfg, const float* __restrict__ gt_bboxes,
+    const int64_t* __restrict__ gt_labels, const int32_t* __restrict__ num_gt,
+    int max_gt, int64_t* __restrict__ labels, float* __restrict__ label_weights,
+    float* __restrict__ bbox_targets, float* __restrict__ vlr, float* __restrict__ im,
+    int32_t* __restrict__ counts) {
+  const int n = blockIdx.y;
+  const int a = blockIdx.x * kBlock + threadIdx.x;
+  const int A = geom.num_anchors, N = geom.num_imgs;
+  if (a >= A) return;
+  const int l = level_of(geom, a);
+  const ld_level_t lv = geom.lv[l];
+  const int r = a - lv.offset;
+  const int y = r / lv.W, x = r - y * lv.W;
+  // fcos_gfl_head.py:548-558: point = index * stride + stride // 2
+  const float px = (float)(x * lv.stride + lv.stride / 2);
+  const float py = (float)(y * lv.stride + lv.stride / 2);
+  const int G = num_gt[n];
+  const float INF = 1e8f;
+  float best = INF;
+  int arg = 0;
+  bool in_some = false;
+  const float sr = (float)lv.stride * cfg.radius;
+  for (int g = 0; g < G; ++g) {
+    const float* gp = gt_bboxes + ((size_t)n * max_gt + g) * 4;
+    const float x0 = gp[0], y0 = gp[1], x1 = gp[2], y1 = gp[3];
+    const float le = px - x0, ri = x1 - px, to = py - y0, bo = y1 - py;
+    const float mn = fminf(fminf(le, to), fminf(ri, bo));
+    const float mx = fmaxf(fmaxf(le, to), fmaxf(ri, bo));
+    bool inside;
+    if (cfg.center_sampling) {
+      const float cx = (x0 + x1) / 2, cy = (y0 + y1) / 2;
+      const float xm = cx - sr, ym = cy - sr, xM = cx + sr, yM = cy + sr;
+      const float c0 = xm > x0 ? xm : x0, c1 = ym > y0 ? ym : y0;
+      const float c2 = xM > x1 ? x1 : xM, c3 = yM > y1 ? y1 : yM;
+      inside = fminf(fminf(px - c0, py - c1), fminf(c2 - px, c3 - py)) > 0.0f;
+    } else {
+      inside = mn > 0.0f;
+    }
+    const bool in_range = mx >= cfg.lo[l] && mx <= cfg.hi[l];
+    float area = (x1 - x0) * (y1 - y0);
+    if (!inside || !in_range) area = INF;
+    if (area < best) {
+      best = area;
+      arg = g;
+    }
+    in_some = in_some || mn > 0.0f;
+  }
+  const size_t o = (size_t)n * A + a;
+  int64_t lab = num_classes;
+  float bt[4] = {0.f, 0.f, 0.f, 0.f}, vl = 0.0f;
+  if (G > 0) {
+    const float* gp = gt_bboxes + ((size_t)n * max_gt + arg) * 4;
+    bt[0] = px - gp[0];
+    bt[1] = py - gp[1];
+    bt[2] = gp[2] - px;
+    bt[3] = gp[3] - py;
+    if (best != INF) {
+      lab = gt_labels[(size_t)n * max_gt + arg];
+      atomicAdd(counts + n, 1);
+      atomicAdd(counts + N + l, 1);
+    } else if (in_some) {
+      vl = 1.0f;
+    }
+  }
+  labels[o] = lab;
+  label_weights[o] = 1.0f;  // FCOS has no valid-region mask and no loss weights
+  reinterpret_cast<float4*>(bbox_targets)[o] = make_float4(bt[0], bt[1], bt[2], bt[3]);
+  vlr[o] = vl;
+  im[o] = 0.0f;
+}
+
+__global__ void fcos_counts_finalize(int N, int L, int32_t* counts) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int s = 0;
+    for (int i = 0; i < N; ++i) s += counts[i];  // ld_fcos_head.py:186-189
+    counts[N + 2 * L] = s;
+  }
+}
+
 __global__ void grid_anchors_kernel(ld_geom_t geom, float* __restrict__ out) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= geom.num_anchors) return;
@@ -436,6 +530,38 @@ extern "C" int ld_atss_targets_ex(const ld_geom_t* geom, const ld_loss_hp_t* hp,
                      max_overlaps);
   hipLaunchKernelGGL(atss_counts_finalize, dim3(1), dim3(64), 0, stream, N, L,
                      counts);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_fcos_targets(const ld_geom_t* geom, int num_classes,
+                               const float* regress_ranges, int center_sampling,
+                               float center_sample_radius, const float* gt_bboxes,
+                               const int64_t* gt_labels, const int32_t* num_gt,
+                               int max_gt, int64_t* labels, float* label_weights,
+                               float* bbox_targets, float* vlr, float* im,
+                               int32_t* counts, ld_stream_t stream_) {
+  if (int e = check_geom(geom)) return e;
+  if (!regress_ranges || !labels || !label_weights || !bbox_targets || !vlr || !im ||
+      !counts || !num_gt || max_gt < 0 || num_classes < 1)
+    return LD_EINVAL;
+  if (max_gt > 0 && (!gt_bboxes || !gt_labels)) return LD_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int N = geom->num_imgs, A = geom->num_anchors, L = geom->num_levels;
+  FcosCfg cfg;
+  for (int l = 0; l < LD_MAX_LEVELS; ++l) {
+    cfg.lo[l] = l < L ? regress_ranges[2 * l] : 0.0f;
+    cfg.hi[l] = l < L ? regress_ranges[2 * l + 1] : 0.0f;
+  }
+  cfg.radius = center_sample_radius;
+  cfg.center_sampling = center_sampling;
+  hipError_t err;
+  if ((err = hipMemsetAsync(counts, 0, sizeof(int32_t) * (N + 2 * L + 1), stream)))
+    return (int)err;
+  hipLaunchKernelGGL(fcos_dense_kernel, dim3((A + kBlock - 1) / kBlock, N), dim3(kBlock),
+                     0, stream, *geom, num_classes, cfg, gt_bboxes, gt_labels, num_gt,
+                     max_gt > 0 ? max_gt : 1, labels, label_weights, bbox_targets, vlr,
+                     im, counts);
+  hipLaunchKernelGGL(fcos_counts_finalize, dim3(1), dim3(64), 0, stream, N, L, counts);
   return (int)hipGetLastError();
 }
 

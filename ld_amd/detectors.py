@@ -188,6 +188,11 @@ class ATSS(SingleStageDetector):
 
 
 @DETECTORS.register_module()
+class FCOS(SingleStageDetector):
+    """fcos.py:6-17 (the detector type of configs/gfl/fcos_gfl_*.py)."""
+
+
+@DETECTORS.register_module()
 class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
     """kd_one_stage.py:12-108: student + frozen teacher (hidden from
     ``parameters()`` / ``state_dict()``), dual forward, LD loss."""

@@ -2,6 +2,8 @@
 mmdet/models/necks/fpn.py:11-221) on the HIP kernels."""
 import torch.nn as nn
 
+import torch
+
 from . import layers as Y
 from .cnn import Conv2d, ConvModule, xavier_init
 from .registry import NECKS
@@ -22,8 +24,6 @@ class FPN(nn.Module):
             raise AssertionError('in_channels must be a list')
         if dict(upsample_cfg) != dict(mode='nearest'):
             raise NotImplementedError('only nearest top-down upsampling')
-        if relu_before_extra_convs:
-            raise NotImplementedError('relu_before_extra_convs')
         if not isinstance(add_extra_convs, (str, bool)):
             raise AssertionError('add_extra_convs: str or bool')
         n_in = len(in_channels)
@@ -71,6 +71,21 @@ class FPN(nn.Module):
             if isinstance(m, Conv2d):
                 xavier_init(m, distribution='uniform')
 
+    def _relu(self, x):
+        """F.relu as the library's affine + ReLU launch with the identity
+        affine (scale = 1 / sqrt(1 + 0) = 1 and shift = 0 exactly)."""
+        c = x.shape[1]
+        if getattr(self, '_relu_c', None) is None or \
+                self._relu_c[0].device != x.device:
+            one = torch.ones(c, device=x.device)
+            zero = torch.zeros(c, device=x.device)
+            self._relu_c = (one, zero)
+        one, zero = self._relu_c
+        n, _, h, w = x.shape
+        y = Y.bn_act(x.reshape(n, c, h * w), one, zero, zero, one, 0.0,
+                     relu=True)
+        return y.reshape(n, c, h, w)
+
     def forward(self, inputs):
         """fpn.py:170-221."""
         assert len(inputs) == len(self.in_channels)
@@ -93,5 +108,8 @@ class FPN(nn.Module):
                 src = outs[-1]
             outs.append(self.fpn_convs[used](src))
             for i in range(used + 1, self.num_outs):
-                outs.append(self.fpn_convs[i](outs[-1]))
+                prev = outs[-1]
+                if self.relu_before_extra_convs:  # fpn.py:213-216
+                    prev = self._relu(prev)
+                outs.append(self.fpn_convs[i](prev))
         return tuple(outs)

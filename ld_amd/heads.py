@@ -702,6 +702,227 @@ class LDATSSHead(ATSSGFLHead):
         return self._atss_loss_dict(table, ATSS_LOSS_KEYS)
 
 
+INF = 1e8
+
+
+@HEADS.register_module()
+class FCOSGFLHead(nn.Module):
+    """fcos_gfl_head.py:52-346 over anchor_free_head.py:15-130: the anchor-free
+    FCOS head with a general-distribution box branch.  Parameters
+    ``cls_convs / reg_convs / conv_cls / conv_reg / conv_centerness / scales``
+    as in the reference; forward returns (cls_scores, bbox_preds,
+    centernesses); points are (x, y) * stride + stride // 2."""
+
+    def __init__(self, num_classes, in_channels, feat_channels=256,
+                 stacked_convs=4, strides=(4, 8, 16, 32, 64),
+                 dcn_on_last_conv=False, conv_bias='auto',
+                 regress_ranges=((-1, 64), (64, 128), (128, 256), (256, 512),
+                                 (512, INF)),
+                 center_sampling=False, center_sample_radius=1.5,
+                 norm_on_bbox=False, centerness_on_reg=False,
+                 loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0,
+                               alpha=0.25, loss_weight=1.0),
+                 loss_bbox=dict(type='IoULoss', loss_weight=1.0),
+                 loss_centerness=dict(type='CrossEntropyLoss',
+                                      use_sigmoid=True, loss_weight=1.0),
+                 reg_max=16, conv_cfg=None,
+                 norm_cfg=dict(type='GN', num_groups=32, requires_grad=True),
+                 train_cfg=None, test_cfg=None):
+        super().__init__()
+        if dcn_on_last_conv:
+            raise NotImplementedError('dcn_on_last_conv')
+        if norm_on_bbox:
+            raise NotImplementedError('norm_on_bbox=True')
+        self.num_classes = self.cls_out_channels = num_classes
+        self.in_channels, self.feat_channels = in_channels, feat_channels
+        self.stacked_convs, self.strides = stacked_convs, list(strides)
+        self.dcn_on_last_conv, self.conv_bias = dcn_on_last_conv, conv_bias
+        self.regress_ranges = regress_ranges
+        self.center_sampling = center_sampling
+        self.center_sample_radius = center_sample_radius
+        self.norm_on_bbox, self.centerness_on_reg = (norm_on_bbox,
+                                                     centerness_on_reg)
+        self.reg_max = reg_max
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_bbox = build_loss(loss_bbox)
+        self.loss_centerness = build_loss(loss_centerness)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.conv_cfg, self.norm_cfg = conv_cfg, norm_cfg
+        self.fp16_enabled = False
+        self.unit_upstream = False
+        self._init_layers()
+        # after the layers, like the reference (state_dict key order)
+        self.integral = Integral(reg_max)
+
+    def _init_layers(self):
+        """fcos_gfl_head.py:134-165."""
+        self.relu = nn.ReLU(inplace=True)
+        self.cls_convs = nn.ModuleList()
+        self.reg_convs = nn.ModuleList()
+        for i in range(self.stacked_convs):
+            chn = self.in_channels if i == 0 else self.feat_channels
+            self.cls_convs.append(
+                ConvModule(chn, self.feat_channels, 3, stride=1, padding=1,
+                           conv_cfg=self.conv_cfg, norm_cfg=self.norm_cfg))
+            self.reg_convs.append(
+                ConvModule(chn, self.feat_channels, 3, stride=1, padding=1,
+                           conv_cfg=self.conv_cfg, norm_cfg=self.norm_cfg))
+        self.conv_cls = Conv2d(self.feat_channels, self.cls_out_channels, 3,
+                               padding=1)
+        self.conv_reg = Conv2d(self.feat_channels, 4 * (self.reg_max + 1), 3,
+                               padding=1)
+        self.conv_centerness = Conv2d(self.feat_channels, 1, 3, padding=1)
+        self.scales = nn.ModuleList([Scale(1.0) for _ in self.strides])
+
+    def init_weights(self):
+        """fcos_gfl_head.py:167-176."""
+        for m in self.cls_convs:
+            normal_init(m.conv, std=0.01)
+        for m in self.reg_convs:
+            normal_init(m.conv, std=0.01)
+        normal_init(self.conv_cls, std=0.01, bias=bias_init_with_prob(0.01))
+        normal_init(self.conv_reg, std=0.01)
+        normal_init(self.conv_centerness, std=0.01)
+
+    def forward(self, feats):
+        """fcos_gfl_head.py:178-224, all levels in one launch per layer."""
+        assert len(feats) == len(self.scales)
+        x3, levels = Y.pack_levels(feats)
+        cls_feat = reg_feat = x3
+        for m in self.cls_convs:
+            cls_feat, _ = m.forward3(cls_feat, levels)
+        for m in self.reg_convs:
+            reg_feat, _ = m.forward3(reg_feat, levels)
+        cls3, _ = self.conv_cls.forward3(cls_feat, levels)
+        reg3, _ = self.conv_reg.forward3(reg_feat, levels)
+        ctr3, _ = self.conv_centerness.forward3(reg_feat, levels)
+        scales = torch.stack([s.scale for s in self.scales])
+        reg3 = Y.scale_levels(reg3, scales, levels)
+        return (Y.split_levels(cls3, levels), Y.split_levels(reg3, levels),
+                Y.split_levels(ctr3, levels))
+
+    # ---------------------------------------------------------------- loss --
+    _norm_reducer = staticmethod(GFLHead._norm_reducer)
+
+    def _check_loss_cfg(self):
+        from .losses import CrossEntropyLoss, FocalLoss, GIoULoss
+        if not isinstance(self.loss_cls, FocalLoss) or \
+                not isinstance(self.loss_bbox, GIoULoss) or \
+                not isinstance(self.loss_centerness, CrossEntropyLoss) or \
+                not self.loss_centerness.use_sigmoid:
+            raise NotImplementedError(
+                'the fused FCOS loss block implements FocalLoss + GIoULoss + '
+                'sigmoid CrossEntropyLoss centerness')
+        if self.loss_cls.gamma != 2.0:
+            raise NotImplementedError('FocalLoss gamma != 2')
+
+    def _hp(self, **over):
+        kw = dict(num_classes=self.num_classes, reg_max=self.reg_max, topk=9,
+                  feat_channels=self.feat_channels,
+                  lw_cls=self.loss_cls.loss_weight, qfl_beta=2.0,
+                  lw_bbox=self.loss_bbox.loss_weight,
+                  giou_eps=getattr(self.loss_bbox, 'eps', 1e-6), lw_dfl=0.0,
+                  lw_ld=0.0, T_ld=1.0, lw_ld_vlr=0.0, T_ld_vlr=1.0, lw_kd=0.0,
+                  T_kd=1.0, lw_im=0.0,
+                  lw_ctr=self.loss_centerness.loss_weight,
+                  focal_alpha=self.loss_cls.alpha,
+                  flags=L.LD_LOSS_ATSS | L.LD_LOSS_FCOS)
+        kw.update(over)
+        return LB.make_hp(**kw)
+
+    def get_targets_batched(self, featmap_sizes, gt_bboxes, gt_labels, device):
+        """get_points + get_targets (ld_fcos_head.py:261-414) for the whole
+        batch in one launch."""
+        return LB.fcos_targets(featmap_sizes, self.strides, gt_bboxes,
+                               gt_labels, self.num_classes,
+                               self.regress_ranges, self.center_sampling,
+                               self.center_sample_radius, device)
+
+    def _run_block(self, hp, cls_scores, bbox_preds, centernesses, gt_bboxes,
+                   gt_labels, t_cls, t_reg, keys):
+        sizes = [tuple(int(v) for v in f.shape[-2:]) for f in cls_scores]
+        assert len(sizes) == len(self.strides)
+        device = cls_scores[0].device
+        targets = self.get_targets_batched(sizes, gt_bboxes, gt_labels, device)
+        dummy_x = [c.detach() for c in cls_scores]
+        hp.feat_channels = cls_scores[0].shape[1]
+        teacher = ([t.detach() for t in t_cls], [t.detach() for t in t_reg],
+                   dummy_x)
+        table, _ = LB.LDLossBlock.apply(hp, targets, teacher,
+                                        self._norm_reducer(),
+                                        self.unit_upstream, *cls_scores,
+                                        *bbox_preds, *dummy_x, *centernesses)
+        self.last_targets = targets
+        d = LossDict((k, [table[r, l] for l in range(table.shape[1])])
+                     for k, r in zip(ATSS_LOSS_KEYS, _ATSS_ROWS) if k in keys)
+        d.table = table
+        d.rows = [r for k, r in zip(ATSS_LOSS_KEYS, _ATSS_ROWS) if k in keys]
+        return d
+
+    def loss(self, cls_scores, bbox_preds, centernesses, gt_bboxes, gt_labels,
+             img_metas, gt_bboxes_ignore=None):
+        """fcos_gfl_head.py:276-345: loss_cls, loss_bbox, loss_centerness."""
+        self._check_loss_cfg()
+        return self._run_block(self._hp(), cls_scores, bbox_preds,
+                               centernesses, gt_bboxes, gt_labels, cls_scores,
+                               bbox_preds, ('loss_cls', 'loss_bbox',
+                                            'loss_centerness'))
+
+    def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None,
+                      gt_bboxes_ignore=None, proposal_cfg=None, **kwargs):
+        if proposal_cfg is not None:
+            raise NotImplementedError('proposal_cfg')
+        return self.loss(*self(x), gt_bboxes, gt_labels, img_metas,
+                         gt_bboxes_ignore=gt_bboxes_ignore)
+
+    def get_bboxes(self, *args, **kwargs):
+        raise NotImplementedError(
+            'FCOSGFLHead.get_bboxes (fcos_gfl_head.py:347-546) is not wired to '
+            'ld_get_bboxes')
+
+
+@HEADS.register_module()
+class LDFCOSHead(FCOSGFLHead):
+    """ld_fcos_head.py:13-445: localization distillation on the FCOS-GFL head:
+    LD on the positives weighted by the max class score, 0.25 x LD on the
+    "remain" points (inside a gt box, assigned to none) weighted by the
+    student's max class score, KD on the positives' class logits."""
+
+    def __init__(self, num_classes, in_channels,
+                 loss_ld=dict(type='LocalizationDistillationLoss',
+                              loss_weight=0.25, T=10),
+                 loss_kd=None, **kwargs):
+        super().__init__(num_classes, in_channels, **kwargs)
+        self.loss_ld = build_loss(loss_ld)
+        self.loss_kd = build_loss(loss_kd)
+
+    def forward_train(self, x, out_teacher, img_metas, gt_bboxes,
+                      gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None,
+                      **kwargs):
+        """ld_fcos_head.py:219-259."""
+        if gt_labels is None:
+            raise NotImplementedError('LDFCOSHead needs gt_labels')
+        if proposal_cfg is not None:
+            raise NotImplementedError('proposal_cfg')
+        return self.loss(*self(x), gt_bboxes, gt_labels, out_teacher,
+                         img_metas, gt_bboxes_ignore=gt_bboxes_ignore)
+
+    def loss(self, cls_scores, bbox_preds, centernesses, gt_bboxes, gt_labels,
+             out_teacher, img_metas, gt_bboxes_ignore=None):
+        """ld_fcos_head.py:138-217 -> the six keys of ATSS_LOSS_KEYS."""
+        self._check_loss_cfg()
+        soft_labels, soft_targets = out_teacher[0], out_teacher[1]
+        # loss_ld_neg = 0.25 * loss_ld(..., avg_factor=4) (ld_fcos_head.py:
+        # 125-129); the block's VLR term is lw_ld_vlr * sum / 16
+        hp = self._hp(lw_ld=self.loss_ld.loss_weight, T_ld=self.loss_ld.T,
+                      lw_ld_vlr=0.25 * 4.0 * self.loss_ld.loss_weight,
+                      T_ld_vlr=self.loss_ld.T,
+                      lw_kd=self.loss_kd.loss_weight, T_kd=self.loss_kd.T)
+        return self._run_block(hp, cls_scores, bbox_preds, centernesses,
+                               gt_bboxes, gt_labels, soft_labels, soft_targets,
+                               ATSS_LOSS_KEYS)
+
+
 class _Marker(nn.Module):
     """Parameter-free placeholder that keeps nn.Sequential's indices (and with
     them the state_dict keys ``reg_conf.0.*`` / ``reg_conf.2.*``) identical to

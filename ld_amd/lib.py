@@ -54,6 +54,7 @@ class LossHpT(C.Structure):
 LD_LOSS_PROB_CLS = 1
 LD_IM_CENTER_INSIDE = 2
 LD_LOSS_ATSS = 4
+LD_LOSS_FCOS = 8
 
 
 class ConvLevelT(C.Structure):
@@ -168,6 +169,11 @@ SIGNATURES = {
                                      _vp, _sz, _vp]),
     'ld_grid_anchors': (C.c_int, [_G, _vp, _vp]),
     'ld_loss_workspace_bytes': (_sz, [_G]),
+    'ld_fcos_targets': (C.c_int, [_G, _i32, C.POINTER(C.c_float), _i32, _f32,
+                                  _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp,
+                                  _vp, _vp]),
+    'ld_loss_prepass_ex': (C.c_int, [_G, _H, _M, _M, _vp, _vp, _vp, _vp, _vp,
+                                     _vp, _vp, _vp, _sz, _vp]),
     'ld_loss_prepass': (C.c_int, [_G, _H, _M, _M, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _sz, _vp]),
     'ld_loss_main': (C.c_int, [_G, _H, _M, _M, _M, _M, _M, _M, _vp, _vp, _vp,

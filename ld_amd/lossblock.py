@@ -120,6 +120,50 @@ def atss_targets(featmap_sizes, strides, img_metas, gt_bboxes, gt_labels, hp,
     return out
 
 
+def fcos_targets(featmap_sizes, strides, gt_bboxes, gt_labels, num_classes,
+                 regress_ranges, center_sampling, center_sample_radius,
+                 device):
+    """Dense FCOS point targets for a batch (ld_fcos_targets): the same dict as
+    :func:`atss_targets` (bbox_targets = (l, t, r, b) distances, vlr = the
+    head's "remain" points)."""
+    lib = L.get_lib()
+    N = len(gt_bboxes)
+    geom = L.make_geom(featmap_sizes, strides, N, 8)
+    A, nl = geom.num_anchors, geom.num_levels
+    num_gt = [int(b.shape[0]) for b in gt_bboxes]
+    max_gt = max(num_gt) if num_gt else 0
+    gtb = torch.zeros((N, max(max_gt, 1), 4), dtype=torch.float32,
+                      device=device)
+    gtl = torch.zeros((N, max(max_gt, 1)), dtype=torch.int64, device=device)
+    for i, (b, l) in enumerate(zip(gt_bboxes, gt_labels)):
+        if num_gt[i]:
+            L.require_device(b, torch.float32, 'gt_bboxes')
+            gtb[i, :num_gt[i]] = b
+            gtl[i, :num_gt[i]] = l
+    ng = _small_int_tensor(tuple(num_gt), device)
+    out = dict(
+        labels=torch.empty((N, A), dtype=torch.int64, device=device),
+        label_weights=torch.empty((N, A), dtype=torch.float32, device=device),
+        bbox_targets=torch.empty((N, A, 4), dtype=torch.float32,
+                                 device=device),
+        vlr=torch.empty((N, A), dtype=torch.float32, device=device),
+        im=torch.empty((N, A), dtype=torch.float32, device=device),
+        counts=torch.empty(N + 2 * nl + 1, dtype=torch.int32, device=device),
+    )
+    flat = [float(min(v, 1e8)) for r in regress_ranges for v in r]
+    assert len(flat) == 2 * nl
+    rr = (C.c_float * len(flat))(*flat)
+    L.check(lib.ld_fcos_targets(
+        C.byref(geom), int(num_classes), rr, 1 if center_sampling else 0,
+        float(center_sample_radius), L.ptr(gtb), L.ptr(gtl), L.ptr(ng), max_gt,
+        L.ptr(out['labels']), L.ptr(out['label_weights']),
+        L.ptr(out['bbox_targets']), L.ptr(out['vlr']), L.ptr(out['im']),
+        L.ptr(out['counts']), L.stream_ptr(device)), 'ld_fcos_targets')
+    out['geom'] = geom
+    out['num_gt'] = num_gt
+    return out
+
+
 def grid_anchors(featmap_sizes, strides, device, anchor_scale=8):
     lib = L.get_lib()
     geom = L.make_geom(featmap_sizes, strides, 1, anchor_scale)
@@ -202,11 +246,12 @@ def loss_block_forward(hp, targets, cls, reg, t_cls, t_reg, x, t_x,
     need = lib.ld_loss_workspace_bytes(C.byref(geom))
     ws = workspace(device, need, 'loss')
     st = L.stream_ptr(device)
-    L.check(lib.ld_loss_prepass(
+    L.check(lib.ld_loss_prepass_ex(
         C.byref(geom), C.byref(hp), C.byref(m_cls), C.byref(m_reg),
         L.ptr(targets['labels']), L.ptr(targets['bbox_targets']),
-        L.ptr(targets['counts']), L.ptr(wt), L.ptr(score), L.ptr(norm),
-        L.ptr(ws), ws.numel(), st), 'ld_loss_prepass')
+        L.ptr(targets['vlr']), L.ptr(targets['counts']), L.ptr(wt),
+        L.ptr(score), L.ptr(norm), L.ptr(ws), ws.numel(), st),
+        'ld_loss_prepass')
     if reduce_norm is not None:
         reduce_norm(norm)
     up = None

@@ -259,6 +259,20 @@ class CrossEntropyLoss(nn.Module):
 
 
 @LOSSES.register_module()
+class IoULoss(nn.Module):
+    """Only *registrable* (FCOSGFLHead's constructor default,
+    fcos_gfl_head.py:111); every FCOS-GFL config overrides it with GIoULoss."""
+
+    def __init__(self, linear=False, eps=1e-6, reduction='mean',
+                 loss_weight=1.0):
+        super().__init__()
+        self.eps, self.reduction, self.loss_weight = eps, reduction, loss_weight
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError('IoULoss is not on the LD train path')
+
+
+@LOSSES.register_module()
 class CIoULoss(nn.Module):
     """Only *registrable*: the GFL teacher configs name it
     (configs/gfl/gfl_r50_fpn_1x_coco.py:43) but a frozen teacher never

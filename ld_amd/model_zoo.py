@@ -173,6 +173,68 @@ def ld_atss_detector(student_depth=50, teacher_depth=101):
                 test_cfg=copy.deepcopy(_TEST_CFG))
 
 
+def _fcos_backbone(depth):
+    """configs/gfl/fcos_gfl_r50_center.py:4-12: caffe-style ResNet, BN frozen."""
+    return dict(type='ResNet', depth=depth, num_stages=4,
+                out_indices=(0, 1, 2, 3), frozen_stages=1,
+                norm_cfg=dict(type='BN', requires_grad=False), norm_eval=True,
+                style='caffe')
+
+
+def _fcos_neck(depth):
+    return dict(type='FPN', in_channels=list(_RESNET_CH[depth]),
+                out_channels=256, start_level=1, add_extra_convs=True,
+                extra_convs_on_inputs=False, num_outs=5,
+                relu_before_extra_convs=True)
+
+
+def _fcos_head_common():
+    """configs/gfl/fcos_gfl_r50_center.py:22-43."""
+    return dict(
+        num_classes=80, in_channels=256, stacked_convs=4, feat_channels=256,
+        strides=[8, 16, 32, 64, 128],
+        loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0,
+                      alpha=0.25, loss_weight=1.0),
+        loss_bbox=dict(type='GIoULoss', loss_weight=1.0),
+        loss_centerness=dict(type='CrossEntropyLoss', use_sigmoid=True,
+                             loss_weight=1.0),
+        norm_on_bbox=False, centerness_on_reg=True, dcn_on_last_conv=False,
+        center_sampling=True, conv_bias=True)
+
+
+_FCOS_TRAIN_CFG = dict(
+    assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.4,
+                  min_pos_iou=0, ignore_iof_thr=-1),
+    allowed_border=-1, pos_weight=-1, debug=False)
+
+
+def fcos_gfl_detector(depth=101):
+    """An FCOS-GFL teacher (configs/gfl/fcos_gfl_r{50,101}_*center.py)."""
+    return dict(type='FCOS', pretrained=None, backbone=_fcos_backbone(depth),
+                neck=_fcos_neck(depth),
+                bbox_head=dict(type='FCOSGFLHead', **_fcos_head_common()),
+                train_cfg=copy.deepcopy(_FCOS_TRAIN_CFG),
+                test_cfg=copy.deepcopy(_TEST_CFG))
+
+
+def ld_fcos_detector(student_depth=50, teacher_depth=101):
+    """configs/ld/ld_r50_fcos_r101_1x.py: LDFCOSHead student <- FCOS-GFL
+    teacher (output_feature=False)."""
+    head = dict(type='LDFCOSHead',
+                loss_ld=dict(type='KnowledgeDistillationKLDivLoss',
+                             loss_weight=0.25, T=10),
+                loss_kd=dict(type='KnowledgeDistillationKLDivLoss',
+                             loss_weight=10, T=2),
+                **_fcos_head_common())
+    return dict(type='KnowledgeDistillationSingleStageDetector',
+                pretrained=None,
+                teacher_config=dict(model=fcos_gfl_detector(teacher_depth)),
+                teacher_ckpt=None, backbone=_fcos_backbone(student_depth),
+                neck=_fcos_neck(student_depth), bbox_head=head,
+                train_cfg=copy.deepcopy(_FCOS_TRAIN_CFG),
+                test_cfg=copy.deepcopy(_TEST_CFG))
+
+
 OPTIMIZER = dict(type='SGD', lr=0.0025, momentum=0.9, weight_decay=0.0001)
 
 

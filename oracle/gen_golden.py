@@ -937,16 +937,99 @@ def gen_lossblock_atss():
     print('lossblock_atss.npz')
 
 
-def gen_e2e_atss():
+def _ld_fcos_head():
+    """LDFCOSHead as configs/ld/ld_r50_fcos_r101_1x.py:26-49 builds it."""
+    from mmdet.models import build_head
+    cfg = dict(
+        type='LDFCOSHead', num_classes=80, in_channels=256, stacked_convs=4,
+        feat_channels=256, strides=[8, 16, 32, 64, 128],
+        loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0,
+                      alpha=0.25, loss_weight=1.0),
+        loss_bbox=dict(type='GIoULoss', loss_weight=1.0),
+        loss_ld=dict(type='KnowledgeDistillationKLDivLoss', loss_weight=0.25,
+                     T=10),
+        loss_kd=dict(type='KnowledgeDistillationKLDivLoss', loss_weight=10,
+                     T=2),
+        loss_centerness=dict(type='CrossEntropyLoss', use_sigmoid=True,
+                             loss_weight=1.0),
+        norm_on_bbox=False, centerness_on_reg=True, dcn_on_last_conv=False,
+        center_sampling=True, conv_bias=True,
+        train_cfg=ref_shim.ConfigDict(
+            assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5,
+                          neg_iou_thr=0.4, min_pos_iou=0, ignore_iof_thr=-1),
+            allowed_border=-1, pos_weight=-1, debug=False),
+        test_cfg=ref_shim.ConfigDict(
+            nms_pre=1000, min_bbox_size=0, score_thr=0.05,
+            nms=dict(type='nms', iou_threshold=0.6), max_per_img=100))
+    return build_head(cfg)
+
+
+def gen_lossblock_fcos():
+    """LDFCOSHead (ld_fcos_head.py): point targets and loss tables + gradients
+    executed by the reference on the LOSSBLOCK_CASES inputs."""
+    head = _ld_fcos_head()
+    d = {}
+    for name, pad, img_shape, num_gt, bseed, hseed, store in LOSSBLOCK_CASES:
+        batch = synthetic.synthetic_batch(
+            num_imgs=len(num_gt), img_shape=img_shape, pad_shape=pad,
+            num_gt=num_gt, seed=bseed)
+        sizes = synthetic.level_shapes(pad)
+        hi = synthetic.synthetic_head_inputs(len(num_gt), sizes, seed=hseed)
+        hi['ctr'] = synthetic.synthetic_centerness(len(num_gt), sizes,
+                                                   seed=hseed)
+        # the reference's targets (labels with the "remain" code C + 1)
+        pts = head.get_points(sizes, torch.float32, 'cpu')
+        labels, bbox_targets = head.get_targets(pts, batch['gt_bboxes'],
+                                                batch['gt_labels'])
+        for l in range(len(sizes)):
+            d[f'{name}_labels_{l}'] = _np(labels[l]).astype(np.int64)
+            d[f'{name}_bbox_targets_{l}'] = _np(bbox_targets[l])
+        for k in ('cls', 'reg', 'ctr'):
+            for t in hi[k]:
+                t.requires_grad_(True)
+        losses = head.loss(hi['cls'], hi['reg'], hi['ctr'],
+                           batch['gt_bboxes'], batch['gt_labels'],
+                           (hi['t_cls'], hi['t_reg'], None),
+                           batch['img_metas'])
+        table = np.stack([np.array([float(v.detach()) for v in losses[k]])
+                          for k in ATSS_KEYS])
+        total = sum(sum(v) for v in losses.values())
+        total.backward()
+        d[name + '_cfg'] = np.array(
+            list(pad) + list(img_shape) + [bseed, hseed])
+        d[name + '_num_gt'] = np.array(num_gt)
+        d[name + '_losses'] = table.astype(np.float64)
+        for k in ('cls', 'reg', 'ctr'):
+            gs = [t.grad if t.grad is not None else torch.zeros_like(t)
+                  for t in hi[k]]
+            d[f'{name}_g{k}_abs_sum'] = np.array(
+                [float(g.double().abs().sum()) for g in gs])
+            for l, g in enumerate(gs):
+                if store:
+                    d[f'{name}_g{k}_{l}'] = _np(g)
+                else:
+                    flat = _np(g).reshape(-1)
+                    d[f'{name}_g{k}_{l}_sample'] = flat[
+                        np.arange(0, flat.size, 1009)]
+        print(f'  lossblock_fcos {name}: total={float(total):.6f}',
+              table.sum(1), 'pos',
+              int(sum(((l_ >= 0) & (l_ < 80)).sum() for l_ in labels)),
+              'remain', int(sum((l_ == 81).sum() for l_ in labels)))
+    np.savez_compressed(os.path.join(OUT, 'lossblock_fcos.npz'), **d)
+
+
+def gen_e2e_atss(cfg_path='configs/ld/ld_r50_atss_r101_1x.py',
+                 out_name='e2e_atss.npz', tag='e2e_atss'):
     """One LD train step of configs/ld/ld_r50_atss_r101_1x.py (LDATSSHead
-    student <- ATSS-GFL R101 teacher) executed by the reference: loss table,
+    student <- ATSS-GFL R101 teacher) -- or, with the other arguments, of
+    configs/ld/ld_r50_fcos_r101_1x.py -- executed by the reference: loss table,
     gradient norms and projections."""
     d = {}
     for name, pad, img_shape, num_gt, bseed in (
             ('tiny', (128, 160), (128, 150), [3, 2], 41),
             ('small', (256, 320), (256, 320), [5, 2], 42)):
         torch.manual_seed(0)
-        det = build_reference_detector('configs/ld/ld_r50_atss_r101_1x.py')
+        det = build_reference_detector(cfg_path)
         det.load_state_dict(
             synthetic.seeded_state_dict(det.state_dict(), seed=1))
         det.teacher_model.load_state_dict(
@@ -980,9 +1063,9 @@ def gen_e2e_atss():
         d[name + '_student_keys'] = np.array(list(det.state_dict().keys()))
         d[name + '_teacher_keys'] = np.array(
             list(det.teacher_model.state_dict().keys()))
-        print(f'  e2e_atss {name}:',
+        print(f'  {tag} {name}:',
               {k: round(v, 6) for k, v in log_vars.items()})
-    np.savez_compressed(os.path.join(OUT, 'e2e_atss.npz'), **d)
+    np.savez_compressed(os.path.join(OUT, out_name), **d)
 
 
 def gen_infer_voting():
@@ -1107,7 +1190,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='kat,anchors,targets,lossblock,e2e,infer,'
                     'lossblock_v2,e2e_v2,imitation,pipeline,infer_voting,'
-                    'lossblock_atss,e2e_atss')
+                    'lossblock_atss,e2e_atss,lossblock_fcos,e2e_fcos')
     ap.add_argument('--e2e-cases', default='')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
@@ -1139,6 +1222,11 @@ def main():
         gen_lossblock_atss()
     if 'e2e_atss' in only:
         gen_e2e_atss()
+    if 'lossblock_fcos' in only:
+        gen_lossblock_fcos()
+    if 'e2e_fcos' in only:
+        gen_e2e_atss('configs/ld/ld_r50_fcos_r101_1x.py', 'e2e_fcos.npz',
+                     'e2e_fcos')
 
 
 if __name__ == '__main__':

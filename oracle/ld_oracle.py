@@ -795,6 +795,181 @@ def ld_atss_loss_block(cls, reg, ctr, t_cls, t_reg, targets, hp=None,
 
 
 # --------------------------------------------------------------------------
+# LDFCOSHead (ld_fcos_head.py over fcos_gfl_head.py)
+# --------------------------------------------------------------------------
+FCOS_RANGES = ((-1, 64), (64, 128), (128, 256), (256, 512), (512, 1e8))
+
+
+def fcos_points(featmap_sizes, strides=(8, 16, 32, 64, 128)):
+    """fcos_gfl_head.py:548-558: (x, y) * stride + stride // 2, row-major."""
+    pts = []
+    for (h, w), s in zip(featmap_sizes, strides):
+        ys, xs = np.meshgrid(np.arange(h), np.arange(w), indexing='ij')
+        pts.append(np.stack([xs.reshape(-1) * s, ys.reshape(-1) * s],
+                            -1).astype(F32) + F32(s // 2))
+    return pts
+
+
+def fcos_targets(featmap_sizes, gt_bboxes, gt_labels, num_classes=80,
+                 strides=(8, 16, 32, 64, 128), regress_ranges=FCOS_RANGES,
+                 center_sampling=True, radius=1.5):
+    """LDFCOSHead.get_targets / _get_target_single (ld_fcos_head.py:261-414).
+    -> dict(labels (N, A) with num_classes + 1 on the "remain" points,
+    bbox_targets (N, A, 4) = (l, t, r, b))."""
+    pts = fcos_points(featmap_sizes, strides)
+    P = np.concatenate(pts)
+    lo = np.concatenate([np.full(len(p), r[0], F32)
+                         for p, r in zip(pts, regress_ranges)])
+    hi = np.concatenate([np.full(len(p), min(r[1], 1e8), F32)
+                         for p, r in zip(pts, regress_ranges)])
+    sr = np.concatenate([np.full(len(p), s * radius, F32)
+                         for p, s in zip(pts, strides)])
+    INF = F32(1e8)
+    labels_all, bt_all = [], []
+    for gb, gl in zip(gt_bboxes, gt_labels):
+        A = P.shape[0]
+        if gb.shape[0] == 0:
+            labels_all.append(np.full(A, num_classes, np.int64))
+            bt_all.append(np.zeros((A, 4), F32))
+            continue
+        gb = gb.astype(F32)
+        xs, ys = P[:, 0:1], P[:, 1:2]
+        left, right = xs - gb[None, :, 0], gb[None, :, 2] - xs
+        top, bottom = ys - gb[None, :, 1], gb[None, :, 3] - ys
+        bt = np.stack([left, top, right, bottom], -1)
+        areas = np.tile(((gb[:, 2] - gb[:, 0]) * (gb[:, 3] - gb[:, 1]))[None],
+                        (A, 1)).astype(F32)
+        if center_sampling:
+            cx = (gb[:, 0] + gb[:, 2]) / F32(2)
+            cy = (gb[:, 1] + gb[:, 3]) / F32(2)
+            xm, ym = cx[None] - sr[:, None], cy[None] - sr[:, None]
+            xM, yM = cx[None] + sr[:, None], cy[None] + sr[:, None]
+            c0 = np.where(xm > gb[None, :, 0], xm, gb[None, :, 0])
+            c1 = np.where(ym > gb[None, :, 1], ym, gb[None, :, 1])
+            c2 = np.where(xM > gb[None, :, 2], gb[None, :, 2], xM)
+            c3 = np.where(yM > gb[None, :, 3], gb[None, :, 3], yM)
+            inside = np.stack([xs - c0, ys - c1, c2 - xs, c3 - ys],
+                              -1).min(-1) > 0
+        else:
+            inside = bt.min(-1) > 0
+        mx = bt.max(-1)
+        in_range = (mx >= lo[:, None]) & (mx <= hi[:, None])
+        areas[~inside] = INF
+        areas[~in_range] = INF
+        arg = areas.argmin(1)  # first minimum, like torch.min
+        mn = areas[np.arange(A), arg]
+        in_some = (bt.min(-1) > 0).any(1)
+        lab = gl[arg].astype(np.int64)
+        lab[mn == INF] = num_classes
+        lab[in_some & (mn == INF)] = num_classes + 1
+        labels_all.append(lab)
+        bt_all.append(bt[np.arange(A), arg].astype(F32))
+    return dict(labels=np.stack(labels_all), bbox_targets=np.stack(bt_all),
+                points=P)
+
+
+def ld_fcos_loss_block(cls, reg, ctr, t_cls, t_reg, targets, hp=None):
+    """LDFCOSHead.loss (ld_fcos_head.py:46-217) on per-level NCHW arrays.
+    -> dict(losses (6, L) in the ATSS key order, grads(cls, reg, ctr))."""
+    H = dict(DEFAULT_HP)
+    H.update(dict(lw_ctr=1.0, focal_alpha=0.25, lw_bbox=1.0))
+    if hp:
+        H.update(hp)
+    C, R = H['num_classes'], H['reg_max'] + 1
+    L = len(cls)
+    labels_all = targets['labels']
+    num_pos = max(float(((labels_all >= 0) & (labels_all < C)).sum()), 1.0)
+    losses = np.zeros((6, L), dtype=F32)
+    state = []
+    csum = np.float32(0)
+    start = 0
+    for l in range(L):
+        n, _, h, w = cls[l].shape
+        A_l = h * w
+        stride = F32(H['strides'][l])
+        sl = slice(start, start + A_l)
+        start += A_l
+        pts = np.tile(targets['points'][sl], (n, 1))
+        labels = labels_all[:, sl].reshape(-1).copy()
+        bt = targets['bbox_targets'][:, sl].reshape(-1, 4)
+        c_r, r_r = _nchw_to_rows(cls[l]), _nchw_to_rows(reg[l])
+        k_r = _nchw_to_rows(ctr[l]).reshape(-1)
+        tc_r, tr_r = _nchw_to_rows(t_cls[l]), _nchw_to_rows(t_reg[l])
+        g_c, g_r = np.zeros_like(c_r), np.zeros_like(r_r)
+        g_k = np.zeros_like(k_r)
+        pos = np.nonzero((labels >= 0) & (labels < C))[0]
+        rem = np.nonzero(labels == C + 1)[0]
+        st = dict(g_c=g_c, g_r=g_r, g_k=g_k,
+                  shapes=(cls[l].shape, reg[l].shape, ctr[l].shape))
+        onehot = np.zeros_like(c_r)
+        if pos.size:
+            onehot[pos, labels[pos]] = 1
+        f, df = focal_elements(c_r, onehot, H['focal_alpha'])
+        loss_cls = F32(H['lw_cls']) * f.sum(dtype=F32) / F32(num_pos)
+        g_c += df * (F32(H['lw_cls']) / F32(num_pos))
+        loss_bbox = loss_ld = loss_kd = loss_ctr = F32(0)
+        smax = _sigmoid(c_r).max(1)
+        if pos.size:
+            pp = pts[pos] / stride
+            tgt_d = bt[pos]
+            lr = tgt_d[:, [0, 2]]
+            tb = tgt_d[:, [1, 3]]
+            ct = np.sqrt((lr.min(1) / lr.max(1)) *
+                         (tb.min(1) / tb.max(1))).astype(F32)
+            dist, p_soft = integral(r_r[pos], H['reg_max'])
+            box = distance2bbox(pp, dist)
+            tgt = distance2bbox(pp, (tgt_d / stride).astype(F32))
+            gl, gbox = giou_loss_rows(box, tgt, H['giou_eps'])
+            loss_bbox = F32(H['lw_bbox']) * (gl * ct).sum(dtype=F32)
+            gdist = np.stack([-gbox[:, 0], -gbox[:, 1], gbox[:, 2],
+                              gbox[:, 3]], -1) * (F32(H['lw_bbox']) *
+                                                  ct)[:, None]
+            proj = np.arange(R, dtype=F32)
+            g_int = p_soft * (proj[None, None, :] - dist[:, :, None])
+            st['bbox_grad'] = (gdist[:, :, None] * g_int).reshape(-1, 4 * R)
+            w4 = np.repeat(smax[pos], 4)
+            kl, kg = kd_kl_rows(r_r[pos].reshape(-1, R),
+                                tr_r[pos].reshape(-1, R), H['T_ld'])
+            loss_ld = F32(H['lw_ld']) * (kl * w4).sum(dtype=F32) / F32(4)
+            g_r[pos] += (kg * (w4 * F32(H['lw_ld']) /
+                               F32(4))[:, None]).reshape(-1, 4 * R)
+            kl, kg = kd_kl_rows(c_r[pos], tc_r[pos], H['T_kd'])
+            loss_kd = F32(H['lw_kd']) * kl.sum(dtype=F32) / F32(pos.size)
+            g_c[pos] += kg * (F32(H['lw_kd']) / F32(pos.size))
+            xk = k_r[pos]
+            bce = _softplus(xk) - ct * xk
+            loss_ctr = F32(H['lw_ctr']) * bce.sum(dtype=F32) / F32(num_pos)
+            g_k[pos] = (_sigmoid(xk) - ct) * F32(H['lw_ctr']) / F32(num_pos)
+            st['pos'] = pos
+            csum = csum + ct.sum(dtype=F32)
+        loss_neg = F32(0)
+        if rem.size:
+            w4 = np.repeat(smax[rem], 4)
+            kl, kg = kd_kl_rows(r_r[rem].reshape(-1, R),
+                                tr_r[rem].reshape(-1, R), H['T_ld'])
+            coef = F32(0.25) * F32(H['lw_ld']) / F32(4)
+            loss_neg = coef * (kl * w4).sum(dtype=F32)
+            g_r[rem] += (kg * (w4 * coef)[:, None]).reshape(-1, 4 * R)
+        losses[:, l] = [loss_cls, loss_bbox, loss_ld, loss_neg, loss_kd,
+                        loss_ctr]
+        state.append(st)
+    avg = float(csum)
+    if avg < 1e-12:
+        avg = 1.0
+    losses[1] /= F32(avg)
+    grads = dict(cls=[], reg=[], ctr=[])
+    for st in state:
+        if 'pos' in st:
+            st['g_r'][st['pos']] += st['bbox_grad'] / F32(avg)
+        grads['cls'].append(_rows_to_nchw(st['g_c'], st['shapes'][0]))
+        grads['reg'].append(_rows_to_nchw(st['g_r'], st['shapes'][1]))
+        grads['ctr'].append(st['g_k'].reshape(
+            st['shapes'][2][0], st['shapes'][2][2], st['shapes'][2][3])[
+                :, None])
+    return dict(losses=losses, grads=grads, num_pos=num_pos, avg_factor=avg)
+
+
+# --------------------------------------------------------------------------
 # the 'gibox' imitation region
 # --------------------------------------------------------------------------
 def gi_region(cls, reg, t_cls, t_reg, prob=False, topn=10, iou_thr=0.3):
