@@ -11,12 +11,15 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+import os
+
 CASES = [  # name, student depth, loss_im weight
-    ('tiny_r18', 18, 0.0),
     ('small_r50', 50, 2.0),
     ('c1_r18', 18, 0.0),
     ('c2_r50', 50, 2.0),
 ]
+if os.environ.get('LD_TEST_FULL') == '1':  # every golden case (slower)
+    CASES.insert(0, ('tiny_r18', 18, 0.0))
 LOSS_KEYS = ['loss_cls', 'loss_bbox', 'loss_dfl', 'loss_ld', 'loss_ld_vlr',
              'loss_kd', 'loss_kd_neg', 'loss_im']
 

