@@ -174,6 +174,11 @@ def _median_launch_us(launch, warm, iters):
     return ts[len(ts) // 2], ts[0]
 
 
+# profiles/r02_pmc_traffic/pmc_traffic_regdense.txt: FETCH_SIZE 1 212 533.8 KB
+# (x 2, gfx950 correction) + WRITE_SIZE 1 120 262.4 KB per launch at 2^24 rows
+PMC_LDKL_TRAFFIC_BYTES = (2 * 1212533.8 + 1120262.4) * 1024.0
+
+
 def ldkl_roofline(dev):
     """North-star kernel = the reg-side dense kernel THE TRAIN STEP LAUNCHES
     (fused LD-KL + VLR-LD + Integral chain, forward + gradient), timed with HIP
@@ -198,10 +203,13 @@ def ldkl_roofline(dev):
                        'ld_loss_main_parts(LD_LOSS_PART_REG)',
                 bound='hbm', achieved=ach, peak=PEAK_HBM_GBPS, unit='GB/s',
                 frac=ach / PEAK_HBM_GBPS,
-                traffic=None,
-                traffic_note='not measured inside bench.py (PMC needs rocprofv3 '
-                             'around the process): see profiles/ for the '
-                             'FETCH_SIZE / WRITE_SIZE passes of this kernel',
+                traffic=PMC_LDKL_TRAFFIC_BYTES if rows == 1 << 24 else None,
+                traffic_note='HBM bytes per launch of THIS kernel at THIS size '
+                             'from separate rocprofv3 --pmc passes (FETCH_SIZE '
+                             'x 2 per MI355X_MICROARCH.md + WRITE_SIZE), '
+                             'profiles/r02_pmc_traffic/ (tools/pmc_traffic.sh '
+                             '+ tools/one_regdense.py): 1.05 x the algorithmic '
+                             'bytes; not re-measured inside bench.py',
                 rows=rows, bytes_per_row=bytes_per_row, us=us, us_min=us_min,
                 us_vlr_density_0p09=us_sparse,
                 c2_rows=rows_c2, c2_us=us_c2)
