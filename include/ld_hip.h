@@ -489,6 +489,14 @@ int ld_conv_bf16_dgrad_c8(const ld_conv_t* c, const void* dy_c8, const void* wt_
                           float* dx, ld_stream_t stream);
 int ld_conv_bf16_tune_dgrad_c8(const ld_conv_t* c, const void* dy_c8,
                                const void* wt_bwd, float* dx, ld_stream_t stream);
+/* Weight gradient with BOTH operands as C8 images (Cin, Cout multiples of 8):
+ * tile rows are positions (16-byte loads, aligned under any tap shift), the
+ * position -> lane transpose the MFMA needs is done by ds_read_b64_tr_b16 in
+ * the LDS read.  fp32 slabs / dw exactly as ld_conv_bf16_wgrad (same workspace
+ * size); the per-element summation order differs from it. */
+int ld_conv_bf16_wgrad_c8(const ld_conv_t* c, const void* x_c8, const void* dy_c8,
+                          float* dw, int accumulate, void* workspace,
+                          size_t workspace_bytes, ld_stream_t stream);
 
 /* Small-Cin variant (the 7x7 stride-2 stem, resnet.py:558-570): flat
  * (ci,kh,kw) reduction; wt = [pad32(Cin*KH*KW)][Cout] image obtained with

@@ -1888,7 +1888,7 @@ int wgrad_run(const ld_conv_t* c, const float* x, const float* dy, float* dw,
   if (family == 1 && ld_bf16_wgrad_tiled(c->Cout, c->Cin, c->Pout))
     k.splits = ld_bf16_wgrad_splits(c->Cout, c->Cin, c->KH * c->KW, k.J);
   const int wmode = wgrad_mode();
-  const int wbk = family == 1 ? 32 : (wmode ? wmode : WBK);
+  const int wbk = family >= 1 ? 32 : (wmode ? wmode : WBK);
   int jchunk = (k.J + k.splits - 1) / k.splits;
   jchunk = (jchunk + wbk - 1) / wbk * wbk;
   k.jchunk = jchunk;
@@ -1901,7 +1901,11 @@ int wgrad_run(const ld_conv_t* c, const float* x, const float* dy, float* dw,
     k.dy_bytes = (unsigned)(yf * 4);
   }
   const int ntaps = c->KH * c->KW;
-  if (family == 1) {
+  if (family == 2) {  // x / dy are bf16 C8 images: half the bytes
+    k.x_bytes = (unsigned)((size_t)c->N * c->Cin * c->Pin * 2);
+    k.dy_bytes = (unsigned)((size_t)c->N * c->Cout * c->Pout * 2);
+    if (int e = ld_bf16_wgrad_c8_launch(k, stream)) return e;
+  } else if (family == 1) {
     if (int e = ld_bf16_wgrad_launch(k, stream)) return e;
   } else if (wmode) {
     const int blocks = ((c->Cout + 63) / 64) * ((c->Cin + 63) / 64) * ntaps * k.splits;
@@ -1939,6 +1943,17 @@ extern "C" int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy
 // bf16-MFMA weight gradient: fp32 x / dy / dw, operands rounded to bf16 on the
 // way into the matrix core, fp32 slabs summed in fixed order.  Same workspace
 // as ld_conv_wgrad.
+// bf16 weight gradient with BOTH operands as C8 images (ld_conv_to_c8 layout;
+// Cin and Cout multiples of 8)
+extern "C" int ld_conv_bf16_wgrad_c8(const ld_conv_t* c, const void* x_c8,
+                                     const void* dy_c8, float* dw, int accumulate,
+                                     void* workspace, size_t workspace_bytes,
+                                     ld_stream_t stream) {
+  if (c && (c->Cin % 8 != 0 || c->Cout % 8 != 0)) return LD_EUNSUPPORTED;
+  return wgrad_run(c, (const float*)x_c8, (const float*)dy_c8, dw, accumulate,
+                   workspace, workspace_bytes, stream, 2);
+}
+
 extern "C" int ld_conv_bf16_wgrad(const ld_conv_t* c, const float* x, const float* dy,
                                   float* dw, int accumulate, void* workspace,
                                   size_t workspace_bytes, ld_stream_t stream) {

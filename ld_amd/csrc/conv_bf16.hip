@@ -801,6 +801,231 @@ __global__ __launch_bounds__(256) void to_c8_kernel(const float* __restrict__ x,
 // of one wave execute in order: no s_barrier anywhere.
 constexpr int WB_J = 32;             // positions per step
 constexpr int WB_PITCH = 2 * WB_J + 16;  // bytes per LDS row
+// ------------------------------------- wgrad, wave-private, C8 operands ----
+// The kernel below (fp32 operands) spends ~200 instructions per 8 MFMAs: both
+// tiles are gathered 4 bytes per lane along positions, converted and written to
+// LDS 2 bytes at a time, and its loads run only one 256-cycle step ahead of a
+// ~2 000-cycle memory latency (profiles/r02_layers_bf16_c8.csv: 100-240 TFLOP/s).
+// With BOTH operands as bf16 channel-blocked images (dY and X as (N, C/8, P, 8),
+// the images the forward / the backward producers already wrote):
+//   * a tile row = one position = 64 channels = eight 16-byte C8 rows: 4 loads +
+//     4 ds_write_b128 per lane, operand and 32-position step, no conversion;
+//     a tap shift moves whole C8 rows (always aligned), padding is the buffer
+//     descriptor's zero;
+//   * the reduction index (position) is the LDS ROW, the MFMA wants it inside a
+//     lane: ds_read_b64_tr_b16 does that transpose in the LDS read -- per
+//     16-lane group it fetches a [4 positions][16 channels] block (each lane
+//     passes the address of one 8-byte piece: row t >> 2, channels 4 (t & 3)..)
+//     and hands lane i the four positions of channel i (measured on the MI355X:
+//     tools/probe/run_tr_probe.py); two such reads = one bf16x8 fragment;
+//   * the loads run NR - 1 steps ahead through a register ring (8 x 16 B per
+//     step and lane).
+// LDS row pitch 144 B: conflict-free ds_write_b128 (36-dword stride) and
+// transpose reads (rows 0 / 36 / 8 / 44 dwords apart, 8 dwords wide).
+constexpr int WC_J = 32;       // positions per step
+constexpr int WC_PITCH = 144;  // bytes per LDS row (64 channels + 16 pad)
+
+__device__ __forceinline__ unsigned long long lds_read_tr(unsigned addr) {
+  unsigned long long v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+template <int NR>
+__global__ __launch_bounds__(64, 2) void conv_wgrad_c8_kernel(WgradK a) {
+  constexpr int TB = 64;
+  constexpr int U = WC_J * (TB / 8) / 64;  // 16-byte units per lane and operand (4)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * WC_J * WC_PITCH];
+  __shared__ int s_geo[LD_MAX_LEVELS * 6];
+  unsigned char* As = lds;                    // [WC_J][WC_PITCH]  dY rows = positions
+  unsigned char* Bs = lds + WC_J * WC_PITCH;  // [WC_J][WC_PITCH]  X
+
+  const int lane = threadIdx.x;
+  const int Cin = __builtin_amdgcn_readfirstlane(a.Cin);
+  const int Cout = __builtin_amdgcn_readfirstlane(a.Cout);
+  const int Pin = __builtin_amdgcn_readfirstlane(a.Pin);
+  const int Pout = __builtin_amdgcn_readfirstlane(a.Pout);
+  const int nlev = __builtin_amdgcn_readfirstlane(a.g.num_levels);
+  const int stride = __builtin_amdgcn_readfirstlane(a.g.stride);
+  const int pad = __builtin_amdgcn_readfirstlane(a.g.pad);
+  const int mt = (Cout + TB - 1) / TB, nt = (Cin + TB - 1) / TB;
+  const int ntaps = a.KH * a.KW;
+  int b = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int ntile = b % nt;
+  b /= nt;
+  const int mtile = b % mt;
+  b /= mt;
+  const int tap = b % ntaps;
+  const int split = b / ntaps;
+  const int m0 = mtile * TB, c0 = ntile * TB;
+  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int jbeg = split * a.jchunk;
+  const int jend = min(a.J, jbeg + a.jchunk);
+
+  if (lane < LD_MAX_LEVELS) {
+    const ld_conv_level_t lv = a.g.lv[lane];
+    s_geo[lane * 6 + 0] = lv.Hin;
+    s_geo[lane * 6 + 1] = lv.Win;
+    s_geo[lane * 6 + 2] = lv.Hout;
+    s_geo[lane * 6 + 3] = lv.Wout;
+    s_geo[lane * 6 + 4] = lv.off_in;
+    s_geo[lane * 6 + 5] = lv.off_out;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // load side: lane = (position kq of the step, C8 block parity); unit i of the
+  // lane is C8 block (lane >> 5) + 2 i of the tile
+  const int kq = lane & (WC_J - 1);
+  const int cb = lane >> 5;
+  const int Co8 = Cout >> 3, Ci8 = Cin >> 3;
+  const rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  const rsrc_t ry = make_rsrc(a.dy, a.dy_bytes);
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  uintx4 a_st[NR][U], b_st[NR][U];
+  auto load_tile = [&](int j0, uintx4* ra, uintx4* rb) {
+    const int j = j0 + kq;
+    unsigned vy = kOOB, vx = kOOB;
+    if (j < jend) {
+      const int n = j / Pout, p = j - n * Pout;
+      int l = 0;
+      for (int i = 1; i < nlev; ++i)
+        if (p >= s_geo[i * 6 + 5]) l = i;
+      const int Hin = s_geo[l * 6 + 0], Win = s_geo[l * 6 + 1];
+      const int Wout = s_geo[l * 6 + 3];
+      const int r = p - s_geo[l * 6 + 5];
+      const int ho = r / Wout, wo = r - ho * Wout;
+      const int hi = ho * stride - pad + kh, wi = wo * stride - pad + kw;
+      vy = (unsigned)((n * Co8 + (m0 >> 3) + cb) * Pout + p) * 16u;
+      if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win)
+        vx = (unsigned)((n * Ci8 + (c0 >> 3) + cb) * Pin + s_geo[l * 6 + 4] +
+                        hi * Win + wi) * 16u;
+    }
+    // C8 blocks past the channel count (ragged last tile) read zeros
+    unsigned da = 2u * (unsigned)Pout * 16u, db = 2u * (unsigned)Pin * 16u;
+    asm volatile("" : "+s"(da), "+s"(db));
+    int na = (Co8 - (m0 >> 3) - cb + 1) / 2, nb = (Ci8 - (c0 >> 3) - cb + 1) / 2;
+    asm volatile("" : "+v"(na), "+v"(nb));
+    unsigned sa = 0, sb = 0;
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      ra[i] = buf_load16(ry, i < na ? vy : kOOB, sa);
+      rb[i] = buf_load16(rx, i < nb ? vx : kOOB, sb);
+      sa += da;
+      sb += db;
+    }
+  };
+  auto store_tile = [&](const uintx4* ra, const uintx4* rb) {
+    unsigned char* ap = As + kq * WC_PITCH + cb * 16;
+    unsigned char* bp = Bs + kq * WC_PITCH + cb * 16;
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      *(uintx4*)(ap + i * 32) = ra[i];
+      *(uintx4*)(bp + i * 32) = rb[i];
+    }
+  };
+  // fragment read: lane l = (group g = l >> 4, t = l & 15); MFMA column
+  // l & 31 = 16 (g & 1) + t, k half g >> 1; this lane's address piece = row
+  // 8 (g >> 1) + (t >> 2) (+ 4 for the second read, + 16 per k16 step), channels
+  // 16 (g & 1) + 4 (t & 3) (+ 32 per column tile)
+  const int g4 = lane >> 4, t16 = lane & 15;
+  const unsigned frag_off = (unsigned)((8 * (g4 >> 1) + (t16 >> 2)) * WC_PITCH +
+                                       (16 * (g4 & 1) + 4 * (t16 & 3)) * 2);
+  const unsigned a_base = (unsigned)(size_t)As + frag_off;
+  const unsigned b_base = (unsigned)(size_t)Bs + frag_off;
+  // raw transpose reads; the data is only valid after the s_waitcnt below,
+  // which takes every result register as an in/out operand so that the
+  // compiler cannot schedule an MFMA in front of it (the loads are inline asm:
+  // hipcc does not count them)
+  auto frag_addr = [&](unsigned base, int s, int tile) -> unsigned {
+    return base + (unsigned)(s * 16 * WC_PITCH + tile * 64);
+  };
+
+  const int nsteps = (jend - jbeg + WC_J - 1) / WC_J;
+#pragma unroll
+  for (int u = 0; u < NR - 1; ++u)
+    if (u < nsteps) load_tile(jbeg + u * WC_J, a_st[u], b_st[u]);
+  for (int base = 0; base < nsteps; base += NR) {
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const int step = base + u;
+      if (step >= nsteps) break;
+      constexpr int ahead = NR - 1;
+      if (step + ahead < nsteps)
+        load_tile(jbeg + (step + ahead) * WC_J, a_st[(u + ahead) % NR],
+                  b_st[(u + ahead) % NR]);
+      store_tile(a_st[u], b_st[u]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      unsigned long long fa[2][2][2], fb[2][2][2];  // [k16 step][tile][half]
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const unsigned aa = frag_addr(a_base, s2, i), ab = frag_addr(b_base, s2, i);
+          fa[s2][i][0] = lds_read_tr(aa);
+          fa[s2][i][1] = lds_read_tr(aa + 4 * WC_PITCH);
+          fb[s2][i][0] = lds_read_tr(ab);
+          fb[s2][i][1] = lds_read_tr(ab + 4 * WC_PITCH);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]),
+                     "+v"(fa[0][1][1]), "+v"(fa[1][0][0]), "+v"(fa[1][0][1]),
+                     "+v"(fa[1][1][0]), "+v"(fa[1][1][1]), "+v"(fb[0][0][0]),
+                     "+v"(fb[0][0][1]), "+v"(fb[0][1][0]), "+v"(fb[0][1][1]),
+                     "+v"(fb[1][0][0]), "+v"(fb[1][0][1]), "+v"(fb[1][1][0]),
+                     "+v"(fb[1][1][1])
+                   :
+                   : "memory");
+      bf16x8 af[2][2], bfr[2][2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          af[s2][i] = __builtin_bit_cast(bf16x8, fa[s2][i]);
+          bfr[s2][i] = __builtin_bit_cast(bf16x8, fb[s2][i]);
+        }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s2][i], bfr[s2][j],
+                                                                acc[i][j], 0, 0, 0);
+      // fragment reads done (lgkmcnt 0) before the next tile's ds_writes
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  // slab store: [split][tap][co][ci], ci fastest (= lane & 31)
+  const int l31 = lane & 31, lk = lane >> 5;
+  float* slab = a.slabs + ((size_t)split * ntaps + tap) * Cout * Cin;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ci = c0 + j * 32 + l31;
+    if (ci >= Cin) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (co < Cout) slab[(size_t)co * Cin + ci] = acc[i][j][r];
+      }
+  }
+}
+
 // VY / VX: the dY / X tile is fetched four positions per lane (one 16-byte load,
 // two v_cvt_pk, one 8-byte LDS write: 8 load instructions per operand and step
 // instead of 32 + 32 conversions + 32 two-byte LDS writes).  Four consecutive
@@ -1629,6 +1854,19 @@ int ld_bf16_wgrad_splits(int Cout, int Cin, int ntaps, int J) {
     --sp;
   }
   return sp;
+}
+
+// both operands as C8 images (k.x / k.dy point at them; extents in bytes)
+int ld_bf16_wgrad_c8_launch(const WgradK& k, hipStream_t stream) {
+  if (k.Cin % 8 != 0 || k.Cout % 8 != 0) return LD_EUNSUPPORTED;
+  const int ntaps = k.KH * k.KW;
+  const int blocks = ((k.Cout + 63) / 64) * ((k.Cin + 63) / 64) * ntaps * k.splits;
+  const char* env = getenv("LD_CONV_WGRAD_C8_RING");
+  if (env && env[0] == '2')
+    hipLaunchKernelGGL(conv_wgrad_c8_kernel<2>, dim3(blocks), dim3(64), 0, stream, k);
+  else
+    hipLaunchKernelGGL(conv_wgrad_c8_kernel<3>, dim3(blocks), dim3(64), 0, stream, k);
+  return (int)hipGetLastError();
 }
 
 int ld_bf16_wgrad_launch(const WgradK& k, hipStream_t stream) {

@@ -56,6 +56,7 @@ struct WgradK {
 // conv_bf16.hip: bf16-MFMA streaming forward / data-gradient launch + tuning
 // (mode 0 = conv, 1 = stride-2 dgrad parity class), wave-private bf16 wgrad.
 int ld_bf16_stream_launch(int mode, const ConvK& k, hipStream_t stream);
+int ld_bf16_wgrad_c8_launch(const WgradK& k, hipStream_t stream);
 int ld_bf16_stream_tune(int mode, const ConvK& k, hipStream_t stream);
 int ld_bf16_wgrad_launch(const WgradK& k, hipStream_t stream);
 bool ld_bf16_wgrad_tiled(int Cout, int Cin, int Pout);     // which bf16 wgrad kernel

@@ -178,6 +178,11 @@ def set_c8(flag):
     _C8[0] = bool(flag)
 
 
+# the C8-operand weight gradient (transpose-read kernel); LD_CONV_WGRAD_C8=0
+# keeps the fp32-operand kernel
+_WGRAD_C8 = [os.environ.get('LD_CONV_WGRAD_C8', '1') == '1']
+
+
 def _use_c8(reduction_channels, ksize=3, stride=1, J=1 << 30, x=None):
     """Whether a conv takes the C8 image of its activation operand.  The GEMM
     itself is faster with it everywhere (profiles/r02_kernels_c8.json: head
@@ -563,6 +568,13 @@ class ConvFn(torch.autograd.Function):
         d, _ = conv_desc(N, cin, cout, kh, kw, stride, pad, levels)
         st = L.stream_ptr(x3.device)
         dx = dw = db = None
+        # bf16 + C8: the weight gradient takes both operands as C8 images
+        # (ld_conv_bf16_wgrad_c8); converting dy first lets the data gradient
+        # below use the same image
+        c8w = ctx.needs_input_grad[1] and _PRECISION[0] == 'bf16' and \
+            _C8[0] and _WGRAD_C8[0] and cin % 32 == 0 and cout % 32 == 0
+        if c8w:
+            to_c8(dy)
         if ctx.needs_input_grad[0]:
             bf16 = _use_bf16(cout)  # the data gradient reduces over Cout
             _, wt_bwd = weight_images(w, True, bf16=bf16, need_fwd=False)
@@ -588,9 +600,11 @@ class ConvFn(torch.autograd.Function):
             need = lib.ld_conv_wgrad_workspace_bytes(C.byref(d))
             ws = workspace(x3.device, need, 'wgrad')
             bf16 = _PRECISION[0] == 'bf16' and cin >= 16
-            wgrad = lib.ld_conv_bf16_wgrad if bf16 else lib.ld_conv_wgrad
+            wgrad = lib.ld_conv_bf16_wgrad_c8 if c8w else \
+                lib.ld_conv_bf16_wgrad if bf16 else lib.ld_conv_wgrad
             with _timed('conv_wgrad_bf16' if bf16 else 'conv_wgrad', d):
-                L.check(wgrad(C.byref(d), L.ptr(x3), L.ptr(dy), L.ptr(dw),
+                xw, dyw = (to_c8(x3), to_c8(dy)) if c8w else (x3, dy)
+                L.check(wgrad(C.byref(d), L.ptr(xw), L.ptr(dyw), L.ptr(dw),
                               0 if sink is None else 1, L.ptr(ws),
                               ws.numel(), st), 'ld_conv_wgrad')
             if sink is not None:

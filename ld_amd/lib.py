@@ -240,6 +240,8 @@ SIGNATURES = {
     'ld_conv_bf16_tune_dgrad': (C.c_int, [_CV, _vp, _vp, _vp, _vp]),
     'ld_conv_bf16_wgrad': (C.c_int, [_CV, _vp, _vp, _vp, _i32, _vp, _sz,
                                      _vp]),
+    'ld_conv_bf16_wgrad_c8': (C.c_int, [_CV, _vp, _vp, _vp, _i32, _vp, _sz,
+                                        _vp]),
     'ld_conv_to_c8': (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     'ld_conv_bf16_forward_c8': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
     'ld_conv_bf16_tune_forward_c8': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
