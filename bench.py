@@ -86,8 +86,9 @@ def kernel_roofline(trainer, dbatch, steps, bf16=False):
         main = {k: v for k, v in agg.items() if k.endswith('_bf16')}
         rest = {k: v for k, v in agg.items() if not k.endswith('_bf16')}
         peak = PEAK_BF16_MFMA_TFLOPS
-        kernel = ('conv (bf16 MFMA 32x32x16, fp32 accumulate: streaming '
-                  'fwd/dgrad + wave-private wgrad, conv_bf16.hip)')
+        kernel = ('conv (bf16 MFMA 32x32x16, fp32 accumulate: LDS-tiled / '
+                  'streaming fwd+dgrad and transpose-read wgrad on bf16 C8 '
+                  'operand images, conv_bf16.hip)')
     else:
         main, rest, peak = agg, {}, PEAK_FP32_MFMA_TFLOPS
         kernel = ('conv (fp32 MFMA 32x32x2 implicit GEMM: streaming fwd/dgrad '

@@ -377,6 +377,12 @@ typedef struct {
    * bit-identical to converting y afterwards -- for the conv that consumes y
    * next.  Needs Cout % 8 == 0. */
   void* y_c8;
+  /* bf16 forward entry points only: the residual as a C8 image instead of the
+   * fp32 `residual` (give one or the other), and -- when y_c8 is given -- y
+   * itself may be NULL: the frozen teacher then keeps ONLY the bf16 image of its
+   * activations (the reference's mixed-precision nets are fp16 end to end the
+   * same way, mmcv auto_fp16). */
+  const void* residual_c8;
 } ld_conv_epilogue_t;
 
 /* (Cout,Cin,KH,KW) parameter -> GEMM images: wt_fwd [tap][Cin_pad][Cout]

@@ -1533,7 +1533,8 @@ namespace {
 int build_forward(const ld_conv_t* c, const float* x, const void* wt_fwd,
                   const ld_conv_epilogue_t* ep, float* y, ConvK& k, int family = 0) {
   if (int e = check_conv(c)) return e;
-  if (!x || !wt_fwd || !y) return LD_EINVAL;
+  if (!x || !wt_fwd) return LD_EINVAL;
+  if (!y && !(family >= 1 && ep && ep->y_c8)) return LD_EINVAL;
   k = ConvK{};
   k.x = x;
   k.wt = (const float*)wt_fwd;
@@ -1544,7 +1545,9 @@ int build_forward(const ld_conv_t* c, const float* x, const void* wt_fwd,
   k.residual = ep ? ep->residual : nullptr;
   k.relu = ep ? ep->relu : 0;
   k.y_c8 = ep ? ep->y_c8 : nullptr;
-  if (k.y_c8 && (family == 0 || c->Cout % 8 != 0)) return LD_EINVAL;
+  k.res_c8 = ep ? ep->residual_c8 : nullptr;
+  if ((k.y_c8 || k.res_c8) && (family == 0 || c->Cout % 8 != 0)) return LD_EINVAL;
+  if (k.res_c8 && k.residual) return LD_EINVAL;
   if ((k.scale == nullptr) != (k.shift == nullptr)) return LD_EINVAL;
   k.N = c->N; k.Cin = c->Cin; k.Cout = c->Cout; k.KH = c->KH; k.KW = c->KW;
   k.g.stride = c->stride; k.g.pad = c->pad; k.Pin = c->Pin; k.Pout = c->Pout;
@@ -1644,7 +1647,7 @@ extern "C" int ld_conv_forward_smallc(const ld_conv_t* c, const float* x,
   k.shift = ep ? ep->shift : nullptr;
   k.residual = ep ? ep->residual : nullptr;
   k.relu = ep ? ep->relu : 0;
-  if (ep && ep->y_c8) return LD_EINVAL;  // bf16 entry points only
+  if (ep && (ep->y_c8 || ep->residual_c8)) return LD_EINVAL;  // bf16 entry points
   if ((k.scale == nullptr) != (k.shift == nullptr)) return LD_EINVAL;
   k.N = c->N; k.Cin = c->Cin; k.Cout = c->Cout; k.KH = c->KH; k.KW = c->KW;
   k.g.stride = c->stride; k.g.pad = c->pad; k.Pin = c->Pin; k.Pout = c->Pout;

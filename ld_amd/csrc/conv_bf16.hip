@@ -258,6 +258,8 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_bf16_kernel(ConvK a) {
 
   // ---- epilogue: direct stores, 32 consecutive positions per accumulator row
   const bool has_res = a.residual != nullptr;
+  const bool res8 = a.res_c8 != nullptr;  // residual as a C8 image
+  const bool has_y = a.y != nullptr;      // fp32 output optional (C8-only nets)
   const bool c8out = a.y_c8 != nullptr;
   const bool relu = a.relu != 0;
   const bool has_aff = a.scale != nullptr, has_bias = a.bias != nullptr;
@@ -289,6 +291,16 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_bf16_kernel(ConvK a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         floatx4_t q;
+        // C8 residual: this lane's four channels = 8 bytes of the C8 row
+        floatx4_t rq = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (MODE == 0 && res8 && rbase + 8 * g < Cout) {
+          const int row0 = rbase + 8 * g;
+          const size_t o =
+              (((size_t)n * (Cout >> 3) + (row0 >> 3)) * a.Pout + p) * 16 +
+              (row0 & 4) * 2;
+          const uintx2 raw = *(const uintx2*)((const char*)a.res_c8 + o);
+          rq = __builtin_convertvector(__builtin_bit_cast(bf16x4, raw), floatx4_t);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
@@ -297,8 +309,9 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_bf16_kernel(ConvK a) {
           if (row < Cout) {
             v = acc[i][j][r] * sc[r] + sh[r];
             if (has_res) v += a.residual[colbase + (size_t)row * prow];
+            if (MODE == 0 && res8) v += rq[e];
             if (relu) v = fmaxf(v, 0.0f);
-            a.y[colbase + (size_t)row * prow] = v;
+            if (has_y) a.y[colbase + (size_t)row * prow] = v;
           }
           q[e] = v;
         }
@@ -503,6 +516,8 @@ __global__ __launch_bounds__(256, 2) void conv_tile_bf16_kernel(ConvK a) {
 
   // ---- epilogue: direct stores, 32 consecutive positions per accumulator row
   const bool has_res = a.residual != nullptr;
+  const bool res8 = a.res_c8 != nullptr;  // residual as a C8 image
+  const bool has_y = a.y != nullptr;      // fp32 output optional (C8-only nets)
   const bool c8out = a.y_c8 != nullptr;
   const bool relu = a.relu != 0;
   const bool has_aff = a.scale != nullptr, has_bias = a.bias != nullptr;
@@ -534,6 +549,16 @@ __global__ __launch_bounds__(256, 2) void conv_tile_bf16_kernel(ConvK a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         floatx4_t q;
+        // C8 residual: this lane's four channels = 8 bytes of the C8 row
+        floatx4_t rq = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (MODE == 0 && res8 && rbase + 8 * g < Cout) {
+          const int row0 = rbase + 8 * g;
+          const size_t o =
+              (((size_t)n * (Cout >> 3) + (row0 >> 3)) * a.Pout + p) * 16 +
+              (row0 & 4) * 2;
+          const uintx2 raw = *(const uintx2*)((const char*)a.res_c8 + o);
+          rq = __builtin_convertvector(__builtin_bit_cast(bf16x4, raw), floatx4_t);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
@@ -542,8 +567,9 @@ __global__ __launch_bounds__(256, 2) void conv_tile_bf16_kernel(ConvK a) {
           if (row < Cout) {
             v = acc[i][j][r] * sc[r] + sh[r];
             if (has_res) v += a.residual[colbase + (size_t)row * prow];
+            if (MODE == 0 && res8) v += rq[e];
             if (relu) v = fmaxf(v, 0.0f);
-            a.y[colbase + (size_t)row * prow] = v;
+            if (has_y) a.y[colbase + (size_t)row * prow] = v;
           }
           q[e] = v;
         }
@@ -717,6 +743,8 @@ __global__ __launch_bounds__(256, 2) void conv_tile_c8_kernel(ConvK a) {
 
   // ---- epilogue: direct stores, 32 consecutive positions per accumulator row
   const bool has_res = a.residual != nullptr;
+  const bool res8 = a.res_c8 != nullptr;  // residual as a C8 image
+  const bool has_y = a.y != nullptr;      // fp32 output optional (C8-only nets)
   const bool c8out = a.y_c8 != nullptr;
   const bool relu = a.relu != 0;
   const bool has_aff = a.scale != nullptr, has_bias = a.bias != nullptr;
@@ -748,6 +776,16 @@ __global__ __launch_bounds__(256, 2) void conv_tile_c8_kernel(ConvK a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         floatx4_t q;
+        // C8 residual: this lane's four channels = 8 bytes of the C8 row
+        floatx4_t rq = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (MODE == 0 && res8 && rbase + 8 * g < Cout) {
+          const int row0 = rbase + 8 * g;
+          const size_t o =
+              (((size_t)n * (Cout >> 3) + (row0 >> 3)) * a.Pout + p) * 16 +
+              (row0 & 4) * 2;
+          const uintx2 raw = *(const uintx2*)((const char*)a.res_c8 + o);
+          rq = __builtin_convertvector(__builtin_bit_cast(bf16x4, raw), floatx4_t);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
@@ -756,8 +794,9 @@ __global__ __launch_bounds__(256, 2) void conv_tile_c8_kernel(ConvK a) {
           if (row < Cout) {
             v = acc[i][j][r] * sc[r] + sh[r];
             if (has_res) v += a.residual[colbase + (size_t)row * prow];
+            if (MODE == 0 && res8) v += rq[e];
             if (relu) v = fmaxf(v, 0.0f);
-            a.y[colbase + (size_t)row * prow] = v;
+            if (has_y) a.y[colbase + (size_t)row * prow] = v;
           }
           q[e] = v;
         }

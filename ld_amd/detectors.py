@@ -216,6 +216,9 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
             # has it)
             for p in self.teacher_model.parameters():
                 p._ld_static = True
+            # bf16 mode: its trunk activations exist only as bf16 C8 images
+            # (resnet.ResNet._c8_only; the fp32 modes are unaffected)
+            self.teacher_model.backbone.c8_activations = True
         if teacher_ckpt is not None:
             from .checkpoint import load_checkpoint
             try:

@@ -235,6 +235,79 @@ def to_c8(x3):
     return out
 
 
+class C8Act:
+    """A frozen activation that exists ONLY as its bf16 C8 image (N, C/8, P, 8).
+
+    The teacher runs under no_grad and nothing but convs read its trunk, so in
+    bf16 mode its conv+BN+ReLU launches skip the fp32 output altogether and
+    take the residual from the C8 image too (ld_conv_epilogue_t.y == NULL,
+    residual_c8): the small stages are HBM-bound, and the fp32 master copy is
+    2/3 of their bytes.  The reference's mixed-precision nets hold half
+    activations end to end the same way (mmcv auto_fp16 on the backbone).
+    Duck-types the few tensor members the conv plumbing touches."""
+    requires_grad = False
+    dtype = torch.float32  # the LOGICAL dtype of the activation
+
+    def __init__(self, buf, shape):
+        self.buf, self.shape, self.device = buf, tuple(shape), buf.device
+
+    def reshape(self, *shape):
+        if len(shape) == 1 and not isinstance(shape[0], int):
+            shape = tuple(shape[0])
+        n, c = self.shape[:2]
+        rest = 1
+        for v in self.shape[2:]:
+            rest *= v
+        if -1 in shape:
+            known = 1
+            for v in shape:
+                known *= v if v != -1 else 1
+            shape = tuple(v if v != -1 else n * c * rest // known
+                          for v in shape)
+        got = 1
+        for v in shape[2:]:
+            got *= v
+        if len(shape) < 3 or shape[0] != n or shape[1] != c or got != rest:
+            raise L.LdError(f'C8Act: cannot view {self.shape} as {shape} '
+                            '(only the position axes may be regrouped)')
+        return C8Act(self.buf, shape)
+
+    view = reshape
+
+    def size(self, i=None):
+        return self.shape if i is None else self.shape[i]
+
+    def dim(self):
+        return len(self.shape)
+
+    def float(self):
+        """fp32 (N, C, ...) copy (tests / debugging only)."""
+        n, c = self.shape[:2]
+        return self.buf.view(n, c // 8, -1, 8).permute(0, 1, 3, 2).reshape(
+            self.shape).float()
+
+
+# inside this scope the fused frozen conv+BN+ReLU launches keep only the C8
+# image of their output (resnet.ResNet.forward opens it for a frozen teacher)
+_C8_ONLY = [False]
+
+
+class c8_only_scope:
+
+    def __enter__(self):
+        self.prev, _C8_ONLY[0] = _C8_ONLY[0], True
+
+    def __exit__(self, *exc):
+        _C8_ONLY[0] = self.prev
+
+
+def c8_only_available(channels):
+    """Whether a frozen chain over these channel counts can run C8-only."""
+    return (_C8[0] and _PRECISION[0] == 'bf16' and
+            os.environ.get('LD_TEACHER_C8_ONLY', '1') == '1' and
+            all(c % 32 == 0 for c in channels))
+
+
 def _register(reg, t):
     if id(t) not in reg:
         reg[id(t)] = weakref.ref(t)
@@ -449,6 +522,9 @@ def _epilogue(bias=None, scale=None, shift=None, residual=None, relu=False,
               y_c8=None):
     ep = L.ConvEpilogueT()
     ep.y_c8 = y_c8.data_ptr() if y_c8 is not None else None
+    ep.residual_c8 = None
+    if isinstance(residual, C8Act):
+        ep.residual_c8, residual = residual.buf.data_ptr(), None
     ep.bias = bias.data_ptr() if bias is not None else None
     ep.scale = scale.data_ptr() if scale is not None else None
     ep.shift = shift.data_ptr() if shift is not None else None
@@ -458,12 +534,16 @@ def _epilogue(bias=None, scale=None, shift=None, residual=None, relu=False,
 
 
 def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
-                     shift=None, residual=None, relu=False, emit_c8=False):
+                     shift=None, residual=None, relu=False, emit_c8=False,
+                     c8_only=False):
     """One implicit-GEMM launch.  Returns (y3, out_levels).  ``emit_c8``: in
     bf16 mode also write the C8 image of y from the epilogue (for a y that goes
-    straight into another conv: the frozen conv+BN+ReLU chains)."""
+    straight into another conv: the frozen conv+BN+ReLU chains).  ``c8_only``:
+    write ONLY that image and return a C8Act.  x3 / residual may be C8Acts."""
     lib = L.get_lib()
-    _dev_f32(x3, 'conv input')
+    in8 = isinstance(x3, C8Act)
+    if not in8:
+        _dev_f32(x3, 'conv input')
     N, cin, P = x3.shape
     cout, cin_w, kh, kw = w.shape
     if cin_w != cin:
@@ -473,23 +553,30 @@ def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
         raise L.LdError(f'conv: input has {P} positions, levels say {d.Pin}')
     smallc = cin < 16
     bf16 = not smallc and _use_bf16(cin)
+    res8 = isinstance(residual, C8Act)
+    if (in8 or res8 or c8_only) and not (
+            bf16 and _C8[0] and cout % 32 == 0 and (not in8 or cin % 32 == 0)):
+        raise L.LdError('conv: C8-only activations need bf16 mode, the C8 path '
+                        'and channel counts that are multiples of 32')
     wt_fwd, _ = weight_images(w, False, smallc, bf16)
-    y3 = torch.empty((N, cout, d.Pout), dtype=torch.float32, device=x3.device)
+    y3 = None if c8_only else torch.empty(
+        (N, cout, d.Pout), dtype=torch.float32, device=x3.device)
     if residual is not None:
-        _dev_f32(residual, 'residual')
-        assert residual.shape == y3.shape
+        if not res8:
+            _dev_f32(residual, 'residual')
+        assert tuple(residual.shape) == (N, cout, d.Pout)
     y_c8 = None
-    if emit_c8 and bf16 and _C8[0] and cout % 32 == 0:
+    if (emit_c8 or c8_only) and bf16 and _C8[0] and cout % 32 == 0:
         y_c8 = torch.empty(N * cout * d.Pout, dtype=torch.bfloat16,
                            device=x3.device)
     ep = _epilogue(bias, scale, shift, residual, relu, y_c8)
-    c8 = bf16 and _use_c8(cin, kh, stride, N * d.Pout, x3)
+    c8 = in8 or (bf16 and _use_c8(cin, kh, stride, N * d.Pout, x3))
     fn = lib.ld_conv_forward_smallc if smallc else (
         lib.ld_conv_bf16_forward_c8 if c8 else
         lib.ld_conv_bf16_forward if bf16 else lib.ld_conv_forward)
     with _timed('conv_fwd_bf16' if bf16 else 'conv_fwd', d):
         # the conversion launch is part of the conv's measured time
-        xin = to_c8(x3) if c8 else x3
+        xin = x3.buf if in8 else to_c8(x3) if c8 else x3
         if not smallc:
             tune = lib.ld_conv_bf16_tune_forward_c8 if c8 else \
                 lib.ld_conv_bf16_tune_forward if bf16 else \
@@ -503,6 +590,8 @@ def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
                                     L.stream_ptr(x3.device)))
         L.check(fn(C.byref(d), L.ptr(xin), L.ptr(wt_fwd), C.byref(ep),
                    L.ptr(y3), L.stream_ptr(x3.device)), 'ld_conv_forward')
+    if c8_only:
+        return C8Act(y_c8, (N, cout, d.Pout)), out_levels
     if y_c8 is not None:
         _attach_c8(y3, y_c8)
     return y3, out_levels
@@ -769,7 +858,7 @@ def conv_bn_act_infer(x3, w, gamma, beta, mean, var, eps, stride, pad, levels,
     scale, shift, _ = bn_prepare(gamma, beta, mean, var, eps)
     return conv_forward_raw(x3, w, stride, pad, levels, scale=scale,
                             shift=shift, residual=residual, relu=relu,
-                            emit_c8=True)
+                            emit_c8=True, c8_only=_C8_ONLY[0])
 
 
 # ---------------------------------------------------------------------------

@@ -97,7 +97,7 @@ class ConvEpilogueT(C.Structure):
     _fields_ = [('bias', C.c_void_p), ('scale', C.c_void_p),
                 ('shift', C.c_void_p), ('residual', C.c_void_p),
                 ('relu', C.c_int32), ('reserved', C.c_int32),
-                ('y_c8', C.c_void_p)]
+                ('y_c8', C.c_void_p), ('residual_c8', C.c_void_p)]
 
 
 class LevelsT(C.Structure):

@@ -282,6 +282,13 @@ class ResNet(nn.Module):
         x4 = Y.maxpool3x3s2(x3.view(n, -1, lv[0][0], lv[0][1]))
         lv = ((x4.shape[2], x4.shape[3]), )
         x3 = x4.reshape(n, x4.shape[1], -1)
+        if self._c8_only():
+            # frozen teacher, bf16 mode: the trunk lives only as bf16 C8 images
+            with Y.c8_only_scope():
+                return self._stages(Y.C8Act(Y.to_c8(x3), x3.shape), lv, n)
+        return self._stages(x3, lv, n)
+
+    def _stages(self, x3, lv, n):
         outs = []
         for i, layer_name in enumerate(self.res_layers):
             for blk in getattr(self, layer_name):
@@ -289,6 +296,27 @@ class ResNet(nn.Module):
             if i in self.out_indices:
                 outs.append(x3.view(n, x3.shape[1], lv[0][0], lv[0][1]))
         return tuple(outs)
+
+    def _c8_only(self):
+        """``c8_activations`` (set by the KD detector on its frozen teacher):
+        under no_grad, with every BN in eval mode and no DCN block, the stages
+        keep only bf16 C8 activations (layers.C8Act) and the neck's lateral
+        convs read those."""
+        if not getattr(self, 'c8_activations', False) or \
+                torch.is_grad_enabled() or self.training:
+            return False
+        plain = getattr(self, '_c8_plain', None)
+        if plain is None:
+            convs = [m for m in self.modules()
+                     if hasattr(m, 'weight') and m.weight.dim() == 4]
+            plain = not any(hasattr(m, 'forward3_fused') for m in convs)
+            stage = [m for name in self.res_layers
+                     for m in getattr(self, name).modules()
+                     if hasattr(m, 'weight') and m.weight.dim() == 4]
+            self._c8_channels = sorted({c for m in stage
+                                        for c in m.weight.shape[:2]})
+            self._c8_plain = plain
+        return plain and Y.c8_only_available(self._c8_channels)
 
     def train(self, mode=True):
         """resnet.py:639-648: keep frozen stages and (norm_eval) all BN in
@@ -299,3 +327,4 @@ class ResNet(nn.Module):
             for m in self.modules():
                 if isinstance(m, BatchNorm2d):
                     m.eval()
+        return self

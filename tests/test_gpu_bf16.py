@@ -353,6 +353,107 @@ def test_conv_epilogue_c8_output(bf16_mode, monkeypatch):
         assert Y.C8_STATS['reused'] == before['reused'] + 1, val
 
 
+def test_conv_c8_only_output_and_c8_residual(bf16_mode, monkeypatch):
+    """C8-only frozen chains: y == NULL + residual_c8.  The image written equals
+    the C8 conversion of the ordinary fp32 launch fed the bf16-ROUNDED residual
+    (bf16 -> fp32 is exact, so the epilogue arithmetic is the same), for every
+    bf16 forward kernel; a C8Act input runs the C8-operand kernel."""
+    from ld_amd import layers as Y
+    dev = _dev()
+    monkeypatch.setattr(Y, '_C8_ALL', True)
+    g = torch.Generator().manual_seed(12)
+    levels = ((12, 20), (6, 10))
+    P = sum(h * w for h, w in levels)
+    x = torch.randn(2, 64, P, generator=g).to(dev)
+    w1 = (torch.randn(96, 64, 3, 3, generator=g) * 0.05).to(dev)
+    scale = (torch.rand(96, generator=g) + 0.5).to(dev)
+    shift = torch.randn(96, generator=g).to(dev)
+    res = torch.randn(2, 96, P, generator=g).to(dev)
+    res8 = Y.C8Act(Y.to_c8(res), res.shape)
+    assert torch.equal(res8.float(), _bf16r(res))
+    x8 = Y.C8Act(Y.to_c8(x), x.shape)
+    for env, val, xin in (('LD_CONV_BF16_SHAPE', '1x1x2x4x1', x),
+                          ('LD_CONV_BF16_SHAPE', '2x1x1x4x4', x),
+                          ('LD_CONV_BF16_SHAPE', '4x2x0x32x2', x),
+                          ('LD_CONV_C8_SHAPE', '2x2x2', x),
+                          ('LD_CONV_C8_SHAPE', '4x4x2', x8)):
+        monkeypatch.setenv(env, val)
+        if env != 'LD_CONV_C8_SHAPE':
+            monkeypatch.setattr(Y, '_use_c8', lambda *a, **k: False)
+        ref, _ = Y.conv_forward_raw(x, w1, 1, 1, levels, scale=scale,
+                                    shift=shift, residual=_bf16r(res),
+                                    relu=True)
+        got, lv = Y.conv_forward_raw(xin, w1, 1, 1, levels, scale=scale,
+                                     shift=shift, residual=res8, relu=True,
+                                     c8_only=True)
+        monkeypatch.undo()
+        monkeypatch.setattr(Y, '_C8_ALL', True)
+        assert isinstance(got, Y.C8Act) and got.shape == (2, 96, P), val
+        assert lv == levels
+        want = ref.to(torch.bfloat16).reshape(2, 12, 8, P).permute(
+            0, 1, 3, 2).reshape(-1)
+        assert torch.equal(got.buf, want), (env, val)
+    # only the position axes of a C8Act can be regrouped
+    v = got.view(2, 96, 12 * 20 + 60, 1)
+    assert v.buf is got.buf and v.reshape(2, 96, -1).shape == (2, 96, P)
+    with pytest.raises(Exception):
+        got.reshape(2, 48, -1)
+
+
+def test_c8_only_needs_bf16_mode():
+    """Outside bf16 mode a C8Act operand is refused, not silently converted."""
+    from ld_amd import layers as Y
+    from ld_amd.lib import LdError
+    dev = _dev()
+    x = torch.randn(1, 64, 40, device=dev)
+    w = torch.randn(64, 64, 1, 1, device=dev)
+    with pytest.raises(LdError):
+        Y.conv_forward_raw(x, w, 1, 0, ((5, 8), ), c8_only=True)
+
+
+def test_teacher_trunk_c8_only_close_to_fp32_master(bf16_mode):
+    """ResNet-50 + FPN under no_grad with ``c8_activations``: the stage outputs
+    are C8Acts, the FPN outputs are ordinary fp32 tensors, and they differ from
+    the fp32-master-activation bf16 run only by the bf16 rounding of the
+    residual trunk (16 blocks): <= 2% of each level's scale (stated)."""
+    from ld_amd import build_backbone, build_neck
+    from ld_amd import layers as Y
+    dev = _dev()
+    torch.manual_seed(3)
+    bb = build_backbone(dict(
+        type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3),
+        frozen_stages=1, norm_cfg=dict(type='BN', requires_grad=True),
+        norm_eval=True, style='pytorch')).to(dev).eval()
+    for m in bb.modules():  # non-trivial BN statistics
+        if hasattr(m, 'running_var'):
+            m.running_var.uniform_(0.5, 1.5)
+            m.running_mean.normal_(0, 0.1)
+            m.weight.data.uniform_(0.5, 1.0)
+    neck = build_neck(dict(type='FPN', in_channels=[256, 512, 1024, 2048],
+                           out_channels=256, start_level=1,
+                           add_extra_convs='on_output', num_outs=5)).to(
+                               dev).eval()
+    img = torch.randn(2, 3, 128, 192, device=dev)
+    with torch.no_grad():
+        feats = bb(img)
+        assert all(isinstance(f, torch.Tensor) for f in feats)
+        want = neck(feats)
+        bb.c8_activations = True
+        feats8 = bb(img)
+        assert all(isinstance(f, Y.C8Act) for f in feats8)
+        assert [f.shape for f in feats8] == [tuple(f.shape) for f in feats]
+        got = neck(feats8)
+        for f8, f in zip(feats8, feats):
+            err = (f8.float() - f).abs().max().item()
+            assert err <= 2e-2 * f.abs().max().item() + 1e-6, err
+    for a, b in zip(got, want):
+        assert isinstance(a, torch.Tensor) and a.dtype == torch.float32
+        assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item()
+    # with gradients enabled the trunk keeps its fp32 activations
+    img.requires_grad_(False)
+    assert all(isinstance(f, torch.Tensor) for f in bb.train()(img))
+
+
 def test_bn_act_c8_side_output(bf16_mode):
     """Eval-BN + residual + ReLU forward: fp32 y identical with and without the
     C8 side output; the image equals a conversion of y."""
