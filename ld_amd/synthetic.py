@@ -188,23 +188,26 @@ def synthetic_head_inputs(num_imgs,
                           num_classes=80,
                           reg_max=16,
                           feat_channels=256,
-                          device='cpu'):
+                          device='cpu',
+                          num_anchors=1):
     """Random student/teacher head outputs and FPN features for loss-block
     parity tests: logits ~ 3*randn (reg), cls ~ 1.2*randn - 4, features ~ randn.
+    ``num_anchors`` > 1: anchor-major channel blocks (RetinaGFLHead).
 
     Returns dict of lists (one tensor per level, NCHW).
     """
     gen = _gen(seed)
     out = dict(cls=[], reg=[], t_cls=[], t_reg=[], x=[], t_x=[])
+    na = num_anchors
     for (h, w) in featmap_sizes:
         out['cls'].append(
-            _normal((num_imgs, num_classes, h, w), gen) * 1.2 - 4.0)
+            _normal((num_imgs, na * num_classes, h, w), gen) * 1.2 - 4.0)
         out['reg'].append(
-            _normal((num_imgs, 4 * (reg_max + 1), h, w), gen) * 3.0)
+            _normal((num_imgs, na * 4 * (reg_max + 1), h, w), gen) * 3.0)
         out['t_cls'].append(
-            _normal((num_imgs, num_classes, h, w), gen) * 1.2 - 4.0)
+            _normal((num_imgs, na * num_classes, h, w), gen) * 1.2 - 4.0)
         out['t_reg'].append(
-            _normal((num_imgs, 4 * (reg_max + 1), h, w), gen) * 3.0)
+            _normal((num_imgs, na * 4 * (reg_max + 1), h, w), gen) * 3.0)
         out['x'].append(
             _normal((num_imgs, feat_channels, h, w), gen))
         out['t_x'].append(

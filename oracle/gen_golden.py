@@ -1018,6 +1018,154 @@ def gen_lossblock_fcos():
     np.savez_compressed(os.path.join(OUT, 'lossblock_fcos.npz'), **d)
 
 
+RETINA_KEYS = ['loss_cls', 'loss_bbox', 'loss_ld', 'loss_ld_vlr',
+               'loss_cls_kd']
+
+
+def _ld_retina_head():
+    """LDRetinaHead as configs/ld/ld_retina_r50_1x.py:28-62 builds it."""
+    from mmdet.models import build_head
+    cfg = dict(
+        type='LDRetinaHead', num_classes=80, in_channels=256, stacked_convs=4,
+        feat_channels=256,
+        anchor_generator=dict(type='AnchorGenerator', octave_base_scale=4,
+                              scales_per_octave=3, ratios=[0.5, 1.0, 2.0],
+                              strides=[8, 16, 32, 64, 128]),
+        bbox_coder=dict(type='DeltaXYWHBBoxCoder',
+                        target_means=[.0, .0, .0, .0],
+                        target_stds=[1.0, 1.0, 1.0, 1.0]),
+        loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0,
+                      alpha=0.25, loss_weight=1.0),
+        loss_bbox=dict(type='GIoULoss', loss_weight=2.0),
+        loss_ld=dict(type='KnowledgeDistillationKLDivLoss', loss_weight=5,
+                     T=10),
+        loss_kd=dict(type='KnowledgeDistillationKLDivLoss', loss_weight=10,
+                     T=8),
+        reg_decoded_bbox=True,
+        train_cfg=ref_shim.ConfigDict(
+            assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5,
+                          neg_iou_thr=0.4, min_pos_iou=0, ignore_iof_thr=-1),
+            allowed_border=-1, pos_weight=-1, debug=False),
+        test_cfg=ref_shim.ConfigDict(
+            nms_pre=1000, min_bbox_size=0, score_thr=0.05,
+            nms=dict(type='nms', iou_threshold=0.6), max_per_img=100))
+    return build_head(cfg)
+
+
+def gen_lossblock_retina():
+    """LDRetinaHead (ld_retina.py): MaxIoU targets + VLR region over the 9
+    anchors per position, loss table (5 keys x 5 levels) and gradients,
+    executed by the reference on the LOSSBLOCK_CASES inputs with 9-anchor head
+    outputs."""
+    head = _ld_retina_head()
+    d = {}
+    for name, pad, img_shape, num_gt, bseed, hseed, store in LOSSBLOCK_CASES:
+        batch = synthetic.synthetic_batch(
+            num_imgs=len(num_gt), img_shape=img_shape, pad_shape=pad,
+            num_gt=num_gt, seed=bseed)
+        sizes = synthetic.level_shapes(pad)
+        hi = synthetic.synthetic_head_inputs(len(num_gt), sizes, seed=hseed,
+                                             num_anchors=9)
+        t0 = time.time()
+        anchor_list, valid_flag_list = head.get_anchors(
+            sizes, batch['img_metas'], device='cpu')
+        if name == 'small':
+            for l, a in enumerate(anchor_list[0]):
+                d[f'anchors_{l}'] = _np(a)
+        tg = head.get_targets(anchor_list, valid_flag_list,
+                              batch['gt_bboxes'], batch['img_metas'],
+                              gt_labels_list=batch['gt_labels'],
+                              label_channels=80)
+        (labels, label_weights, bbox_targets, bbox_weights, num_pos, num_neg,
+         vlr) = tg
+        d[name + '_num_total_pos'] = np.array(num_pos)
+        for l in range(len(sizes)):
+            d[f'{name}_labels_{l}'] = _np(labels[l]).astype(np.int64)
+            d[f'{name}_label_weights_{l}'] = _np(label_weights[l])
+            d[f'{name}_vlr_{l}'] = _np(vlr[l])
+            bw = _np(bbox_weights[l])
+            d[f'{name}_bbox_pos_{l}'] = _np(bbox_targets[l])[bw[..., 0] > 0]
+        for k in ('cls', 'reg'):
+            for t in hi[k]:
+                t.requires_grad_(True)
+        losses = head.loss(hi['cls'], hi['reg'], batch['gt_bboxes'],
+                           batch['gt_labels'], (hi['t_cls'], hi['t_reg']),
+                           batch['img_metas'])
+        table = np.stack([np.array([float(v.detach()) for v in losses[k]])
+                          for k in RETINA_KEYS])
+        total = sum(sum(v) for v in losses.values())
+        total.backward()
+        d[name + '_cfg'] = np.array(
+            list(pad) + list(img_shape) + [bseed, hseed])
+        d[name + '_num_gt'] = np.array(num_gt)
+        d[name + '_losses'] = table.astype(np.float64)
+        for k in ('cls', 'reg'):
+            gs = [t.grad if t.grad is not None else torch.zeros_like(t)
+                  for t in hi[k]]
+            d[f'{name}_g{k}_abs_sum'] = np.array(
+                [float(g.double().abs().sum()) for g in gs])
+            d[f'{name}_g{k}_sum'] = np.array(
+                [float(g.double().sum()) for g in gs])
+            for l, g in enumerate(gs):
+                # 1 332 channels: sampled even for the small cases (every 11th
+                # element; every 1009th at the C2 size)
+                flat = _np(g).reshape(-1)
+                d[f'{name}_g{k}_{l}_sample'] = flat[
+                    np.arange(0, flat.size, 11 if store else 1009)]
+        print(f'  lossblock_retina {name}: {time.time() - t0:.2f}s total='
+              f'{float(total):.6f}', table.sum(1), 'pos', num_pos, 'ignored',
+              int(sum((w == 0).sum() for w in label_weights)), 'vlr',
+              int(sum((v > 0).sum() for v in vlr)))
+    np.savez_compressed(os.path.join(OUT, 'lossblock_retina.npz'), **d)
+
+
+def gen_e2e_retina():
+    """One LD train step of configs/ld/ld_retina_r50_1x.py (LDRetinaHead
+    student <- RetinaGFL R101 teacher) executed by the reference."""
+    d = {}
+    for name, pad, img_shape, num_gt, bseed in (
+            ('tiny', (128, 160), (128, 150), [3, 2], 41),
+            ('small', (256, 320), (256, 320), [5, 2], 42)):
+        torch.manual_seed(0)
+        det = build_reference_detector('configs/ld/ld_retina_r50_1x.py')
+        det.load_state_dict(
+            synthetic.seeded_state_dict(det.state_dict(), seed=1))
+        det.teacher_model.load_state_dict(
+            synthetic.seeded_state_dict(det.teacher_model.state_dict(),
+                                        seed=2))
+        det.train()
+        batch = synthetic.synthetic_batch(
+            num_imgs=len(num_gt), img_shape=img_shape, pad_shape=pad,
+            num_gt=num_gt, seed=bseed)
+        losses = det.forward_train(batch['img'], batch['img_metas'],
+                                   batch['gt_bboxes'], batch['gt_labels'])
+        table = np.stack([np.array([float(v.detach()) for v in losses[k]])
+                          for k in RETINA_KEYS])
+        loss, log_vars = det._parse_losses(losses)
+        loss.backward()
+        d[name + '_cfg'] = np.array(list(pad) + list(img_shape) + [bseed])
+        d[name + '_num_gt'] = np.array(num_gt)
+        d[name + '_losses'] = table.astype(np.float64)
+        names, norms, proj = [], [], []
+        for k, p in det.named_parameters():
+            if p.grad is not None:
+                names.append(k)
+                norms.append(float(p.grad.double().norm()))
+                gflat = p.grad.double().reshape(-1).numpy()
+                proj.append([float(gflat @ synthetic.grad_probe(gflat.size,
+                                                                sd))
+                             for sd in (0, 1)])
+        d[name + '_grad_names'] = np.array(names)
+        d[name + '_grad_norms'] = np.array(norms)
+        d[name + '_grad_proj'] = np.array(proj)
+        d[name + '_student_keys'] = np.array(list(det.state_dict().keys()))
+        d[name + '_teacher_keys'] = np.array(
+            list(det.teacher_model.state_dict().keys()))
+        print(f'  e2e_retina {name}:',
+              {k: round(v, 6) for k, v in log_vars.items()})
+    np.savez_compressed(os.path.join(OUT, 'e2e_retina.npz'), **d)
+
+
 def gen_e2e_atss(cfg_path='configs/ld/ld_r50_atss_r101_1x.py',
                  out_name='e2e_atss.npz', tag='e2e_atss'):
     """One LD train step of configs/ld/ld_r50_atss_r101_1x.py (LDATSSHead
@@ -1190,7 +1338,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='kat,anchors,targets,lossblock,e2e,infer,'
                     'lossblock_v2,e2e_v2,imitation,pipeline,infer_voting,'
-                    'lossblock_atss,e2e_atss,lossblock_fcos,e2e_fcos')
+                    'lossblock_atss,e2e_atss,lossblock_fcos,e2e_fcos,'
+                    'lossblock_retina,e2e_retina')
     ap.add_argument('--e2e-cases', default='')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
@@ -1227,6 +1376,10 @@ def main():
     if 'e2e_fcos' in only:
         gen_e2e_atss('configs/ld/ld_r50_fcos_r101_1x.py', 'e2e_fcos.npz',
                      'e2e_fcos')
+    if 'lossblock_retina' in only:
+        gen_lossblock_retina()
+    if 'e2e_retina' in only:
+        gen_e2e_retina()
 
 
 if __name__ == '__main__':

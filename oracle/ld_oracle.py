@@ -795,6 +795,204 @@ def ld_atss_loss_block(cls, reg, ctr, t_cls, t_reg, targets, hp=None,
 
 
 # --------------------------------------------------------------------------
+# LDRetinaHead (ld_retina.py over retina_gfl_head.py / anchor_head.py)
+# --------------------------------------------------------------------------
+def retina_base_anchors(stride, octave_base_scale=4, scales_per_octave=3,
+                        ratios=(0.5, 1.0, 2.0)):
+    """anchor_generator.py:142-185 (scale_major, center_offset = 0): the
+    ratios x scales base anchors of one level, ratio-major, in fp32 exactly as
+    the torch expressions evaluate."""
+    scales = (np.array([2 ** (i / scales_per_octave)
+                        for i in range(scales_per_octave)]) *
+              octave_base_scale).astype(F32)
+    ratios = np.asarray(ratios, dtype=F32)
+    h_ratios = np.sqrt(ratios)
+    w_ratios = (F32(1) / h_ratios).astype(F32)
+    ws = (F32(stride) * w_ratios[:, None] * scales[None, :]).reshape(-1)
+    hs = (F32(stride) * h_ratios[:, None] * scales[None, :]).reshape(-1)
+    z = F32(0)
+    return np.stack([z - F32(0.5) * ws, z - F32(0.5) * hs, z + F32(0.5) * ws,
+                     z + F32(0.5) * hs], -1).astype(F32)
+
+
+def retina_grid_anchors(featmap_sizes, strides=(8, 16, 32, 64, 128), **kw):
+    """anchor_generator.py:229-270: per level (H*W*B, 4), position-major with
+    the base anchor fastest."""
+    out = []
+    for (h, w), s in zip(featmap_sizes, strides):
+        base = retina_base_anchors(s, **kw)
+        sx = np.arange(w, dtype=F32) * F32(s)
+        sy = np.arange(h, dtype=F32) * F32(s)
+        xx, yy = np.tile(sx, h), np.repeat(sy, w)
+        shifts = np.stack([xx, yy, xx, yy], 1)
+        out.append((base[None, :, :] + shifts[:, None, :]).reshape(
+            -1, 4).astype(F32))
+    return out
+
+
+def max_iou_assign(anchors, gts, pos_iou_thr=0.5, neg_iou_thr=0.4,
+                   min_pos_iou=0.0):
+    """MaxIoUAssigner.assign_wrt_overlaps
+    (core/bbox/assigners/max_iou_assigner.py:131-212) with
+    match_low_quality = gt_max_assign_all = True and no ignore boxes:
+    -> gt_inds (A,) int64: -1 ignore, 0 negative, g + 1 positive."""
+    anchors = np.asarray(anchors, dtype=F32)
+    gts = np.asarray(gts, dtype=F32).reshape(-1, 4)
+    A, G = anchors.shape[0], gts.shape[0]
+    out = np.full(A, -1, dtype=np.int64)
+    if G == 0 or A == 0:
+        out[:] = 0
+        return out
+    ov = bbox_overlaps(gts, anchors)  # (G, A), as the reference orients it
+    max_ov, arg = ov.max(0), ov.argmax(0)
+    gt_max = ov.max(1)
+    out[(max_ov >= 0) & (max_ov < F32(neg_iou_thr))] = 0
+    pos = max_ov >= F32(pos_iou_thr)
+    out[pos] = arg[pos] + 1
+    for g in range(G):  # low-quality matches; a later gt overrides
+        if gt_max[g] >= F32(min_pos_iou):
+            out[ov[g] == gt_max[g]] = g + 1
+    return out
+
+
+def retina_targets(featmap_sizes, img_metas, gt_bboxes, gt_labels,
+                   strides=(8, 16, 32, 64, 128), num_classes=80,
+                   pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0.0):
+    """LDRetinaHead.get_targets / _get_targets_single (ld_retina.py:256-470)
+    for a batch: dense (N, A*B) arrays in the reference's anchor order (level,
+    position, base anchor).  allowed_border = -1 -> inside == valid."""
+    per_level = retina_grid_anchors(featmap_sizes, strides)
+    B = per_level[0].shape[0] // (featmap_sizes[0][0] * featmap_sizes[0][1])
+    anchors = np.concatenate(per_level)
+    num_level = [a.shape[0] for a in per_level]
+    A = anchors.shape[0]
+    keys = ('labels', 'label_weights', 'bbox_targets', 'pos_mask', 'vlr',
+            'gt_inds')
+    rows = {k: [] for k in keys}
+    total = 0
+    for meta, gb, gl in zip(img_metas, gt_bboxes, gt_labels):
+        gb = np.asarray(gb, dtype=F32).reshape(-1, 4)
+        gl = np.asarray(gl)
+        inside = np.concatenate(
+            [np.repeat(f, B) for f in
+             valid_flags(featmap_sizes, meta['pad_shape'], strides)])
+        anc = anchors[inside]
+        nl_inside, s0 = [], 0
+        for n in num_level:
+            nl_inside.append(int(inside[s0:s0 + n].sum()))
+            s0 += n
+        gi = max_iou_assign(anc, gb, pos_iou_thr, neg_iou_thr, min_pos_iou)
+        vl = vlr_region(anc, nl_inside, gb, 9)
+        pos = gi > 0
+        lab_i = np.full(anc.shape[0], num_classes, dtype=np.int64)
+        lw_i = np.zeros(anc.shape[0], dtype=F32)
+        bt_i = np.zeros((anc.shape[0], 4), dtype=F32)
+        if pos.any():
+            bt_i[pos] = gb[gi[pos] - 1]
+            lab_i[pos] = gl[gi[pos] - 1]
+            lw_i[pos] = 1.0
+        lw_i[gi == 0] = 1.0
+        lab = np.full(A, num_classes, dtype=np.int64)
+        lw, bt = np.zeros(A, dtype=F32), np.zeros((A, 4), dtype=F32)
+        pm, vf = np.zeros(A, dtype=bool), np.zeros(A, dtype=F32)
+        gif = np.full(A, -1, dtype=np.int64)
+        lab[inside], lw[inside], bt[inside] = lab_i, lw_i, bt_i
+        pm[inside], vf[inside], gif[inside] = pos, vl, gi
+        for k, v in zip(keys, (lab, lw, bt, pm, vf, gif)):
+            rows[k].append(v)
+        total += max(int(pos.sum()), 1)
+    out = {k: np.stack(v) for k, v in rows.items()}
+    out.update(anchors=anchors, num_level=num_level, num_base=B,
+               num_total_pos=total)
+    return out
+
+
+def ld_retina_loss_block(cls, reg, t_cls, t_reg, targets, hp=None):
+    """LDRetinaHead.loss / loss_single (ld_retina.py:41-137,187-254) on
+    per-level NCHW numpy arrays (channels = base anchor x {80, 68}).  Returns
+    dict(losses=(5, L) [loss_cls, loss_bbox, loss_ld, loss_ld_vlr,
+    loss_cls_kd], grads=dict(cls, reg) of the sum of all entries).  NOTE the
+    LD terms take the softmax over all 68 corner logits of an anchor (the head
+    passes (rows, 68) to the KL loss, ld_retina.py:87-110), unlike LDHead's
+    17-bin rows; num_total_samples is the local count (no reduce_mean)."""
+    H = dict(DEFAULT_HP)
+    H.update(dict(lw_ld=5.0, T_ld=10.0, lw_kd=10.0, T_kd=8.0,
+                  focal_alpha=0.25, vlr_factor=0.03))
+    if hp:
+        H.update(hp)
+    C, R = H['num_classes'], H['reg_max'] + 1
+    L = len(cls)
+    nts = F32(targets['num_total_pos'])
+    losses = np.zeros((5, L), dtype=F32)
+    grads = dict(cls=[], reg=[])
+    start = 0
+    for l in range(L):
+        n = cls[l].shape[0]
+        A_l = targets['num_level'][l]
+        stride = F32(H['strides'][l])
+        sl = slice(start, start + A_l)
+        start += A_l
+        anchors = np.tile(targets['anchors'][sl], (n, 1))
+        labels = targets['labels'][:, sl].reshape(-1)
+        lw = targets['label_weights'][:, sl].reshape(-1)
+        bt = targets['bbox_targets'][:, sl].reshape(-1, 4) / stride
+        posm = targets['pos_mask'][:, sl].reshape(-1)
+        vlr = targets['vlr'][:, sl].reshape(-1).copy()
+        c_r = _nchw_to_rows(cls[l]).reshape(-1, C)
+        r_r = _nchw_to_rows(reg[l]).reshape(-1, 4 * R)
+        tc_r = _nchw_to_rows(t_cls[l]).reshape(-1, C)
+        tr_r = _nchw_to_rows(t_reg[l]).reshape(-1, 4 * R)
+        g_c, g_r = np.zeros_like(c_r), np.zeros_like(r_r)
+        pos = np.nonzero(posm)[0]
+        # FocalLoss (ld_retina.py:80-81)
+        onehot = np.zeros_like(c_r)
+        fg = np.nonzero((labels >= 0) & (labels < C))[0]
+        onehot[fg, labels[fg]] = 1
+        f, df = focal_elements(c_r, onehot, H['focal_alpha'])
+        loss_cls = F32(H['lw_cls']) * (f.sum(1, dtype=F32) * lw).sum(
+            dtype=F32) / nts
+        g_c += df * (lw * F32(H['lw_cls']) / nts)[:, None]
+        # LD over the 68 logits of each anchor, weights = max class score on
+        # the positives / VLR value on the background (ld_retina.py:99-110)
+        w_pos = _sigmoid(c_r).max(1) * posm.astype(F32)
+        vlr[labels != C] = 0
+        act = np.nonzero((w_pos > 0) | (vlr > 0))[0]
+        loss_ld = loss_vlr = F32(0)
+        if act.size:
+            kl, kg = kd_kl_rows(r_r[act], tr_r[act], H['T_ld'])
+            c1 = F32(H['lw_ld']) / F32(4)
+            c2 = F32(H['vlr_factor']) * F32(H['lw_ld']) / F32(4)
+            loss_ld = c1 * (kl * w_pos[act]).sum(dtype=F32)
+            loss_vlr = c2 * (kl * vlr[act]).sum(dtype=F32)
+            g_r[act] += kg * (c1 * w_pos[act] + c2 * vlr[act])[:, None]
+        loss_bbox = loss_kd = F32(0)
+        if pos.size:
+            actr = np.stack([(anchors[pos, 0] + anchors[pos, 2]) / F32(2),
+                             (anchors[pos, 1] + anchors[pos, 3]) / F32(2)],
+                            -1) / stride
+            dist, p_soft = integral(r_r[pos], H['reg_max'])
+            box = distance2bbox(actr, dist)
+            gl, gbox = giou_loss_rows(box, bt[pos], H['giou_eps'])
+            cb = F32(H['lw_bbox']) / nts
+            loss_bbox = cb * gl.sum(dtype=F32)
+            gdist = np.stack([-gbox[:, 0], -gbox[:, 1], gbox[:, 2],
+                              gbox[:, 3]], -1) * cb
+            proj = np.arange(R, dtype=F32)
+            g_int = p_soft * (proj[None, None, :] - dist[:, :, None])
+            g_r[pos] += (gdist[:, :, None] * g_int).reshape(-1, 4 * R)
+            kl, kg = kd_kl_rows(c_r[pos], tc_r[pos], H['T_kd'])
+            ck = F32(H['lw_kd']) / F32(pos.size)
+            loss_kd = ck * kl.sum(dtype=F32)
+            g_c[pos] += kg * ck
+        losses[:, l] = [loss_cls, loss_bbox, loss_ld, loss_vlr, loss_kd]
+        grads['cls'].append(_rows_to_nchw(g_c.reshape(-1, cls[l].shape[1]),
+                                          cls[l].shape))
+        grads['reg'].append(_rows_to_nchw(g_r.reshape(-1, reg[l].shape[1]),
+                                          reg[l].shape))
+    return dict(losses=losses, grads=grads, num_total_samples=float(nts))
+
+
+# --------------------------------------------------------------------------
 # LDFCOSHead (ld_fcos_head.py over fcos_gfl_head.py)
 # --------------------------------------------------------------------------
 FCOS_RANGES = ((-1, 64), (64, 128), (128, 256), (256, 512), (512, 1e8))
