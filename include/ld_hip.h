@@ -111,6 +111,19 @@ typedef struct {
  * VLR term is weighted by vlr * max_c sigmoid(cls) (the "remain" points,
  * ld_fcos_head.py:117-131; set lw_ld_vlr = lw_ld for its 0.25 factor). */
 #define LD_LOSS_FCOS 8
+/* LDRetinaHead over RetinaGFLHead (ld_retina.py:41-137), B anchors per cell:
+ * the caller views its (N, B * C, H, W) maps as (N * B, C, H, W) -- N * B
+ * pseudo-images with one anchor per cell -- and passes geom.num_imgs = N * B
+ * with the target arrays of ld_retina_targets.  FocalLoss (focal_alpha) on
+ * every anchor with label_weights (0 in the ignore band); GIoU with weight 1
+ * on the positives; loss_cls and loss_bbox divided by num_total_pos
+ * (counts[num_imgs + 2L], LOCAL: the head takes no cross-rank mean); LD and
+ * the VLR term take the softmax over ALL 68 corner logits of an anchor (the
+ * head hands (rows, 68) to the KL loss, ld_retina.py:87-110), weights max_c
+ * sigmoid(cls) on the positives / the VLR value on background anchors, both
+ * with avg_factor 4 (set lw_ld_vlr = 0.03 * 4 * lw_ld, T_ld_vlr = T_ld); no DFL
+ * (lw_dfl = 0); KD on the positives' class logits as in LDHead. */
+#define LD_LOSS_RETINA 16
 
 /* ---- library ------------------------------------------------------------ */
 /* ABI version of this header; bump on any signature change. */
@@ -179,6 +192,32 @@ int ld_fcos_targets(const ld_geom_t* geom, int num_classes,
                     int64_t* labels, float* label_weights, float* bbox_targets,
                     float* vlr, float* im, int32_t* counts, ld_stream_t stream);
 int ld_grid_anchors(const ld_geom_t* geom, float* anchors, ld_stream_t stream);
+
+/* MaxIoU targets for a head with ``num_base`` anchors per cell
+ * (LDRetinaHead.get_targets / _get_targets_single, ld_retina.py:256-470):
+ * MaxIoUAssigner.assign (max_iou_assigner.py:93-212; match_low_quality and
+ * gt_max_assign_all on, no ignore boxes, float neg_iou_thr) + PseudoSampler +
+ * the head's get_vlr_region (ld_retina.py:478-603).  ``geom`` describes the N
+ * real images and the H x W cells; ``anchors`` is the explicit list
+ * (num_anchors * num_base, 4) in AnchorGenerator.grid_anchors order (level,
+ * cell, base anchor fastest).  Outputs use the PSEUDO-IMAGE layout
+ * [(n * num_base + b) * num_anchors + cell] (see LD_LOSS_RETINA): labels
+ * (background = num_classes), label_weights (1 on positives and negatives, 0 in
+ * the band between the thresholds and outside the valid region), bbox_targets
+ * (the matched gt box, xyxy pixels), vlr, im (zeros), optional gt_inds (-1
+ * ignored / 0 negative / g + 1).  counts: int32[N * num_base + 2L + 1]: positives
+ * per pseudo-image, per level, (unused), and at [N * num_base + 2L] the
+ * reference's num_total_pos = sum over REAL images of max(P_i, 1). */
+size_t ld_retina_targets_workspace_bytes(const ld_geom_t* geom, int num_base,
+                                         int max_gt);
+int ld_retina_targets(const ld_geom_t* geom, int num_base, const float* anchors,
+                      int num_classes, float pos_iou_thr, float neg_iou_thr,
+                      float min_pos_iou, int topk, const float* gt_bboxes,
+                      const int64_t* gt_labels, const int32_t* num_gt, int max_gt,
+                      const int32_t* valid_hw, int64_t* labels,
+                      float* label_weights, float* bbox_targets, float* vlr,
+                      float* im, int32_t* counts, int64_t* gt_inds,
+                      void* workspace, size_t workspace_bytes, ld_stream_t stream);
 
 /* ---- fused loss block ----------------------------------------------------
  * Replaces LDHead.loss_single for all levels and images, forward AND gradient

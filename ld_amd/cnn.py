@@ -336,16 +336,25 @@ class ConvModule(nn.Module):
             constant_init(self.norm, 1, bias=0)
 
     def forward3(self, x3, levels, activate=True, norm=True):
-        y3, lv = self.conv.forward3(x3, levels)
         act = activate and self.with_activation
+        if act and not (norm and self.with_norm):
+            # conv (+bias) -> ReLU (RetinaGFLHead's towers, norm_cfg=None)
+            c = self.conv
+            if type(c) is Conv2d and not (torch.is_grad_enabled() and (
+                    x3.requires_grad or c.weight.requires_grad or
+                    (c.bias is not None and c.bias.requires_grad))):
+                return Y.conv_forward_raw(x3, c.weight, c.stride[0],
+                                          c.padding[0], levels, bias=c.bias,
+                                          relu=True, emit_c8=True)
+            y3, lv = c.forward3(x3, levels)
+            return Y.relu(y3), lv
+        y3, lv = self.conv.forward3(x3, levels)
         if norm and self.with_norm:
             n = self.norm
             if isinstance(n, GroupNorm):
                 y3 = n.forward3(y3, lv, relu=act)
             else:
                 y3 = n.forward3(y3, None, relu=act)
-        elif act:
-            raise NotImplementedError('conv -> ReLU without a norm layer')
         return y3, lv
 
     def forward(self, x, activate=True, norm=True):

@@ -117,30 +117,34 @@ class BboxOverlaps2D:
 # --------------------------------------------------------- anchor generator --
 @ANCHOR_GENERATORS.register_module()
 class AnchorGenerator:
-    """mmdet/core/anchor/anchor_generator.py:9-346 for the configuration every
-    LD/GFL config uses: one square anchor per cell (ratios=[1.0],
-    scales_per_octave=1), side = octave_base_scale * stride, centred on the
-    cell origin (center_offset=0)."""
+    """mmdet/core/anchor/anchor_generator.py:9-346, center_offset = 0.
+
+    Two regimes:
+      * one square anchor per cell (ratios=[1.0], scales_per_octave=1: every
+        GFL / ATSS / LD config) -- the anchors are implicit in the kernels
+        (side = octave_base_scale * stride, centred on the cell origin);
+      * ratios x scales anchors per cell (RetinaGFLHead / LDRetinaHead) -- an
+        explicit, cached (A * B, 4) list in the reference's order (cell, then
+        base anchor; ratio-major base anchors), built with the reference's fp32
+        expressions so MaxIoU thresholds compare the same bits."""
 
     def __init__(self, strides, ratios, scales=None, base_sizes=None,
                  scale_major=True, octave_base_scale=None,
                  scales_per_octave=None, centers=None, center_offset=0.):
         if center_offset != 0 or centers is not None:
             raise NotImplementedError('center_offset / centers')
-        if list(ratios) != [1.0]:
-            raise NotImplementedError('only ratios=[1.0] (one square anchor)')
+        if not scale_major:
+            raise NotImplementedError('scale_major=False')
         if (octave_base_scale is not None and scales_per_octave is not None):
-            if scales_per_octave != 1 or scales is not None:
-                raise NotImplementedError('scales_per_octave != 1')
-            scale = float(octave_base_scale)
-        elif scales is not None and len(scales) == 1:
-            scale = float(scales[0])
-        else:
+            if scales is not None:
+                raise ValueError('scales and octave_base_scale with '
+                                 'scales_per_octave cannot be set at the same '
+                                 'time')
+            scales = [2 ** (i / scales_per_octave) * octave_base_scale
+                      for i in range(scales_per_octave)]
+        elif scales is None:
             raise ValueError('Either scales or octave_base_scale with '
                              'scales_per_octave should be set')
-        if scale != int(scale):
-            raise NotImplementedError('non-integer anchor scale')
-        self.anchor_scale = int(scale)
         self.strides = [(s, s) if isinstance(s, int) else tuple(s)
                         for s in strides]
         for s in self.strides:
@@ -150,16 +154,21 @@ class AnchorGenerator:
             if base_sizes is None else list(base_sizes)
         if self.base_sizes != [min(s) for s in self.strides]:
             raise NotImplementedError('base_sizes != strides')
-        self.ratios = torch.Tensor(ratios)
-        self.scales = torch.Tensor([scale])
+        self.ratios = torch.Tensor(list(ratios))
+        self.scales = torch.Tensor(list(scales))
+        self.single_square = (list(ratios) == [1.0] and len(scales) == 1 and
+                              float(scales[0]) == int(scales[0]))
+        self.anchor_scale = int(scales[0]) if self.single_square else None
         self.octave_base_scale = octave_base_scale
         self.scales_per_octave = scales_per_octave
         self.scale_major, self.centers = scale_major, centers
         self.center_offset = center_offset
+        self._grid_cache = {}
 
     @property
     def num_base_anchors(self):
-        return [1 for _ in self.strides]
+        return [self.ratios.numel() * self.scales.numel()
+                for _ in self.strides]
 
     @property
     def num_levels(self):
@@ -167,42 +176,69 @@ class AnchorGenerator:
 
     @property
     def base_anchors(self):
-        """CPU tensors, as in the reference (gen_base_anchors)."""
+        """CPU tensors, as in the reference (gen_base_anchors,
+        anchor_generator.py:142-185)."""
         out = []
-        for s in self.strides:
-            half = 0.5 * s[0] * self.anchor_scale
-            out.append(torch.tensor([[-half, -half, half, half]]))
+        h_ratios = torch.sqrt(self.ratios)
+        w_ratios = 1 / h_ratios
+        for size in self.base_sizes:
+            ws = (size * w_ratios[:, None] * self.scales[None, :]).view(-1)
+            hs = (size * h_ratios[:, None] * self.scales[None, :]).view(-1)
+            out.append(torch.stack([0. - 0.5 * ws, 0. - 0.5 * hs,
+                                    0. + 0.5 * ws, 0. + 0.5 * hs], dim=-1))
         return out
 
     def grid_anchors(self, featmap_sizes, device='cuda'):
         assert self.num_levels == len(featmap_sizes)
-        flat = LB.grid_anchors([tuple(int(v) for v in s)
-                                for s in featmap_sizes],
-                               [s[0] for s in self.strides],
-                               torch.device(device), self.anchor_scale)
-        out, off = [], 0
-        for h, w in featmap_sizes:
-            out.append(flat[off:off + int(h) * int(w)])
-            off += int(h) * int(w)
-        return out
+        sizes = [tuple(int(v) for v in s) for s in featmap_sizes]
+        if self.single_square:
+            flat = LB.grid_anchors(sizes, [s[0] for s in self.strides],
+                                   torch.device(device), self.anchor_scale)
+            out, off = [], 0
+            for h, w in sizes:
+                out.append(flat[off:off + h * w])
+                off += h * w
+            return out
+        key = (tuple(sizes), str(device))
+        hit = self._grid_cache.get(key)
+        if hit is None:
+            # constants of the geometry, built once per pyramid shape
+            hit = []
+            for (h, w), s, base in zip(sizes, self.strides,
+                                       self.base_anchors):
+                sx = torch.arange(0, w, device=device) * s[0]
+                sy = torch.arange(0, h, device=device) * s[1]
+                xx, yy = sx.repeat(h), sy.view(-1, 1).repeat(1, w).view(-1)
+                base = base.to(device)
+                shifts = torch.stack([xx, yy, xx, yy], dim=-1).type_as(base)
+                hit.append((base[None, :, :] + shifts[:, None, :]).view(-1, 4))
+            if len(self._grid_cache) > 16:
+                self._grid_cache.clear()
+            self._grid_cache[key] = hit
+        return hit
 
     def valid_flags(self, featmap_sizes, pad_shape, device='cuda'):
         """anchor_generator.py:272-328."""
         assert self.num_levels == len(featmap_sizes)
         flags = []
-        for (fh, fw), s in zip(featmap_sizes, self.strides):
+        for (fh, fw), s, nb in zip(featmap_sizes, self.strides,
+                                   self.num_base_anchors):
             h, w = pad_shape[:2]
             vh = min(int(math.ceil(h / s[1])), int(fh))
             vw = min(int(math.ceil(w / s[0])), int(fw))
             f = torch.zeros((int(fh), int(fw)), dtype=torch.bool,
                             device=device)
             f[:vh, :vw] = True
-            flags.append(f.reshape(-1))
+            f = f.reshape(-1)
+            if nb > 1:
+                f = f[:, None].expand(f.numel(), nb).reshape(-1)
+            flags.append(f)
         return flags
 
     def __repr__(self):
         return (f'{self.__class__.__name__}(strides={self.strides}, '
-                f'anchor_scale={self.anchor_scale})')
+                f'ratios={self.ratios.tolist()}, '
+                f'scales={self.scales.tolist()})')
 
 
 # --------------------------------------------------- assign / sample results --
@@ -279,6 +315,53 @@ class DeltaXYWHBBoxCoder:
         raise NotImplementedError('DeltaXYWHBBoxCoder is not on the LD path')
 
     decode = encode
+
+
+# ---------------------------------------------------------- MaxIoU assigner --
+@BBOX_ASSIGNERS.register_module()
+class MaxIoUAssigner:
+    """mmdet/core/bbox/assigners/max_iou_assigner.py:9-212 for the RetinaGFL /
+    LDRetina configs: float thresholds, match_low_quality with
+    gt_max_assign_all, no ignore regions.  ``assign`` runs the batched HIP
+    target kernel (ld_retina_targets) on one image's explicit box list."""
+
+    def __init__(self, pos_iou_thr, neg_iou_thr, min_pos_iou=.0,
+                 gt_max_assign_all=True, ignore_iof_thr=-1,
+                 ignore_wrt_candidates=True, match_low_quality=True,
+                 gpu_assign_thr=-1,
+                 iou_calculator=dict(type='BboxOverlaps2D')):
+        if isinstance(neg_iou_thr, (tuple, list)):
+            raise NotImplementedError('neg_iou_thr as an interval')
+        if not (gt_max_assign_all and match_low_quality):
+            raise NotImplementedError('gt_max_assign_all / match_low_quality '
+                                      '= False')
+        self.pos_iou_thr, self.neg_iou_thr = pos_iou_thr, neg_iou_thr
+        self.min_pos_iou = min_pos_iou
+        self.gt_max_assign_all = gt_max_assign_all
+        self.ignore_iof_thr = ignore_iof_thr
+        self.ignore_wrt_candidates = ignore_wrt_candidates
+        self.gpu_assign_thr = gpu_assign_thr
+        self.match_low_quality = match_low_quality
+        self.iou_calculator = build_iou_calculator(iou_calculator)
+
+    def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None,
+               gt_labels=None):
+        if self.ignore_iof_thr > 0 and gt_bboxes_ignore is not None and \
+                gt_bboxes_ignore.numel() > 0:
+            raise NotImplementedError('ignore regions (ignore_iof_thr > 0)')
+        A = bboxes.size(0)
+        t = LB.retina_targets(
+            [(A, 1)], [1], [dict(pad_shape=(A, 1))], [gt_bboxes],
+            [gt_labels if gt_labels is not None else
+             gt_bboxes.new_zeros(gt_bboxes.size(0), dtype=torch.long)],
+            [bboxes[:, :4].contiguous()], 1, self, 80, bboxes.device,
+            want_gt_inds=True)
+        gt_inds = t['gt_inds'][0]
+        labels = None
+        if gt_labels is not None:
+            labels = torch.where(gt_inds > 0, t['labels'][0],
+                                 torch.full_like(gt_inds, -1))
+        return AssignResult(gt_bboxes.size(0), gt_inds, None, labels=labels)
 
 
 # ------------------------------------------------------------ ATSS assigner --

@@ -72,6 +72,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // (ld_atss.py:245-249)
 __device__ __forceinline__ float avg_divisor(const ld_loss_hp_t& hp, const float* norm) {
   if (hp.flags & LD_LOSS_ATSS) return norm[1] < 1e-12f ? 1.0f : norm[1];
+  // LDRetinaHead: loss_bbox(avg_factor = num_total_samples), ld_retina.py:104-108
+  if (hp.flags & LD_LOSS_RETINA) return fmaxf(norm[0], 1.0f);
   return norm[1] + 1e-6f;
 }
 
@@ -271,7 +273,10 @@ __global__ __launch_bounds__(kBlk) void loss_pos_kernel(
       const float up_bbox = upstream ? upstream[1 * L + c.l] : 1.0f;
       const float inv_avg = 1.0f / avg_divisor(hp, norm);
       // GIoU weight: max class score (LDHead) / centerness target (LDATSSHead)
-      const float wt = (hp.flags & LD_LOSS_ATSS) ? score[c.o] : weight_targets[c.o];
+      // ... / 1 (LDRetinaHead: bbox_weights, ld_retina.py:104-108)
+      const float wt = (hp.flags & LD_LOSS_RETINA) ? 1.0f
+                       : (hp.flags & LD_LOSS_ATSS) ? score[c.o]
+                                                   : weight_targets[c.o];
       const float c_bbox = up_bbox * hp.lw_bbox * wt * inv_avg;
       float e[4];
 #pragma unroll
@@ -331,6 +336,8 @@ __global__ __launch_bounds__(kBlk) void loss_reg_dense_kernel(
     // the "remain" flag times max_c sigmoid(cls) (ld_fcos_head.py:122-123)
     float v = vlr[c.o];
     if ((hp.flags & LD_LOSS_FCOS) && v > 0.0f) v *= weight_targets[c.o];
+    const bool retina = (hp.flags & LD_LOSS_RETINA) != 0;
+    if (retina && pos) v = 0.0f;  // vlr_weights[labels != bg] = 0, ld_retina.py:103
     const bool rem = v > 0.0f;
     float gr[K17];
 #pragma unroll
@@ -351,7 +358,37 @@ __global__ __launch_bounds__(kBlk) void loss_reg_dense_kernel(
         sv[k] = NT ? __builtin_nontemporal_load(ps) : *ps;
         tv[k] = NT ? __builtin_nontemporal_load(pt) : *pt;
       }
-      if (hp.T_ld == hp.T_ld_vlr) {
+      if (retina) {
+        // KL over the 68 logits of the anchor (all four sides): the statistics
+        // span the other three side-threads' channels too -- re-read here (they
+        // are L2 hits); this thread then owns the terms of its own 17 bins
+        const float T = hp.T_ld, invT = 1.0f / hp.T_ld;
+        float ms = sv[0], mt = tv[0];
+        for (int ch = 0; ch < 4 * K17; ++ch) {
+          ms = fmaxf(ms, *chan_ptr(reg, c, ch));
+          mt = fmaxf(mt, *chan_ptr(t_reg, c, ch));
+        }
+        float zs = 0.0f, zt = 0.0f;
+        for (int ch = 0; ch < 4 * K17; ++ch) {
+          zs += expf((*chan_ptr(reg, c, ch) - ms) * invT);
+          zt += expf((*chan_ptr(t_reg, c, ch) - mt) * invT);
+        }
+        const float lzs = logf(zs), lzt = logf(zt), rzs = 1.0f / zs, rzt = 1.0f / zt;
+        float kl = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K17; ++k) {
+          const float as = (sv[k] - ms) * invT, at = (tv[k] - mt) * invT;
+          const float ps = expf(as) * rzs, pt = expf(at) * rzt;
+          kl += pt * ((at - lzt) - (as - lzs));
+          d[k] = ps - pt;
+        }
+        kl *= T * T / (float)(4 * K17);
+        s_ld = wt * kl;
+        s_vlr = v * kl;
+        const float cg = (c_ld + (rem ? c_vlr : 0.0f)) * (T / (float)(4 * K17));
+#pragma unroll
+        for (int k = 0; k < K17; ++k) gr[k] = cg * d[k];
+      } else if (hp.T_ld == hp.T_ld_vlr) {
         const float T = hp.T_ld;
         const float kl = ld::kl_rows<K17>(sv, tv, 1.0f / T, T, d);
         s_ld = wt * kl;
@@ -444,7 +481,7 @@ __global__ __launch_bounds__(kBlk) void loss_cls_dense_kernel(
   const int NC = hp.num_classes;  // foreground classes: labels in [0, NC)
   const int C = hp.cls_channels > 0 ? hp.cls_channels : NC;
   const bool prob = (hp.flags & LD_LOSS_PROB_CLS) != 0;
-  const bool focal = (hp.flags & LD_LOSS_ATSS) != 0;
+  const bool focal = (hp.flags & (LD_LOSS_ATSS | LD_LOSS_RETINA)) != 0;
   const int ch0 = blockIdx.z * kClsChunk;
   const int ch1 = min(C, ch0 + kClsChunk);
   float s_cls = 0.0f, s_kd = 0.0f;
@@ -952,6 +989,10 @@ extern "C" int ld_loss_main_parts(
   if (((hp->flags & LD_LOSS_PROB_CLS) != 0) != split)
     return LD_EINVAL;  // probabilities cannot carry the KD logits, and vice versa
   if ((hp->flags & LD_LOSS_ATSS) && (hp->flags & LD_LOSS_PROB_CLS)) return LD_EINVAL;
+  if ((hp->flags & LD_LOSS_RETINA) &&
+      ((hp->flags & (LD_LOSS_ATSS | LD_LOSS_FCOS | LD_LOSS_PROB_CLS)) ||
+       hp->T_ld != hp->T_ld_vlr))
+    return LD_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   const LossWs w = loss_ws(*geom);
   const BlockMap& bm = w.bm256;

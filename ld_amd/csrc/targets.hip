@@ -91,9 +91,11 @@ template <int KMAX>
 __global__ __launch_bounds__(kBlock) void atss_select_kernel(
     ld_geom_t geom, int topk, const float* __restrict__ anchors,
     const float* __restrict__ gt_bboxes, const int32_t* __restrict__ num_gt,
-    int max_gt, const int32_t* __restrict__ valid_hw,
+    int max_gt, const int32_t* __restrict__ valid_hw, int wmul,
     unsigned long long* __restrict__ keys, float* __restrict__ thr_out,
     float* __restrict__ colmax_out) {
+  // wmul: the valid width counts positions; a multi-anchor level is laid out
+  // as H x (W * wmul) with the base anchor fastest (ld_retina_targets)
   const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   if (g >= num_gt[n]) return;
   const float* gp = gt_bboxes + ((size_t)n * max_gt + g) * 4;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void atss_select_kernel(
   for (int l = 0; l < geom.num_levels; ++l) {
     const ld_level_t lv = geom.lv[l];
     const int vh = valid_hw[((size_t)n * geom.num_levels + l) * 2 + 0];
-    const int vw = valid_hw[((size_t)n * geom.num_levels + l) * 2 + 1];
+    const int vw = valid_hw[((size_t)n * geom.num_levels + l) * 2 + 1] * wmul;
     const int nvalid = vh * vw;
     const int k = min(topk, nvalid);
     const float half = 0.5f * (float)(geom.anchor_scale * lv.stride);
@@ -336,6 +338,133 @@ __global__ void atss_counts_finalize(int N, int L, int32_t* counts) {
   }
 }
 
+// ------------------------------------------- MaxIoU targets, B anchors/cell --
+// LDRetinaHead._get_targets_single (ld_retina.py:256-362): MaxIoUAssigner
+// (max_iou_assigner.py:131-212, match_low_quality + gt_max_assign_all, no
+// ignore boxes) + PseudoSampler + the head's own get_vlr_region
+// (ld_retina.py:478-603, the ATSS VLR formula over all B anchors of a cell).
+// Thread = one anchor in the reference's order (level, position, base anchor);
+// outputs go to the PSEUDO-IMAGE layout (n * B + b, level offset + position):
+// an (N, B * C, H, W) head map is the (N * B, C, H, W) map of N * B images
+// with one anchor per cell, which is what the loss-block kernels sweep.
+struct MaxIouCfg {
+  float pos_thr, neg_thr, min_pos;
+  int num_base;
+};
+
+__global__ __launch_bounds__(kBlock) void maxiou_dense_kernel(
+    ld_geom_t geom /* flattened: W * B wide levels */, int num_classes, MaxIouCfg cfg,
+    const float* __restrict__ anchors, const float* __restrict__ gt_bboxes,
+    const int64_t* __restrict__ gt_labels, const int32_t* __restrict__ num_gt, int max_gt,
+    const int32_t* __restrict__ valid_hw, const float* __restrict__ thr,
+    const float* __restrict__ colmax, int64_t* __restrict__ labels,
+    float* __restrict__ label_weights, float* __restrict__ bbox_targets,
+    float* __restrict__ vlr, float* __restrict__ im, int32_t* __restrict__ counts,
+    int64_t* __restrict__ gt_inds_out) {
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const int a = blockIdx.x * kBlock + tid;
+  const int AB = geom.num_anchors, L = geom.num_levels, B = cfg.num_base;
+  const int NB = geom.num_imgs * B, A = AB / B;
+  const int G = num_gt[n];
+  __shared__ float4 s_gt[kGtChunk];
+  __shared__ float s_thr[kGtChunk];
+  __shared__ float s_cm[kGtChunk];
+  bool valid = false;
+  Box ab{0, 0, 0, 0};
+  int l = 0, p = 0, b = 0;
+  if (a < AB) {
+    l = level_of(geom, a);
+    const ld_level_t lv = geom.lv[l];
+    const int r = a - lv.offset;
+    p = r / B;
+    b = r - p * B;
+    const int W = lv.W / B;
+    const int y = p / W, x = p - y * W;
+    const int vh = valid_hw[((size_t)n * L + l) * 2 + 0];
+    const int vw = valid_hw[((size_t)n * L + l) * 2 + 1];
+    valid = (y < vh) && (x < vw);
+    const float4 q = reinterpret_cast<const float4*>(anchors)[a];
+    ab = Box{q.x, q.y, q.z, q.w};
+  }
+  float vmax = ld::kNegInf, mx = ld::kNegInf;
+  int arg = 0, lowq = -1;
+  for (int g0 = 0; g0 < G; g0 += kGtChunk) {
+    const int gc = min(kGtChunk, G - g0);
+    __syncthreads();
+    if (tid < gc) {
+      const float* gp = gt_bboxes + ((size_t)n * max_gt + g0 + tid) * 4;
+      s_gt[tid] = make_float4(gp[0], gp[1], gp[2], gp[3]);
+      s_thr[tid] = thr[(size_t)n * max_gt + g0 + tid];
+      s_cm[tid] = colmax[(size_t)n * max_gt + g0 + tid];
+    }
+    __syncthreads();
+    if (valid) {
+      for (int j = 0; j < gc; ++j) {
+        const float4 q = s_gt[j];
+        const Box gt{q.x, q.y, q.z, q.w};
+        const float iou = ld::iou_pair(ab, gt);
+        const float di = ld::diou_pair(ab, gt);
+        const float t = s_thr[j];
+        if ((di < t) && (di >= 0.25f * t)) vmax = fmaxf(vmax, iou);
+        if (iou > mx) {  // first maximum: torch.max(dim=0) on CPU
+          mx = iou;
+          arg = g0 + j;
+        }
+        // every anchor that attains a gt's best IoU is its match; the loop
+        // over gts lets a later one override (max_iou_assigner.py:196-204)
+        if (s_cm[j] >= cfg.min_pos && iou == s_cm[j]) lowq = g0 + j;
+      }
+    }
+  }
+  if (a >= AB) return;
+  const int lvoff = geom.lv[l].offset / B;
+  const size_t o = ((size_t)n * B + b) * A + lvoff + p;
+  int64_t lab = num_classes, gind = -1;
+  float lw = 0.0f, bt[4] = {0, 0, 0, 0}, vl = 0.0f;
+  if (valid) {
+    if (G == 0) {
+      gind = 0;
+    } else if (lowq >= 0) {
+      gind = lowq + 1;
+    } else if (mx >= cfg.pos_thr) {
+      gind = arg + 1;
+    } else if (mx >= 0.0f && mx < cfg.neg_thr) {
+      gind = 0;
+    }
+    if (gind > 0) {
+      const int g = (int)gind - 1;
+      const float* gp = gt_bboxes + ((size_t)n * max_gt + g) * 4;
+      bt[0] = gp[0];
+      bt[1] = gp[1];
+      bt[2] = gp[2];
+      bt[3] = gp[3];
+      lab = gt_labels[(size_t)n * max_gt + g];
+      atomicAdd(counts + n * B + b, 1);
+      atomicAdd(counts + NB + l, 1);
+    }
+    lw = gind >= 0 ? 1.0f : 0.0f;  // the band between the thresholds is ignored
+    vl = (vmax != ld::kNegInf) ? vmax : 0.0f;
+  }
+  labels[o] = lab;
+  label_weights[o] = lw;
+  reinterpret_cast<float4*>(bbox_targets)[o] = make_float4(bt[0], bt[1], bt[2], bt[3]);
+  vlr[o] = vl;
+  im[o] = 0.0f;
+  if (gt_inds_out) gt_inds_out[o] = gind;
+}
+
+__global__ void maxiou_counts_finalize(int N, int B, int L, int32_t* counts) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int s = 0;
+    for (int i = 0; i < N; ++i) {  // per REAL image: sum over its B pseudo-images
+      int p = 0;
+      for (int b = 0; b < B; ++b) p += counts[i * B + b];
+      s += max(p, 1);  // ld_retina.py:449
+    }
+    counts[N * B + 2 * L] = s;
+  }
+}
+
 // ------------------------------------------------------ FCOS point targets ---
 // LDFCOSHead._get_target_single (ld_fcos_head.py:261-353) for every point of
 // every image: the object with the smallest area among those whose (centre-
@@ -515,11 +644,11 @@ extern "C" int ld_atss_targets_ex(const ld_geom_t* geom, const ld_loss_hp_t* hp,
     if (hp->topk <= 9)
       hipLaunchKernelGGL(atss_select_kernel<9>, grid, dim3(kBlock), 0, stream,
                          *geom, hp->topk, anchors, gt_bboxes, num_gt, max_gt,
-                         valid_hw, keys, thr, colmax);
+                         valid_hw, 1, keys, thr, colmax);
     else
       hipLaunchKernelGGL(atss_select_kernel<16>, grid, dim3(kBlock), 0, stream,
                          *geom, hp->topk, anchors, gt_bboxes, num_gt, max_gt,
-                         valid_hw, keys, thr, colmax);
+                         valid_hw, 1, keys, thr, colmax);
   }
   dim3 gridb((A + kBlock - 1) / kBlock, N);
   hipLaunchKernelGGL(atss_dense_kernel, gridb, dim3(kBlock), 0, stream, *geom,
@@ -529,6 +658,75 @@ extern "C" int ld_atss_targets_ex(const ld_geom_t* geom, const ld_loss_hp_t* hp,
                      labels, label_weights, bbox_targets, vlr, im, counts, gt_inds,
                      max_overlaps);
   hipLaunchKernelGGL(atss_counts_finalize, dim3(1), dim3(64), 0, stream, N, L,
+                     counts);
+  return (int)hipGetLastError();
+}
+
+namespace {
+// the reference-ordered anchor list of a B-anchor head as single-anchor levels
+// of width W * B
+ld_geom_t flatten_geom(const ld_geom_t& g, int B) {
+  ld_geom_t f = g;
+  for (int l = 0; l < g.num_levels; ++l) {
+    f.lv[l].W = g.lv[l].W * B;
+    f.lv[l].offset = g.lv[l].offset * B;
+  }
+  f.num_anchors = g.num_anchors * B;
+  return f;
+}
+}  // namespace
+
+extern "C" size_t ld_retina_targets_workspace_bytes(const ld_geom_t* geom, int num_base,
+                                                     int max_gt) {
+  if (check_geom(geom) != 0 || num_base < 1 || max_gt < 0) return 0;
+  const ld_geom_t f = flatten_geom(*geom, num_base);
+  return ld_atss_targets_workspace_bytes(&f, max_gt);
+}
+
+extern "C" int ld_retina_targets(const ld_geom_t* geom, int num_base, const float* anchors,
+                                 int num_classes, float pos_iou_thr, float neg_iou_thr,
+                                 float min_pos_iou, int topk, const float* gt_bboxes,
+                                 const int64_t* gt_labels, const int32_t* num_gt,
+                                 int max_gt, const int32_t* valid_hw, int64_t* labels,
+                                 float* label_weights, float* bbox_targets, float* vlr,
+                                 float* im, int32_t* counts, int64_t* gt_inds,
+                                 void* workspace, size_t workspace_bytes,
+                                 ld_stream_t stream_) {
+  if (int e = check_geom(geom)) return e;
+  if (num_base < 1 || num_base > 16 || !anchors || num_classes < 1 || !labels ||
+      !label_weights || !bbox_targets || !vlr || !im || !counts || !num_gt ||
+      !valid_hw || max_gt < 0)
+    return LD_EINVAL;
+  if (max_gt > 0 && (!gt_bboxes || !gt_labels)) return LD_EINVAL;
+  if (topk < 1 || topk > 9) return LD_EUNSUPPORTED;
+  const size_t need = ld_retina_targets_workspace_bytes(geom, num_base, max_gt);
+  if (!workspace || workspace_bytes < need) return LD_ENOSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const ld_geom_t f = flatten_geom(*geom, num_base);
+  const int N = f.num_imgs, AB = f.num_anchors, L = f.num_levels;
+  char* ws = (char*)workspace;
+  const size_t keys_b = align_up((size_t)N * AB * 8, 256);
+  const size_t per_gt = align_up((size_t)N * (max_gt > 0 ? max_gt : 1) * 4, 256);
+  unsigned long long* keys = (unsigned long long*)ws;
+  float* thr = (float*)(ws + keys_b);
+  float* colmax = (float*)(ws + keys_b + per_gt);
+  hipError_t err;
+  if ((err = hipMemsetAsync(keys, 0, (size_t)N * AB * 8, stream))) return (int)err;
+  if ((err = hipMemsetAsync(counts, 0, sizeof(int32_t) * (N * num_base + 2 * L + 1),
+                            stream)))
+    return (int)err;
+  // per gt: the VLR threshold (mean + std IoU of the topk closest anchors of every
+  // level) and its best IoU over all valid anchors
+  if (max_gt > 0)
+    hipLaunchKernelGGL(atss_select_kernel<9>, dim3(max_gt, N), dim3(kBlock), 0, stream, f,
+                       topk, anchors, gt_bboxes, num_gt, max_gt, valid_hw, num_base, keys,
+                       thr, colmax);
+  MaxIouCfg cfg{pos_iou_thr, neg_iou_thr, min_pos_iou, num_base};
+  hipLaunchKernelGGL(maxiou_dense_kernel, dim3((AB + kBlock - 1) / kBlock, N),
+                     dim3(kBlock), 0, stream, f, num_classes, cfg, anchors, gt_bboxes,
+                     gt_labels, num_gt, max_gt > 0 ? max_gt : 1, valid_hw, thr, colmax,
+                     labels, label_weights, bbox_targets, vlr, im, counts, gt_inds);
+  hipLaunchKernelGGL(maxiou_counts_finalize, dim3(1), dim3(64), 0, stream, N, num_base, L,
                      counts);
   return (int)hipGetLastError();
 }

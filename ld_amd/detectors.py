@@ -193,6 +193,11 @@ class FCOS(SingleStageDetector):
 
 
 @DETECTORS.register_module()
+class RetinaNet(SingleStageDetector):
+    """retinanet.py:6-17 (the detector type of configs/gfl/retinagfl_*.py)."""
+
+
+@DETECTORS.register_module()
 class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
     """kd_one_stage.py:12-108: student + frozen teacher (hidden from
     ``parameters()`` / ``state_dict()``), dual forward, LD loss."""

@@ -923,6 +923,257 @@ class LDFCOSHead(FCOSGFLHead):
                                ATSS_LOSS_KEYS)
 
 
+RETINA_LOSS_KEYS = ['loss_cls', 'loss_bbox', 'loss_ld', 'loss_ld_vlr',
+                    'loss_cls_kd']
+# rows of the fused block's (8, L) table that carry them (LD_LOSS_RETINA)
+_RETINA_ROWS = [0, 1, 3, 4, 5]
+
+
+@HEADS.register_module()
+class RetinaGFLHead(nn.Module):
+    """retina_gfl_head.py:50-330 over anchor_head.py:14-173: the RetinaNet head
+    (ratios x scales anchors per cell, conv + ReLU towers without a norm
+    layer) with a general-distribution box branch.  ``atss_cls`` /
+    ``atss_reg`` predictor names as in the reference; forward returns
+    (cls_scores (N, B * C, H, W), bbox_preds (N, B * 68, H, W)) lists.
+
+    Loss execution: the B anchors of a cell are B pseudo-images of the fused
+    one-anchor-per-cell loss block (an (N, B * C, H, W) map IS the (N * B, C,
+    H, W) map of them), targets come from ld_retina_targets."""
+
+    def __init__(self, num_classes, in_channels, stacked_convs=4,
+                 conv_cfg=None, norm_cfg=None, reg_max=16, feat_channels=256,
+                 anchor_generator=dict(type='AnchorGenerator',
+                                       octave_base_scale=4,
+                                       scales_per_octave=3,
+                                       ratios=[0.5, 1.0, 2.0],
+                                       strides=[8, 16, 32, 64, 128]),
+                 bbox_coder=dict(type='DeltaXYWHBBoxCoder',
+                                 target_means=(.0, .0, .0, .0),
+                                 target_stds=(1.0, 1.0, 1.0, 1.0)),
+                 reg_decoded_bbox=False,
+                 loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True,
+                               loss_weight=1.0),
+                 loss_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0,
+                                loss_weight=1.0),
+                 train_cfg=None, test_cfg=None):
+        super().__init__()
+        self.stacked_convs, self.conv_cfg, self.norm_cfg = (stacked_convs,
+                                                            conv_cfg, norm_cfg)
+        self.reg_max = reg_max
+        self.in_channels, self.num_classes = in_channels, num_classes
+        self.feat_channels = feat_channels
+        self.use_sigmoid_cls = loss_cls.get('use_sigmoid', False)
+        self.sampling = loss_cls['type'] not in [
+            'FocalLoss', 'GHMC', 'QualityFocalLoss']
+        self.cls_out_channels = num_classes if self.use_sigmoid_cls \
+            else num_classes + 1
+        self.reg_decoded_bbox = reg_decoded_bbox
+        self.bbox_coder = build_bbox_coder(bbox_coder)
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_bbox = build_loss(loss_bbox)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        if self.train_cfg:
+            self.assigner = build_assigner(self.train_cfg.assigner)
+            self.sampler = build_sampler(dict(type='PseudoSampler'),
+                                         context=self)
+        self.fp16_enabled = False
+        self.anchor_generator = build_anchor_generator(anchor_generator)
+        self.num_anchors = self.anchor_generator.num_base_anchors[0]
+        self._init_layers()
+        self.integral = Integral(self.reg_max)
+        self.unit_upstream = False
+
+    def _init_layers(self):
+        """retina_gfl_head.py:231-264."""
+        self.relu = nn.ReLU(inplace=True)
+        self.cls_convs = nn.ModuleList()
+        self.reg_convs = nn.ModuleList()
+        for i in range(self.stacked_convs):
+            chn = self.in_channels if i == 0 else self.feat_channels
+            self.cls_convs.append(
+                ConvModule(chn, self.feat_channels, 3, stride=1, padding=1,
+                           conv_cfg=self.conv_cfg, norm_cfg=self.norm_cfg))
+            self.reg_convs.append(
+                ConvModule(chn, self.feat_channels, 3, stride=1, padding=1,
+                           conv_cfg=self.conv_cfg, norm_cfg=self.norm_cfg))
+        self.atss_cls = Conv2d(self.feat_channels,
+                               self.num_anchors * self.cls_out_channels, 3,
+                               padding=1)
+        self.atss_reg = Conv2d(self.feat_channels,
+                               self.num_anchors * (self.reg_max + 1) * 4, 3,
+                               padding=1)
+
+    def init_weights(self):
+        """retina_gfl_head.py:266-274."""
+        for m in self.cls_convs:
+            normal_init(m.conv, std=0.01)
+        for m in self.reg_convs:
+            normal_init(m.conv, std=0.01)
+        normal_init(self.atss_cls, std=0.01, bias=bias_init_with_prob(0.01))
+        normal_init(self.atss_reg, std=0.01)
+
+    def forward(self, feats):
+        """retina_gfl_head.py:276-299, all levels in one launch per layer."""
+        x3, levels = Y.pack_levels(feats)
+        cls_feat = reg_feat = x3
+        for m in self.cls_convs:
+            cls_feat, _ = m.forward3(cls_feat, levels)
+        for m in self.reg_convs:
+            reg_feat, _ = m.forward3(reg_feat, levels)
+        cls3, _ = self.atss_cls.forward3(cls_feat, levels)
+        reg3, _ = self.atss_reg.forward3(reg_feat, levels)
+        return Y.split_levels(cls3, levels), Y.split_levels(reg3, levels)
+
+    anchor_center = GFLHead.anchor_center
+    get_anchors = GFLHead.get_anchors
+
+    # ---------------------------------------------------------------- loss --
+    def _check_loss_cfg(self):
+        from .losses import FocalLoss, GIoULoss
+        if not isinstance(self.loss_cls, FocalLoss) or \
+                not isinstance(self.loss_bbox, GIoULoss) or \
+                not self.reg_decoded_bbox:
+            raise NotImplementedError(
+                'the fused RetinaGFL loss block implements FocalLoss + '
+                'GIoULoss on decoded boxes (reg_decoded_bbox=True)')
+        if self.loss_cls.gamma != 2.0:
+            raise NotImplementedError('FocalLoss gamma != 2')
+        if self.train_cfg.get('allowed_border', -1) >= 0:
+            raise NotImplementedError('allowed_border >= 0')
+        if self.train_cfg.get('pos_weight', -1) > 0:
+            raise NotImplementedError('pos_weight > 0')
+        if type(self.assigner).__name__ != 'MaxIoUAssigner':
+            raise NotImplementedError(
+                f'{type(self.assigner).__name__}: the RetinaGFL targets kernel '
+                'implements MaxIoUAssigner')
+
+    def _hp(self, **over):
+        kw = dict(num_classes=self.num_classes, reg_max=self.reg_max, topk=9,
+                  feat_channels=self.feat_channels,
+                  lw_cls=self.loss_cls.loss_weight, qfl_beta=2.0,
+                  lw_bbox=self.loss_bbox.loss_weight,
+                  giou_eps=getattr(self.loss_bbox, 'eps', 1e-6), lw_dfl=0.0,
+                  lw_ld=0.0, T_ld=1.0, lw_ld_vlr=0.0, T_ld_vlr=1.0, lw_kd=0.0,
+                  T_kd=1.0, lw_im=0.0, focal_alpha=self.loss_cls.alpha,
+                  flags=L.LD_LOSS_RETINA)
+        kw.update(over)
+        return LB.make_hp(**kw)
+
+    def get_targets_batched(self, featmap_sizes, img_metas, gt_bboxes,
+                            gt_labels, device, want_gt_inds=False):
+        """get_anchors + get_targets (ld_retina.py:364-470) for the whole
+        batch: three launches."""
+        strides = [s[0] for s in self.anchor_generator.strides]
+        if gt_labels is None:
+            gt_labels = [b.new_zeros(b.shape[0], dtype=torch.long)
+                         for b in gt_bboxes]
+        anchors = self.anchor_generator.grid_anchors(featmap_sizes, device)
+        return LB.retina_targets(featmap_sizes, strides, img_metas, gt_bboxes,
+                                 gt_labels, anchors, self.num_anchors,
+                                 self.assigner, self.num_classes, device,
+                                 want_gt_inds=want_gt_inds)
+
+    def _pseudo(self, maps, channels):
+        """(N, B * C, H, W) -> the (N * B, C, H, W) view of the same memory."""
+        B = self.num_anchors
+        return [t.view(t.shape[0] * B, channels, t.shape[2], t.shape[3])
+                for t in maps]
+
+    def _run_block(self, hp, cls_scores, bbox_preds, gt_bboxes, gt_labels,
+                   img_metas, t_cls, t_reg, keys):
+        sizes = [tuple(int(v) for v in f.shape[-2:]) for f in cls_scores]
+        assert len(sizes) == self.anchor_generator.num_levels
+        device = cls_scores[0].device
+        targets = self.get_targets_batched(sizes, img_metas, gt_bboxes,
+                                           gt_labels, device)
+        C_, R4 = self.cls_out_channels, 4 * (self.reg_max + 1)
+        cls_p, reg_p = self._pseudo(cls_scores, C_), self._pseudo(bbox_preds,
+                                                                  R4)
+        t_cls_p = self._pseudo([t.detach() for t in t_cls], C_)
+        t_reg_p = self._pseudo([t.detach() for t in t_reg], R4)
+        dummy_x = [c.detach() for c in cls_p]
+        hp.feat_channels = C_
+        # num_total_samples is the LOCAL count (ld_retina.py:228-229): no
+        # cross-rank reduction of the normaliser
+        table, _ = LB.LDLossBlock.apply(hp, targets, (t_cls_p, t_reg_p,
+                                                      dummy_x), None,
+                                        self.unit_upstream, *cls_p, *reg_p,
+                                        *dummy_x)
+        self.last_targets = targets
+        d = LossDict((k, [table[r, l] for l in range(table.shape[1])])
+                     for k, r in zip(RETINA_LOSS_KEYS, _RETINA_ROWS)
+                     if k in keys)
+        d.table = table
+        d.rows = [r for k, r in zip(RETINA_LOSS_KEYS, _RETINA_ROWS)
+                  if k in keys]
+        return d
+
+    def loss(self, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas,
+             gt_bboxes_ignore=None):
+        """retina_gfl_head.py:157-229: loss_cls, loss_bbox."""
+        self._check_loss_cfg()
+        return self._run_block(self._hp(), cls_scores, bbox_preds, gt_bboxes,
+                               gt_labels, img_metas, cls_scores, bbox_preds,
+                               ('loss_cls', 'loss_bbox'))
+
+    def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None,
+                      gt_bboxes_ignore=None, proposal_cfg=None, **kwargs):
+        if proposal_cfg is not None:
+            raise NotImplementedError('proposal_cfg')
+        return self.loss(*self(x), gt_bboxes, gt_labels, img_metas,
+                         gt_bboxes_ignore=gt_bboxes_ignore)
+
+    def get_bboxes(self, *args, **kwargs):
+        raise NotImplementedError(
+            'RetinaGFLHead.get_bboxes (retina_gfl_head.py:301-330: top-k over '
+            'the B anchors of a level) is not wired to ld_get_bboxes')
+
+
+@HEADS.register_module()
+class LDRetinaHead(RetinaGFLHead):
+    """ld_retina.py:13-636: localization distillation on the RetinaGFL head --
+    LD over the 68 corner logits of every positive anchor weighted by its max
+    class score, 0.03 x the same on the valuable localisation region of the
+    background anchors, KD on the positives' class logits.  The detector calls
+    it with output_feature=False: forward_train(x, out_teacher, img_metas,
+    ...)."""
+
+    def __init__(self, num_classes, in_channels,
+                 loss_ld=dict(type='LocalizationDistillationLoss',
+                              loss_weight=0.25, T=10),
+                 loss_kd=None, **kwargs):
+        super().__init__(num_classes, in_channels, **kwargs)
+        self.loss_ld = build_loss(loss_ld)
+        self.loss_kd = build_loss(loss_kd)
+
+    def forward_train(self, x, out_teacher, img_metas, gt_bboxes,
+                      gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None,
+                      **kwargs):
+        """ld_retina.py:139-185."""
+        if gt_labels is None:
+            raise NotImplementedError('LDRetinaHead needs gt_labels')
+        if proposal_cfg is not None:
+            raise NotImplementedError('proposal_cfg')
+        return self.loss(*self(x), gt_bboxes, gt_labels, out_teacher,
+                         img_metas, gt_bboxes_ignore=gt_bboxes_ignore)
+
+    def loss(self, cls_scores, bbox_preds, gt_bboxes, gt_labels, out_teacher,
+             img_metas, gt_bboxes_ignore=None):
+        """ld_retina.py:187-254 -> the five keys of RETINA_LOSS_KEYS."""
+        self._check_loss_cfg()
+        soft_labels, soft_targets = out_teacher[0], out_teacher[1]
+        # loss_ld_vlr = 0.03 * loss_ld(..., avg_factor=4) (ld_retina.py:109-110);
+        # the block's VLR term is lw_ld_vlr * sum / 16
+        hp = self._hp(lw_ld=self.loss_ld.loss_weight, T_ld=self.loss_ld.T,
+                      lw_ld_vlr=0.03 * 4.0 * self.loss_ld.loss_weight,
+                      T_ld_vlr=self.loss_ld.T,
+                      lw_kd=self.loss_kd.loss_weight, T_kd=self.loss_kd.T)
+        return self._run_block(hp, cls_scores, bbox_preds, gt_bboxes,
+                               gt_labels, img_metas, soft_labels, soft_targets,
+                               RETINA_LOSS_KEYS)
+
+
 class _Marker(nn.Module):
     """Parameter-free placeholder that keeps nn.Sequential's indices (and with
     them the state_dict keys ``reg_conf.0.*`` / ``reg_conf.2.*``) identical to

@@ -850,6 +850,23 @@ def bn_act(x3, gamma, beta, mean, var, eps, residual=None, relu=True):
     return y
 
 
+_RELU_CONSTS = {}
+
+
+def relu(x3):
+    """F.relu on an (N, C, P) tensor as the affine + ReLU launch with the
+    identity affine (scale = 1 / sqrt(1 + 0) = 1 and shift = 0 exactly);
+    differentiable."""
+    key = (str(x3.device), int(x3.shape[1]))
+    c = _RELU_CONSTS.get(key)
+    if c is None:
+        c = (torch.ones(key[1], device=x3.device),
+             torch.zeros(key[1], device=x3.device))
+        _RELU_CONSTS[key] = c
+    one, zero = c
+    return bn_act(x3, one, zero, zero, one, 0.0, relu=True)
+
+
 def conv_bn_act_infer(x3, w, gamma, beta, mean, var, eps, stride, pad, levels,
                       residual=None, relu=True):
     """Inference-only conv -> BN(eval) -> (+residual) -> ReLU as ONE launch

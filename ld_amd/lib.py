@@ -55,6 +55,7 @@ LD_LOSS_PROB_CLS = 1
 LD_IM_CENTER_INSIDE = 2
 LD_LOSS_ATSS = 4
 LD_LOSS_FCOS = 8
+LD_LOSS_RETINA = 16
 
 
 class ConvLevelT(C.Structure):
@@ -151,7 +152,7 @@ def save_tune_table(path):
     return get_lib().ld_conv_tune_save(str(path).encode())
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 _G, _H, _M = C.POINTER(GeomT), C.POINTER(LossHpT), C.POINTER(MapsT)
 _CV, _EP, _LV = C.POINTER(ConvT), C.POINTER(ConvEpilogueT), C.POINTER(LevelsT)
@@ -172,6 +173,10 @@ SIGNATURES = {
     'ld_fcos_targets': (C.c_int, [_G, _i32, C.POINTER(C.c_float), _i32, _f32,
                                   _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp]),
+    'ld_retina_targets_workspace_bytes': (_sz, [_G, _i32, _i32]),
+    'ld_retina_targets': (C.c_int, [_G, _i32, _vp, _i32, _f32, _f32, _f32, _i32,
+                                    _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
+                                    _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'ld_loss_prepass_ex': (C.c_int, [_G, _H, _M, _M, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _vp, _vp, _sz, _vp]),
     'ld_loss_prepass': (C.c_int, [_G, _H, _M, _M, _vp, _vp, _vp, _vp, _vp,

@@ -164,6 +164,66 @@ def fcos_targets(featmap_sizes, strides, gt_bboxes, gt_labels, num_classes,
     return out
 
 
+def retina_targets(featmap_sizes, strides, img_metas, gt_bboxes, gt_labels,
+                   anchors, num_base, assigner, num_classes, device,
+                   want_gt_inds=False):
+    """MaxIoU + VLR targets of a ``num_base``-anchors-per-cell head for a batch
+    (ld_retina_targets).  ``anchors``: the per-level explicit lists of
+    AnchorGenerator.grid_anchors.  Arrays come back in the pseudo-image layout
+    (N * num_base, A) the loss block sweeps (include/ld_hip.h LD_LOSS_RETINA);
+    ``geom`` in the result is that pseudo-image geometry."""
+    lib = L.get_lib()
+    N, B = len(img_metas), int(num_base)
+    geom = L.make_geom(featmap_sizes, strides, N, 8)
+    A, nl = geom.num_anchors, geom.num_levels
+    flat = anchors[0] if len(anchors) == 1 else torch.cat(list(anchors))
+    flat = L.require_device(flat.contiguous(), torch.float32, 'anchors')
+    if flat.shape != (A * B, 4):
+        raise L.LdError(f'retina_targets: {tuple(flat.shape)} anchors for '
+                        f'{A} cells x {B}')
+    num_gt = [int(b.shape[0]) for b in gt_bboxes]
+    max_gt = max(num_gt) if num_gt else 0
+    gtb = torch.zeros((N, max(max_gt, 1), 4), dtype=torch.float32,
+                      device=device)
+    gtl = torch.zeros((N, max(max_gt, 1)), dtype=torch.int64, device=device)
+    for i, (b, l) in enumerate(zip(gt_bboxes, gt_labels)):
+        if num_gt[i]:
+            L.require_device(b, torch.float32, 'gt_bboxes')
+            gtb[i, :num_gt[i]] = b
+            gtl[i, :num_gt[i]] = l
+    ng = _small_int_tensor(tuple(num_gt), device)
+    vhw = _small_int_tensor(
+        tuple(tuple(r) for r in valid_hw_from_metas(featmap_sizes, strides,
+                                                    img_metas)), device)
+    NB = N * B
+    out = dict(
+        labels=torch.empty((NB, A), dtype=torch.int64, device=device),
+        label_weights=torch.empty((NB, A), dtype=torch.float32, device=device),
+        bbox_targets=torch.empty((NB, A, 4), dtype=torch.float32,
+                                 device=device),
+        vlr=torch.empty((NB, A), dtype=torch.float32, device=device),
+        im=torch.empty((NB, A), dtype=torch.float32, device=device),
+        counts=torch.empty(NB + 2 * nl + 1, dtype=torch.int32, device=device),
+    )
+    if want_gt_inds:
+        out['gt_inds'] = torch.empty((NB, A), dtype=torch.int64,
+                                     device=device)
+    need = lib.ld_retina_targets_workspace_bytes(C.byref(geom), B, max_gt)
+    ws = workspace(device, need, 'targets')
+    L.check(lib.ld_retina_targets(
+        C.byref(geom), B, L.ptr(flat), int(num_classes),
+        float(assigner.pos_iou_thr), float(assigner.neg_iou_thr),
+        float(assigner.min_pos_iou), 9, L.ptr(gtb), L.ptr(gtl), L.ptr(ng),
+        max_gt, L.ptr(vhw), L.ptr(out['labels']), L.ptr(out['label_weights']),
+        L.ptr(out['bbox_targets']), L.ptr(out['vlr']), L.ptr(out['im']),
+        L.ptr(out['counts']), L.ptr(out.get('gt_inds')), L.ptr(ws),
+        ws.numel(), L.stream_ptr(device)), 'ld_retina_targets')
+    out['geom'] = L.make_geom(featmap_sizes, strides, NB, 8)
+    out['num_gt'] = num_gt
+    out['num_base'] = B
+    return out
+
+
 def grid_anchors(featmap_sizes, strides, device, anchor_scale=8):
     lib = L.get_lib()
     geom = L.make_geom(featmap_sizes, strides, 1, anchor_scale)

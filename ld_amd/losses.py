@@ -273,6 +273,21 @@ class IoULoss(nn.Module):
 
 
 @LOSSES.register_module()
+class SmoothL1Loss(nn.Module):
+    """Only *registrable* (AnchorHead's constructor default, anchor_head.py:47-48,
+    inherited by RetinaGFLHead); every RetinaGFL config overrides it with
+    GIoULoss on decoded boxes."""
+
+    def __init__(self, beta=1.0, reduction='mean', loss_weight=1.0):
+        super().__init__()
+        self.beta, self.reduction, self.loss_weight = (beta, reduction,
+                                                       loss_weight)
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError('SmoothL1Loss is not on the LD train path')
+
+
+@LOSSES.register_module()
 class CIoULoss(nn.Module):
     """Only *registrable*: the GFL teacher configs name it
     (configs/gfl/gfl_r50_fpn_1x_coco.py:43) but a frozen teacher never

@@ -256,3 +256,53 @@ def build_seeded_ld_detector(student_depth=50, teacher_depth=101, device=None,
         det.to(device)
     det.train()
     return det
+
+
+# ---------------------------------------------------------------- RetinaGFL --
+def _retina_head_common():
+    return dict(
+        num_classes=80, in_channels=256, stacked_convs=4, feat_channels=256,
+        anchor_generator=dict(type='AnchorGenerator', octave_base_scale=4,
+                              scales_per_octave=3, ratios=[0.5, 1.0, 2.0],
+                              strides=[8, 16, 32, 64, 128]),
+        bbox_coder=dict(type='DeltaXYWHBBoxCoder',
+                        target_means=[.0, .0, .0, .0],
+                        target_stds=[1.0, 1.0, 1.0, 1.0]),
+        loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0,
+                      alpha=0.25, loss_weight=1.0),
+        loss_bbox=dict(type='GIoULoss', loss_weight=2.0),
+        reg_decoded_bbox=True)
+
+
+def _retina_neck(depth=50):
+    return dict(type='FPN', in_channels=list(_RESNET_CH[depth]),
+                out_channels=256, start_level=1, add_extra_convs='on_input',
+                num_outs=5)
+
+
+def retina_gfl_detector(depth=101):
+    """A RetinaGFL teacher (configs/gfl/retinagfl_r101_2x_coco.py)."""
+    return dict(type='RetinaNet', pretrained=None,
+                backbone=_backbone(depth), neck=_retina_neck(depth),
+                bbox_head=dict(type='RetinaGFLHead', **_retina_head_common()),
+                train_cfg=copy.deepcopy(_FCOS_TRAIN_CFG),
+                test_cfg=copy.deepcopy(_TEST_CFG))
+
+
+def ld_retina_detector(student_depth=50, teacher_depth=101):
+    """configs/ld/ld_retina_r50_1x.py: LDRetinaHead student <- RetinaGFL
+    teacher (output_feature=False)."""
+    head = dict(type='LDRetinaHead',
+                loss_ld=dict(type='KnowledgeDistillationKLDivLoss',
+                             loss_weight=5, T=10),
+                loss_kd=dict(type='KnowledgeDistillationKLDivLoss',
+                             loss_weight=10, T=8),
+                **_retina_head_common())
+    return dict(type='KnowledgeDistillationSingleStageDetector',
+                pretrained=None,
+                teacher_config=dict(model=retina_gfl_detector(teacher_depth)),
+                teacher_ckpt=None, output_feature=False,
+                backbone=_backbone(student_depth),
+                neck=_retina_neck(student_depth),
+                bbox_head=head, train_cfg=copy.deepcopy(_FCOS_TRAIN_CFG),
+                test_cfg=copy.deepcopy(_TEST_CFG))
