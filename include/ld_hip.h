@@ -757,6 +757,20 @@ int ld_get_bboxes_voting(const ld_geom_t* g, const ld_maps_t* cls, const ld_maps
                   float iou_thr, int max_per_img, float* dets, int64_t* labels,
                   int32_t* counts, void* workspace, size_t workspace_bytes,
                   ld_stream_t stream);
+/* Both variants behind one entry point.  flags: LD_INFER_VOTING = the
+ * score-voting Cluster-DIoU-NMS above; LD_INFER_PROB = the class maps already
+ * hold probabilities and no sigmoid is applied -- GFocalHead.get_bboxes
+ * (gfocal_head.py:317-596: cls_score = sigmoid(cls) * quality comes out of the
+ * head, and num_classes = 81 there because use_sigmoid=False makes the
+ * background column an ordinary score channel, anchor_head.py:68-71). */
+#define LD_INFER_VOTING 1
+#define LD_INFER_PROB 2
+int ld_get_bboxes_ex(const ld_geom_t* g, const ld_maps_t* cls, const ld_maps_t* reg,
+                     int num_classes, int reg_max, const float* img_hw,
+                     const float* scale_factors, int nms_pre, float score_thr,
+                     float iou_thr, int max_per_img, int flags, float* dets,
+                     int64_t* labels, int32_t* counts, void* workspace,
+                     size_t workspace_bytes, ld_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,7 @@ struct Plan {
   int keyoff[LD_MAX_LEVELS]; // first key of the level inside an image's keys
   int keys_per_img;
   int cand_cap;              // candidate capacity per image (pow2)
+  int prob;                  // the class maps hold probabilities (GFocalHead)
 };
 
 inline int next_pow2(int v) {
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void infer_keys_kernel(Plan p, ld_maps_t cls,
     const float* base = cls.ptr[l] + (size_t)n * cls.stride_n[l] + a;
     float m = base[0];
     for (int c = 1; c < p.C; ++c) m = fmaxf(m, base[(size_t)c * cls.stride_c[l]]);
-    key = make_key(sigmoidf_(m), (unsigned)a);
+    key = make_key(p.prob ? m : sigmoidf_(m), (unsigned)a);
   }
   keys[(size_t)n * p.keys_per_img + p.keyoff[l] + a] = key;
 }
@@ -272,7 +273,8 @@ __global__ __launch_bounds__(256) void infer_decode_kernel(
   float* so = scores + ((size_t)n * p.Ktot + slot) * p.C;
   bool any = false;
   for (int c = 0; c < p.C; ++c) {
-    const float sc = sigmoidf_(cbase[(size_t)c * cls.stride_c[l]]);
+    const float raw = cbase[(size_t)c * cls.stride_c[l]];
+    const float sc = p.prob ? raw : sigmoidf_(raw);
     so[c] = sc;
     if (sc > score_thr) {
       any = true;
@@ -504,6 +506,7 @@ int make_plan(const ld_geom_t* g, int num_classes, int nms_pre, Plan* p) {
   p->N = g->num_imgs;
   p->L = g->num_levels;
   p->C = num_classes;
+  p->prob = 0;
   int koff = 0, keyoff = 0;
   for (int l = 0; l < p->L; ++l) {
     p->H[l] = g->lv[l].H;
@@ -572,9 +575,10 @@ static int get_bboxes_impl(const ld_geom_t* g, const ld_maps_t* cls,
                            int nms_pre, float score_thr, float iou_thr,
                            int max_per_img, float* dets, int64_t* labels,
                            int32_t* counts, void* workspace, size_t workspace_bytes,
-                           ld_stream_t stream_, bool voting) {
+                           ld_stream_t stream_, bool voting, bool prob = false) {
   Plan p;
   if (int e = make_plan(g, num_classes, nms_pre, &p)) return e;
+  p.prob = prob ? 1 : 0;
   if (!cls || !reg || !img_hw || !dets || !labels || !counts) return LD_EINVAL;
   if (reg_max != 16) return LD_EUNSUPPORTED;  // 17-bin Integral only
   if (max_per_img < 1 || max_per_img > kMaxKeep) return LD_EUNSUPPORTED;
@@ -693,4 +697,18 @@ extern "C" int ld_get_bboxes_voting(const ld_geom_t* g, const ld_maps_t* cls,
   return get_bboxes_impl(g, cls, reg, num_classes, reg_max, img_hw, scale_factors,
                          nms_pre, score_thr, iou_thr, max_per_img, dets, labels,
                          counts, workspace, workspace_bytes, stream, true);
+}
+
+extern "C" int ld_get_bboxes_ex(const ld_geom_t* g, const ld_maps_t* cls,
+                                const ld_maps_t* reg, int num_classes, int reg_max,
+                                const float* img_hw, const float* scale_factors,
+                                int nms_pre, float score_thr, float iou_thr,
+                                int max_per_img, int flags, float* dets,
+                                int64_t* labels, int32_t* counts, void* workspace,
+                                size_t workspace_bytes, ld_stream_t stream) {
+  if (flags & ~(LD_INFER_VOTING | LD_INFER_PROB)) return LD_EINVAL;
+  return get_bboxes_impl(g, cls, reg, num_classes, reg_max, img_hw, scale_factors,
+                         nms_pre, score_thr, iou_thr, max_per_img, dets, labels,
+                         counts, workspace, workspace_bytes, stream,
+                         (flags & LD_INFER_VOTING) != 0, (flags & LD_INFER_PROB) != 0);
 }

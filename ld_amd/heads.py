@@ -396,6 +396,11 @@ class GFLHead(nn.Module):
         """anchor_head.py:497-589 + gfl_head.py:354-451 + multiclass_nms, one
         C-ABI call for the whole batch (ld_get_bboxes).  Returns, per image,
         ``(det_bboxes (k, 5), det_labels (k,))`` like the reference."""
+        return self._get_bboxes(cls_scores, bbox_preds, img_metas, cfg,
+                                rescale, with_nms, prob=False)
+
+    def _get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg, rescale,
+                    with_nms, prob):
         cfg = self.test_cfg if cfg is None else cfg
         if cfg is None:
             raise ValueError('get_bboxes needs a test_cfg')
@@ -422,7 +427,8 @@ class GFLHead(nn.Module):
             strides, shapes, sfs, nms_pre=get('nms_pre', -1),
             score_thr=get('score_thr'), iou_thr=nms['iou_threshold'],
             max_per_img=get('max_per_img'), num_classes=self.cls_out_channels,
-            reg_max=self.reg_max, voting=nms_type == 'voting_cluster_diounms')
+            reg_max=self.reg_max, voting=nms_type == 'voting_cluster_diounms',
+            prob=prob)
 
 
 @HEADS.register_module()
@@ -1291,11 +1297,16 @@ class GFocalHead(GFLHead):
         return self.loss(*outs, gt_bboxes, gt_labels, img_metas,
                          gt_bboxes_ignore=gt_bboxes_ignore)
 
-    def get_bboxes(self, *args, **kwargs):
-        raise NotImplementedError(
-            'GFocalHead.get_bboxes (gfocal_head.py:354-451) is not wired to '
-            'ld_get_bboxes yet: inference is a "next" row of SURVEY.md '
-            'section 8f and is built for GFLHead / LDHead only')
+    def get_bboxes(self, cls_scores, bbox_preds, cls_feat, img_metas, cfg=None,
+                   rescale=False, with_nms=True):
+        """gfocal_head.py:317-596: GFLHead's pipeline on the head's own
+        probabilities (cls_score = sigmoid(cls) * quality, no second sigmoid)
+        over all cls_out_channels = num_classes + 1 score channels -- the
+        reference's background column is an ordinary class here, label 80
+        included.  ``cls_feat`` (the third head output) is unused, as in the
+        reference."""
+        return self._get_bboxes(cls_scores, bbox_preds, img_metas, cfg,
+                                rescale, with_nms, prob=True)
 
 
 @HEADS.register_module()

@@ -56,6 +56,8 @@ LD_IM_CENTER_INSIDE = 2
 LD_LOSS_ATSS = 4
 LD_LOSS_FCOS = 8
 LD_LOSS_RETINA = 16
+LD_INFER_VOTING = 1
+LD_INFER_PROB = 2
 
 
 class ConvLevelT(C.Structure):
@@ -228,6 +230,9 @@ SIGNATURES = {
                                 _f32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     'ld_get_bboxes_voting': (C.c_int, [_G, _M, _M, _i32, _i32, _vp, _vp, _i32, _f32,
                                 _f32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'ld_get_bboxes_ex': (C.c_int, [_G, _M, _M, _i32, _i32, _vp, _vp, _i32, _f32,
+                                   _f32, _i32, _i32, _vp, _vp, _vp, _vp, _sz,
+                                   _vp]),
     'ld_conv_weight_transform_batch': (C.c_int, [_vp, _vp, _i32, _vp]),
     'ld_bn_prepare_batch': (C.c_int, [_vp, _vp, _i32, _vp]),
     'ld_conv_forward': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),

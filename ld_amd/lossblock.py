@@ -444,9 +444,10 @@ def kl_integral_dense(s_reg, t_reg, weight, T=10.0, scale=1.0, with_grad=True):
 # ---------------------------------------------------------------------------
 def get_bboxes(cls_scores, bbox_preds, strides, img_shapes, scale_factors=None,
                nms_pre=1000, score_thr=0.05, iou_thr=0.6, max_per_img=100,
-               num_classes=None, reg_max=16, voting=False):
-    """GFLHead.get_bboxes on the device (ld_get_bboxes; ``voting`` = the
-    score-voting Cluster-DIoU-NMS variant, ld_get_bboxes_voting).  ``cls_scores`` /
+               num_classes=None, reg_max=16, voting=False, prob=False):
+    """GFLHead.get_bboxes on the device (ld_get_bboxes_ex; ``voting`` = the
+    score-voting Cluster-DIoU-NMS variant, ``prob`` = the class maps hold
+    probabilities: GFocalHead.get_bboxes).  ``cls_scores`` /
     ``bbox_preds``: per-level NCHW maps; ``img_shapes``: per image (h, w[, c]);
     ``scale_factors``: per image 4 values (rescale=True) or None.
     -> list of (dets (k, 5), labels (k,)) device tensors, one pair per image."""
@@ -470,11 +471,12 @@ def get_bboxes(cls_scores, bbox_preds, strides, img_shapes, scale_factors=None,
     dets = torch.empty((N, max_per_img, 5), dtype=torch.float32, device=dev)
     labels = torch.empty((N, max_per_img), dtype=torch.int64, device=dev)
     counts = torch.empty((N, ), dtype=torch.int32, device=dev)
-    fn = lib.ld_get_bboxes_voting if voting else lib.ld_get_bboxes
-    L.check(fn(C.byref(g), C.byref(cm), C.byref(rm), C_, int(reg_max),
-               L.ptr(hw), L.ptr(sf), int(nms_pre), float(score_thr),
-               float(iou_thr), int(max_per_img), L.ptr(dets), L.ptr(labels),
-               L.ptr(counts), L.ptr(ws), ws.numel(), L.stream_ptr(dev)),
-            'ld_get_bboxes')
+    flags = (L.LD_INFER_VOTING if voting else 0) | \
+        (L.LD_INFER_PROB if prob else 0)
+    L.check(lib.ld_get_bboxes_ex(
+        C.byref(g), C.byref(cm), C.byref(rm), C_, int(reg_max), L.ptr(hw),
+        L.ptr(sf), int(nms_pre), float(score_thr), float(iou_thr),
+        int(max_per_img), flags, L.ptr(dets), L.ptr(labels), L.ptr(counts),
+        L.ptr(ws), ws.numel(), L.stream_ptr(dev)), 'ld_get_bboxes_ex')
     ks = counts.cpu().tolist()  # the one sync of the call
     return [(dets[n, :k], labels[n, :k]) for n, k in enumerate(ks)]

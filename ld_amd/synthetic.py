@@ -318,3 +318,27 @@ def infer_inputs(case, device='cpu'):
                   scale_factor=np.array(f, dtype=np.float32))
              for s_, f in zip(img_shapes, sfs)]
     return cls, reg, metas
+
+
+# ---------------------------------------------------------------------------
+# GFocalHead.get_bboxes (GFLv2: the maps already hold probabilities, 81
+# channels because use_sigmoid=False -> cls_out_channels = num_classes + 1)
+# ---------------------------------------------------------------------------
+INFER_V2_CASES = ['small', 'small_topk', 'c2']
+
+
+def infer_inputs_prob(case, device='cpu'):
+    """(cls_scores as probabilities (N, 81, H, W), bbox_preds, img_metas) of an
+    INFER_CASES row: sigmoid of 81-channel synthetic logits (the sigmoid is
+    part of the INPUT here, both paths receive the same floats)."""
+    import numpy as np
+    name, pad, img_shapes, sfs, seed, nms_pre, cs, sh, store = case
+    sizes = level_shapes(pad)
+    hi = synthetic_head_inputs(len(img_shapes), sizes, seed=seed + 1000,
+                               num_classes=81)
+    cls = [torch.sigmoid(c * cs + sh).to(device) for c in hi['cls']]
+    reg = [r.to(device) for r in hi['reg']]
+    metas = [dict(img_shape=s_, pad_shape=tuple(pad) + (3, ),
+                  scale_factor=np.array(f, dtype=np.float32))
+             for s_, f in zip(img_shapes, sfs)]
+    return cls, reg, metas

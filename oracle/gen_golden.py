@@ -852,6 +852,38 @@ def gen_infer():
     np.savez_compressed(os.path.join(OUT, 'infer.npz'), **d)
 
 
+def gen_infer_v2():
+    """GFocalHead.get_bboxes (gfocal_head.py:317-596; LDv2Head inherits it):
+    no sigmoid -- the maps are cls_score = sigmoid(cls) * quality -- and 81
+    score channels (use_sigmoid=False)."""
+    import mmcv
+    head = _ldv2_head()
+    d = {}
+    for case in synthetic.INFER_CASES:
+        name, pad, img_shapes, sfs, seed, nms_pre, cs, sh, store = case
+        if name not in synthetic.INFER_V2_CASES:
+            continue
+        cls, reg, metas = synthetic.infer_inputs_prob(case)
+        cfg = mmcv.ConfigDict(dict(nms_pre=nms_pre, min_bbox_size=0,
+                                   score_thr=0.05,
+                                   nms=dict(type='nms', iou_threshold=0.6),
+                                   max_per_img=100))
+        for rescale in (False, True):
+            res = head.get_bboxes(cls, reg, None, metas, cfg=cfg,
+                                  rescale=rescale)
+            tag = f'{name}_r{int(rescale)}'
+            for i, (db, dl) in enumerate(res):
+                d[f'{tag}_bboxes_{i}'] = _np(db).astype(np.float32)
+                d[f'{tag}_labels_{i}'] = _np(dl).astype(np.int64)
+        d[name + '_cfg'] = np.array(list(pad) + [seed, nms_pre])
+        print(f'[infer_v2] {name}: dets',
+              [int(d[f"{name}_r0_labels_{i}"].shape[0])
+               for i in range(len(img_shapes))], 'labels == 80 present:',
+              [bool((d[f"{name}_r0_labels_{i}"] == 80).any())
+               for i in range(len(img_shapes))])
+    np.savez_compressed(os.path.join(OUT, 'infer_v2.npz'), **d)
+
+
 def _ld_atss_head():
     """LDATSSHead as configs/ld/ld_r50_atss_r101_1x.py:29-58 builds it."""
     from mmdet.models import build_head
@@ -1339,7 +1371,7 @@ def main():
     ap.add_argument('--only', default='kat,anchors,targets,lossblock,e2e,infer,'
                     'lossblock_v2,e2e_v2,imitation,pipeline,infer_voting,'
                     'lossblock_atss,e2e_atss,lossblock_fcos,e2e_fcos,'
-                    'lossblock_retina,e2e_retina')
+                    'lossblock_retina,e2e_retina,infer_v2')
     ap.add_argument('--e2e-cases', default='')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
@@ -1376,6 +1408,8 @@ def main():
     if 'e2e_fcos' in only:
         gen_e2e_atss('configs/ld/ld_r50_fcos_r101_1x.py', 'e2e_fcos.npz',
                      'e2e_fcos')
+    if 'infer_v2' in only:
+        gen_infer_v2()
     if 'lossblock_retina' in only:
         gen_lossblock_retina()
     if 'e2e_retina' in only:

@@ -1341,7 +1341,7 @@ def multiclass_nms_voting(bboxes, scores, score_thr, iou_thr, max_num):
 
 
 def get_bboxes_pre_nms(cls_scores, bbox_preds, img_shapes, nms_pre,
-                       strides=(8, 16, 32, 64, 128), reg_max=16):
+                       strides=(8, 16, 32, 64, 128), reg_max=16, prob=False):
     """gfl_head.py:391-424: per level sigmoid scores, Integral * stride, top
     nms_pre anchors by max class score (when the level has more), decode about
     the anchor centres, clamp to the image.  Inputs NCHW per level.
@@ -1357,7 +1357,9 @@ def get_bboxes_pre_nms(cls_scores, bbox_preds, img_shapes, nms_pre,
         ctr = np.stack([(anc[:, 0] + anc[:, 2]) / F32(2),
                         (anc[:, 1] + anc[:, 3]) / F32(2)], 1).astype(F32)
         for n in range(N):
-            sc = _sigmoid(cls[n].transpose(1, 2, 0).reshape(-1, C).astype(F32))
+            sc = cls[n].transpose(1, 2, 0).reshape(-1, C).astype(F32)
+            if not prob:  # GFocalHead's maps are probabilities already
+                sc = _sigmoid(sc)
             rg = reg[n].transpose(1, 2, 0).reshape(-1, 4 * (reg_max + 1))
             dist = (integral(rg.astype(F32), reg_max)[0] * F32(s)).astype(F32)
             c = ctr
@@ -1376,10 +1378,12 @@ def get_bboxes_pre_nms(cls_scores, bbox_preds, img_shapes, nms_pre,
 
 def get_bboxes(cls_scores, bbox_preds, img_shapes, scale_factors, nms_pre=1000,
                score_thr=0.05, iou_thr=0.6, max_per_img=100, rescale=False,
-               voting=False):
-    """GFLHead.get_bboxes.  -> per image (dets (k, 5), labels (k))."""
+               voting=False, prob=False):
+    """GFLHead.get_bboxes (prob=True: GFocalHead.get_bboxes,
+    gfocal_head.py:517-596).  -> per image (dets (k, 5), labels (k))."""
     out = []
-    pre = get_bboxes_pre_nms(cls_scores, bbox_preds, img_shapes, nms_pre)
+    pre = get_bboxes_pre_nms(cls_scores, bbox_preds, img_shapes, nms_pre,
+                             prob=prob)
     for n, (bb, sc) in enumerate(pre):
         if rescale:
             bb = (bb / np.asarray(scale_factors[n], F32)[None]).astype(F32)

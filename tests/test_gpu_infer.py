@@ -236,3 +236,67 @@ def test_voting_head_api():
     with pytest.raises(NotImplementedError):
         tc['nms'] = dict(type='soft_nms', iou_threshold=0.6)
         head.get_bboxes(cls, reg, metas, cfg=tc)
+
+
+# ---------------------------------------------------------------------------
+# GFocalHead.get_bboxes (GFLv2 / LDv2Head: BASELINE config 5's student)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('rescale', [False, True], ids=['r0', 'r1'])
+@pytest.mark.parametrize('name', synthetic.INFER_V2_CASES)
+def test_gfocal_get_bboxes_vs_reference_golden(golden, name, rescale):
+    """LD_INFER_PROB: no sigmoid, 81 score channels; against the reference's
+    GFocalHead.get_bboxes outputs (tests/golden/infer_v2.npz)."""
+    from ld_amd import lossblock as LB
+    dev = torch.device('cuda:0')
+    g = golden['infer_v2']
+    case = CASES[name]
+    cls, reg, metas = synthetic.infer_inputs_prob(case, device=dev)
+    shapes = [m['img_shape'] for m in metas]
+    sfs = [m['scale_factor'] for m in metas] if rescale else None
+    res = LB.get_bboxes(cls, reg, STRIDES, shapes, sfs, nms_pre=case[5],
+                        score_thr=0.05, iou_thr=0.6, max_per_img=100,
+                        prob=True)
+    seen80 = False
+    for i, (d, l) in enumerate(res):
+        tag = f'{name}_r{int(rescale)}'
+        dets, labels = d.cpu().numpy(), l.cpu().numpy()
+        _same(dets, labels, g[f'{tag}_bboxes_{i}'], g[f'{tag}_labels_{i}'],
+              f'v2 {tag} image {i}')
+        seen80 = seen80 or bool((labels == 80).any())
+    assert seen80
+
+
+def test_gfocal_head_api_and_detector_simple_test():
+    """GFocalHead.get_bboxes(cls_scores, bbox_preds, cls_feat, img_metas, ...)
+    (the reference's four-positional signature) and the LDv2 detector's
+    simple_test through it."""
+    from ld_amd import model_zoo, synthetic as S
+    from ld_amd.registry import build_detector
+    dev = torch.device('cuda:0')
+    det = build_detector(model_zoo.ldv2_detector(18, 18))
+    det.load_state_dict(S.seeded_state_dict(det.state_dict(), seed=1))
+    det.to(dev).eval()
+    det.bbox_head.test_cfg['score_thr'] = 0.001
+    batch = S.synthetic_batch(2, (120, 150), (128, 160), [2, 3], 7)
+    img = batch['img'].to(dev)
+    metas = batch['img_metas']
+    for m, sf in zip(metas, (1.0, 1.25)):
+        m['scale_factor'] = np.array([sf] * 4, dtype=np.float32)
+    res = det(img=[img], img_metas=[metas], return_loss=False, rescale=True)
+    with torch.no_grad():
+        outs = det.bbox_head(det.extract_feat(img))
+        assert len(outs) == 3
+        ref = det.bbox_head.get_bboxes(*outs, metas, rescale=True)
+        # probabilities in, so the plain-GFL entry on logit(p) must agree
+        cls_p = [c.clamp(1e-6, 1 - 1e-6) for c in outs[0]]
+    total = 0
+    for per_cls, (db, dl) in zip(res, ref):
+        assert len(per_cls) == 80
+        db, dl = db.cpu().numpy(), dl.cpu().numpy()
+        for c, arr in enumerate(per_cls):
+            assert np.array_equal(arr, db[dl == c])
+        total += db.shape[0]
+        assert db.shape[0] <= 100 and np.all(np.diff(db[:, 4]) <= 0)
+        assert db[:, 4].max() <= 1.0 and db[:, 4].min() > 0.001
+    assert total > 0
+    assert cls_p[0].shape[1] == 81

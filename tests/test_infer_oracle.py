@@ -147,3 +147,31 @@ def test_voting_nms_vs_reference(golden, name, thr):
                     dets[0, :4] - plain[i][0][0, :4]).max()))
     if case[6]:
         assert moved > 1e-2, 'clustered case: voting must move the top box'
+
+
+@pytest.mark.parametrize('name', synthetic.INFER_V2_CASES)
+def test_gfocal_get_bboxes_vs_reference(golden, name):
+    """GFocalHead.get_bboxes (prob=True: no sigmoid, 81 score channels with
+    the background column an ordinary class) against the reference's outputs
+    (tests/golden/infer_v2.npz)."""
+    g = golden['infer_v2']
+    case = CASES[name]
+    cls, reg, metas = synthetic.infer_inputs_prob(case)
+    cls, reg = [c.numpy() for c in cls], [r.numpy() for r in reg]
+    shapes = [m['img_shape'] for m in metas]
+    sfs = [m['scale_factor'] for m in metas]
+    seen80 = False
+    for rs in (0, 1):
+        res = O.get_bboxes(cls, reg, shapes, sfs, nms_pre=case[5],
+                           rescale=bool(rs), prob=True)
+        for i, (dets, labels) in enumerate(res):
+            gd = g[f'{name}_r{rs}_bboxes_{i}']
+            gl = g[f'{name}_r{rs}_labels_{i}']
+            assert dets.shape == gd.shape
+            assert np.array_equal(labels, gl)
+            np.testing.assert_allclose(dets[:, :4], gd[:, :4], atol=1e-3,
+                                       rtol=0)
+            np.testing.assert_allclose(dets[:, 4], gd[:, 4], atol=1e-6,
+                                       rtol=0)
+            seen80 = seen80 or bool((labels == 80).any())
+    assert seen80  # the 81st channel really takes part
