@@ -762,11 +762,26 @@ int ld_get_bboxes_voting(const ld_geom_t* g, const ld_maps_t* cls, const ld_maps
  * hold probabilities and no sigmoid is applied -- GFocalHead.get_bboxes
  * (gfocal_head.py:317-596: cls_score = sigmoid(cls) * quality comes out of the
  * head, and num_classes = 81 there because use_sigmoid=False makes the
- * background column an ordinary score channel, anchor_head.py:68-71). */
+ * background column an ordinary score channel, anchor_head.py:68-71).
+ * ``ctr`` (nullable): per-level (N, 1, H, W) centerness logits of ATSSGFLHead /
+ * FCOSGFLHead (atss_gfl_head.py:420-575, fcos_gfl_head.py:347-546): the top-k
+ * key becomes max_c score_c * sigmoid(centerness) and the factor multiplies
+ * every candidate's score AFTER the score_thr test (multiclass_nms
+ * score_factors, bbox_nms.py:114-123); not combinable with LD_INFER_VOTING.
+ * LD_INFER_POINTS: decode about the FCOS points (x, y) * stride + stride / 2
+ * (fcos_gfl_head.py:548-558) instead of the anchor centres (x, y) * stride.
+ * ``num_base`` > 1 (RetinaGFLHead._get_bboxes, retina_gfl_head.py:301-412): the
+ * maps are (N, num_base * C, H, W) / (N, num_base * 68, H, W); candidates are
+ * the rows (cell, base anchor) in that order, top-k per level over all of
+ * them, decoded about the shared cell centre.  Workspace: the _ex_ size. */
 #define LD_INFER_VOTING 1
 #define LD_INFER_PROB 2
+#define LD_INFER_POINTS 4
+size_t ld_get_bboxes_ex_workspace_bytes(const ld_geom_t* g, int num_classes,
+                                       int num_base, int nms_pre);
 int ld_get_bboxes_ex(const ld_geom_t* g, const ld_maps_t* cls, const ld_maps_t* reg,
-                     int num_classes, int reg_max, const float* img_hw,
+                     const ld_maps_t* ctr, int num_classes, int num_base,
+                     int reg_max, const float* img_hw,
                      const float* scale_factors, int nms_pre, float score_thr,
                      float iou_thr, int max_per_img, int flags, float* dets,
                      int64_t* labels, int32_t* counts, void* workspace,

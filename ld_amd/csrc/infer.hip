@@ -54,6 +54,10 @@ struct Plan {
   int keys_per_img;
   int cand_cap;              // candidate capacity per image (pow2)
   int prob;                  // the class maps hold probabilities (GFocalHead)
+  int has_ctr;               // score factor sigmoid(centerness) (ATSS / FCOS heads)
+  int points;                // FCOS points (x, y) * s + s / 2 instead of anchor centres
+  int B;                     // anchors per cell (RetinaGFLHead: rows = cell * B + b,
+                             // channels = b * C + c / b * 68 + side * 17 + k)
 };
 
 inline int next_pow2(int v) {
@@ -70,6 +74,7 @@ __device__ __forceinline__ unsigned long long make_key(float score, unsigned idx
 
 // ---- 1. keys ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void infer_keys_kernel(Plan p, ld_maps_t cls,
+                                                        ld_maps_t ctr,
                                                         unsigned long long* keys) {
   const int l = blockIdx.y, n = blockIdx.z;
   if (p.pad[l] == 0) return;
@@ -77,10 +82,17 @@ __global__ __launch_bounds__(256) void infer_keys_kernel(Plan p, ld_maps_t cls,
   if (a >= p.pad[l]) return;
   unsigned long long key = 0ull;
   if (a < p.A[l]) {
-    const float* base = cls.ptr[l] + (size_t)n * cls.stride_n[l] + a;
+    const int cell = a / p.B, b = a - cell * p.B;
+    const float* base = cls.ptr[l] + (size_t)n * cls.stride_n[l] +
+                        (size_t)b * p.C * cls.stride_c[l] + cell;
     float m = base[0];
     for (int c = 1; c < p.C; ++c) m = fmaxf(m, base[(size_t)c * cls.stride_c[l]]);
-    key = make_key(p.prob ? m : sigmoidf_(m), (unsigned)a);
+    float sc = p.prob ? m : sigmoidf_(m);
+    // (scores * centerness[..., None]).max(-1), atss_gfl_head.py:509: the
+    // product is monotonic in the score, so the max commutes with it
+    if (p.has_ctr)
+      sc = sc * sigmoidf_(ctr.ptr[l][(size_t)n * ctr.stride_n[l] + cell]);
+    key = make_key(sc, (unsigned)a);
   }
   keys[(size_t)n * p.keys_per_img + p.keyoff[l] + a] = key;
 }
@@ -224,8 +236,9 @@ __global__ __launch_bounds__(kSortThreads) void infer_topk_sort_kernel(
 
 // ---- 3. decode -----------------------------------------------------------------
 __global__ __launch_bounds__(256) void infer_decode_kernel(
-    Plan p, ld_maps_t cls, ld_maps_t reg, const unsigned long long* keys,
-    const float* img_hw, const float* scale_factors, float score_thr, float* boxes,
+    Plan p, ld_maps_t cls, ld_maps_t reg, ld_maps_t ctr,
+    const unsigned long long* keys, const float* img_hw, const float* scale_factors,
+    float score_thr, float* boxes,
     float* scores, unsigned long long* cand, int* cand_count, unsigned* max_coord) {
   const int n = blockIdx.y;
   const int slot = blockIdx.x * 256 + threadIdx.x;
@@ -240,11 +253,15 @@ __global__ __launch_bounds__(256) void infer_decode_kernel(
     a = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
   }
   const int W = p.W[l], s = p.stride[l];
-  const int y = a / W, x = a - y * W;
+  const int cell = a / p.B, b = a - cell * p.B;
+  const int y = cell / W, x = cell - y * W;
   // anchor centre (AnchorGenerator, center_offset 0: the cell's top-left corner)
-  const float cx = (float)(x * s), cy = (float)(y * s);
+  // FCOS points: + stride // 2 (fcos_gfl_head.py:548-558)
+  const int half = p.points ? s / 2 : 0;
+  const float cx = (float)(x * s + half), cy = (float)(y * s + half);
   // Integral * stride (gfl_head.py:32-44, :405)
-  const float* rbase = reg.ptr[l] + (size_t)n * reg.stride_n[l] + a;
+  const float* rbase = reg.ptr[l] + (size_t)n * reg.stride_n[l] +
+                       (size_t)b * 68 * reg.stride_c[l] + cell;
   float d[4];
 #pragma unroll
   for (int side = 0; side < 4; ++side) {
@@ -269,9 +286,14 @@ __global__ __launch_bounds__(256) void infer_decode_kernel(
 #pragma unroll
   for (int k = 0; k < 4; ++k) bo[k] = bx[k];
   // scores + candidates
-  const float* cbase = cls.ptr[l] + (size_t)n * cls.stride_n[l] + a;
+  const float* cbase = cls.ptr[l] + (size_t)n * cls.stride_n[l] +
+                       (size_t)b * p.C * cls.stride_c[l] + cell;
   float* so = scores + ((size_t)n * p.Ktot + slot) * p.C;
   bool any = false;
+  // multiclass_nms(score_factors=centerness): the factor multiplies the score
+  // AFTER the threshold test (bbox_nms.py:114-123)
+  const float fac =
+      p.has_ctr ? sigmoidf_(ctr.ptr[l][(size_t)n * ctr.stride_n[l] + cell]) : 1.0f;
   for (int c = 0; c < p.C; ++c) {
     const float raw = cbase[(size_t)c * cls.stride_c[l]];
     const float sc = p.prob ? raw : sigmoidf_(raw);
@@ -280,7 +302,8 @@ __global__ __launch_bounds__(256) void infer_decode_kernel(
       any = true;
       const int pos = atomicAdd(&cand_count[n], 1);
       if (pos < p.cand_cap)
-        cand[(size_t)n * p.cand_cap + pos] = make_key(sc, (unsigned)(slot * p.C + c));
+        cand[(size_t)n * p.cand_cap + pos] =
+            make_key(p.has_ctr ? sc * fac : sc, (unsigned)(slot * p.C + c));
     }
   }
   if (any) {
@@ -499,20 +522,22 @@ __global__ __launch_bounds__(256) void infer_vote_kernel(
   if (t < 4) dets[((size_t)n * max_keep + q) * 5 + t] = red[t][0] / red[4][0];
 }
 
-int make_plan(const ld_geom_t* g, int num_classes, int nms_pre, Plan* p) {
+int make_plan(const ld_geom_t* g, int num_classes, int nms_pre, Plan* p,
+              int num_base = 1) {
   if (!g || g->num_levels < 1 || g->num_levels > LD_MAX_LEVELS || g->num_imgs < 1 ||
-      num_classes < 1)
+      num_classes < 1 || num_base < 1 || num_base > 64)
     return LD_EINVAL;
+  p->B = num_base;
   p->N = g->num_imgs;
   p->L = g->num_levels;
   p->C = num_classes;
-  p->prob = 0;
+  p->prob = p->has_ctr = p->points = 0;
   int koff = 0, keyoff = 0;
   for (int l = 0; l < p->L; ++l) {
     p->H[l] = g->lv[l].H;
     p->W[l] = g->lv[l].W;
     p->stride[l] = g->lv[l].stride;
-    p->A[l] = g->lv[l].H * g->lv[l].W;
+    p->A[l] = g->lv[l].H * g->lv[l].W * num_base;
     if (p->A[l] < 1) return LD_EINVAL;
     const bool sorted = nms_pre > 0 && p->A[l] > nms_pre;
     p->K[l] = sorted ? nms_pre : p->A[l];
@@ -569,16 +594,29 @@ extern "C" size_t ld_get_bboxes_workspace_bytes(const ld_geom_t* g, int num_clas
   return layout(p).total;
 }
 
+extern "C" size_t ld_get_bboxes_ex_workspace_bytes(const ld_geom_t* g, int num_classes,
+                                                   int num_base, int nms_pre) {
+  Plan p;
+  if (make_plan(g, num_classes, nms_pre, &p, num_base) != 0) return 0;
+  return layout(p).total;
+}
+
 static int get_bboxes_impl(const ld_geom_t* g, const ld_maps_t* cls,
                            const ld_maps_t* reg, int num_classes, int reg_max,
                            const float* img_hw, const float* scale_factors,
                            int nms_pre, float score_thr, float iou_thr,
                            int max_per_img, float* dets, int64_t* labels,
                            int32_t* counts, void* workspace, size_t workspace_bytes,
-                           ld_stream_t stream_, bool voting, bool prob = false) {
+                           ld_stream_t stream_, bool voting, bool prob = false,
+                           const ld_maps_t* ctr = nullptr, bool points = false,
+                           int num_base = 1) {
   Plan p;
-  if (int e = make_plan(g, num_classes, nms_pre, &p)) return e;
+  if (int e = make_plan(g, num_classes, nms_pre, &p, num_base)) return e;
   p.prob = prob ? 1 : 0;
+  p.has_ctr = ctr ? 1 : 0;
+  p.points = points ? 1 : 0;
+  if (ctr && voting) return LD_EUNSUPPORTED;
+  ld_maps_t ctr_maps = ctr ? *ctr : ld_maps_t{};
   if (!cls || !reg || !img_hw || !dets || !labels || !counts) return LD_EINVAL;
   if (reg_max != 16) return LD_EUNSUPPORTED;  // 17-bin Integral only
   if (max_per_img < 1 || max_per_img > kMaxKeep) return LD_EUNSUPPORTED;
@@ -614,7 +652,7 @@ static int get_bboxes_impl(const ld_geom_t* g, const ld_maps_t* cls,
   const bool fast_topk = !force_global && nms_pre <= kSelN;
   if (nsorted > 0) {
     hipLaunchKernelGGL(infer_keys_kernel, dim3((maxpad + 255) / 256, p.L, p.N),
-                       dim3(256), 0, stream, p, *cls, keys);
+                       dim3(256), 0, stream, p, *cls, ctr_maps, keys);
     if (fast_topk)
       hipLaunchKernelGGL(infer_topk_select_kernel, dim3(nsorted, p.N),
                          dim3(kSortThreads), 0, stream, p, keys);
@@ -623,7 +661,7 @@ static int get_bboxes_impl(const ld_geom_t* g, const ld_maps_t* cls,
                          dim3(kSortThreads), 0, stream, p, keys);
   }
   hipLaunchKernelGGL(infer_decode_kernel, dim3((p.Ktot + 255) / 256, p.N), dim3(256), 0,
-                     stream, p, *cls, *reg, keys, img_hw, scale_factors, score_thr,
+                     stream, p, *cls, *reg, ctr_maps, keys, img_hw, scale_factors, score_thr,
                      boxes, scores, cand, count, maxc);
   bool need_global = force_global;
   if (!force_global) {
@@ -700,15 +738,17 @@ extern "C" int ld_get_bboxes_voting(const ld_geom_t* g, const ld_maps_t* cls,
 }
 
 extern "C" int ld_get_bboxes_ex(const ld_geom_t* g, const ld_maps_t* cls,
-                                const ld_maps_t* reg, int num_classes, int reg_max,
+                                const ld_maps_t* reg, const ld_maps_t* ctr,
+                                int num_classes, int num_base, int reg_max,
                                 const float* img_hw, const float* scale_factors,
                                 int nms_pre, float score_thr, float iou_thr,
                                 int max_per_img, int flags, float* dets,
                                 int64_t* labels, int32_t* counts, void* workspace,
                                 size_t workspace_bytes, ld_stream_t stream) {
-  if (flags & ~(LD_INFER_VOTING | LD_INFER_PROB)) return LD_EINVAL;
+  if (flags & ~(LD_INFER_VOTING | LD_INFER_PROB | LD_INFER_POINTS)) return LD_EINVAL;
   return get_bboxes_impl(g, cls, reg, num_classes, reg_max, img_hw, scale_factors,
                          nms_pre, score_thr, iou_thr, max_per_img, dets, labels,
                          counts, workspace, workspace_bytes, stream,
-                         (flags & LD_INFER_VOTING) != 0, (flags & LD_INFER_PROB) != 0);
+                         (flags & LD_INFER_VOTING) != 0, (flags & LD_INFER_PROB) != 0,
+                         ctr, (flags & LD_INFER_POINTS) != 0, num_base);
 }

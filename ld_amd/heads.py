@@ -400,7 +400,8 @@ class GFLHead(nn.Module):
                                 rescale, with_nms, prob=False)
 
     def _get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg, rescale,
-                    with_nms, prob):
+                    with_nms, prob, centernesses=None, points=False,
+                    strides=None, num_base=1):
         cfg = self.test_cfg if cfg is None else cfg
         if cfg is None:
             raise ValueError('get_bboxes needs a test_cfg')
@@ -416,8 +417,10 @@ class GFLHead(nn.Module):
         get = cfg.get if hasattr(cfg, 'get') else lambda k, d=None: cfg[k]
         if get('min_bbox_size', 0) not in (0, -1):
             raise NotImplementedError('min_bbox_size > 0')
+        if centernesses is not None and nms_type != 'nms':
+            raise NotImplementedError('score voting with centerness factors')
         strides = [s[0] if isinstance(s, (tuple, list)) else s
-                   for s in self.anchor_generator.strides]
+                   for s in (strides or self.anchor_generator.strides)]
         N = cls_scores[0].shape[0]
         shapes = [img_metas[i]['img_shape'] for i in range(N)]
         sfs = [img_metas[i]['scale_factor'] for i in range(N)] if rescale \
@@ -428,7 +431,9 @@ class GFLHead(nn.Module):
             score_thr=get('score_thr'), iou_thr=nms['iou_threshold'],
             max_per_img=get('max_per_img'), num_classes=self.cls_out_channels,
             reg_max=self.reg_max, voting=nms_type == 'voting_cluster_diounms',
-            prob=prob)
+            prob=prob, centernesses=None if centernesses is None else
+            [c.detach() for c in centernesses], points=points,
+            num_base=num_base)
 
 
 @HEADS.register_module()
@@ -646,10 +651,14 @@ class ATSSGFLHead(GFLHead):
         return self._atss_loss_dict(table, ('loss_cls', 'loss_bbox',
                                             'loss_centerness'))
 
-    def get_bboxes(self, *args, **kwargs):
-        raise NotImplementedError(
-            'ATSSGFLHead.get_bboxes (centerness-weighted scores, '
-            'atss_gfl_head.py:420-560) is not wired to ld_get_bboxes')
+    def get_bboxes(self, cls_scores, bbox_preds, centernesses, img_metas,
+                   cfg=None, rescale=False, with_nms=True):
+        """atss_gfl_head.py:420-575: GFLHead's pipeline with the top-k key
+        max_c score_c * sigmoid(centerness) and the centerness as
+        multiclass_nms' score factor (applied after the threshold test)."""
+        return self._get_bboxes(cls_scores, bbox_preds, img_metas, cfg,
+                                rescale, with_nms, prob=False,
+                                centernesses=centernesses)
 
 
 @HEADS.register_module()
@@ -881,10 +890,14 @@ class FCOSGFLHead(nn.Module):
         return self.loss(*self(x), gt_bboxes, gt_labels, img_metas,
                          gt_bboxes_ignore=gt_bboxes_ignore)
 
-    def get_bboxes(self, *args, **kwargs):
-        raise NotImplementedError(
-            'FCOSGFLHead.get_bboxes (fcos_gfl_head.py:347-546) is not wired to '
-            'ld_get_bboxes')
+    def get_bboxes(self, cls_scores, bbox_preds, centernesses, img_metas,
+                   cfg=None, rescale=False, with_nms=True):
+        """fcos_gfl_head.py:347-546: as ATSSGFLHead.get_bboxes, decoded about
+        the FCOS points (x, y) * stride + stride // 2."""
+        return GFLHead._get_bboxes(self, cls_scores, bbox_preds, img_metas,
+                                   cfg, rescale, with_nms, prob=False,
+                                   centernesses=centernesses, points=True,
+                                   strides=self.strides)
 
 
 @HEADS.register_module()
@@ -1130,10 +1143,14 @@ class RetinaGFLHead(nn.Module):
         return self.loss(*self(x), gt_bboxes, gt_labels, img_metas,
                          gt_bboxes_ignore=gt_bboxes_ignore)
 
-    def get_bboxes(self, *args, **kwargs):
-        raise NotImplementedError(
-            'RetinaGFLHead.get_bboxes (retina_gfl_head.py:301-330: top-k over '
-            'the B anchors of a level) is not wired to ld_get_bboxes')
+    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg=None,
+                   rescale=False, with_nms=True):
+        """anchor_head.py:497-589 + retina_gfl_head.py:301-412: sigmoid scores,
+        Integral * stride, per-level top-nms_pre over all (cell, base anchor)
+        rows, decode about the cell centre, multiclass_nms."""
+        return GFLHead._get_bboxes(self, cls_scores, bbox_preds, img_metas,
+                                   cfg, rescale, with_nms, prob=False,
+                                   num_base=self.num_anchors)
 
 
 @HEADS.register_module()

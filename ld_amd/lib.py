@@ -58,6 +58,7 @@ LD_LOSS_FCOS = 8
 LD_LOSS_RETINA = 16
 LD_INFER_VOTING = 1
 LD_INFER_PROB = 2
+LD_INFER_POINTS = 4
 
 
 class ConvLevelT(C.Structure):
@@ -230,7 +231,8 @@ SIGNATURES = {
                                 _f32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     'ld_get_bboxes_voting': (C.c_int, [_G, _M, _M, _i32, _i32, _vp, _vp, _i32, _f32,
                                 _f32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'ld_get_bboxes_ex': (C.c_int, [_G, _M, _M, _i32, _i32, _vp, _vp, _i32, _f32,
+    'ld_get_bboxes_ex_workspace_bytes': (_sz, [_G, _i32, _i32, _i32]),
+    'ld_get_bboxes_ex': (C.c_int, [_G, _M, _M, _M, _i32, _i32, _i32, _vp, _vp, _i32, _f32,
                                    _f32, _i32, _i32, _vp, _vp, _vp, _vp, _sz,
                                    _vp]),
     'ld_conv_weight_transform_batch': (C.c_int, [_vp, _vp, _i32, _vp]),

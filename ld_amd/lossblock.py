@@ -444,17 +444,24 @@ def kl_integral_dense(s_reg, t_reg, weight, T=10.0, scale=1.0, with_grad=True):
 # ---------------------------------------------------------------------------
 def get_bboxes(cls_scores, bbox_preds, strides, img_shapes, scale_factors=None,
                nms_pre=1000, score_thr=0.05, iou_thr=0.6, max_per_img=100,
-               num_classes=None, reg_max=16, voting=False, prob=False):
+               num_classes=None, reg_max=16, voting=False, prob=False,
+               centernesses=None, points=False, num_base=1):
     """GFLHead.get_bboxes on the device (ld_get_bboxes_ex; ``voting`` = the
     score-voting Cluster-DIoU-NMS variant, ``prob`` = the class maps hold
-    probabilities: GFocalHead.get_bboxes).  ``cls_scores`` /
+    probabilities: GFocalHead.get_bboxes; ``centernesses`` / ``points``: the
+    ATSSGFLHead / FCOSGFLHead variants).  ``cls_scores`` /
     ``bbox_preds``: per-level NCHW maps; ``img_shapes``: per image (h, w[, c]);
     ``scale_factors``: per image 4 values (rescale=True) or None.
     -> list of (dets (k, 5), labels (k,)) device tensors, one pair per image."""
     lib = L.get_lib()
     dev = cls_scores[0].device
     N = cls_scores[0].shape[0]
-    C_ = int(num_classes or cls_scores[0].shape[1])
+    B_ = int(num_base)
+    C_ = int(num_classes or cls_scores[0].shape[1] // B_)
+    if cls_scores[0].shape[1] != B_ * C_ or \
+            bbox_preds[0].shape[1] != B_ * 4 * (reg_max + 1):
+        raise L.LdError('get_bboxes: channel counts do not match num_base x '
+                        '(num_classes, 4 * (reg_max + 1))')
     sizes = [tuple(int(v) for v in c.shape[-2:]) for c in cls_scores]
     g = L.make_geom(sizes, strides, N)
     cm, rm = L.make_maps(cls_scores), L.make_maps(bbox_preds)
@@ -464,7 +471,8 @@ def get_bboxes(cls_scores, bbox_preds, strides, img_shapes, scale_factors=None,
     if scale_factors is not None:
         sf = torch.tensor([[float(v) for v in f] for f in scale_factors],
                           dtype=torch.float32).to(dev)
-    need = lib.ld_get_bboxes_workspace_bytes(C.byref(g), C_, int(nms_pre))
+    need = lib.ld_get_bboxes_ex_workspace_bytes(C.byref(g), C_, B_,
+                                                int(nms_pre))
     if need == 0:
         raise L.LdError('ld_get_bboxes: bad geometry')
     ws = workspace(dev, need, 'infer')
@@ -472,9 +480,13 @@ def get_bboxes(cls_scores, bbox_preds, strides, img_shapes, scale_factors=None,
     labels = torch.empty((N, max_per_img), dtype=torch.int64, device=dev)
     counts = torch.empty((N, ), dtype=torch.int32, device=dev)
     flags = (L.LD_INFER_VOTING if voting else 0) | \
-        (L.LD_INFER_PROB if prob else 0)
+        (L.LD_INFER_PROB if prob else 0) | \
+        (L.LD_INFER_POINTS if points else 0)
+    km = C.byref(L.make_maps(centernesses)) if centernesses is not None \
+        else None
     L.check(lib.ld_get_bboxes_ex(
-        C.byref(g), C.byref(cm), C.byref(rm), C_, int(reg_max), L.ptr(hw),
+        C.byref(g), C.byref(cm), C.byref(rm), km, C_, B_, int(reg_max),
+        L.ptr(hw),
         L.ptr(sf), int(nms_pre), float(score_thr), float(iou_thr),
         int(max_per_img), flags, L.ptr(dets), L.ptr(labels), L.ptr(counts),
         L.ptr(ws), ws.numel(), L.stream_ptr(dev)), 'ld_get_bboxes_ex')

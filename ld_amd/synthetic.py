@@ -342,3 +342,19 @@ def infer_inputs_prob(case, device='cpu'):
                   scale_factor=np.array(f, dtype=np.float32))
              for s_, f in zip(img_shapes, sfs)]
     return cls, reg, metas
+
+
+def infer_inputs_retina(case, device='cpu'):
+    """(cls_scores (N, 9 * 80, H, W), bbox_preds (N, 9 * 68, H, W), img_metas)
+    of an INFER_CASES row for the 9-anchor RetinaGFL head."""
+    import numpy as np
+    name, pad, img_shapes, sfs, seed, nms_pre, cs, sh, store = case
+    sizes = level_shapes(pad)
+    hi = synthetic_head_inputs(len(img_shapes), sizes, seed=seed + 2000,
+                               num_anchors=9)
+    cls = [(c * cs + sh).to(device) for c in hi['cls']]
+    reg = [r.to(device) for r in hi['reg']]
+    metas = [dict(img_shape=s_, pad_shape=tuple(pad) + (3, ),
+                  scale_factor=np.array(f, dtype=np.float32))
+             for s_, f in zip(img_shapes, sfs)]
+    return cls, reg, metas

@@ -884,6 +884,67 @@ def gen_infer_v2():
     np.savez_compressed(os.path.join(OUT, 'infer_v2.npz'), **d)
 
 
+def gen_infer_ctr():
+    """ATSSGFLHead / FCOSGFLHead get_bboxes (atss_gfl_head.py:420-575,
+    fcos_gfl_head.py:347-546): centerness-weighted top-k and scores
+    (multiclass_nms score_factors), FCOS points for the latter."""
+    import mmcv
+    d = {}
+    for tag, head in (('atss', _ld_atss_head()), ('fcos', _ld_fcos_head())):
+        for case in synthetic.INFER_CASES:
+            name, pad, img_shapes, sfs, seed, nms_pre, cs, sh, store = case
+            if name not in synthetic.INFER_V2_CASES:
+                continue
+            cls, reg, metas = synthetic.infer_inputs(case)
+            ctr = synthetic.synthetic_centerness(
+                len(img_shapes), synthetic.level_shapes(pad), seed=seed)
+            cfg = mmcv.ConfigDict(dict(nms_pre=nms_pre, min_bbox_size=0,
+                                       score_thr=0.05,
+                                       nms=dict(type='nms', iou_threshold=0.6),
+                                       max_per_img=100))
+            for rescale in (False, True):
+                res = head.get_bboxes(cls, reg, ctr, metas, cfg=cfg,
+                                      rescale=rescale)
+                key = f'{tag}_{name}_r{int(rescale)}'
+                for i, (db, dl) in enumerate(res):
+                    d[f'{key}_bboxes_{i}'] = _np(db).astype(np.float32)
+                    d[f'{key}_labels_{i}'] = _np(dl).astype(np.int64)
+            print(f'[infer_ctr] {tag} {name}: dets',
+                  [int(d[f"{tag}_{name}_r0_labels_{i}"].shape[0])
+                   for i in range(len(img_shapes))], 'min score',
+                  [float(d[f"{tag}_{name}_r0_bboxes_{i}"][:, 4].min())
+                   for i in range(len(img_shapes))])
+    np.savez_compressed(os.path.join(OUT, 'infer_ctr.npz'), **d)
+
+
+def gen_infer_retina():
+    """RetinaGFLHead / LDRetinaHead get_bboxes (retina_gfl_head.py:301-412;
+    anchor_head.py:497-589): 9 anchors per cell, top-k per level over all
+    (cell, anchor) rows."""
+    import mmcv
+    head = _ld_retina_head()
+    d = {}
+    for case in synthetic.INFER_CASES:
+        name, pad, img_shapes, sfs, seed, nms_pre, cs, sh, store = case
+        if name not in synthetic.INFER_V2_CASES:
+            continue
+        cls, reg, metas = synthetic.infer_inputs_retina(case)
+        cfg = mmcv.ConfigDict(dict(nms_pre=nms_pre, min_bbox_size=0,
+                                   score_thr=0.05,
+                                   nms=dict(type='nms', iou_threshold=0.6),
+                                   max_per_img=100))
+        for rescale in (False, True):
+            res = head.get_bboxes(cls, reg, metas, cfg=cfg, rescale=rescale)
+            key = f'{name}_r{int(rescale)}'
+            for i, (db, dl) in enumerate(res):
+                d[f'{key}_bboxes_{i}'] = _np(db).astype(np.float32)
+                d[f'{key}_labels_{i}'] = _np(dl).astype(np.int64)
+        print(f'[infer_retina] {name}: dets',
+              [int(d[f"{name}_r0_labels_{i}"].shape[0])
+               for i in range(len(img_shapes))])
+    np.savez_compressed(os.path.join(OUT, 'infer_retina.npz'), **d)
+
+
 def _ld_atss_head():
     """LDATSSHead as configs/ld/ld_r50_atss_r101_1x.py:29-58 builds it."""
     from mmdet.models import build_head
@@ -1371,7 +1432,8 @@ def main():
     ap.add_argument('--only', default='kat,anchors,targets,lossblock,e2e,infer,'
                     'lossblock_v2,e2e_v2,imitation,pipeline,infer_voting,'
                     'lossblock_atss,e2e_atss,lossblock_fcos,e2e_fcos,'
-                    'lossblock_retina,e2e_retina,infer_v2')
+                    'lossblock_retina,e2e_retina,infer_v2,infer_ctr,'
+                    'infer_retina')
     ap.add_argument('--e2e-cases', default='')
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
@@ -1410,6 +1472,10 @@ def main():
                      'e2e_fcos')
     if 'infer_v2' in only:
         gen_infer_v2()
+    if 'infer_ctr' in only:
+        gen_infer_ctr()
+    if 'infer_retina' in only:
+        gen_infer_retina()
     if 'lossblock_retina' in only:
         gen_lossblock_retina()
     if 'e2e_retina' in only:

@@ -1263,9 +1263,12 @@ def batched_nms(boxes, scores, labels, iou_thr, split_thr=10000):
     return keep[np.argsort(-scores[keep], kind='stable')]
 
 
-def multiclass_nms(bboxes, scores, score_thr, iou_thr, max_num):
+def multiclass_nms(bboxes, scores, score_thr, iou_thr, max_num,
+                   score_factors=None):
     """bbox_nms.py:70-195 with nms_cfg type 'nms'.  bboxes (n, 4), scores
-    (n, C) WITHOUT the padded background column.  -> dets (k, 5), labels (k)."""
+    (n, C) WITHOUT the padded background column; score_factors (n,) multiply
+    the scores AFTER the threshold test (:114-123).
+    -> dets (k, 5), labels (k)."""
     n, C = scores.shape
     flat_s = scores.reshape(-1)
     valid = np.nonzero(flat_s > F32(score_thr))[0]  # row-major: anchor, class
@@ -1273,6 +1276,8 @@ def multiclass_nms(bboxes, scores, score_thr, iou_thr, max_num):
         return np.zeros((0, 5), F32), np.zeros(0, np.int64)
     a_idx, labels = valid // C, valid % C
     b, s = bboxes[a_idx].astype(F32), flat_s[valid].astype(F32)
+    if score_factors is not None:
+        s = (s * score_factors.astype(F32)[a_idx]).astype(F32)
     keep = batched_nms(b, s, labels, iou_thr)
     if max_num > 0:
         keep = keep[:max_num]
@@ -1341,21 +1346,31 @@ def multiclass_nms_voting(bboxes, scores, score_thr, iou_thr, max_num):
 
 
 def get_bboxes_pre_nms(cls_scores, bbox_preds, img_shapes, nms_pre,
-                       strides=(8, 16, 32, 64, 128), reg_max=16, prob=False):
+                       strides=(8, 16, 32, 64, 128), reg_max=16, prob=False,
+                       centernesses=None, points=False, num_base=1):
     """gfl_head.py:391-424: per level sigmoid scores, Integral * stride, top
     nms_pre anchors by max class score (when the level has more), decode about
     the anchor centres, clamp to the image.  Inputs NCHW per level.
-    -> per image (boxes (K, 4), scores (K, C)), levels concatenated in order."""
+    -> per image (boxes (K, 4), scores (K, C)), levels concatenated in order.
+    ``centernesses`` (ATSSGFLHead / FCOSGFLHead, atss_gfl_head.py:487-523):
+    the top-k key is max_c(score_c * sigmoid(centerness)) and a third array,
+    the factors (K,), is returned; ``points``: FCOS points (x, y) * s + s // 2
+    instead of anchor centres (fcos_gfl_head.py:548-558)."""
     N = cls_scores[0].shape[0]
     sizes = [tuple(c.shape[2:]) for c in cls_scores]
     anchors = grid_anchors(sizes, strides)
     boxes = [[] for _ in range(N)]
     scores = [[] for _ in range(N)]
+    factors = [[] for _ in range(N)]
+    if num_base > 1:  # RetinaGFLHead: rows = (cell, base anchor)
+        anchors = retina_grid_anchors(sizes, strides)
     for l, (cls, reg, s) in enumerate(zip(cls_scores, bbox_preds, strides)):
-        C = cls.shape[1]
+        C = cls.shape[1] // num_base
         anc = anchors[l]
         ctr = np.stack([(anc[:, 0] + anc[:, 2]) / F32(2),
                         (anc[:, 1] + anc[:, 3]) / F32(2)], 1).astype(F32)
+        if points:
+            ctr = (ctr + F32(s // 2)).astype(F32)
         for n in range(N):
             sc = cls[n].transpose(1, 2, 0).reshape(-1, C).astype(F32)
             if not prob:  # GFocalHead's maps are probabilities already
@@ -1363,30 +1378,50 @@ def get_bboxes_pre_nms(cls_scores, bbox_preds, img_shapes, nms_pre,
             rg = reg[n].transpose(1, 2, 0).reshape(-1, 4 * (reg_max + 1))
             dist = (integral(rg.astype(F32), reg_max)[0] * F32(s)).astype(F32)
             c = ctr
+            cen = None
+            if centernesses is not None:
+                cen = _sigmoid(centernesses[l][n].reshape(-1).astype(F32))
             if nms_pre > 0 and sc.shape[0] > nms_pre:
-                top = np.argsort(-sc.max(1), kind='stable')[:nms_pre]
+                key = sc.max(1) if cen is None else \
+                    (sc * cen[:, None]).astype(F32).max(1)
+                top = np.argsort(-key, kind='stable')[:nms_pre]
                 sc, dist, c = sc[top], dist[top], ctr[top]
+                cen = None if cen is None else cen[top]
             bb = distance2bbox(c, dist).astype(F32)
             H, W = F32(img_shapes[n][0]), F32(img_shapes[n][1])
             bb[:, 0::2] = np.clip(bb[:, 0::2], F32(0), W)
             bb[:, 1::2] = np.clip(bb[:, 1::2], F32(0), H)
             boxes[n].append(bb)
             scores[n].append(sc)
+            factors[n].append(cen)
+    if centernesses is not None:
+        return [(np.concatenate(b), np.concatenate(s), np.concatenate(f))
+                for b, s, f in zip(boxes, scores, factors)]
     return [(np.concatenate(b), np.concatenate(s))
             for b, s in zip(boxes, scores)]
 
 
 def get_bboxes(cls_scores, bbox_preds, img_shapes, scale_factors, nms_pre=1000,
                score_thr=0.05, iou_thr=0.6, max_per_img=100, rescale=False,
-               voting=False, prob=False):
+               voting=False, prob=False, centernesses=None, points=False,
+               num_base=1):
     """GFLHead.get_bboxes (prob=True: GFocalHead.get_bboxes,
-    gfocal_head.py:517-596).  -> per image (dets (k, 5), labels (k))."""
+    gfocal_head.py:517-596; centernesses: ATSSGFLHead / FCOSGFLHead
+    get_bboxes, points=True for the latter).
+    -> per image (dets (k, 5), labels (k))."""
     out = []
     pre = get_bboxes_pre_nms(cls_scores, bbox_preds, img_shapes, nms_pre,
-                             prob=prob)
-    for n, (bb, sc) in enumerate(pre):
+                             prob=prob, centernesses=centernesses,
+                             points=points, num_base=num_base)
+    for n, item in enumerate(pre):
+        bb, sc = item[0], item[1]
         if rescale:
             bb = (bb / np.asarray(scale_factors[n], F32)[None]).astype(F32)
+        if centernesses is not None:
+            assert not voting
+            out.append(multiclass_nms(bb, sc, score_thr, iou_thr, max_per_img,
+                                      score_factors=item[2]))
+            continue
         fn = multiclass_nms_voting if voting else multiclass_nms
         out.append(fn(bb, sc, score_thr, iou_thr, max_per_img))
     return out

@@ -300,3 +300,113 @@ def test_gfocal_head_api_and_detector_simple_test():
         assert db[:, 4].max() <= 1.0 and db[:, 4].min() > 0.001
     assert total > 0
     assert cls_p[0].shape[1] == 81
+
+
+# ---------------------------------------------------------------------------
+# ATSSGFLHead / FCOSGFLHead get_bboxes (centerness factor, FCOS points)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('kind', ['atss', 'fcos'])
+@pytest.mark.parametrize('rescale', [False, True], ids=['r0', 'r1'])
+@pytest.mark.parametrize('name', synthetic.INFER_V2_CASES)
+def test_centerness_get_bboxes_vs_reference_golden(golden, name, rescale, kind):
+    from ld_amd import lossblock as LB
+    dev = torch.device('cuda:0')
+    g = golden['infer_ctr']
+    case = CASES[name]
+    cls, reg, metas = synthetic.infer_inputs(case, device=dev)
+    ctr = synthetic.synthetic_centerness(
+        len(metas), synthetic.level_shapes(case[1]), seed=case[4], device=dev)
+    shapes = [m['img_shape'] for m in metas]
+    sfs = [m['scale_factor'] for m in metas] if rescale else None
+    res = LB.get_bboxes(cls, reg, STRIDES, shapes, sfs, nms_pre=case[5],
+                        score_thr=0.05, iou_thr=0.6, max_per_img=100,
+                        centernesses=ctr, points=kind == 'fcos')
+    for i, (d, l) in enumerate(res):
+        tag = f'{kind}_{name}_r{int(rescale)}'
+        _same(d.cpu().numpy(), l.cpu().numpy(), g[f'{tag}_bboxes_{i}'],
+              g[f'{tag}_labels_{i}'], f'{tag} image {i}')
+
+
+def test_atss_fcos_head_get_bboxes_api():
+    """ATSSGFLHead / FCOSGFLHead.get_bboxes(cls, reg, centernesses, metas):
+    equal to the C-ABI-level call; the FCOS boxes differ from the ATSS ones by
+    the half-stride point offset."""
+    from ld_amd import lossblock as LB
+    from ld_amd.config import ConfigDict
+    from ld_amd.registry import build_head
+    from ld_amd import model_zoo
+    dev = torch.device('cuda:0')
+    case = CASES['small']
+    cls, reg, metas = synthetic.infer_inputs(case, device=dev)
+    ctr = synthetic.synthetic_centerness(
+        len(metas), synthetic.level_shapes(case[1]), seed=case[4], device=dev)
+    test_cfg = ConfigDict.wrap(dict(
+        nms_pre=1000, min_bbox_size=0, score_thr=0.05,
+        nms=dict(type='nms', iou_threshold=0.6), max_per_img=100))
+    out = {}
+    for kind, hc in (('atss', model_zoo.atss_gfl_detector(50)['bbox_head']),
+                     ('fcos', model_zoo.fcos_gfl_detector(50)['bbox_head'])):
+        head = build_head(dict(hc, test_cfg=test_cfg)).to(dev)
+        got = head.get_bboxes(cls, reg, ctr, metas, rescale=True)
+        want = LB.get_bboxes(cls, reg, STRIDES,
+                             [m['img_shape'] for m in metas],
+                             [m['scale_factor'] for m in metas], nms_pre=1000,
+                             score_thr=0.05, iou_thr=0.6, max_per_img=100,
+                             centernesses=ctr, points=kind == 'fcos')
+        for (a, b), (c, d) in zip(got, want):
+            assert torch.equal(a, c) and torch.equal(b, d)
+        out[kind] = got
+        with pytest.raises(NotImplementedError):
+            head.get_bboxes(cls, reg, ctr, metas, cfg=ConfigDict.wrap(dict(
+                test_cfg, nms=dict(type='voting_cluster_diounms',
+                                   iou_threshold=0.6))))
+    assert not torch.equal(out['atss'][0][0], out['fcos'][0][0])
+
+
+# ---------------------------------------------------------------------------
+# RetinaGFLHead get_bboxes (9 anchors per cell)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('rescale', [False, True], ids=['r0', 'r1'])
+@pytest.mark.parametrize('name', synthetic.INFER_V2_CASES)
+def test_retina_get_bboxes_vs_reference_golden(golden, name, rescale):
+    from ld_amd import lossblock as LB
+    dev = torch.device('cuda:0')
+    g = golden['infer_retina']
+    case = CASES[name]
+    cls, reg, metas = synthetic.infer_inputs_retina(case, device=dev)
+    shapes = [m['img_shape'] for m in metas]
+    sfs = [m['scale_factor'] for m in metas] if rescale else None
+    res = LB.get_bboxes(cls, reg, STRIDES, shapes, sfs, nms_pre=case[5],
+                        score_thr=0.05, iou_thr=0.6, max_per_img=100,
+                        num_base=9)
+    for i, (d, l) in enumerate(res):
+        tag = f'{name}_r{int(rescale)}'
+        _same(d.cpu().numpy(), l.cpu().numpy(), g[f'{tag}_bboxes_{i}'],
+              g[f'{tag}_labels_{i}'], f'retina {tag} image {i}')
+
+
+def test_retina_detector_simple_test():
+    """The LD-Retina detector's simple_test through RetinaGFLHead.get_bboxes
+    (level-sliced views of the (N, 720, P) head output)."""
+    from ld_amd import model_zoo, synthetic as S
+    from ld_amd.registry import build_detector
+    dev = torch.device('cuda:0')
+    det = build_detector(model_zoo.ld_retina_detector(18, 18))
+    det.load_state_dict(S.seeded_state_dict(det.state_dict(), seed=1))
+    det.to(dev).eval()
+    det.bbox_head.test_cfg['score_thr'] = 0.001
+    batch = S.synthetic_batch(2, (120, 150), (128, 160), [2, 3], 7)
+    img = batch['img'].to(dev)
+    metas = batch['img_metas']
+    for m, sf in zip(metas, (1.0, 1.25)):
+        m['scale_factor'] = np.array([sf] * 4, dtype=np.float32)
+    res = det(img=[img], img_metas=[metas], return_loss=False, rescale=True)
+    with torch.no_grad():
+        outs = det.bbox_head(det.extract_feat(img))
+        ref = det.bbox_head.get_bboxes(*outs, metas, rescale=True)
+    for per_cls, (db, dl) in zip(res, ref):
+        db, dl = db.cpu().numpy(), dl.cpu().numpy()
+        assert len(per_cls) == 80 and db.shape[0] <= 100
+        for c, arr in enumerate(per_cls):
+            assert np.array_equal(arr, db[dl == c])
+        assert np.all(np.diff(db[:, 4]) <= 0)

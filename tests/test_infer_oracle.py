@@ -175,3 +175,58 @@ def test_gfocal_get_bboxes_vs_reference(golden, name):
                                        rtol=0)
             seen80 = seen80 or bool((labels == 80).any())
     assert seen80  # the 81st channel really takes part
+
+
+@pytest.mark.parametrize('kind', ['atss', 'fcos'])
+@pytest.mark.parametrize('name', synthetic.INFER_V2_CASES)
+def test_centerness_get_bboxes_vs_reference(golden, name, kind):
+    """ATSSGFLHead / FCOSGFLHead get_bboxes: top-k by score x centerness, the
+    factor applied to the scores after the threshold test, FCOS points; against
+    the reference's outputs (tests/golden/infer_ctr.npz)."""
+    g = golden['infer_ctr']
+    case = CASES[name]
+    cls, reg, shapes, sfs = _inputs(case)
+    ctr = [c.numpy() for c in synthetic.synthetic_centerness(
+        len(shapes), synthetic.level_shapes(case[1]), seed=case[4])]
+    below = False
+    for rs in (0, 1):
+        res = O.get_bboxes(cls, reg, shapes, sfs, nms_pre=case[5],
+                           rescale=bool(rs), centernesses=ctr,
+                           points=kind == 'fcos')
+        for i, (dets, labels) in enumerate(res):
+            gd = g[f'{kind}_{name}_r{rs}_bboxes_{i}']
+            gl = g[f'{kind}_{name}_r{rs}_labels_{i}']
+            assert dets.shape == gd.shape
+            assert np.array_equal(labels, gl)
+            np.testing.assert_allclose(dets[:, :4], gd[:, :4], atol=1e-3,
+                                       rtol=0)
+            np.testing.assert_allclose(dets[:, 4], gd[:, 4], atol=1e-6,
+                                       rtol=0)
+            below = below or bool((dets[:, 4] < 0.05).any())
+    if name == 'small_topk':
+        assert below  # a final score may sit below score_thr: factor applied after
+
+
+@pytest.mark.parametrize('name', synthetic.INFER_V2_CASES)
+def test_retina_get_bboxes_vs_reference(golden, name):
+    """RetinaGFLHead.get_bboxes: 9 anchors per cell, top-k per level over all
+    (cell, anchor) rows; against the reference's outputs
+    (tests/golden/infer_retina.npz)."""
+    g = golden['infer_retina']
+    case = CASES[name]
+    cls, reg, metas = synthetic.infer_inputs_retina(case)
+    cls, reg = [c.numpy() for c in cls], [r.numpy() for r in reg]
+    shapes = [m['img_shape'] for m in metas]
+    sfs = [m['scale_factor'] for m in metas]
+    for rs in (0, 1):
+        res = O.get_bboxes(cls, reg, shapes, sfs, nms_pre=case[5],
+                           rescale=bool(rs), num_base=9)
+        for i, (dets, labels) in enumerate(res):
+            gd = g[f'{name}_r{rs}_bboxes_{i}']
+            gl = g[f'{name}_r{rs}_labels_{i}']
+            assert dets.shape == gd.shape
+            assert np.array_equal(labels, gl)
+            np.testing.assert_allclose(dets[:, :4], gd[:, :4], atol=1e-3,
+                                       rtol=0)
+            np.testing.assert_allclose(dets[:, 4], gd[:, 4], atol=1e-6,
+                                       rtol=0)
