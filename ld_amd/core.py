@@ -217,6 +217,17 @@ class AnchorGenerator:
             self._grid_cache[key] = hit
         return hit
 
+    def grid_anchors_flat(self, featmap_sizes, device='cuda'):
+        """All levels of :meth:`grid_anchors` as one cached (A * B, 4) tensor
+        (what the batched target kernels take)."""
+        sizes = [tuple(int(v) for v in s) for s in featmap_sizes]
+        key = ('flat', tuple(sizes), str(device))
+        hit = self._grid_cache.get(key)
+        if hit is None:
+            hit = torch.cat(list(self.grid_anchors(sizes, device))).contiguous()
+            self._grid_cache[key] = hit
+        return hit
+
     def valid_flags(self, featmap_sizes, pad_shape, device='cuda'):
         """anchor_generator.py:272-328."""
         assert self.num_levels == len(featmap_sizes)

@@ -1087,7 +1087,8 @@ class RetinaGFLHead(nn.Module):
         if gt_labels is None:
             gt_labels = [b.new_zeros(b.shape[0], dtype=torch.long)
                          for b in gt_bboxes]
-        anchors = self.anchor_generator.grid_anchors(featmap_sizes, device)
+        anchors = [self.anchor_generator.grid_anchors_flat(featmap_sizes,
+                                                           device)]
         return LB.retina_targets(featmap_sizes, strides, img_metas, gt_bboxes,
                                  gt_labels, anchors, self.num_anchors,
                                  self.assigner, self.num_classes, device,

@@ -102,3 +102,49 @@ def test_max_iou_assign_hand_case():
     # gt 1's best (IoU ~0.21 < 0.4) -> low-quality positive; anchor 4: negative
     assert gi.tolist() == [1, 1, 2, -1, 0]
     assert O.max_iou_assign(anchors, np.zeros((0, 4))).tolist() == [0] * 5
+
+
+def test_reference_retina_anchor_kat():
+    """The reference's own known-answer test for the ratios x scales anchor
+    generator (tests/test_anchor.py:190-288, test_retina_anchor): base anchors
+    (allclose, as there), valid-pixel counts [57600, 14400, 3600, 900, 225] at
+    (640, 640), nine base anchors per level -- for BOTH the product class
+    (ld_amd.core.AnchorGenerator, host code) and the oracle."""
+    import torch
+    from ld_amd.registry import build_anchor_generator
+    ag = build_anchor_generator(dict(
+        type='AnchorGenerator', octave_base_scale=4, scales_per_octave=3,
+        ratios=[0.5, 1.0, 2.0], strides=[8, 16, 32, 64, 128]))
+    level0 = np.array([[-22.6274, -11.3137, 22.6274, 11.3137],
+                       [-28.5088, -14.2544, 28.5088, 14.2544],
+                       [-35.9188, -17.9594, 35.9188, 17.9594],
+                       [-16.0000, -16.0000, 16.0000, 16.0000],
+                       [-20.1587, -20.1587, 20.1587, 20.1587],
+                       [-25.3984, -25.3984, 25.3984, 25.3984],
+                       [-11.3137, -22.6274, 11.3137, 22.6274],
+                       [-14.2544, -28.5088, 14.2544, 28.5088],
+                       [-17.9594, -35.9188, 17.9594, 35.9188]], np.float32)
+    for l, base in enumerate(ag.base_anchors):
+        # every level is level 0 scaled by the stride ratio (the reference's
+        # table lists all five; they are 2^l multiples to its 4 decimals)
+        want = torch.tensor(level0 * 2 ** l)
+        assert base.allclose(want, rtol=1e-5, atol=2e-4 * 2 ** l), l
+        assert np.allclose(O.retina_base_anchors(8 * 2 ** l), want.numpy(),
+                           rtol=1e-5, atol=2e-4 * 2 ** l)
+        assert np.array_equal(O.retina_base_anchors(8 * 2 ** l), base.numpy())
+    assert ag.num_base_anchors == [9, 9, 9, 9, 9]
+    sizes = [(80, 80), (40, 40), (20, 20), (10, 10), (5, 5)]
+    flags = ag.valid_flags(sizes, (640, 640), 'cpu')
+    assert [int(f.sum()) for f in flags] == [57600, 14400, 3600, 900, 225]
+    anchors = ag.grid_anchors(sizes, 'cpu')
+    assert len(anchors) == 5
+    assert [a.shape[0] for a in anchors] == [h * w * 9 for h, w in sizes]
+    for a, b in zip(anchors, O.retina_grid_anchors(sizes)):
+        assert np.array_equal(a.numpy(), b)
+    # the single-square generator of the GFL configs still reports one anchor
+    sq = build_anchor_generator(dict(
+        type='AnchorGenerator', ratios=[1.0], octave_base_scale=8,
+        scales_per_octave=1, strides=[8, 16, 32, 64, 128]))
+    assert sq.num_base_anchors == [1] * 5 and sq.single_square
+    assert torch.equal(sq.base_anchors[1],
+                       torch.tensor([[-64., -64., 64., 64.]]))
