@@ -53,4 +53,16 @@ else:
 for _ in range(6):
     run()
 torch.cuda.synchronize()
+reps = int(os.environ.get('LD_ONE_CONV_REPS', '0'))
+if reps:  # event-timed average (the PMC runs leave this off)
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    flop = 2.0 * N * d.Pout * cin * cout * k * k
+    print(f'{which} {kind} LD_CONV_WGRAD={os.environ.get("LD_CONV_WGRAD", "-")}: '
+          f'{us:.1f} us, {flop / us / 1e6:.1f} TFLOP/s')
 print('done')
