@@ -786,6 +786,20 @@ int ld_get_bboxes_ex(const ld_geom_t* g, const ld_maps_t* cls, const ld_maps_t* 
                      float iou_thr, int max_per_img, int flags, float* dets,
                      int64_t* labels, int32_t* counts, void* workspace,
                      size_t workspace_bytes, ld_stream_t stream);
+/* get_bboxes(with_nms=False) of the same heads: stages 1-3 only (per-level top
+ * nms_pre, Integral * stride, decode + clamp, optional rescale).  Outputs, per
+ * image, the K = ld_get_bboxes_num_selected() rows in level order (within a
+ * sorted level: descending key, as torch.topk returns them): boxes (N, K, 4),
+ * scores (N, K, num_classes) WITHOUT the reference's zero background column,
+ * and, with ``ctr``, the centerness factors (N, K).  Workspace: the _ex_ size. */
+int ld_get_bboxes_num_selected(const ld_geom_t* g, int num_base, int nms_pre);
+int ld_get_bboxes_pre_nms(const ld_geom_t* g, const ld_maps_t* cls,
+                          const ld_maps_t* reg, const ld_maps_t* ctr,
+                          int num_classes, int num_base, int reg_max,
+                          const float* img_hw, const float* scale_factors,
+                          int nms_pre, int flags, float* boxes, float* scores,
+                          float* factors, void* workspace, size_t workspace_bytes,
+                          ld_stream_t stream);
 
 #ifdef __cplusplus
 }

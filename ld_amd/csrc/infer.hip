@@ -239,7 +239,8 @@ __global__ __launch_bounds__(256) void infer_decode_kernel(
     Plan p, ld_maps_t cls, ld_maps_t reg, ld_maps_t ctr,
     const unsigned long long* keys, const float* img_hw, const float* scale_factors,
     float score_thr, float* boxes,
-    float* scores, unsigned long long* cand, int* cand_count, unsigned* max_coord) {
+    float* scores, unsigned long long* cand, int* cand_count, unsigned* max_coord,
+    float* factors) {
   const int n = blockIdx.y;
   const int slot = blockIdx.x * 256 + threadIdx.x;
   if (slot >= p.Ktot) return;
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(256) void infer_decode_kernel(
   // AFTER the threshold test (bbox_nms.py:114-123)
   const float fac =
       p.has_ctr ? sigmoidf_(ctr.ptr[l][(size_t)n * ctr.stride_n[l] + cell]) : 1.0f;
+  if (factors) factors[(size_t)n * p.Ktot + slot] = fac;
   for (int c = 0; c < p.C; ++c) {
     const float raw = cbase[(size_t)c * cls.stride_c[l]];
     const float sc = p.prob ? raw : sigmoidf_(raw);
@@ -609,7 +611,8 @@ static int get_bboxes_impl(const ld_geom_t* g, const ld_maps_t* cls,
                            int32_t* counts, void* workspace, size_t workspace_bytes,
                            ld_stream_t stream_, bool voting, bool prob = false,
                            const ld_maps_t* ctr = nullptr, bool points = false,
-                           int num_base = 1) {
+                           int num_base = 1, float* pre_boxes = nullptr,
+                           float* pre_scores = nullptr, float* pre_factors = nullptr) {
   Plan p;
   if (int e = make_plan(g, num_classes, nms_pre, &p, num_base)) return e;
   p.prob = prob ? 1 : 0;
@@ -617,7 +620,10 @@ static int get_bboxes_impl(const ld_geom_t* g, const ld_maps_t* cls,
   p.points = points ? 1 : 0;
   if (ctr && voting) return LD_EUNSUPPORTED;
   ld_maps_t ctr_maps = ctr ? *ctr : ld_maps_t{};
-  if (!cls || !reg || !img_hw || !dets || !labels || !counts) return LD_EINVAL;
+  const bool pre_only = pre_boxes != nullptr;
+  if (!cls || !reg || !img_hw) return LD_EINVAL;
+  if (pre_only ? !pre_scores : (!dets || !labels || !counts)) return LD_EINVAL;
+  if (pre_only) max_per_img = 1;  // unused
   if (reg_max != 16) return LD_EUNSUPPORTED;  // 17-bin Integral only
   if (max_per_img < 1 || max_per_img > kMaxKeep) return LD_EUNSUPPORTED;
   // a negative threshold would suppress ACROSS classes in the reference (IoU 0
@@ -662,7 +668,18 @@ static int get_bboxes_impl(const ld_geom_t* g, const ld_maps_t* cls,
   }
   hipLaunchKernelGGL(infer_decode_kernel, dim3((p.Ktot + 255) / 256, p.N), dim3(256), 0,
                      stream, p, *cls, *reg, ctr_maps, keys, img_hw, scale_factors, score_thr,
-                     boxes, scores, cand, count, maxc);
+                     boxes, scores, cand, count, maxc, pre_factors);
+  if (pre_only) {
+    // with_nms=False: the per-level selection + decode is the result
+    if ((err = hipMemcpyAsync(pre_boxes, boxes, (size_t)p.N * p.Ktot * 4 * sizeof(float),
+                              hipMemcpyDeviceToDevice, stream)))
+      return (int)err;
+    if ((err = hipMemcpyAsync(pre_scores, scores,
+                              (size_t)p.N * p.Ktot * p.C * sizeof(float),
+                              hipMemcpyDeviceToDevice, stream)))
+      return (int)err;
+    return (int)hipGetLastError();
+  }
   bool need_global = force_global;
   if (!force_global) {
     // fast path: NMS over the kSelN best candidates of every image
@@ -751,4 +768,25 @@ extern "C" int ld_get_bboxes_ex(const ld_geom_t* g, const ld_maps_t* cls,
                          counts, workspace, workspace_bytes, stream,
                          (flags & LD_INFER_VOTING) != 0, (flags & LD_INFER_PROB) != 0,
                          ctr, (flags & LD_INFER_POINTS) != 0, num_base);
+}
+
+extern "C" int ld_get_bboxes_num_selected(const ld_geom_t* g, int num_base, int nms_pre) {
+  Plan p;
+  if (make_plan(g, 1, nms_pre, &p, num_base) != 0) return -1;
+  return p.Ktot;
+}
+
+extern "C" int ld_get_bboxes_pre_nms(const ld_geom_t* g, const ld_maps_t* cls,
+                                     const ld_maps_t* reg, const ld_maps_t* ctr,
+                                     int num_classes, int num_base, int reg_max,
+                                     const float* img_hw, const float* scale_factors,
+                                     int nms_pre, int flags, float* boxes, float* scores,
+                                     float* factors, void* workspace,
+                                     size_t workspace_bytes, ld_stream_t stream) {
+  if (flags & ~(LD_INFER_PROB | LD_INFER_POINTS)) return LD_EINVAL;
+  if (!boxes || !scores || (factors && !ctr)) return LD_EINVAL;
+  return get_bboxes_impl(g, cls, reg, num_classes, reg_max, img_hw, scale_factors,
+                         nms_pre, 0.0f, 0.5f, 1, nullptr, nullptr, nullptr, workspace,
+                         workspace_bytes, stream, false, (flags & LD_INFER_PROB) != 0, ctr,
+                         (flags & LD_INFER_POINTS) != 0, num_base, boxes, scores, factors);
 }

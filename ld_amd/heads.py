@@ -405,9 +405,6 @@ class GFLHead(nn.Module):
         cfg = self.test_cfg if cfg is None else cfg
         if cfg is None:
             raise ValueError('get_bboxes needs a test_cfg')
-        if not with_nms:
-            raise NotImplementedError('with_nms=False (raw per-level boxes) is '
-                                      'not wired; SURVEY.md section 8f')
         nms = cfg['nms'] if isinstance(cfg, dict) else cfg.nms
         nms_type = nms.get('type', 'nms')
         if nms_type not in ('nms', 'voting_cluster_diounms'):
@@ -417,8 +414,10 @@ class GFLHead(nn.Module):
         get = cfg.get if hasattr(cfg, 'get') else lambda k, d=None: cfg[k]
         if get('min_bbox_size', 0) not in (0, -1):
             raise NotImplementedError('min_bbox_size > 0')
-        if centernesses is not None and nms_type != 'nms':
+        if centernesses is not None and nms_type != 'nms' and with_nms:
             raise NotImplementedError('score voting with centerness factors')
+        if not with_nms:
+            nms_type = 'nms'  # the nms config is not consulted
         strides = [s[0] if isinstance(s, (tuple, list)) else s
                    for s in (strides or self.anchor_generator.strides)]
         N = cls_scores[0].shape[0]
@@ -433,7 +432,7 @@ class GFLHead(nn.Module):
             reg_max=self.reg_max, voting=nms_type == 'voting_cluster_diounms',
             prob=prob, centernesses=None if centernesses is None else
             [c.detach() for c in centernesses], points=points,
-            num_base=num_base)
+            num_base=num_base, with_nms=with_nms)
 
 
 @HEADS.register_module()

@@ -231,6 +231,10 @@ SIGNATURES = {
                                 _f32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     'ld_get_bboxes_voting': (C.c_int, [_G, _M, _M, _i32, _i32, _vp, _vp, _i32, _f32,
                                 _f32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'ld_get_bboxes_num_selected': (C.c_int, [_G, _i32, _i32]),
+    'ld_get_bboxes_pre_nms': (C.c_int, [_G, _M, _M, _M, _i32, _i32, _i32, _vp,
+                                        _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz,
+                                        _vp]),
     'ld_get_bboxes_ex_workspace_bytes': (_sz, [_G, _i32, _i32, _i32]),
     'ld_get_bboxes_ex': (C.c_int, [_G, _M, _M, _M, _i32, _i32, _i32, _vp, _vp, _i32, _f32,
                                    _f32, _i32, _i32, _vp, _vp, _vp, _vp, _sz,

@@ -445,7 +445,7 @@ def kl_integral_dense(s_reg, t_reg, weight, T=10.0, scale=1.0, with_grad=True):
 def get_bboxes(cls_scores, bbox_preds, strides, img_shapes, scale_factors=None,
                nms_pre=1000, score_thr=0.05, iou_thr=0.6, max_per_img=100,
                num_classes=None, reg_max=16, voting=False, prob=False,
-               centernesses=None, points=False, num_base=1):
+               centernesses=None, points=False, num_base=1, with_nms=True):
     """GFLHead.get_bboxes on the device (ld_get_bboxes_ex; ``voting`` = the
     score-voting Cluster-DIoU-NMS variant, ``prob`` = the class maps hold
     probabilities: GFocalHead.get_bboxes; ``centernesses`` / ``points``: the
@@ -476,14 +476,34 @@ def get_bboxes(cls_scores, bbox_preds, strides, img_shapes, scale_factors=None,
     if need == 0:
         raise L.LdError('ld_get_bboxes: bad geometry')
     ws = workspace(dev, need, 'infer')
+    pflags = (L.LD_INFER_PROB if prob else 0) | \
+        (L.LD_INFER_POINTS if points else 0)
+    flags = pflags | (L.LD_INFER_VOTING if voting else 0)
+    km = C.byref(L.make_maps(centernesses)) if centernesses is not None \
+        else None
+    if not with_nms:
+        # get_bboxes(with_nms=False): per image (mlvl_bboxes (K, 4), mlvl_scores
+        # (K, C + 1) with the reference's zero background column[, factors (K,)])
+        if voting:
+            raise L.LdError('with_nms=False has no nms type')
+        K = lib.ld_get_bboxes_num_selected(C.byref(g), B_, int(nms_pre))
+        boxes = torch.empty((N, K, 4), dtype=torch.float32, device=dev)
+        scores = torch.zeros((N, K, C_ + 1), dtype=torch.float32, device=dev)
+        raw = torch.empty((N, K, C_), dtype=torch.float32, device=dev)
+        fac = torch.empty((N, K), dtype=torch.float32, device=dev) \
+            if centernesses is not None else None
+        L.check(lib.ld_get_bboxes_pre_nms(
+            C.byref(g), C.byref(cm), C.byref(rm), km, C_, B_, int(reg_max),
+            L.ptr(hw), L.ptr(sf), int(nms_pre), pflags, L.ptr(boxes),
+            L.ptr(raw), L.ptr(fac), L.ptr(ws), ws.numel(),
+            L.stream_ptr(dev)), 'ld_get_bboxes_pre_nms')
+        scores[:, :, :C_] = raw
+        if fac is not None:
+            return [(boxes[n], scores[n], fac[n]) for n in range(N)]
+        return [(boxes[n], scores[n]) for n in range(N)]
     dets = torch.empty((N, max_per_img, 5), dtype=torch.float32, device=dev)
     labels = torch.empty((N, max_per_img), dtype=torch.int64, device=dev)
     counts = torch.empty((N, ), dtype=torch.int32, device=dev)
-    flags = (L.LD_INFER_VOTING if voting else 0) | \
-        (L.LD_INFER_PROB if prob else 0) | \
-        (L.LD_INFER_POINTS if points else 0)
-    km = C.byref(L.make_maps(centernesses)) if centernesses is not None \
-        else None
     L.check(lib.ld_get_bboxes_ex(
         C.byref(g), C.byref(cm), C.byref(rm), km, C_, B_, int(reg_max),
         L.ptr(hw),

@@ -410,3 +410,63 @@ def test_retina_detector_simple_test():
         for c, arr in enumerate(per_cls):
             assert np.array_equal(arr, db[dl == c])
         assert np.all(np.diff(db[:, 4]) <= 0)
+
+
+# ---------------------------------------------------------------------------
+# get_bboxes(with_nms=False): the pre-NMS stage (ld_get_bboxes_pre_nms)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['small', 'small_topk', 'c2'])
+def test_with_nms_false_vs_reference_golden(golden, name):
+    """GFLHead.get_bboxes(..., with_nms=False) -> per image (mlvl_bboxes,
+    mlvl_scores with the zero background column) against the reference's own
+    pre-NMS outputs (tests/golden/infer.npz: stored arrays for the small cases,
+    counts / sums / per-row max scores at the C2 size).  Rows inside a sorted
+    level may swap where two max-scores tie to 1e-7 (torch.topk's order)."""
+    from ld_amd.config import ConfigDict
+    from ld_amd.registry import build_head
+    from ld_amd import model_zoo
+    dev = torch.device('cuda:0')
+    g = golden['infer']
+    case = CASES[name]
+    cls, reg, metas = synthetic.infer_inputs(case, device=dev)
+    hc = dict(model_zoo.gfl_detector(50)['bbox_head'])
+    head = build_head(dict(hc, test_cfg=ConfigDict.wrap(dict(
+        nms_pre=case[5], min_bbox_size=0, score_thr=0.05,
+        nms=dict(type='nms', iou_threshold=0.6), max_per_img=100)))).to(dev)
+    res = head.get_bboxes(cls, reg, metas, rescale=False, with_nms=False)
+    for i, (bb, sc) in enumerate(res):
+        bb, sc = bb.cpu().numpy(), sc.cpu().numpy()
+        assert bb.shape[0] == int(g[f'{name}_pre_count_{i}'])
+        assert sc.shape == (bb.shape[0], 81) and not sc[:, 80].any()
+        sc = sc[:, :80]
+        assert int((sc > np.float32(0.05)).sum()) == \
+            int(g[f'{name}_candidates_{i}'])
+        if case[8]:
+            gb, gs = g[f'{name}_pre_bboxes_{i}'], g[f'{name}_pre_scores_{i}']
+            # match rows up to swaps between equal-key neighbours
+            key_d, key_g = sc.max(1), gs.max(1)
+            np.testing.assert_allclose(key_d, key_g, atol=1e-6, rtol=0)
+            bad = (np.abs(bb - gb).max(1) > 1e-3) | \
+                (np.abs(sc - gs).max(1) > 1e-6)
+            for r in np.nonzero(bad)[0]:
+                nb = [q for q in (r - 1, r + 1) if 0 <= q < len(bad) and
+                      abs(float(key_g[q]) - float(key_g[r])) <= 5e-7]
+                assert any(np.abs(bb[r] - gb[q]).max() <= 1e-3 and
+                           np.abs(sc[r] - gs[q]).max() <= 1e-6 for q in nb), r
+        else:
+            np.testing.assert_allclose(sc.max(1), g[f'{name}_pre_maxscore_{i}'],
+                                       atol=1e-6, rtol=0)
+            np.testing.assert_allclose(
+                float(sc.astype(np.float64).sum()),
+                float(g[f'{name}_pre_scores_sum_{i}']), rtol=1e-5)
+            np.testing.assert_allclose(
+                float(bb.astype(np.float64).sum()),
+                float(g[f'{name}_pre_bboxes_sum_{i}']), rtol=1e-5)
+    # the centerness heads return the factors as a third array
+    ctr = synthetic.synthetic_centerness(
+        len(metas), synthetic.level_shapes(case[1]), seed=case[4], device=dev)
+    ah = build_head(dict(model_zoo.atss_gfl_detector(50)['bbox_head'],
+                         test_cfg=head.test_cfg)).to(dev)
+    out = ah.get_bboxes(cls, reg, ctr, metas, with_nms=False)
+    assert len(out[0]) == 3 and out[0][2].shape == (out[0][0].shape[0], )
+    assert float(out[0][2].min()) > 0 and float(out[0][2].max()) < 1
