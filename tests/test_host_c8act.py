@@ -89,3 +89,29 @@ def test_resnet_keeps_fp32_activations_outside_the_conditions():
             assert not bb._c8_only()          # fp32 mode
     finally:
         Y._PRECISION[0] = prev
+
+
+def test_retina_pseudo_image_views_share_memory():
+    """RetinaGFLHead._pseudo: an (N, B * C, H, W) level map -- a strided slice
+    of the level-concatenated (N, B * C, P) head output -- viewed as (N * B, C,
+    H, W) WITHOUT a copy; gradients written through the view land in the
+    original layout (what the fused loss block relies on)."""
+    from ld_amd import model_zoo
+    from ld_amd.registry import build_head
+    head = build_head(dict(model_zoo.retina_gfl_detector(50)['bbox_head']))
+    assert head.num_anchors == 9
+    N, P = 2, 6 * 5 + 3 * 3
+    full = torch.arange(N * 720 * P, dtype=torch.float32).reshape(N, 720, P)
+    lv0 = full[:, :, :30].view(N, 720, 6, 5)      # non-contiguous level slice
+    lv1 = full[:, :, 30:].view(N, 720, 3, 3)
+    p0, p1 = head._pseudo([lv0, lv1], 80)
+    assert p0.shape == (N * 9, 80, 6, 5) and p1.shape == (N * 9, 80, 3, 3)
+    assert p0.data_ptr() == lv0.data_ptr() and p1.data_ptr() == lv1.data_ptr()
+    # pseudo-image n * 9 + b, class c  ==  image n, channel b * 80 + c
+    for n, b, c in ((0, 0, 0), (1, 4, 17), (1, 8, 79)):
+        assert torch.equal(p0[n * 9 + b, c], lv0[n, b * 80 + c])
+        assert torch.equal(p1[n * 9 + b, c], lv1[n, b * 80 + c])
+    assert p0.stride() == (80 * P, P, 5, 1)
+    # a contiguous gradient in the pseudo layout IS the (N, 720, H, W) gradient
+    g = torch.randn(N * 9, 80, 6, 5)
+    assert torch.equal(g.view(N, 720, 6, 5)[1, 4 * 80 + 17], g[1 * 9 + 4, 17])
