@@ -286,6 +286,19 @@ int ld_loss_main(const ld_geom_t* geom, const ld_loss_hp_t* hp,
 #define LD_LOSS_PART_CLS 4
 #define LD_LOSS_PART_IM 8
 #define LD_LOSS_PART_ALL 15
+/* Selects the kernel the REG part launches (benchmarking / A-B tests; the
+ * default is the measured best, profiles/r03_ldkl_variants.json).  variant:
+ * bits 0-1 log2(anchors per thread: 1, 2, 4) | bit 2 non-temporal loads | bit 3
+ * non-temporal stores | bit 4 hardware exp / rcp | bit 5 the four sides of an
+ * anchor chunk in adjacent workgroups | bit 6 the NT bits also apply to maps
+ * that fit the Infinity Cache | bit 7 (1 anchor per thread only) hold the
+ * kernel to 64 VGPRs = 8 waves per SIMD | bit 16 (with bit 5) those four
+ * workgroups on one XCD | bits 8-15 KiB of dynamic LDS per workgroup
+ * (occupancy throttle); < 0 = the round-2 kernel (which LD_LOSS_RETINA and
+ * T_ld != T_ld_vlr always use).  Returns the previous value (-1 if it was
+ * negative), LD_EINVAL on a malformed word.  Not thread-safe; set it between
+ * launches. */
+int ld_loss_set_reg_variant(int variant);
 /* LD_LOSS_ATSS only: the centerness term.  ctr / grad_ctr: (N, 1, H_l, W_l)
  * maps; score = the centerness targets ld_loss_prepass wrote; call between
  * ld_loss_main_parts and ld_loss_finalize (same workspace). */
@@ -681,6 +694,25 @@ int ld_quality_backward(const float* reg, const float* cls_feat, const float* qu
                         float* g_w1, float* g_b1, float* g_w2, float* g_b2,
                         int accumulate, void* workspace, size_t workspace_bytes,
                         ld_stream_t stream);
+
+/* ---- grouped convolution, forward only (config 5's X-101 teacher) --------------
+ * The 3x3 conv2 of ResNeXt's Bottleneck (mmdet/models/backbones/resnext.py:49-61,
+ * nn.Conv2d(width, width, 3, stride, padding=1, groups=32, bias=False)) and,
+ * with K = 1, the grouped GEMM behind a grouped deformable conv (:62-74 over
+ * ld_deform_im2col's columns).  x (N, Cin, Hin*Win), y (N, Cout, Hout*Wout)
+ * fp32 NCHW; Cin % groups == Cout % groups == 0, Cout / groups in {4, 8, 16, 32},
+ * K in {1, 3}.  wimage = ld_gconv_weight_transform of the PyTorch weight
+ * (Cout, Cin/groups, K, K): [group][ci][tap][co], so the Cout/groups weights of
+ * one (ci, tap) are consecutive dwords at a wave-uniform address (scalar loads).
+ * Epilogue: y = relu?(scale[c] * acc + shift[c]) (eval-mode BN folded in; both
+ * NULL = plain conv).  VALU kernel: 9-72 flop/B, HBM/L1-bound, not MFMA work. */
+size_t ld_gconv_weight_image_floats(int Cout, int Cin, int groups, int K);
+int ld_gconv_weight_transform(const float* w, int Cout, int Cin, int groups, int K,
+                              float* image, ld_stream_t stream);
+int ld_gconv_forward(const float* x, const float* wimage, float* y, int N, int Cin,
+                     int Cout, int groups, int K, int stride, int pad, int Hin, int Win,
+                     const float* scale, const float* shift, int relu,
+                     ld_stream_t stream);
 
 /* ---- deformable convolution v1, forward only (config 4's R101-DCN teacher) ---
  * mmcv.ops.DeformConv2dPack under resnet.py:171-194 (deform_groups = 1,

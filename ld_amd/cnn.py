@@ -107,6 +107,64 @@ class Conv2d(nn.Module):
                 f'padding={self.padding}, bias={self.bias is not None}')
 
 
+class GroupedConv2d(nn.Module):
+    """nn.Conv2d(..., groups=G > 1)'s parameters and keys: ``weight`` (Cout,
+    Cin / G, k, k).  FORWARD ONLY -- it exists for the frozen ResNeXt teacher of
+    BASELINE config 5 (resnext.py:49-61: the 3x3 conv2 of every Bottleneck,
+    groups = 32); runs ld_gconv_forward with the following eval-mode BN and ReLU
+    folded into its epilogue (``forward3_fused``, the hook resnet._conv_bn
+    takes for forward-only convs)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1,
+                 padding=0, dilation=1, groups=1, bias=False):
+        super().__init__()
+        k, s, p, d = (_pair(kernel_size), _pair(stride), _pair(padding),
+                      _pair(dilation))
+        if k[0] != k[1] or s[0] != s[1] or p[0] != p[1]:
+            raise NotImplementedError('only square kernels/strides/pads')
+        if d != (1, 1) or bias:
+            raise NotImplementedError('grouped conv: no dilation, no bias '
+                                      '(resnext.py:49-61)')
+        if in_channels % groups or out_channels % groups or \
+                out_channels // groups not in (4, 8, 16, 32) or \
+                k[0] not in (1, 3):
+            raise NotImplementedError(
+                f'grouped conv {in_channels}->{out_channels} / {groups} k{k[0]}: '
+                'built for 4 / 8 / 16 / 32 output channels per group, k 1 or 3')
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = k, s, p
+        self.groups = groups
+        self.weight = nn.Parameter(
+            torch.empty(out_channels, in_channels // groups, k[0], k[1]))
+        self.bias = None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+    def forward3_fused(self, x3, levels, scale=None, shift=None, residual=None,
+                       relu=False):
+        if torch.is_grad_enabled() and (x3.requires_grad or
+                                        self.weight.requires_grad):
+            raise NotImplementedError(
+                'grouped convs are forward-only here (the frozen ResNeXt '
+                'teacher of config 5): call them under torch.no_grad()')
+        if residual is not None:
+            raise NotImplementedError('grouped conv with a fused residual')
+        return Y.gconv_forward(x3, self.weight, self.groups, self.stride[0],
+                               self.padding[0], levels, scale, shift, relu)
+
+    def forward3(self, x3, levels):
+        return self.forward3_fused(x3, levels)
+
+    def forward(self, x):
+        n, c, h, w = x.shape
+        y3, lv = self.forward3(x.reshape(n, c, h * w), ((h, w), ))
+        return y3.view(n, self.out_channels, lv[0][0], lv[0][1])
+
+    def extra_repr(self):
+        return (f'{self.in_channels}, {self.out_channels}, '
+                f'kernel_size={self.kernel_size}, stride={self.stride}, '
+                f'padding={self.padding}, groups={self.groups}, bias=False')
+
+
 class DeformConv2dPack(nn.Module):
     """mmcv.ops.DeformConv2dPack (conv type 'DCN'): deformable convolution v1
     whose offsets come from its own ``conv_offset`` 3x3 conv (zero-initialised,
@@ -123,15 +181,19 @@ class DeformConv2dPack(nn.Module):
                       _pair(dilation))
         if k[0] != k[1] or s[0] != s[1] or p[0] != p[1] or d[0] != d[1]:
             raise NotImplementedError('only square kernels/strides/pads')
-        if groups != 1 or deform_groups != 1 or bias:
+        if deform_groups != 1 or bias:
             raise NotImplementedError(
-                'DCN: groups = deform_groups = 1 and no bias (the '
-                'configs/gfl/*dconv* settings) are built')
+                'DCN: deform_groups = 1 and no bias (the configs/gfl/*dconv* '
+                'and configs/imv2/gflv2_x101* settings) are built')
+        if groups != 1 and (in_channels % groups or out_channels % groups or
+                            out_channels // groups not in (4, 8, 16, 32)):
+            raise NotImplementedError(
+                f'grouped DCN {in_channels}->{out_channels} / {groups}')
         self.in_channels, self.out_channels = in_channels, out_channels
         self.kernel_size, self.stride, self.padding, self.dilation = k, s, p, d
         self.groups, self.deform_groups = groups, deform_groups
         self.weight = nn.Parameter(
-            torch.empty(out_channels, in_channels, k[0], k[1]))
+            torch.empty(out_channels, in_channels // groups, k[0], k[1]))
         self.bias = None
         self.conv_offset = Conv2d(in_channels, deform_groups * 2 * k[0] * k[1],
                                   k[0], stride=s[0], padding=p[0], bias=True)
@@ -179,6 +241,15 @@ class DeformConv2dPack(nn.Module):
             bias=self.conv_offset.bias)
         (ho, wo), = out_levels
         col = Y.deform_im2col(x3, off3, h, w, k, s, p, 1)
+        if self.groups != 1:
+            # grouped DCN (ResNeXt-DCN, resnext.py:62-74): rows [g * cg * k * k,
+            # (g + 1) * cg * k * k) of the column tensor feed group g -- a grouped
+            # 1x1 conv over Cin * k * k channels
+            if residual is not None:
+                raise NotImplementedError('grouped DCN with a fused residual')
+            y3, _ = Y.gconv_forward(col, self._weight_2d(), self.groups, 1, 0,
+                                    ((ho, wo), ), scale, shift, relu)
+            return y3, out_levels
         y3, _ = Y.conv_forward_raw(col, self._weight_2d(), 1, 0,
                                    ((ho, wo), ), scale=scale, shift=shift,
                                    residual=residual, relu=relu)
@@ -254,6 +325,8 @@ def build_conv_layer(cfg, *args, **kwargs):
         cfg = dict(type='Conv2d')
     layer_type = cfg['type'] if isinstance(cfg, dict) else cfg
     if layer_type in ('Conv2d', 'Conv'):
+        if kwargs.get('groups', 1) != 1:
+            return GroupedConv2d(*args, **kwargs)
         return Conv2d(*args, **kwargs)
     if layer_type == 'DCN':
         kw = {k: v for k, v in cfg.items() if k != 'type'}

@@ -247,6 +247,51 @@ LD_HD float kl_rows(const float* s, const float* t, float invT, float T,
   return acc * (T * T) / (float)K;
 }
 
+// Register-lean form of kl_rows for the dense sweep (round 3): the same KL
+// (kd_loss.py:27-36) with the row statistics folded so that nothing but the two
+// logit rows stays live --
+//   kl = T^2/K * [ 1/(T z_t) * sum_k e_t,k ((t_k - m_t) - (s_k - m_s)) + log z_s - log z_t ]
+// (sum_k pt_k = 1 moves the two log-sum-exp terms out of the sum).  On return
+// s[k] = ps_k - pt_k (the gradient direction) and t[k] = e_t,k; 34 live values
+// instead of kl_rows' 85.  FAST: exp / reciprocal through the hardware
+// v_exp_f32 / v_rcp_f32 (1 ulp) instead of the correctly rounded library forms.
+#if defined(__HIP_DEVICE_COMPILE__)
+LD_HD float fast_exp2_(float x) { return __builtin_amdgcn_exp2f(x); }
+LD_HD float fast_rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+#else
+LD_HD float fast_exp2_(float x) { return exp2f(x); }
+LD_HD float fast_rcp_(float x) { return 1.0f / x; }
+#endif
+
+template <int K, bool FAST>
+LD_HD float kl_rows_inplace(float* s, float* t, float invT, float T) {
+  float ms = s[0], mt = t[0];
+#pragma unroll
+  for (int k = 1; k < K; ++k) {
+    ms = fmaxf_(ms, s[k]);
+    mt = fmaxf_(mt, t[k]);
+  }
+  const float c = FAST ? invT * 1.44269504088896341f : invT;
+  float zs = 0.0f, zt = 0.0f, acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float ds = s[k] - ms, dt = t[k] - mt;
+    const float es = FAST ? fast_exp2_(ds * c) : expf(ds * c);
+    const float et = FAST ? fast_exp2_(dt * c) : expf(dt * c);
+    zs += es;
+    zt += et;
+    acc = fmaf(et, dt - ds, acc);
+    s[k] = es;
+    t[k] = et;
+  }
+  const float rzs = FAST ? fast_rcp_(zs) : 1.0f / zs;
+  const float rzt = FAST ? fast_rcp_(zt) : 1.0f / zt;
+  const float kl = (acc * rzt * invT + (logf(zs) - logf(zt))) * ((T * T) / (float)K);
+#pragma unroll
+  for (int k = 0; k < K; ++k) s[k] = fmaf(s[k], rzs, -(t[k] * rzt));
+  return kl;
+}
+
 // Softmax over one 17-bin side + its expectation (Integral, gfl_head.py:32-44).
 template <int K>
 LD_HD float softmax_expect(const float* s, float* p /* [K] out */) {
@@ -297,6 +342,44 @@ LD_HD float dfl_side(const float* s, const float* p, float y, float* wl_out,
   *wr_out = wr;
   *yl_out = yl;
   (void)p;
+  return -ll * wl - lr * wr;
+}
+
+// softmax_expect + dfl_side fused and IN PLACE (the same op sequence, so the same
+// bits): on return s[k] = softmax(s)_k, *e_out = the Integral expectation, and
+// the DFL value of target y is returned.  34 -> 17 live values for the dense
+// sweep's rare positive anchors.
+template <int K>
+LD_HD float softmax_dfl_inplace(float* s, float y, float* e_out, float* wl_out,
+                                float* wr_out, int* yl_out) {
+  const int yl = (int)y;
+  const float wl = (float)(yl + 1) - y, wr = y - (float)yl;
+  float m = s[0];
+#pragma unroll
+  for (int k = 1; k < K; ++k) m = fmaxf_(m, s[k]);
+  float z = 0.0f, sl = 0.0f, sr = 0.0f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    sl = (k == yl) ? s[k] : sl;
+    sr = (k == yl + 1) ? s[k] : sr;
+    s[k] = expf(s[k] - m);
+    z += s[k];
+  }
+  const float lz = logf(z), rz = 1.0f / z;
+  float e = 0.0f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    s[k] *= rz;
+    e += s[k] * (float)k;
+  }
+  // yl + 1 <= K - 1 (y <= reg_max - 0.1); a bin outside [0, K) contributes
+  // log p = 0 exactly as dfl_side's unmatched select does
+  const float ll = (yl >= 0 && yl < K) ? sl - m - lz : 0.0f;
+  const float lr = (yl + 1 >= 0 && yl + 1 < K) ? sr - m - lz : 0.0f;
+  *e_out = e;
+  *wl_out = wl;
+  *wr_out = wr;
+  *yl_out = yl;
   return -ll * wl - lr * wr;
 }
 

@@ -462,6 +462,283 @@ __global__ __launch_bounds__(kBlk) void loss_reg_dense_kernel(
   }
 }
 
+typedef __amdgpu_buffer_rsrc_t lrsrc_t;
+__device__ __forceinline__ lrsrc_t lean_rsrc(const void* p, unsigned bytes) {
+  const uintptr_t u = (uintptr_t)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  void* q = (void*)(((uintptr_t)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes),
+                                           0x00020000);
+}
+// R floats per access (float / float2 / float4)
+template <int R>
+struct VecT;
+template <>
+struct VecT<1> { typedef float T; };
+template <>
+struct VecT<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <>
+struct VecT<4> { typedef float T __attribute__((ext_vector_type(4))); };
+
+// buffer access of R floats: lane byte offset in a VGPR, plane offset in an SGPR;
+// aux 2 = the non-temporal ("nt") cache policy
+template <int R, bool NT>
+__device__ __forceinline__ typename VecT<R>::T lean_load(lrsrc_t r, unsigned voff,
+                                                         unsigned soff) {
+  typedef typename VecT<R>::T V;
+  soff = __builtin_amdgcn_readfirstlane(soff);
+  if constexpr (R == 1)
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, NT ? 2 : 0));
+  else if constexpr (R == 2)
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, NT ? 2 : 0));
+  else
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, NT ? 2 : 0));
+}
+template <int R, bool NT>
+__device__ __forceinline__ void lean_store(typename VecT<R>::T v, lrsrc_t r, unsigned voff,
+                                           unsigned soff) {
+  soff = __builtin_amdgcn_readfirstlane(soff);
+  if constexpr (R == 1)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, NT ? 2 : 0);
+  else if constexpr (R == 2) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, voff, soff, NT ? 2 : 0);
+  } else {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, voff, soff, NT ? 2 : 0);
+  }
+}
+
+// ------------------- reg side, dense, register-lean (round 3, the default) ----
+// Same terms as loss_reg_dense_kernel for every head whose LD and VLR-LD terms
+// share one temperature and one 17-bin softmax per side (LDHead, LDv2Head,
+// LDATSSHead, LDFCOSHead); LDRetinaHead and T_ld != T_ld_vlr keep the kernel
+// above.  What changed, and why (0.66-0.68 of 8 TB/s at 1.05 x
+// the algorithmic traffic = an occupancy / issue problem, not a bytes problem):
+//   * the kernel above holds 149 VGPRs (+ 8 B scratch): 3 waves per SIMD.  Here
+//     the KL runs in place on the two logit rows (ld::kl_rows_inplace, 34 live
+//     values per anchor) and the rare positive anchors RE-LOAD their 17 student
+//     logits for the DFL + GIoU chain instead of keeping them live through the
+//     KL -- the common path fits 64 VGPRs at VEC = 1: 8 waves per SIMD;
+//   * VEC consecutive anchors of a plane per thread (8 / 16-byte accesses, a
+//     wavefront request covers 512 B / 1 KiB of each channel plane);
+//   * loads and stores take their non-temporal flavour separately (NTL / NTS);
+//   * side_fast: the 4 sides of an anchor chunk in 4 ADJACENT workgroups (they
+//     share the label / VLR lines) instead of 4 sweeps over the planes.
+// The (VEC, NTL, NTS, FAST, side_fast) actually launched is one measured
+// choice (g_reg_variant below; profiles/r03_ldkl_variants.json).
+template <int VEC, bool NTL, bool NTS, bool FAST, int WPE>
+__global__ __launch_bounds__(kBlk, WPE) void loss_reg_lean_kernel(
+    ld_geom_t geom, ld_loss_hp_t hp, BlockMap bm, BlockMap bmv, int side_fast,
+    ld_maps_t reg, ld_maps_t t_reg, const int64_t* __restrict__ labels,
+    const float* __restrict__ bbox_targets, const float* __restrict__ vlr,
+    const float* __restrict__ weight_targets, const float* __restrict__ norm,
+    const float* __restrict__ upstream, const float* __restrict__ posrec,
+    ld_maps_t grad_reg, float* __restrict__ partial) {
+  typedef typename VecT<VEC>::T V;
+  __shared__ float lds4[4];
+  int side = (int)blockIdx.z, bxv = (int)blockIdx.x;
+  if (side_fast == 1) {
+    side = (int)(blockIdx.x & 3);
+    bxv = (int)(blockIdx.x >> 2);
+  } else if (side_fast == 2) {
+    // the 4 sides of a chunk on ONE XCD (block b runs on XCD b % 8), back to
+    // back: they share the chunk's label / VLR lines in that XCD's L2.  Blocks
+    // beyond the last full group of 32 keep the plain side-fast order.
+    const unsigned b = blockIdx.x, full = (gridDim.x >> 5) << 5;
+    if (b < full) {
+      const unsigned q = b >> 3, x = b & 7;
+      side = (int)(q & 3);
+      bxv = (int)((q >> 2) * 8 + x);
+    } else {
+      side = (int)(b & 3);
+      bxv = (int)(b >> 2);
+    }
+  }
+  const int n = blockIdx.y;
+  const int l = block_level(bmv, geom.num_levels, bxv);
+  const ld_level_t lv = geom.lv[l];
+  const int HW = lv.H * lv.W;
+  const int wg = bxv - bmv.blk_start[l];
+  const int r0 = (wg * kBlk + (int)threadIdx.x) * VEC;
+  const size_t o0 = (size_t)n * geom.num_anchors + lv.offset + r0;
+  // one buffer descriptor per map (base = this image's level map, wave-uniform)
+  // + a 32-bit lane offset + the channel-plane offset in an SGPR: no per-channel
+  // 64-bit address registers (the flat form cost 2 x 34 VGPRs)
+  const size_t cs = reg.stride_c[l], ct = t_reg.stride_c[l], cg_ = grad_reg.stride_c[l];
+  const float* ps0 = reg.ptr[l] + (size_t)n * reg.stride_n[l];
+  const float* pt0 = t_reg.ptr[l] + (size_t)n * t_reg.stride_n[l];
+  float* pg0 = grad_reg.ptr[l] + (size_t)n * grad_reg.stride_n[l];
+  const lrsrc_t rs = lean_rsrc(ps0, (unsigned)(cs * 4 * (4 * K17)));
+  const lrsrc_t rt = lean_rsrc(pt0, (unsigned)(ct * 4 * (4 * K17)));
+  const lrsrc_t rg = lean_rsrc(pg0, (unsigned)(cg_ * 4 * (4 * K17)));
+  const unsigned ro = (unsigned)r0 * 4u;  // byte offset of this thread in a plane
+  const unsigned cs4 = (unsigned)(cs * 4), ct4 = (unsigned)(ct * 4), cg4 = (unsigned)(cg_ * 4);
+  const unsigned ss = (unsigned)(side * K17) * cs4;
+  const unsigned st = (unsigned)(side * K17) * ct4;
+  const unsigned sg = (unsigned)(side * K17) * cg4;
+  // vector access needs every plane of this level aligned for this thread
+  const bool full = r0 + VEC <= HW;
+  bool vec_ok = full;
+  if (VEC > 1) {
+    const uintptr_t m = (uintptr_t)(VEC * 4 - 1);
+    vec_ok = full && (((uintptr_t)ps0 | (uintptr_t)pt0 | (uintptr_t)pg0 |
+                       (uintptr_t)cs4 | (uintptr_t)ct4 | (uintptr_t)cg4) & m) == 0;
+  }
+  float wt[VEC], vv[VEC];
+  bool pos[VEC], act[VEC];
+  bool need = false, anypos = false;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    act[j] = r0 + j < HW;
+    pos[j] = false;
+    wt[j] = 0.0f;
+    vv[j] = 0.0f;
+    if (act[j]) {
+      const int64_t lab = labels[o0 + j];
+      pos[j] = lab >= 0 && lab < hp.num_classes;
+      float v = vlr[o0 + j];
+      if ((hp.flags & LD_LOSS_FCOS) && v > 0.0f) v *= weight_targets[o0 + j];
+      vv[j] = v > 0.0f ? v : 0.0f;
+      if (pos[j]) wt[j] = weight_targets[o0 + j];
+      need = need || pos[j] || v > 0.0f;
+      anypos = anypos || pos[j];
+    }
+  }
+  const int L = geom.num_levels;
+  const float T = hp.T_ld;
+  const float k_ld = (upstream ? upstream[3 * L + l] : 1.0f) * hp.lw_ld * 0.25f *
+                     (T / (float)K17);  // /4.0
+  const float k_vlr = (upstream ? upstream[4 * L + l] : 1.0f) * hp.lw_ld_vlr * 0.0625f *
+                      (T / (float)K17);  // /16.0
+  float s_dfl = 0.0f, s_ld = 0.0f, s_vlr = 0.0f;
+  if (vec_ok && !anypos) {
+    // ---- the dense path: VEC anchors, vector access, no positives ----------
+    float sv[VEC][K17], tv[VEC][K17];
+    if (need) {
+#pragma unroll
+      for (int k = 0; k < K17; ++k) {
+        const V a = lean_load<VEC, NTL>(rs, ro, ss + k * cs4);
+        const V b = lean_load<VEC, NTL>(rt, ro, st + k * ct4);
+        const float* af = reinterpret_cast<const float*>(&a);
+        const float* bf = reinterpret_cast<const float*>(&b);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          sv[j][k] = af[j];
+          tv[j][k] = bf[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float kl = ld::kl_rows_inplace<K17, FAST>(sv[j], tv[j], 1.0f / T, T);
+        s_vlr += vv[j] * kl;  // wt = 0 here: no LD term away from the positives
+        const float cg = k_vlr * vv[j];
+#pragma unroll
+        for (int k = 0; k < K17; ++k) sv[j][k] *= cg;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+#pragma unroll
+        for (int k = 0; k < K17; ++k) sv[j][k] = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < K17; ++k) {
+      V g;
+      float* gf = reinterpret_cast<float*>(&g);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) gf[j] = sv[j][k];
+      lean_store<VEC, NTS>(g, rg, ro, sg + k * cg4);
+    }
+  } else {
+    // ---- threads holding a positive anchor, an unaligned level or the level
+    // tail: one anchor at a time, scalar access.  Positives (~0.1 % of the
+    // anchors) add DFL + the GIoU chain through Integral from the T = 1
+    // softmax of the student row, read again after the KL is done with it.
+    for (int j = 0; j < VEC; ++j) {
+      if (r0 + j >= HW) break;
+      const size_t o = o0 + j;
+      const int64_t lab = labels[o];
+      const bool p_ = lab >= 0 && lab < hp.num_classes;
+      float v = vlr[o];
+      if ((hp.flags & LD_LOSS_FCOS) && v > 0.0f) v *= weight_targets[o];
+      v = v > 0.0f ? v : 0.0f;
+      const float w = p_ ? weight_targets[o] : 0.0f;
+      const unsigned rj = ro + 4u * (unsigned)j;
+      float a[K17];
+      if (p_ || v > 0.0f) {
+        float b[K17];
+#pragma unroll
+        for (int k = 0; k < K17; ++k) {
+          a[k] = lean_load<1, false>(rs, rj, ss + k * cs4);
+          b[k] = lean_load<1, false>(rt, rj, st + k * ct4);
+        }
+        const float kl = ld::kl_rows_inplace<K17, FAST>(a, b, 1.0f / T, T);
+        s_ld += w * kl;
+        s_vlr += v * kl;
+        const float cg = k_ld * w + k_vlr * v;
+#pragma unroll
+        for (int k = 0; k < K17; ++k) a[k] *= cg;
+      } else {
+#pragma unroll
+        for (int k = 0; k < K17; ++k) a[k] = 0.0f;
+      }
+      if (p_) {
+        // (scheduling fence: hoisting these loads above the KL would keep 51
+        // row values live at once and set the whole kernel's VGPR count)
+        __builtin_amdgcn_sched_barrier(0);
+        float p[K17];
+#pragma unroll
+        for (int k = 0; k < K17; ++k) p[k] = lean_load<1, false>(rs, rj, ss + k * cs4);
+        const float up_dfl = upstream ? upstream[2 * L + l] : 1.0f;
+        const float inv_avg = 1.0f / avg_divisor(hp, norm);
+        const float c_dfl = up_dfl * hp.lw_dfl * w * 0.25f * inv_avg;
+        const float stride = (float)lv.stride;
+        const bool fcos = (hp.flags & LD_LOSS_FCOS) != 0;
+        const int r = r0 + j, y = r / lv.W, x = r - y * lv.W;
+        const float cx = (float)x + (fcos ? 0.5f : 0.0f);
+        const float cy = (float)y + (fcos ? 0.5f : 0.0f);
+        const float4 t4 = reinterpret_cast<const float4*>(bbox_targets)[o];
+        const Box tb = target_box(fcos, cx, cy, t4, stride);
+        const float dist = side == 0   ? cx - tb.x1
+                           : side == 1 ? cy - tb.y1
+                           : side == 2 ? tb.x2 - cx
+                                       : tb.y2 - cy;
+        const float ytgt = ld::clamp_dist(dist, (float)hp.reg_max);
+        float e, wl, wr;
+        int yl;
+        const float dl = ld::softmax_dfl_inplace<K17>(p, ytgt, &e, &wl, &wr, &yl);
+        s_dfl += w * dl;
+        const float gd = posrec[o * kPosRec + side];  // d total / d E_side (GIoU)
+#pragma unroll
+        for (int k = 0; k < K17; ++k) {
+          const float gk = p[k] - (k == yl ? wl : 0.0f) - (k == yl + 1 ? wr : 0.0f);
+          a[k] += c_dfl * gk + gd * p[k] * ((float)k - e);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < K17; ++k) lean_store<1, false>(a[k], rg, rj, sg + k * cg4);
+    }
+  }
+  s_dfl = block_sum(s_dfl, lds4);
+  s_ld = block_sum(s_ld, lds4);
+  s_vlr = block_sum(s_vlr, lds4);
+  if (threadIdx.x == 0) {
+    // this workgroup covers VEC 256-anchor slots of the finalise kernel's map
+    const size_t nb = (size_t)gridDim.y * bm.blocks_per_img;
+    const int b0 = bm.blk_start[l] + wg * VEC, b1 = bm.blk_start[l + 1];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      if (b0 + j >= b1) break;
+      const size_t at = (size_t)n * bm.blocks_per_img + b0 + j;
+      partial[((size_t)S_DFL * kZMax + side) * nb + at] = j == 0 ? s_dfl : 0.0f;
+      partial[((size_t)S_LD * kZMax + side) * nb + at] = j == 0 ? s_ld : 0.0f;
+      partial[((size_t)S_VLR * kZMax + side) * nb + at] = j == 0 ? s_vlr : 0.0f;
+    }
+  }
+}
+
 // ------------------------------------------- cls side, dense: QFL (+ KD) -----
 // SPLIT_KD = false (LDHead): KD runs on the class logits themselves and its
 // gradient adds into grad_cls.  SPLIT_KD = true (LDv2Head): cls holds the
@@ -797,14 +1074,6 @@ __global__ __launch_bounds__(kWave) void loss_finalize_kernel(
 // streaming, so occupancy (bytes in flight) is what sets the rate.  R floats
 // are moved per access (float / float2 / float4); NT selects non-temporal
 // (streaming) loads and stores.
-template <int R>
-struct VecT;
-template <>
-struct VecT<1> { typedef float T; };
-template <>
-struct VecT<2> { typedef float T __attribute__((ext_vector_type(2))); };
-template <>
-struct VecT<4> { typedef float T __attribute__((ext_vector_type(4))); };
 
 template <int R, bool NT>
 __device__ __forceinline__ void vload(const float* p, float* out) {
@@ -915,7 +1184,91 @@ LossWs loss_ws(const ld_geom_t& g) {
   return w;
 }
 inline int im_chunk(int ch) { return max(32, (ch + kZMax - 1) / kZMax); }
+
+// ---- which reg-side kernel ld_loss_main_parts launches ----------------------
+// variant word: bits 0-1 log2(VEC) | bit 2 NT loads | bit 3 NT stores | bit 4
+// FAST (v_exp_f32 / v_rcp_f32) | bit 5 side_fast | bit 6 "NT bits also apply
+// below the Infinity-Cache size" | bit 7 VEC 1 held to 64 VGPRs (8 waves per
+// SIMD) | bits 8-15 KiB of dynamic LDS per workgroup (an occupancy throttle for
+// experiments) | bit 16 (with bit 5) the 4 sides of a chunk on one XCD; < 0 =
+// the round-2 kernel.
+// Default = the measured best of profiles/r03_ldkl_variants.json.
+// vec 1, NT loads + stores, hardware exp, side-fast: 568-571 us at 2^24 rows =
+// 0.76 of 8 TB/s (round-2 kernel: 665-743 us), 11.2 us at the C2 step size
+#define LD_REG_VARIANT_DEFAULT (0 | 4 | 8 | 16 | 32)
+int g_reg_variant = LD_REG_VARIANT_DEFAULT;
+
+template <int VEC, bool NTL, bool NTS>
+void launch_reg_lean_t(bool fast, bool w8, dim3 grid, size_t lds, hipStream_t stream,
+                       const ld_geom_t& geom, const ld_loss_hp_t& hp, const BlockMap& bm,
+                       const BlockMap& bmv, int side_fast, const ld_maps_t& reg,
+                       const ld_maps_t& t_reg, const int64_t* labels,
+                       const float* bbox_targets, const float* vlr,
+                       const float* weight_targets, const float* norm,
+                       const float* upstream, const float* posrec,
+                       const ld_maps_t& grad_reg, float* partial) {
+#define LD_LEAN_GO(F, W)                                                                  \
+  hipLaunchKernelGGL((loss_reg_lean_kernel<VEC, NTL, NTS, F, W>), grid, dim3(kBlk), lds,  \
+                     stream, geom, hp, bm, bmv, side_fast, reg, t_reg, labels,            \
+                     bbox_targets, vlr, weight_targets, norm, upstream, posrec, grad_reg, \
+                     partial)
+  // WPE = minimum waves per SIMD the register allocator is held to.  1 = its own
+  // choice: VEC 1 -> 79 VGPRs (6 waves) with FAST, 86 (5) without; VEC 2 -> 109 /
+  // 125 (4); VEC 4 -> 173 / 177 (2).  8 (VEC 1 only, on request) -> 64 VGPRs with
+  // 12 dwords of spill, all but 2 of them in the rare positives path.
+  if (VEC == 1 && w8) {
+    if (fast) LD_LEAN_GO(true, (VEC == 1 ? 8 : 1));
+    else LD_LEAN_GO(false, (VEC == 1 ? 8 : 1));
+  } else {
+    if (fast) LD_LEAN_GO(true, 1);
+    else LD_LEAN_GO(false, 1);
+  }
+#undef LD_LEAN_GO
+}
+
+void launch_reg_lean(int variant, bool big, const ld_geom_t& geom, const ld_loss_hp_t& hp,
+                     const BlockMap& bm, unsigned by, const ld_maps_t& reg,
+                     const ld_maps_t& t_reg, const int64_t* labels,
+                     const float* bbox_targets, const float* vlr,
+                     const float* weight_targets, const float* norm, const float* upstream,
+                     const float* posrec, const ld_maps_t& grad_reg, float* partial,
+                     hipStream_t stream) {
+  const int vec = 1 << (variant & 3);
+  // at train-step sizes the gradient is re-read by the next kernel and the
+  // logits were just written: keep them cached unless bit 6 says otherwise
+  const bool nt_on = big || (variant & 64);
+  const bool ntl = nt_on && (variant & 4), nts = nt_on && (variant & 8);
+  const bool fast = (variant & 16) != 0, w8 = (variant & 128) != 0;
+  const int side_fast = (variant & 32) ? ((variant & 0x10000) ? 2 : 1) : 0;
+  const size_t lds = (size_t)((variant >> 8) & 0xff) << 10;
+  const BlockMap bmv = make_block_map(geom, kBlk * vec);
+  const dim3 grid = side_fast ? dim3(bmv.blocks_per_img * 4, by, 1)
+                              : dim3(bmv.blocks_per_img, by, 4);
+#define LD_LEAN(V, L, S)                                                               \
+  launch_reg_lean_t<V, L, S>(fast, w8, grid, lds, stream, geom, hp, bm, bmv, side_fast, reg, \
+                             t_reg, labels, bbox_targets, vlr, weight_targets, norm,    \
+                             upstream, posrec, grad_reg, partial)
+#define LD_LEAN_V(V)                          \
+  do {                                        \
+    if (ntl && nts) LD_LEAN(V, true, true);   \
+    else if (ntl) LD_LEAN(V, true, false);    \
+    else if (nts) LD_LEAN(V, false, true);    \
+    else LD_LEAN(V, false, false);            \
+  } while (0)
+  if (vec == 4) LD_LEAN_V(4);
+  else if (vec == 2) LD_LEAN_V(2);
+  else LD_LEAN_V(1);
+#undef LD_LEAN_V
+#undef LD_LEAN
+}
 }  // namespace
+
+extern "C" int ld_loss_set_reg_variant(int variant) {
+  const int prev = g_reg_variant;
+  if (variant >= 0 && (variant & 3) == 3) return LD_EINVAL;
+  g_reg_variant = variant;
+  return prev < 0 ? -1 : prev;
+}
 
 extern "C" size_t ld_loss_workspace_bytes(const ld_geom_t* geom) {
   if (check_geom(geom) != 0) return 0;
@@ -1004,7 +1357,15 @@ extern "C" int ld_loss_main_parts(
                        bm, split ? *kd_s : *cls, split ? *kd_t : *t_cls, *reg, labels,
                        bbox_targets, weight_targets, score, norm, upstream, posrec,
                        partial);
-  if (parts & LD_LOSS_PART_REG) {
+  const bool lean_ok = !(hp->flags & LD_LOSS_RETINA) && hp->T_ld == hp->T_ld_vlr &&
+                       g_reg_variant >= 0;
+  if ((parts & LD_LOSS_PART_REG) && lean_ok) {
+    const size_t bytes = (size_t)geom->num_imgs * geom->num_anchors * 68 * 4 * 3;
+    const bool big = bytes > ((size_t)192 << 20);
+    launch_reg_lean(g_reg_variant, big, *geom, *hp, bm, by, *reg, *t_reg, labels,
+                    bbox_targets, vlr, weight_targets, norm, upstream, posrec, *grad_reg,
+                    partial, stream);
+  } else if (parts & LD_LOSS_PART_REG) {
     // streaming (non-temporal) access once the three 68-channel maps exceed what
     // the 256 MiB Infinity Cache can hold; at train-step sizes the gradient is
     // re-read by the next kernel and should stay cached

@@ -1119,6 +1119,52 @@ def deform_im2col(x3, off3, h, w, k, stride, pad, dilation):
     return col
 
 
+def gconv_weight_image(w, groups):
+    """[group][ci][tap][co] image of a grouped conv weight (Cout, Cin/groups, K,
+    K), cached on the tensor (the X-101 teacher is frozen)."""
+    lib = L.get_lib()
+    _dev_f32(w, 'grouped conv weight')
+    stamp = (w._version, w.data_ptr(), groups)
+    hit = getattr(w, '_ld_gimg', None)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    cout, cin_g, k, _ = w.shape
+    img = torch.empty(lib.ld_gconv_weight_image_floats(cout, cin_g * groups,
+                                                       groups, k),
+                      dtype=torch.float32, device=w.device)
+    L.check(lib.ld_gconv_weight_transform(
+        L.ptr(w.detach().contiguous()), cout, cin_g * groups, groups, k,
+        L.ptr(img), L.stream_ptr(w.device)), 'ld_gconv_weight_transform')
+    try:
+        w._ld_gimg = (stamp, img)
+    except AttributeError:
+        pass
+    return img
+
+
+def gconv_forward(x3, w, groups, stride, pad, levels, scale=None, shift=None,
+                  relu=False):
+    """Grouped conv forward (ld_gconv_forward), single level, forward only:
+    (N, Cin, H*W) -> ((N, Cout, Ho*Wo), ((Ho, Wo),))."""
+    lib = L.get_lib()
+    _dev_f32(x3, 'grouped conv input')
+    if len(levels) != 1:
+        raise NotImplementedError('grouped conv on level-concatenated tensors')
+    (h, wd), = levels
+    N, cin, P = x3.shape
+    cout, cin_g, k, _ = w.shape
+    if P != h * wd or cin != cin_g * groups:
+        raise L.LdError('gconv_forward: shape mismatch')
+    ho, wo = out_size(h, k, stride, pad), out_size(wd, k, stride, pad)
+    img = gconv_weight_image(w, groups)
+    y = torch.empty((N, cout, ho * wo), dtype=torch.float32, device=x3.device)
+    L.check(lib.ld_gconv_forward(
+        L.ptr(x3.contiguous()), L.ptr(img), L.ptr(y), N, cin, cout, groups, k,
+        stride, pad, h, wd, L.ptr(scale), L.ptr(shift), 1 if relu else 0,
+        L.stream_ptr(x3.device)), 'ld_gconv_forward')
+    return y, ((ho, wo), )
+
+
 class QualityFn(torch.autograd.Function):
     """GFLv2's distribution-guided quality branch on level-concatenated
     tensors (gfocal_head.py:201-217): (reg3 (N, 68, P), cls_feat3 (N, C, P),

@@ -208,6 +208,13 @@ SIGNATURES = {
     'ld_loss_finalize': (C.c_int, [_G, _H, _vp, _vp, _vp, _vp, _vp]),
     'ld_loss_centerness': (C.c_int, [_G, _H, _M, _vp, _vp, _vp, _vp, _M, _vp,
                                      _sz, _vp]),
+    'ld_loss_set_reg_variant': (C.c_int, [_i32]),
+    'ld_gconv_weight_image_floats': (_sz, [_i32, _i32, _i32, _i32]),
+    'ld_gconv_weight_transform': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp,
+                                            _vp]),
+    'ld_gconv_forward': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+                                   _i32, _i32, _i32, _i32, _vp, _vp, _i32,
+                                   _vp]),
     'ld_kl_integral_dense': (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _vp,
                                        _vp, _vp, _vp]),
     'ld_kd_kl_rows': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp,

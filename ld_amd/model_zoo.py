@@ -26,6 +26,22 @@ def _backbone(depth):
                 style='pytorch')
 
 
+def _x101_backbone(depth=101, dcn=False):
+    """The ResNeXt-101 32x4d teacher backbone of
+    configs/imv2/gflv2_x101_fpn_2x_coco.py:8-20.  ``dcn=True`` keeps that
+    file's grouped DCN in c4-c5 (parity unpinned: mmcv's op is absent from the
+    reference checkout); the pinned composition runs without it."""
+    cfg = dict(type='ResNeXt', depth=depth, groups=32, base_width=4,
+               num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+               norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True,
+               style='pytorch')
+    if dcn:
+        cfg.update(dcn=dict(type='DCN', deform_groups=1,
+                            fallback_on_stride=False),
+                   stage_with_dcn=(False, False, True, True))
+    return cfg
+
+
 def _neck(depth):
     return dict(type='FPN', in_channels=list(_RESNET_CH[depth]),
                 out_channels=256, start_level=1, add_extra_convs='on_output',
@@ -103,6 +119,18 @@ def gflv2_detector(depth=101):
                 neck=_neck(depth), bbox_head=head,
                 train_cfg=copy.deepcopy(_TRAIN_CFG),
                 test_cfg=copy.deepcopy(_TEST_CFG))
+
+
+def ldv2_x101_detector(student_depth=50, imitation_method='finegrained',
+                       loss_im_weight=2.0, dcn=False):
+    """BASELINE config 5 as worded -- "ldv2 + imitation_method='finegrain',
+    R50 <- X101": configs/ldv2/ld_r50_gflv2_r101_fpn_1x.py whose GFLv2 teacher
+    takes the ResNeXt-101 32x4d backbone of
+    configs/imv2/gflv2_x101_fpn_2x_coco.py:8-20 (the reference
+    ships no such file; this is the composition)."""
+    cfg = ldv2_detector(student_depth, 101, imitation_method, loss_im_weight)
+    cfg['teacher_config']['model']['backbone'] = _x101_backbone(101, dcn)
+    return cfg
 
 
 def ldv2_detector(student_depth=50, teacher_depth=101,

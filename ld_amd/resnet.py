@@ -9,13 +9,15 @@ Execution plan per block:
   * trainable: conv (MFMA fwd/dgrad/wgrad) + one fused BN-affine/add/ReLU
     elementwise kernel, keeping the conv output for the gamma/beta gradients.
 """
+import math
+
 import torch
 import torch.nn as nn
 
 from . import layers as Y
 from . import lib as L
-from .cnn import (BatchNorm2d, Conv2d, build_conv_layer, build_norm_layer,
-                  constant_init, kaiming_init)
+from .cnn import (BatchNorm2d, Conv2d, GroupedConv2d, build_conv_layer,
+                  build_norm_layer, constant_init, kaiming_init)
 from .registry import BACKBONES
 
 
@@ -162,6 +164,49 @@ class ResLayer(nn.Sequential):
         super().__init__(*layers)
 
 
+class ResNeXtBottleneck(Bottleneck):
+    """Bottleneck block of ResNeXt (mmdet/models/backbones/resnext.py:11-85):
+    conv1 / conv3 go through ``width = floor(planes * base_width /
+    base_channels) * groups`` channels and conv2 is the grouped 3x3 (or a
+    grouped DCN when the stage has ``dcn``).  Same module and state_dict names
+    as the parent; the constructor builds the parent first and replaces the
+    three convs / norms exactly as the reference does."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, groups=1, base_width=4,
+                 base_channels=64, **kwargs):
+        super().__init__(inplanes, planes, **kwargs)
+        norm_cfg = kwargs.get('norm_cfg', dict(type='BN'))
+        conv_cfg = kwargs.get('conv_cfg', None)
+        width = planes if groups == 1 else \
+            math.floor(planes * (base_width / base_channels)) * groups
+        self.norm1_name, norm1 = build_norm_layer(norm_cfg, width, postfix=1)
+        self.norm2_name, norm2 = build_norm_layer(norm_cfg, width, postfix=2)
+        self.norm3_name, norm3 = build_norm_layer(
+            norm_cfg, planes * self.expansion, postfix=3)
+        self.conv1 = build_conv_layer(conv_cfg, inplanes, width, 1,
+                                      stride=self.conv1_stride, bias=False)
+        self.add_module(self.norm1_name, norm1)
+        fallback_on_stride = False
+        dcn = None
+        if self.with_dcn:
+            dcn = dict(self.dcn)
+            fallback_on_stride = dcn.pop('fallback_on_stride', False)
+        if not self.with_dcn or fallback_on_stride:
+            self.conv2 = build_conv_layer(conv_cfg, width, width, 3,
+                                          stride=self.conv2_stride, padding=1,
+                                          groups=groups, bias=False)
+        else:
+            assert conv_cfg is None, 'conv_cfg must be None for DCN'
+            self.conv2 = build_conv_layer(dcn, width, width, 3,
+                                          stride=self.conv2_stride, padding=1,
+                                          groups=groups, bias=False)
+        self.add_module(self.norm2_name, norm2)
+        self.conv3 = build_conv_layer(conv_cfg, width,
+                                      planes * self.expansion, 1, bias=False)
+        self.add_module(self.norm3_name, norm3)
+
+
 @BACKBONES.register_module()
 class ResNet(nn.Module):
     arch_settings = {
@@ -214,10 +259,10 @@ class ResNet(nn.Module):
             planes = base_channels * 2**i
             stage_dcn = dcn if (dcn is not None and stage_with_dcn[i]) \
                 else None
-            res_layer = ResLayer(self.block, self.inplanes, planes, num_blocks,
-                                 stride=strides[i], style=self.style,
-                                 conv_cfg=conv_cfg, norm_cfg=norm_cfg,
-                                 dcn=stage_dcn)
+            res_layer = self.make_res_layer(
+                block=self.block, inplanes=self.inplanes, planes=planes,
+                num_blocks=num_blocks, stride=strides[i], style=self.style,
+                conv_cfg=conv_cfg, norm_cfg=norm_cfg, dcn=stage_dcn)
             self.inplanes = planes * self.block.expansion
             layer_name = f'layer{i + 1}'
             self.add_module(layer_name, res_layer)
@@ -225,6 +270,10 @@ class ResNet(nn.Module):
         self._freeze_stages()
         self.feat_dim = self.block.expansion * base_channels * 2**(
             len(self.stage_blocks) - 1)
+
+    def make_res_layer(self, **kwargs):
+        """resnet.py:515-517 (the hook ResNeXt overrides)."""
+        return ResLayer(**kwargs)
 
     @property
     def norm1(self):
@@ -251,7 +300,7 @@ class ResNet(nn.Module):
             load_checkpoint(self, pretrained, strict=False)
         elif pretrained is None:
             for m in self.modules():
-                if isinstance(m, Conv2d):
+                if isinstance(m, (Conv2d, GroupedConv2d)):
                     kaiming_init(m)
                 elif isinstance(m, BatchNorm2d):
                     constant_init(m, 1)
@@ -328,3 +377,25 @@ class ResNet(nn.Module):
                 if isinstance(m, BatchNorm2d):
                     m.eval()
         return self
+
+
+@BACKBONES.register_module()
+class ResNeXt(ResNet):
+    """ResNeXt backbone (mmdet/models/backbones/resnext.py:88-153): ResNet with
+    grouped Bottlenecks.  Here it is the frozen X-101 (32x4d) TEACHER of
+    BASELINE config 5 -- its grouped convs are forward-only
+    (ld_amd/csrc/gconv.hip), so it must run under ``torch.no_grad()`` with
+    ``norm_eval=True``."""
+    arch_settings = {
+        50: (ResNeXtBottleneck, (3, 4, 6, 3)),
+        101: (ResNeXtBottleneck, (3, 4, 23, 3)),
+        152: (ResNeXtBottleneck, (3, 8, 36, 3))
+    }
+
+    def __init__(self, groups=1, base_width=4, **kwargs):
+        self.groups, self.base_width = groups, base_width
+        super().__init__(**kwargs)
+
+    def make_res_layer(self, **kwargs):
+        return ResLayer(groups=self.groups, base_width=self.base_width,
+                        base_channels=self.base_channels, **kwargs)
