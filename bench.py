@@ -53,7 +53,32 @@ def parse():
                     help='skip the hipGraph-replay leg')
     ap.add_argument('--no-bf16', action='store_true',
                     help='skip the bf16 (BASELINE config 3) leg')
+    ap.add_argument('--config', type=int, default=2, choices=(2, 4, 5),
+                    help='BASELINE.json configs[] entry (1-based): 2 = the '
+                    'headline R50<-R101 fp32 step (default); 4 = R101 <- '
+                    'R101-DCN (ld_r101_gflv1_r101dcn_fpn_coco_2x); 5 = LDv2 '
+                    'R50 <- X101 \'finegrained\'')
     return ap.parse_args()
+
+
+# per-config workload: detector builder, name, analytic conv GFLOP per image
+# 
+def _workload(cfg_id):
+    from ld_amd import model_zoo
+    if cfg_id == 4:
+        return (lambda dev: model_zoo.build_seeded(
+            model_zoo.ld_r101_dcn_detector(), dev),
+            'ld_r101_gflv1_r101dcn_fpn_coco_2x (BASELINE.json configs[3]): '
+            'GFocal-R101 student <- R101-DCN(c3-c5) teacher, fp32', 2324.0)
+    if cfg_id == 5:
+        return (lambda dev: model_zoo.build_seeded(
+            model_zoo.ldv2_x101_detector(), dev),
+            'ldv2 R50 <- X101 (32x4d), imitation \'finegrained\' (BASELINE.json '
+            'configs[4], the composition of SURVEY Q10): LDv2Head student <- '
+            'GFLv2 ResNeXt-101 teacher, fp32', None)
+    return (lambda dev: model_zoo.build_seeded_ld_detector(50, 101, dev),
+            'ld_r50_gflv1_r101_fpn_coco_1x (BASELINE.json configs[1]): '
+            'GFocal-R50 student <- R101 teacher, fp32', 1835.7)
 
 
 def make_batch(bs, num_gt, seed, dev):
@@ -180,6 +205,46 @@ def _median_launch_us(launch, warm, iters):
 PMC_LDKL_TRAFFIC_BYTES = (2 * 1212533.8 + 1120262.4) * 1024.0
 
 
+def hbm_ceilings(dev):
+    """What the memory system delivers, measured in THIS process right next to
+    the LD-KL kernel: a 16-byte-per-lane
+    non-temporal copy, and the kernel's own 34-read / 17-write channel-plane
+    pattern with the arithmetic removed (ld_probe_copy / ld_probe_planes,
+    ld_amd/csrc/probe.hip)."""
+    import ctypes as C
+    from ld_amd import lib as L
+    lib = L.get_lib()
+    st = L.stream_ptr(dev)
+    out = {}
+    n = 1 << 28  # 1 GiB per array: well past the 256 MiB Infinity Cache
+    src = torch.randn(n, device=dev)
+    dst = torch.empty_like(src)
+
+    def copy():
+        L.check(lib.ld_probe_copy(L.ptr(src), L.ptr(dst), n, 4, 1, st),
+                'ld_probe_copy')
+    us, _ = _median_launch_us(copy, 3, 11)
+    out['copy_16B_nt_GBps'] = 8.0 * n / (us * 1e-6) / 1e9
+    del src, dst
+    rows = 1 << 22
+    s = torch.randn(68 * rows, device=dev)
+    t = torch.randn(68 * rows, device=dev)
+    g = torch.empty_like(s)
+
+    def planes():
+        L.check(lib.ld_probe_planes(L.ptr(s), L.ptr(t), L.ptr(g), rows, 1, 1,
+                                    st), 'ld_probe_planes')
+    us, _ = _median_launch_us(planes, 3, 11)
+    out['pattern_no_math_GBps'] = 204.0 * 4 * rows / (us * 1e-6) / 1e9
+    out['note'] = ('copy = float4 non-temporal copy of 1 GiB; pattern = the '
+                   'kernel\'s 34 read + 17 write channel planes per side '
+                   '(2^22 x 4 row-sides, side-fast mapping) with out = s - t '
+                   'instead of the KL')
+    del s, t, g
+    torch.cuda.empty_cache()
+    return out
+
+
 def ldkl_roofline(dev):
     """North-star kernel = the reg-side dense kernel THE TRAIN STEP LAUNCHES
     (fused LD-KL + VLR-LD + Integral chain, forward + gradient), timed with HIP
@@ -199,9 +264,14 @@ def ldkl_roofline(dev):
         dev, [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)],
         [8, 16, 32, 64, 128], 2, 0.09, seed=2)
     us_c2, _ = _median_launch_us(c2, 10, 51)
-    return dict(kernel='loss_reg_dense_kernel (the train step\'s fused LD-KL + '
+    del c2
+    ceil = hbm_ceilings(dev)
+    return dict(kernel='loss_reg_lean_kernel (the train step\'s fused LD-KL + '
                        'VLR-LD + Integral chain, fwd+grad) via '
                        'ld_loss_main_parts(LD_LOSS_PART_REG)',
+                ceilings_same_process=ceil,
+                frac_of_copy_ceiling=ach / ceil['copy_16B_nt_GBps'],
+                frac_of_pattern_ceiling=ach / ceil['pattern_no_math_GBps'],
                 bound='hbm', achieved=ach, peak=PEAK_HBM_GBPS, unit='GB/s',
                 frac=ach / PEAK_HBM_GBPS,
                 traffic=PMC_LDKL_TRAFFIC_BYTES if rows == 1 << 24 else None,
@@ -311,7 +381,8 @@ def main():
             print(f'[bench] early LD-KL leg failed: {e!r}', file=sys.stderr)
         torch.cuda.empty_cache()
 
-    det = model_zoo.build_seeded_ld_detector(50, 101, dev)
+    build_det, workload_name, gflop_per_img = _workload(args.config)
+    det = build_det(dev)
     trainer = SGDTrainer(det, lr=model_zoo.OPTIMIZER['lr'],
                          momentum=model_zoo.OPTIMIZER['momentum'],
                          weight_decay=model_zoo.OPTIMIZER['weight_decay'])
@@ -357,9 +428,7 @@ def main():
             'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {
-                'workload': 'ld_r50_gflv1_r101_fpn_coco_1x (BASELINE.json '
-                            'configs[1]): GFocal-R50 student <- R101 teacher, '
-                            'fp32, 800x1333 padded to 800x1344, '
+                'workload': workload_name + ', 800x1333 padded to 800x1344, '
                             f'{args.num_gt} GT/img',
                 'global_batch': args.batch_per_gpu * world,
                 'batch_per_gpu': args.batch_per_gpu,
@@ -381,8 +450,10 @@ def main():
         res['roofline'] = roof
         # step-level view of the same bound: analytic conv FLOPs per image
         # (1835.7 GFLOP) / step time
-        res['roofline']['step_tflops_analytic'] = \
-            1835.7e9 * args.batch_per_gpu / (res['ms_per_step'] * 1e-3) / 1e12
+        if gflop_per_img is not None:
+            res['roofline']['step_tflops_analytic'] = \
+                gflop_per_img * 1e9 * args.batch_per_gpu / \
+                (res['ms_per_step'] * 1e-3) / 1e12
         after = ldkl_roofline(dev)
         if ldkl_first is not None:
             ldkl_first['us_after_train_legs'] = after['us']
@@ -417,8 +488,10 @@ def main():
                 'last_loss': lossb, 'dtype': 'bf16 operands / f32 accumulate',
             }
             if roofb is not None:
-                roofb['step_tflops_analytic'] = \
-                    1835.7e9 * args.batch_per_gpu / (dtb / args.steps) / 1e12
+                if gflop_per_img is not None:
+                    roofb['step_tflops_analytic'] = \
+                        gflop_per_img * 1e9 * args.batch_per_gpu / \
+                        (dtb / args.steps) / 1e12
                 res['roofline_bf16'] = roofb
     # ---- graph leg: the same step replayed from one captured hipGraph (the
     # ~750 launches of a step cost ~13 ms of Python + ctypes on the host, which
@@ -434,13 +507,20 @@ def main():
                 trainer.step(dbatch)  # images of the mode exist before capture
                 torch.cuda.synchronize()
                 gs = GraphedStep(trainer, dbatch, warmup=2)
-                for _ in range(args.warmup):
+                # a FRESH batch per replay, with a different number of GT
+                # boxes (the captured step pads to max_gt with device-side
+                # counts): what a real epoch hands the step
+                fresh = [make_batch(args.batch_per_gpu, g, 4321 + rank + g,
+                                    dev)[1] for g in (5, 11, args.num_gt)]
+                for i in range(args.warmup):
+                    gs.copy_inputs(fresh[i % len(fresh)])
                     gs.replay()
                 if world > 1:
                     dist.barrier()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for _ in range(args.steps):
+                for i in range(args.steps):
+                    gs.copy_inputs(fresh[i % len(fresh)])
                     out = gs.replay()
                 if world > 1:
                     dist.barrier()
@@ -454,7 +534,9 @@ def main():
                     'value': args.batch_per_gpu * world * args.steps / dtg,
                     'unit': 'images/sec',
                     'ms_per_step': dtg / args.steps * 1e3,
-                    'last_loss': float(out['log_vars']['loss'])}
+                    'last_loss': float(out['log_vars']['loss']),
+                    'fresh_batch_per_replay': True,
+                    'gt_per_image_cycle': [5, 11, args.num_gt]}
                 del gs
             except Exception as e:  # report, never lose the headline line
                 graph_res[mode] = {'error': f'{type(e).__name__}: {e}'[:300]}
@@ -463,7 +545,8 @@ def main():
             res['hipgraph_step'] = graph_res
     if world > 1:
         dist.barrier()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and \
+            args.config == 2:  # the CPU port restates configs[1]'s nets
         res['cpu_baseline'] = cpu_baseline(cpu_batch)
     if rank == 0:
         print(json.dumps(res), flush=True)

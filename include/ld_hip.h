@@ -668,6 +668,12 @@ int ld_scale_levels_backward(const ld_levels_t* lv, const float* dy, const float
 int ld_sgd_step(float* params, const float* grads, float* momentum_buf, size_t n,
                 float lr, float momentum, float weight_decay, float grad_scale,
                 ld_stream_t stream);
+/* The same update with hyper = {lr, momentum, weight_decay, grad_scale} read
+ * from DEVICE memory (bit-identical arithmetic): inside a captured hipGraph the
+ * by-value arguments above are frozen, a buffer is not -- the host rewrites it
+ * between replays (learning-rate schedules, apis/train.py:88 + lr hooks). */
+int ld_sgd_step_dev(float* params, const float* grads, float* momentum_buf, size_t n,
+                    const float* hyper, ld_stream_t stream);
 
 /* ---- GFLv2 distribution-guided quality branch (config 5, R-V2) ----------------
  * GFocalHead.forward_single's tail (gfocal_head.py:201-217) for all levels and
@@ -694,6 +700,20 @@ int ld_quality_backward(const float* reg, const float* cls_feat, const float* qu
                         float* g_w1, float* g_b1, float* g_w2, float* g_b2,
                         int accumulate, void* workspace, size_t workspace_bytes,
                         ld_stream_t stream);
+
+/* ---- measurement support: HBM streaming ceilings ------------------------------
+ * Not on the train step.  bench.py times these in the same process as the
+ * LD-KL kernel so its roofline fraction can be read against what the memory
+ * system delivers for (a) a plain copy of n floats (width = 1 or 4 floats per
+ * lane, nt = non-temporal access; 8 n bytes move) and (b) the LD-KL kernel's own
+ * access pattern without its arithmetic: s, t, g are (68, rows) channel-major
+ * maps, every (row, side) thread reads 17 + 17 planes and writes 17 (204 bytes
+ * per row-side); side_fast = the four sides of a 256-row chunk in adjacent
+ * workgroups (the mapping the train step's kernel uses). */
+int ld_probe_copy(const float* src, float* dst, int64_t n, int width, int nt,
+                  ld_stream_t stream);
+int ld_probe_planes(const float* s, const float* t, float* g, int64_t rows, int nt,
+                    int side_fast, ld_stream_t stream);
 
 /* ---- grouped convolution, forward only (config 5's X-101 teacher) --------------
  * The 3x3 conv2 of ResNeXt's Bottleneck (mmdet/models/backbones/resnext.py:49-61,

@@ -146,12 +146,16 @@ __device__ __forceinline__ bool tap_offset(const Geo& a, int l, int ho, int wo,
 // ---- shape-tuning table (one instance, defined in conv.hip) ----------------
 // key: 18 ints = {MODE, Cin, Cout, KH, KW, stride, pad, J, num_levels, Hin0,
 // Win0, ph, pw, relu, has_residual, has_affine, family, 0}; family 0 = fp32
-// streaming kernels, 1 = bf16 streaming kernels.  value: {tm, tn, wvm, d, ks}.
+// streaming kernels, 1 = bf16 streaming kernels.  value: {tm, tn, wvm, d, ks
+// [, cap]}.
 struct LdTuneKey {
   int v[18];
 };
 struct LdTuneCfg {
   int tm, tn, wvm, d, ks;
+  // fp32 streaming family only: workgroups per CU the launch is held to through
+  // dynamic LDS (0 = whatever the registers allow).  See launch_stream_cfg.
+  int cap = 0;
 };
 bool ld_tune_lookup(const LdTuneKey& key, LdTuneCfg* out);
 void ld_tune_store(const LdTuneKey& key, const LdTuneCfg& cfg);

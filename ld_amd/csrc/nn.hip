@@ -755,6 +755,36 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p,
   }
 }
 
+// the same update with (lr, mu, wd, gscale) read from device memory: a captured
+// hipGraph replays the launch with its ARGUMENTS frozen, so a learning-rate
+// schedule must reach the kernel through a buffer the host rewrites between
+// replays (train.GraphedStep)
+__global__ __launch_bounds__(256) void sgd_dev_kernel(float* __restrict__ p,
+                                                      const float* __restrict__ g,
+                                                      float* __restrict__ buf, size_t n,
+                                                      const float* __restrict__ hyper) {
+  const float lr = hyper[0], mu = hyper[1], wd = hyper[2], gscale = hyper[3];
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    float4 pv = *reinterpret_cast<float4*>(p + i);
+    const float4 gv = *reinterpret_cast<const float4*>(g + i);
+    float4 bv = *reinterpret_cast<float4*>(buf + i);
+    bv.x = mu * bv.x + (gv.x * gscale + wd * pv.x);
+    bv.y = mu * bv.y + (gv.y * gscale + wd * pv.y);
+    bv.z = mu * bv.z + (gv.z * gscale + wd * pv.z);
+    bv.w = mu * bv.w + (gv.w * gscale + wd * pv.w);
+    pv.x -= lr * bv.x; pv.y -= lr * bv.y; pv.z -= lr * bv.z; pv.w -= lr * bv.w;
+    *reinterpret_cast<float4*>(p + i) = pv;
+    *reinterpret_cast<float4*>(buf + i) = bv;
+  } else {
+    for (size_t k = i; k < n; ++k) {
+      const float b = mu * buf[k] + (g[k] * gscale + wd * p[k]);
+      buf[k] = b;
+      p[k] -= lr * b;
+    }
+  }
+}
+
 Levels make_levels(const ld_levels_t* lv) {
   Levels k;
   k.num_levels = lv->num_levels;
@@ -1111,6 +1141,18 @@ extern "C" int ld_scale_levels_backward(const ld_levels_t* lv, const float* dy,
                        LD_STREAM, (const double*)workspace, k.num_levels, dscales,
                        accumulate);
   }
+  return (int)hipGetLastError();
+}
+
+extern "C" int ld_sgd_step_dev(float* params, const float* grads, float* momentum_buf,
+                               size_t n, const float* hyper, ld_stream_t stream) {
+  if (!params || !grads || !momentum_buf || !hyper) return LD_EINVAL;
+  if (n == 0) return 0;
+  if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)momentum_buf) % 16)
+    return LD_EINVAL;
+  const size_t threads = (n + 3) / 4;
+  hipLaunchKernelGGL(sgd_dev_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256),
+                     0, LD_STREAM, params, grads, momentum_buf, n, hyper);
   return (int)hipGetLastError();
 }
 

@@ -1,12 +1,14 @@
-// HBM streaming ceilings measured in the same process as the LD-KL kernel
-// (tools/ldkl_variants.py): what the memory system gives for
+// HBM streaming ceilings, measured by bench.py in the same process as the LD-KL
+// kernel (and by tools/ldkl_variants.py): what the memory system gives for
 //   (a) a plain copy (1 read : 1 write), 4 / 16 bytes per lane, NT or not;
 //   (b) the LD-KL kernel's own pattern with the arithmetic removed: 34 read
 //       planes + 17 write planes per side, channel planes `rows` floats apart,
 //       2 reads : 1 write -- the ceiling the fused kernel can approach.
-// gfx950 only; built by tools/ldkl_variants.py with hipcc.
+// Measurement support, not on the train step.  gfx950 only.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "../../include/ld_hip.h"
 
 namespace {
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -61,8 +63,9 @@ __global__ __launch_bounds__(256) void planes_kernel(const float* __restrict__ s
 }
 }  // namespace
 
-extern "C" int probe_copy(const float* src, float* dst, int64_t n, int width, int nt,
-                          void* stream) {
+extern "C" int ld_probe_copy(const float* src, float* dst, int64_t n, int width, int nt,
+                             ld_stream_t stream) {
+  if (!src || !dst || n < 1 || (width != 1 && width != 4) || n % width) return LD_EINVAL;
   const int64_t threads = n / width;
   const dim3 grid((unsigned)((threads + 255) / 256));
   hipStream_t st = (hipStream_t)stream;
@@ -76,8 +79,9 @@ extern "C" int probe_copy(const float* src, float* dst, int64_t n, int width, in
   return (int)hipGetLastError();
 }
 
-extern "C" int probe_planes(const float* s, const float* t, float* g, int64_t rows, int nt,
-                            int side_fast, void* stream) {
+extern "C" int ld_probe_planes(const float* s, const float* t, float* g, int64_t rows,
+                               int nt, int side_fast, ld_stream_t stream) {
+  if (!s || !t || !g || rows < 1) return LD_EINVAL;
   const unsigned nb = (unsigned)((rows + 255) / 256);
   const dim3 grid = side_fast ? dim3(nb * 4, 1) : dim3(nb, 4);
   hipStream_t st = (hipStream_t)stream;

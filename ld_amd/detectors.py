@@ -250,8 +250,13 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
         return teacher_x, out_teacher
 
     @staticmethod
-    def _img_key(img):
-        return (img.data_ptr(), img._version, tuple(img.shape))
+    def _same_batch(entry, img):
+        """A prefetched entry belongs to ``img`` iff it was computed from that
+        very tensor OBJECT at its current version.  (Round 2 compared
+        data_ptr / _version / shape: a freed batch whose storage the caching
+        allocator hands to the next one collides on all three.)  The queue
+        keeps the tensor alive, so identity is meaningful."""
+        return entry['img'] is img and entry['version'] == img._version
 
     def prefetch_teacher(self, img):
         """Software pipelining across steps.  The frozen teacher depends on the
@@ -278,8 +283,14 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
         # its own
         if not hasattr(self, '_prefetched') or self._prefetched is None:
             self._prefetched = []
-        self._prefetched.append((self._img_key(img), teacher_x, out_teacher,
-                                 done))
+        self._prefetched.append(dict(img=img, version=img._version,
+                                     teacher_x=teacher_x,
+                                     out_teacher=out_teacher, done=done))
+        # a caller that announces batches it never trains on must not pin
+        # their teacher outputs forever: two steps of look-ahead at most
+        while len(self._prefetched) > 2:
+            self._prefetched.pop(0)
+            self.prefetch_dropped = getattr(self, 'prefetch_dropped', 0) + 1
         return True
 
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels,
@@ -294,17 +305,26 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
         side = None
         queue = getattr(self, '_prefetched', None) or []
         pre = None
-        if queue and queue[0][0] == self._img_key(img):
-            pre = queue.pop(0)
-        else:
-            queue.clear()  # a different batch arrived: drop stale prefetches
+        # SGDTrainer.step enqueues the prefetch of batch i + 1 BEFORE batch i
+        # gets here, so at step 0 the queue holds [pre(1)] and no entry matches:
+        # that is not staleness (round 2 cleared the queue there, and then
+        # never hit again).  Take the first entry made from THIS tensor; entries
+        # ahead of it were announced but skipped and are dropped; on no match
+        # the queue is left alone (prefetch_teacher bounds its length).
+        for i, e in enumerate(queue):
+            if self._same_batch(e, img):
+                pre = e
+                self.prefetch_dropped = getattr(self, 'prefetch_dropped', 0) + i
+                del queue[:i + 1]
+                break
         if pre is not None:
+            self.prefetch_hits = getattr(self, 'prefetch_hits', 0) + 1
             main = torch.cuda.current_stream(img.device)
-            teacher_x, out_teacher = pre[1], pre[2]
+            teacher_x, out_teacher = pre['teacher_x'], pre['out_teacher']
             x = self.extract_feat(img)
             # wait for THAT forward only: the stream may already hold the
             # prefetch of the following batch
-            main.wait_event(pre[3])
+            main.wait_event(pre['done'])
             for t in list(teacher_x) + [t for lvl in out_teacher for t in lvl]:
                 t.record_stream(main)
             return self._head_train(x, out_teacher, teacher_x, img_metas,

@@ -328,6 +328,14 @@ class GFLHead(nn.Module):
         """AnchorHead.get_anchors + LDHead.get_targets for the whole batch in
         two launches (ld_head.py:377-577)."""
         strides = [s[0] for s in self.anchor_generator.strides]
+        if not self.anchor_generator.single_square:
+            # the implicit-anchor kernels build the one square anchor of a cell
+            # from an INTEGER scale (octave_base_scale * stride)
+            raise NotImplementedError(
+                f'{type(self).__name__}: one anchor per cell with a non-integer '
+                'scale or ratio != 1 (anchor_generator.py:78-98); the '
+                'single-anchor target kernels take ratios=[1.0] with an integer '
+                'octave_base_scale')
         if gt_labels is None:
             gt_labels = [b.new_zeros(b.shape[0], dtype=torch.long)
                          for b in gt_bboxes]

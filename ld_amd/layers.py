@@ -1223,14 +1223,25 @@ class QualityFn(torch.autograd.Function):
 
 
 def sgd_step(params_flat, grads_flat, momentum_flat, lr, momentum,
-             weight_decay, grad_scale=1.0):
+             weight_decay, grad_scale=1.0, hyper=None):
+    """``hyper``: optional device tensor [lr, momentum, weight_decay,
+    grad_scale]; when given the kernel reads the four values from it (the
+    by-value arguments are ignored) -- the form a captured hipGraph needs."""
     lib = L.get_lib()
     for t in (params_flat, grads_flat, momentum_flat):
         _dev_f32(t, 'sgd arena')
-    L.check(lib.ld_sgd_step(L.ptr(params_flat), L.ptr(grads_flat),
-                            L.ptr(momentum_flat), params_flat.numel(), lr,
-                            momentum, weight_decay, grad_scale,
-                            L.stream_ptr(params_flat.device)), 'ld_sgd_step')
+    if hyper is not None:
+        _dev_f32(hyper, 'sgd hyper-parameters')
+        L.check(lib.ld_sgd_step_dev(
+            L.ptr(params_flat), L.ptr(grads_flat), L.ptr(momentum_flat),
+            params_flat.numel(), L.ptr(hyper),
+            L.stream_ptr(params_flat.device)), 'ld_sgd_step_dev')
+    else:
+        L.check(lib.ld_sgd_step(L.ptr(params_flat), L.ptr(grads_flat),
+                                L.ptr(momentum_flat), params_flat.numel(), lr,
+                                momentum, weight_decay, grad_scale,
+                                L.stream_ptr(params_flat.device)),
+                'ld_sgd_step')
     bump_param_generation()
     refresh_params(params_flat.device)
 

@@ -209,6 +209,8 @@ SIGNATURES = {
     'ld_loss_centerness': (C.c_int, [_G, _H, _M, _vp, _vp, _vp, _vp, _M, _vp,
                                      _sz, _vp]),
     'ld_loss_set_reg_variant': (C.c_int, [_i32]),
+    'ld_probe_copy': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    'ld_probe_planes': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     'ld_gconv_weight_image_floats': (_sz, [_i32, _i32, _i32, _i32]),
     'ld_gconv_weight_transform': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp,
                                             _vp]),
@@ -309,6 +311,7 @@ SIGNATURES = {
                                            _i32, _vp, _sz, _vp]),
     'ld_sgd_step': (C.c_int, [_vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32,
                               _vp]),
+    'ld_sgd_step_dev': (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
 }
 
 

@@ -76,6 +76,93 @@ def _small_int_tensor(values, device):
     return t[0]
 
 
+class StaticTargets:
+    """Fixed-address ground-truth / valid-region buffers for a captured train
+    step (train.GraphedStep).  A hipGraph replays launches with their pointer
+    and by-value arguments frozen, while the reference's batches carry a
+    different number of boxes every iteration
+    (mmdet/models/detectors/kd_one_stage.py:52-65): so the boxes live in
+    (N, max_gt, 4) / (N, max_gt) buffers padded to ``max_gt``, the per-image
+    COUNT lives on the device (the target kernels already loop to a run-time
+    count and index with the ``max_gt`` stride), and the per-level valid region
+    of ``img_metas[i]['pad_shape']`` is a device buffer too.  ``load`` rewrites
+    all of them from a new batch -- outside the graph, before a replay.
+    Attached to ``img_metas[0]['ld_static_targets']``; the target wrappers below
+    then use these buffers instead of building their own."""
+
+    def __init__(self, num_imgs, max_gt, device):
+        self.N, self.max_gt, self.device = int(num_imgs), int(max_gt), device
+        if self.max_gt < 1:
+            raise ValueError('max_gt must be >= 1')
+        self.gtb = torch.zeros((self.N, self.max_gt, 4), dtype=torch.float32,
+                               device=device)
+        self.gtl = torch.zeros((self.N, self.max_gt), dtype=torch.int64,
+                               device=device)
+        self.ng = torch.zeros(self.N, dtype=torch.int32, device=device)
+        self._ng_host = torch.zeros(self.N, dtype=torch.int32).pin_memory()
+        self.vhw = self._vhw_host = None
+        self.geometry = None   # (featmap_sizes, strides) the vhw buffer is for
+        self.metas = None
+        self.num_gt = [0] * self.N
+
+    def load(self, img_metas, gt_bboxes, gt_labels):
+        if len(img_metas) != self.N or len(gt_bboxes) != self.N:
+            raise ValueError(f'StaticTargets holds {self.N} images')
+        num_gt = [int(b.shape[0]) for b in gt_bboxes]
+        if max(num_gt) > self.max_gt:
+            raise ValueError(f'{max(num_gt)} GT boxes in one image, the '
+                             f'captured step holds at most {self.max_gt}')
+        for i, (b, l) in enumerate(zip(gt_bboxes, gt_labels)):
+            if b.data_ptr() == self.gtb[i].data_ptr():
+                continue  # the caller handed our own padded views back
+            if num_gt[i]:
+                self.gtb[i, :num_gt[i]].copy_(b, non_blocking=True)
+                self.gtl[i, :num_gt[i]].copy_(l, non_blocking=True)
+            self._ng_host[i] = num_gt[i]
+            self.num_gt[i] = num_gt[i]
+        self.ng.copy_(self._ng_host, non_blocking=True)
+        self.metas = [dict((k, v) for k, v in m.items()
+                           if k != 'ld_static_targets') for m in img_metas]
+        if self.geometry is not None:
+            self._fill_vhw()
+
+    def views(self):
+        """Per-image (max_gt, 4) / (max_gt,) views with the mmdet list layout."""
+        return ([self.gtb[i] for i in range(self.N)],
+                [self.gtl[i] for i in range(self.N)])
+
+    def _fill_vhw(self):
+        rows = valid_hw_from_metas(self.geometry[0], self.geometry[1],
+                                   self.metas)
+        flat = torch.tensor(rows, dtype=torch.int32).reshape(-1)
+        if self.vhw is None or self.vhw.numel() != flat.numel():
+            if torch.cuda.is_current_stream_capturing():
+                raise L.LdError('StaticTargets: the valid-region buffer must '
+                                'exist before capture (run a warm-up step)')
+            self.vhw = torch.zeros(flat.numel(), dtype=torch.int32,
+                                   device=self.device)
+            self._vhw_host = torch.zeros(flat.numel(),
+                                         dtype=torch.int32).pin_memory()
+        self._vhw_host.copy_(flat)
+        self.vhw.copy_(self._vhw_host, non_blocking=True)
+
+    def valid_hw(self, featmap_sizes, strides):
+        key = (tuple(tuple(s) for s in featmap_sizes),
+               tuple(s[0] if isinstance(s, (tuple, list)) else s
+                     for s in strides))
+        if self.geometry is None or self.geometry != key:
+            if torch.cuda.is_current_stream_capturing():
+                raise L.LdError('StaticTargets: pyramid geometry changed '
+                                'inside a capture')
+            self.geometry = key
+            self._fill_vhw()
+        return self.vhw
+
+
+def _static_targets(img_metas):
+    return img_metas[0].get('ld_static_targets') if img_metas else None
+
+
 def atss_targets(featmap_sizes, strides, img_metas, gt_bboxes, gt_labels, hp,
                  device, anchor_scale=8):
     """Dense ATSS / VLR / IM targets for a batch (see ld_atss_targets in
@@ -84,20 +171,28 @@ def atss_targets(featmap_sizes, strides, img_metas, gt_bboxes, gt_labels, hp,
     N = len(img_metas)
     geom = L.make_geom(featmap_sizes, strides, N, anchor_scale)
     A, nl = geom.num_anchors, geom.num_levels
-    num_gt = [int(b.shape[0]) for b in gt_bboxes]
-    max_gt = max(num_gt) if num_gt else 0
-    gtb = torch.zeros((N, max(max_gt, 1), 4), dtype=torch.float32,
-                      device=device)
-    gtl = torch.zeros((N, max(max_gt, 1)), dtype=torch.int64, device=device)
-    for i, (b, l) in enumerate(zip(gt_bboxes, gt_labels)):
-        if num_gt[i]:
-            L.require_device(b, torch.float32, 'gt_bboxes')
-            gtb[i, :num_gt[i]] = b
-            gtl[i, :num_gt[i]] = l
-    ng = _small_int_tensor(tuple(num_gt), device)
-    vhw = _small_int_tensor(
-        tuple(tuple(r) for r in valid_hw_from_metas(featmap_sizes, strides,
-                                                    img_metas)), device)
+    st = _static_targets(img_metas)
+    if st is not None:
+        # captured step: padded boxes + device-side counts at fixed addresses
+        gtb, gtl, ng, max_gt = st.gtb, st.gtl, st.ng, st.max_gt
+        num_gt = list(st.num_gt)
+        vhw = st.valid_hw(featmap_sizes, strides)
+    else:
+        num_gt = [int(b.shape[0]) for b in gt_bboxes]
+        max_gt = max(num_gt) if num_gt else 0
+        gtb = torch.zeros((N, max(max_gt, 1), 4), dtype=torch.float32,
+                          device=device)
+        gtl = torch.zeros((N, max(max_gt, 1)), dtype=torch.int64,
+                          device=device)
+        for i, (b, l) in enumerate(zip(gt_bboxes, gt_labels)):
+            if num_gt[i]:
+                L.require_device(b, torch.float32, 'gt_bboxes')
+                gtb[i, :num_gt[i]] = b
+                gtl[i, :num_gt[i]] = l
+        ng = _small_int_tensor(tuple(num_gt), device)
+        vhw = _small_int_tensor(
+            tuple(tuple(r) for r in valid_hw_from_metas(featmap_sizes, strides,
+                                                        img_metas)), device)
     out = dict(
         labels=torch.empty((N, A), dtype=torch.int64, device=device),
         label_weights=torch.empty((N, A), dtype=torch.float32, device=device),

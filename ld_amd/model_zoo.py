@@ -266,6 +266,37 @@ def ld_fcos_detector(student_depth=50, teacher_depth=101):
 OPTIMIZER = dict(type='SGD', lr=0.0025, momentum=0.9, weight_decay=0.0001)
 
 
+def ld_r101_dcn_detector(loss_im_weight=0.0):
+    """BASELINE config 4, configs/ld/ld_r101_gflv1_r101dcn_fpn_coco_2x.py: the
+    r18 config's head (loss_ld only; its default 'gibox' imitation has weight 0,
+    evaluated as 'finegrained' x 0 like config 1) on a ResNet-101
+    student, with the R101 teacher of
+    configs/gfl/gfl_r101_fpn_dconv_c3-c5_mstrain_2x_coco.py:6-12 (DCNv1 in
+    c3-c5)."""
+    cfg = ld_detector(101, 101, loss_im_weight=loss_im_weight,
+                      with_vlr_kd=False)
+    cfg['teacher_config']['model']['backbone'].update(
+        dcn=dict(type='DCN', deform_groups=1, fallback_on_stride=False),
+        stage_with_dcn=(False, True, True, True))
+    return cfg
+
+
+def build_seeded(cfg, device=None, student_seed=1, teacher_seed=2):
+    """Any KD detector config with the deterministic synthetic weights."""
+    from . import synthetic
+    from .registry import build_detector
+    det = build_detector(cfg)
+    det.load_state_dict(synthetic.seeded_state_dict(det.state_dict(),
+                                                    seed=student_seed))
+    det.teacher_model.load_state_dict(
+        synthetic.seeded_state_dict(det.teacher_model.state_dict(),
+                                    seed=teacher_seed))
+    if device is not None:
+        det.to(device)
+    det.train()
+    return det
+
+
 def build_seeded_ld_detector(student_depth=50, teacher_depth=101, device=None,
                              loss_im_weight=2.0, student_seed=1,
                              teacher_seed=2):

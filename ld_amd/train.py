@@ -71,7 +71,7 @@ class GradArena:
     that must also start from rank 0's values."""
 
     def __init__(self, params, bucket_bytes=32 << 20, align=64,
-                 extra_state=()):
+                 extra_state=(), tail_bytes=8 << 20):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError('no trainable parameters')
@@ -99,15 +99,29 @@ class GradArena:
             # message; frozen parameters and buffers go packed per dtype
             dist.broadcast(self.flat_param, src=0)
             broadcast_tensors(list(extra_state), src=0)
-        # buckets: contiguous [start, end) ranges of the arena
+        # buckets: contiguous [start, end) ranges of the arena.  The LAST bucket
+        # completes when backward does, so nothing is left to hide its
+        # all-reduce behind: it is cut small (``tail_bytes``, the stem-side
+        # layers) while the others stay large (``bucket_bytes``: few, big
+        # messages for the point-to-point xGMI links).
+        ends = [offs[i + 1] if i + 1 < len(offs) else off
+                for i in range(len(order))]
+        tail_from = len(order)  # first parameter of the tail bucket
+        tail_cap = max(tail_bytes // 4, 0)
+        if tail_cap and off > tail_cap + max(bucket_bytes // 4, 1):
+            while tail_from > 1 and off - offs[tail_from - 1] <= tail_cap:
+                tail_from -= 1
+            if off - (offs[tail_from] if tail_from < len(order) else off) == 0:
+                tail_from = len(order)
         self.buckets, start, count = [], 0, 0
         cap = max(bucket_bytes // 4, 1)
         self.bucket_of = {}
-        for i, (p, o) in enumerate(zip(order, offs)):
-            end = offs[i + 1] if i + 1 < len(offs) else off
+        for i, p in enumerate(order):
+            end = ends[i]
             self.bucket_of[id(p)] = len(self.buckets)
             count += 1
-            if end - start >= cap or i + 1 == len(order):
+            if end - start >= cap or i + 1 == len(order) or \
+                    i + 1 == tail_from:
                 self.buckets.append(dict(start=start, end=end, n=count))
                 start, count = end, 0
         self._ready = [0] * len(self.buckets)
@@ -167,16 +181,40 @@ class SGDTrainer:
     (with overlapped gradient all-reduce) -> SGD step."""
 
     def __init__(self, model, lr, momentum=0.9, weight_decay=1e-4,
-                 bucket_bytes=32 << 20):
+                 bucket_bytes=32 << 20, tail_bytes=8 << 20):
         self.model = model
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         frozen = [p for p in model.parameters() if not p.requires_grad]
         self.arena = GradArena(list(model.parameters()), bucket_bytes,
-                               extra_state=frozen + list(model.buffers()))
+                               extra_state=frozen + list(model.buffers()),
+                               tail_bytes=tail_bytes)
         self.flat_momentum = torch.zeros_like(self.arena.flat_param)
         self.check_grads = os.environ.get('LD_CHECK_GRADS', '0') == '1'
         self.iter = 0
         self.epoch = 0
+        self._hyper_dev = self._hyper_host = None
+
+    def enable_device_hyper(self):
+        """Route lr / momentum / weight decay / the 1/world gradient scale to the
+        optimizer launch through a device buffer (ld_sgd_step_dev) instead of
+        by-value kernel arguments -- the form a captured hipGraph needs, since a
+        replay re-issues the launch with its arguments frozen.  The buffer is
+        refreshed from ``self.lr`` ... before every eager step and before every
+        ``GraphedStep.replay``; the arithmetic is bit-identical."""
+        if self._hyper_dev is None:
+            dev = self.arena.flat_param.device
+            self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+            self._hyper_dev = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._push_hyper()
+
+    def _push_hyper(self):
+        if self._hyper_dev is None or \
+                torch.cuda.is_current_stream_capturing():
+            return
+        h = self._hyper_host
+        h[0], h[1], h[2] = self.lr, self.momentum, self.weight_decay
+        h[3] = 1.0 / _world()
+        self._hyper_dev.copy_(h, non_blocking=True)
 
     # -- optimizer state in torch.optim.SGD's wire format (checkpoints) -------
     def _all_params(self):
@@ -267,9 +305,10 @@ class SGDTrainer:
                     'gradient this step; the fused SGD launch would still '
                     'decay them (torch.optim.SGD would not)')
         self.arena.finish()
+        self._push_hyper()
         Y.sgd_step(self.arena.flat_param, self.arena.flat_grad,
                    self.flat_momentum, self.lr, self.momentum,
-                   self.weight_decay, 1.0 / _world())
+                   self.weight_decay, 1.0 / _world(), hyper=self._hyper_dev)
         self.iter += 1
         return dict(loss=loss.detach(), log_vars=log_vars,
                     num_samples=len(data['img_metas']))
@@ -279,55 +318,109 @@ class GraphedStep:
     """The steady-state train step captured ONCE into a hipGraph and replayed:
     ~750 launches per step (conv / norm / loss / optimizer kernels, the
     teacher's side stream included) become one graph launch, which takes the
-    Python + ctypes enqueue cost (~13 ms per C2 step, profiles/
-    r01 host profile) off the critical path -- it matters once the kernels are
-    faster than the host (the bf16 mode).
+    Python + ctypes enqueue cost (~13 ms per C2 step) off the critical path --
+    it matters once the kernels are faster than the host (the bf16 mode).
 
-    Contract: ``data`` holds the STATIC input buffers; a new batch is copied
-    into them (``copy_inputs``) before ``replay()``.  The shapes of the batch
-    (image size, number of GT boxes per image) are frozen into the graph, as is
-    the precision mode.  Every launch entry point of libldhip.so only enqueues
-    (no timing, no synchronisation: include/ld_hip.h), which is what makes the
-    step capturable; shape tuning must have happened before (ld_conv_tune_*
-    refuse a capturing stream).  With world_size > 1 the bucketed RCCL
-    all-reduces are captured like any other launch.
+    What a replay can change, and how (a hipGraph freezes every pointer and
+    by-value argument of the launches it recorded):
+      * the image batch: ``copy_inputs`` writes into the captured ``img`` buffer;
+      * the ground truth, with ANY number of boxes per image up to ``max_gt``
+        (the reference's batches differ every iteration,
+        kd_one_stage.py:52-65): boxes / labels live in padded
+        ``lossblock.StaticTargets`` buffers with the per-image count on the
+        device -- the ATSS kernels loop to that run-time count;
+      * the per-image ``pad_shape`` (valid anchor region): a device buffer that
+        ``copy_inputs`` rewrites from the new ``img_metas``;
+      * lr / momentum / weight decay: the optimizer launch reads them from a
+        device buffer (``SGDTrainer.enable_device_hyper`` / ``ld_sgd_step_dev``)
+        refreshed from ``trainer.lr`` ... before every replay, so lr schedules
+        and ``load_state_dict`` take effect.
+    What stays frozen: the padded image SHAPE (capture one GraphedStep per
+    (H, W) bucket), the batch size, the precision mode, the model structure.
+    Heads whose targets do not come from ``lossblock.atss_targets`` (LDFCOSHead,
+    LDRetinaHead) keep the box COUNT frozen as well and ``copy_inputs`` refuses
+    a different one.
+
+    Every launch entry point of libldhip.so only enqueues (no timing, no
+    synchronisation: include/ld_hip.h), which is what makes the step capturable;
+    shape tuning must have happened before (ld_conv_tune_* refuse a capturing
+    stream).  With world_size > 1 the bucketed RCCL all-reduces are captured
+    like any other launch.
     """
 
-    def __init__(self, trainer, data, warmup=2):
-        self.trainer, self.data = trainer, data
+    def __init__(self, trainer, data, warmup=2, max_gt=128):
+        from . import lossblock as LB
+        self.trainer = trainer
         dev = data['img'].device
+        n = len(data['img_metas'])
+        max_gt = max(int(max_gt), max(int(b.shape[0])
+                                      for b in data['gt_bboxes']))
+        self.static = LB.StaticTargets(n, max_gt, dev)
+        self.static.load(data['img_metas'], data['gt_bboxes'],
+                         data['gt_labels'])
+        head = getattr(trainer.model, 'bbox_head', None)
+        self.dynamic_gt = type(head).__name__ in (
+            'GFLHead', 'LDHead', 'GFocalHead', 'LDv2Head', 'ATSSGFLHead',
+            'LDATSSHead')
+        metas = [dict(m) for m in data['img_metas']]
+        if self.dynamic_gt:
+            metas[0]['ld_static_targets'] = self.static
+            gtb, gtl = self.static.views()
+        else:
+            gtb, gtl = list(data['gt_bboxes']), list(data['gt_labels'])
+        self.data = dict(img=data['img'], img_metas=metas, gt_bboxes=gtb,
+                         gt_labels=gtl)
+        trainer.enable_device_hyper()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            # allocator / caches / weight images reach steady state on the
-            # capture stream's own key before anything is recorded
+            # allocator / caches / weight images / the valid-region buffer
+            # reach steady state on the capture stream's own key before
+            # anything is recorded
             for _ in range(warmup):
-                trainer.step(data)
+                trainer.step(self.data)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=side):
-            out = trainer.step(data)
+            out = trainer.step(self.data)
         self._loss = out['loss']
         lv = out['log_vars']
         self._log_keys, self._log_tensor = list(lv._keys), lv._tensor
         self.num_samples = out['num_samples']
 
     def copy_inputs(self, data):
-        """New batch of the SAME shapes into the captured input buffers."""
-        self.data['img'].copy_(data['img'], non_blocking=True)
+        """A new batch into the captured buffers: same padded image shape, any
+        number of GT boxes per image up to ``max_gt``, any ``pad_shape``."""
+        if data['img'].shape != self.data['img'].shape:
+            raise ValueError(
+                f"GraphedStep captured images of shape "
+                f"{tuple(self.data['img'].shape)}, got "
+                f"{tuple(data['img'].shape)}: capture one step per shape")
+        if data['img'].data_ptr() != self.data['img'].data_ptr():
+            self.data['img'].copy_(data['img'], non_blocking=True)
+        if self.dynamic_gt:
+            self.static.load(data['img_metas'], data['gt_bboxes'],
+                             data['gt_labels'])
+            return
         for k in ('gt_bboxes', 'gt_labels'):
             for dst, src in zip(self.data[k], data[k]):
                 if dst.shape != src.shape:
                     raise ValueError(
-                        'GraphedStep: the number of GT boxes per image is '
-                        'frozen into the captured graph')
+                        'GraphedStep: this head\'s targets keep the number of '
+                        'GT boxes per image frozen in the captured graph')
                 dst.copy_(src, non_blocking=True)
+        for a, b in zip(self.data['img_metas'], data['img_metas']):
+            if tuple(a['pad_shape']) != tuple(b['pad_shape']):
+                raise ValueError('GraphedStep: this head keeps pad_shape '
+                                 'frozen in the captured graph')
 
     def replay(self):
         from .heads import LazyScalars
+        self.trainer._push_hyper()
         self.graph.replay()
         self.trainer.iter += 1
         return dict(loss=self._loss,
                     log_vars=LazyScalars(self._log_keys, self._log_tensor),
                     num_samples=self.num_samples)
+

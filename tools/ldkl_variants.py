@@ -6,14 +6,13 @@
     roofline_ldkl geometry) and at the C2 step size;
   * HBM ceilings measured in the same process: plain copies and the kernel's own
     34-read / 17-write plane pattern with the arithmetic removed
-    (tools/probe/stream_probe.hip).
+    (ld_probe_copy / ld_probe_planes, ld_amd/csrc/probe.hip).
 
 Writes gpurun_out/ldkl_variants.json.
 """
 import ctypes as C
 import json
 import os
-import subprocess
 import sys
 
 import torch
@@ -24,18 +23,6 @@ import bench  # noqa: E402
 from ld_amd import lib as L  # noqa: E402
 from ld_amd import lossblock as LB  # noqa: E402
 from ld_amd import synthetic  # noqa: E402
-
-HERE = os.path.join(REPO, 'tools', 'probe')
-SO = os.path.join(HERE, 'libstreamprobe.so')
-
-
-def build_probe():
-    if not os.path.exists(SO):
-        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950',
-                               '-O3', '-std=c++17', '-shared', '-fPIC', '-o',
-                               SO, os.path.join(HERE, 'stream_probe.hip')])
-    return C.CDLL(SO)
-
 
 def variant_word(vec=1, ntl=1, nts=1, fast=0, side_fast=0, small_nt=0, w8=0,
                  lds_kb=0, xcd=0):
@@ -97,7 +84,6 @@ def correctness(lib, dev, variants):
 def main():
     dev = torch.device('cuda:0')
     lib = L.get_lib()
-    probe = build_probe()
     res = dict(device=torch.cuda.get_device_name(0))
     variants = []
     if os.environ.get('LDKL_ROUND', '2') == '1':  # the first sweep (session 3)
@@ -142,10 +128,8 @@ def main():
     for width in (1, 4):
         for nt in (0, 1):
             def run():
-                assert probe.probe_copy(C.c_void_p(src.data_ptr()),
-                                        C.c_void_p(dst.data_ptr()),
-                                        C.c_int64(n), width, nt,
-                                        C.c_void_p(st)) == 0
+                L.check(lib.ld_probe_copy(L.ptr(src), L.ptr(dst), n, width, nt,
+                                          C.c_void_p(st)), 'ld_probe_copy')
             us, usm = med_us(run, 3, 11)
             ceil.append(dict(kind='copy', bytes_per_lane=4 * width, nt=nt,
                              us=us, tbps=2 * 4 * n / us / 1e6,
@@ -159,11 +143,9 @@ def main():
     for nt in (0, 1):
         for sf in (0, 1):
             def run():
-                assert probe.probe_planes(C.c_void_p(s.data_ptr()),
-                                          C.c_void_p(t.data_ptr()),
-                                          C.c_void_p(g.data_ptr()),
-                                          C.c_int64(rows), nt, sf,
-                                          C.c_void_p(st)) == 0
+                L.check(lib.ld_probe_planes(L.ptr(s), L.ptr(t), L.ptr(g), rows,
+                                            nt, sf, C.c_void_p(st)),
+                        'ld_probe_planes')
             us, usm = med_us(run, 3, 21)
             ceil.append(dict(kind='planes 34r+17w, no math', nt=nt,
                              side_fast=sf, us=us,

@@ -29,6 +29,11 @@ def main():
     from ld_amd import model_zoo, synthetic
     from ld_amd.train import GraphedStep, SGDTrainer
     dev = torch.device('cuda:0')
+    if 'RANK' in os.environ:  # under torch.distributed.run: RCCL group
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(dev)
+        dist.init_process_group('nccl', device_id=dev)
     Y.set_precision(args.mode)
     det = model_zoo.build_seeded_ld_detector(50, 101, dev)
     tr = SGDTrainer(det, lr=model_zoo.OPTIMIZER['lr'])
@@ -77,6 +82,9 @@ def main():
                         f'{100 * t / tot:.2f}\n')
         print('conv total %.2f ms/step; wrote %s' %
               (tot / args.steps * 1e3, args.layers))
+    if 'RANK' in os.environ:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':
