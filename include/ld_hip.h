@@ -416,7 +416,8 @@ typedef struct {
 /* Fused forward epilogue, applied in this order:
  *   v = acc; if scale: v = v*scale[co] + shift[co]  (frozen/eval BatchNorm,
  *   resnet.py:639-648); if bias: v += bias[co]; if residual: v += residual;
- *   if relu: v = max(v, 0).  Any pointer may be NULL. */
+ *   if relu: v = max(v, 0).  Any pointer may be NULL.  (With y_raw: scale and
+ *   bias together are not supported -- a conv followed by a norm has no bias.) */
 typedef struct {
   const float* bias;
   const float* scale;
@@ -435,6 +436,13 @@ typedef struct {
    * activations (the reference's mixed-precision nets are fp16 end to end the
    * same way, mmcv auto_fp16). */
   const void* residual_c8;
+  /* Second output, same shape as y (forward entry points, MODE 0): the conv
+   * result BEFORE scale / shift / residual / relu (acc + bias).  A trainable
+   * conv -> eval-BN -> ReLU pair then runs as ONE launch: y is what the next
+   * layer reads, y_raw is what the BN backward needs for d(gamma)
+   * (resnet.py:639-648 keeps BN in eval mode; its affine stays trainable).
+   * NULL = not written. */
+  float* y_raw;
 } ld_conv_epilogue_t;
 
 /* (Cout,Cin,KH,KW) parameter -> GEMM images: wt_fwd [tap][Cin_pad][Cout]

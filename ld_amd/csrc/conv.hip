@@ -429,6 +429,8 @@ __global__ __launch_bounds__(64 * WVM * WVN * KG) void conv_igemm_kernel(ConvK a
         const int row = rbase + (r & 3) + 8 * (r >> 2);
         if (m0 + row >= a.Cout) continue;
         float v = acc[i][j][r] * s_scale[row] + s_shift[row];
+        if (MODE == 0 && a.y_raw)
+          a.y_raw[colbase + (size_t)(m0 + row) * prow] = acc[i][j][r];
         if (has_res) v += res[r];
         if (relu) v = fmaxf(v, 0.0f);
         a.y[colbase + (size_t)(m0 + row) * prow] = v;
@@ -678,9 +680,173 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_kernel(ConvK a) {
         const int row = rbase + (r & 3) + 8 * (r >> 2);
         if (row >= Cout) continue;
         float v = acc[i][j][r] * sc[r] + sh[r];
+        if (MODE == 0 && a.y_raw) a.y_raw[colbase + (size_t)row * prow] = acc[i][j][r];
         if (has_res) v += a.residual[colbase + (size_t)row * prow];
         if (relu) v = fmaxf(v, 0.0f);
         a.y[colbase + (size_t)row * prow] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------- the 7x7 stem, streaming ----
+// Small-Cin forward conv (the ResNet stem: 3 -> 64, 7x7, stride 2, pad 3 --
+// resnet.py:536-548) with the FLAT reduction index k = (ci, kh, kw), in the
+// same LDS-free design as conv_stream_kernel: round 2 ran it on the older LDS
+// tiling (conv_igemm_kernel MODE 2) at 49.6 TFLOP/s, 0.2 ms per launch.
+//   A (weights) lane l <- Wt[k + (l>>5)][co0 + (l&31)]     image [Kpad][Cout],
+//               zero rows for k >= Cin*KH*KW (so the k-tail needs no masking)
+//   B (pixels)  lane l <- X[n][ci][ho*S - P + kh][wo*S - P + kw] for ITS k =
+//               2*step + (l>>5): each half-wave walks its own (ci, kh, kw)
+//               counter in steps of 2 -- a few VALU ops per k-pair against
+//               TM*TN*64 MFMA cycles
+// Four waves of a workgroup own four neighbouring column tiles (all of Cout
+// each: TM = Cout / 32), D k-pairs of operands in flight per wave.
+template <int TM, int TN, int D>
+__global__ __launch_bounds__(256, 2) void conv_stem_kernel(ConvK a) {
+  static_assert(D * (TM + TN) < 64, "ring exceeds the 6-bit vmcnt counter");
+  constexpr int WN = TN * 32;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int l31 = lane & 31, lk = lane >> 5;
+  const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int n0 = (tile * 4 + wave) * WN;
+  if (n0 >= a.J) return;  // waves are independent: no barriers below
+  const int Cout = __builtin_amdgcn_readfirstlane(a.Cout);
+  const int KH = __builtin_amdgcn_readfirstlane(a.KH);
+  const int KW = __builtin_amdgcn_readfirstlane(a.KW);
+  const int Pin = __builtin_amdgcn_readfirstlane(a.Pin);
+  const int K = __builtin_amdgcn_readfirstlane(a.Cin * a.KH * a.KW);
+  const int npairs = __builtin_amdgcn_readfirstlane(a.Kpad / 2);
+
+  int bHin[TN], bWin[TN], boff[TN], bh0[TN], bw0[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int jb = n0 + j * 32 + l31;
+    bHin[j] = 0;  // Hin = 0 -> every tap out of range -> kOOB -> zeros
+    bWin[j] = 0;
+    boff[j] = 0;
+    bh0[j] = 0;
+    bw0[j] = 0;
+    if (jb < a.J) {
+      const int n = jb / a.Pout, p = jb - n * a.Pout;
+      int bl, bho, bwo;
+      locate_out(a.g, p, bl, bho, bwo);
+      bHin[j] = a.g.lv[bl].Hin;
+      bWin[j] = a.g.lv[bl].Win;
+      boff[j] = n * a.Cin * Pin + a.g.lv[bl].off_in;
+      bh0[j] = bho * a.g.stride - a.g.pad;
+      bw0[j] = bwo * a.g.stride - a.g.pad;
+    }
+  }
+  unsigned va[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int co = i * 32 + l31;
+    va[i] = co < Cout ? (unsigned)(lk * Cout + co) * 4u : kOOB;
+  }
+  const rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  const rsrc_t rw = make_rsrc(a.wt, a.wt_bytes);
+
+  // this half-wave's reduction cursor: k = 2 * step + lk -> (ci, kh, kw)
+  int kk = lk, kci = 0, kkh = 0, kkw = lk;
+  if (kkw >= KW) {  // KW == 1
+    kkw -= KW;
+    if (++kkh >= KH) {
+      kkh = 0;
+      ++kci;
+    }
+  }
+  auto step2 = [&]() {  // advance the cursor by two
+    kk += 2;
+    kkw += 2;
+    while (kkw >= KW) {
+      kkw -= KW;
+      if (++kkh >= KH) {
+        kkh = 0;
+        ++kci;
+      }
+    }
+  };
+  float ra[D][TM], rb[D][TN];
+  auto load_kp = [&](int d, int pair) {
+    const unsigned sa = (unsigned)(2 * pair) * (unsigned)Cout * 4u;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ra[d][i] = buf_load(rw, va[i], sa);
+    const bool kin = kk < K;
+    const int cbase = kci * Pin;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int hi = bh0[j] + kkh, wi = bw0[j] + kkw;
+      const bool ok = kin && hi >= 0 && hi < bHin[j] && wi >= 0 && wi < bWin[j];
+      const unsigned vb = ok ? (unsigned)(boff[j] + cbase + hi * bWin[j] + wi) * 4u : kOOB;
+      rb[d][j] = buf_load(rx, vb, 0);
+    }
+    step2();
+  };
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  auto mfma_kp = [&](int d) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][i], rb[d][j],
+                                                         acc[i][j], 0, 0, 0);
+  };
+  // npairs is a multiple of D (Kpad is a multiple of 32, D <= 16)
+  const int nchunks = npairs / D;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    load_kp(d, d);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int c = 1; c < nchunks; ++c) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      mfma_kp(d);
+      __builtin_amdgcn_sched_barrier(0);
+      load_kp(d, c * D + d);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) mfma_kp(d);
+
+  // ---- epilogue (as conv_stream_kernel's, no residual on the stem) ----------
+  const bool relu = a.relu != 0;
+  const bool has_aff = a.scale != nullptr, has_bias = a.bias != nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int rbase = i * 32 + 4 * lk;
+    float sc[16], sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = min(rbase + (r & 3) + 8 * (r >> 2), Cout - 1);
+      sc[r] = has_aff ? a.scale[row] : 1.0f;
+      sh[r] = has_aff ? a.shift[row] : 0.0f;
+      if (has_bias) sh[r] += a.bias[row];
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int jc = n0 + j * 32 + l31;
+      if (jc >= a.J) continue;
+      const int n = jc / a.Pout;
+      const int p = jc - n * a.Pout;
+      const size_t colbase = (size_t)n * Cout * a.Pout + p;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        if (row >= Cout) continue;
+        float v = acc[i][j][r] * sc[r] + sh[r];
+        if (a.residual) v += a.residual[colbase + (size_t)row * a.Pout];
+        if (relu) v = fmaxf(v, 0.0f);
+        a.y[colbase + (size_t)row * a.Pout] = v;
       }
     }
   }
@@ -1584,6 +1750,8 @@ int build_forward(const ld_conv_t* c, const float* x, const void* wt_fwd,
   k.relu = ep ? ep->relu : 0;
   k.y_c8 = ep ? ep->y_c8 : nullptr;
   k.res_c8 = ep ? ep->residual_c8 : nullptr;
+  k.y_raw = ep ? ep->y_raw : nullptr;
+  if (k.y_raw && (k.bias || !y)) return LD_EINVAL;  // raw = acc: no bias, y needed
   if ((k.y_c8 || k.res_c8) && (family == 0 || c->Cout % 8 != 0)) return LD_EINVAL;
   if (k.res_c8 && k.residual) return LD_EINVAL;
   if ((k.scale == nullptr) != (k.shift == nullptr)) return LD_EINVAL;
@@ -1685,7 +1853,7 @@ extern "C" int ld_conv_forward_smallc(const ld_conv_t* c, const float* x,
   k.shift = ep ? ep->shift : nullptr;
   k.residual = ep ? ep->residual : nullptr;
   k.relu = ep ? ep->relu : 0;
-  if (ep && (ep->y_c8 || ep->residual_c8)) return LD_EINVAL;  // bf16 entry points
+  if (ep && (ep->y_c8 || ep->residual_c8 || ep->y_raw)) return LD_EINVAL;
   if ((k.scale == nullptr) != (k.shift == nullptr)) return LD_EINVAL;
   k.N = c->N; k.Cin = c->Cin; k.Cout = c->Cout; k.KH = c->KH; k.KW = c->KW;
   k.g.stride = c->stride; k.g.pad = c->pad; k.Pin = c->Pin; k.Pout = c->Pout;
@@ -1696,6 +1864,26 @@ extern "C" int ld_conv_forward_smallc(const ld_conv_t* c, const float* x,
   if (int e = set_extents(k, (size_t)c->N * c->Cin * c->Pin,
                           (size_t)k.Kpad * c->Cout))
     return e;
+  // streaming stem kernel: all of Cout in one wave tile (32 or 64 channels);
+  // LD_CONV_STEM=0 keeps the round-2 LDS tiling
+  static const bool stem_on = [] {
+    const char* e = getenv("LD_CONV_STEM");
+    return !(e && e[0] == '0');
+  }();
+  if (stem_on && (c->Cout == 64 || c->Cout == 32) && k.Kpad % 32 == 0 &&
+      (size_t)c->N * c->Cout * c->Pout * 4 < (size_t)kOOB) {
+    hipStream_t st = (hipStream_t)stream;
+    // 2 x 2 wave tiles of 32: 64 channels x 64 positions per wave, 4 waves per
+    // workgroup, 8 k-pairs in flight
+    if (c->Cout == 64) {
+      const int nb = (k.J + 4 * 64 - 1) / (4 * 64);
+      hipLaunchKernelGGL((conv_stem_kernel<2, 2, 8>), dim3(nb), dim3(256), 0, st, k);
+    } else {
+      const int nb = (k.J + 4 * 128 - 1) / (4 * 128);
+      hipLaunchKernelGGL((conv_stem_kernel<1, 4, 8>), dim3(nb), dim3(256), 0, st, k);
+    }
+    return (int)hipGetLastError();
+  }
   return launch_igemm<2>(k, (hipStream_t)stream);
 }
 

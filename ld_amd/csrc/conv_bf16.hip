@@ -308,6 +308,7 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_bf16_kernel(ConvK a) {
           float v = 0.0f;
           if (row < Cout) {
             v = acc[i][j][r] * sc[r] + sh[r];
+            if (MODE == 0 && a.y_raw) a.y_raw[colbase + (size_t)row * prow] = acc[i][j][r];
             if (has_res) v += a.residual[colbase + (size_t)row * prow];
             if (MODE == 0 && res8) v += rq[e];
             if (relu) v = fmaxf(v, 0.0f);
@@ -566,6 +567,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile_bf16_kernel(ConvK a) {
           float v = 0.0f;
           if (row < Cout) {
             v = acc[i][j][r] * sc[r] + sh[r];
+            if (MODE == 0 && a.y_raw) a.y_raw[colbase + (size_t)row * prow] = acc[i][j][r];
             if (has_res) v += a.residual[colbase + (size_t)row * prow];
             if (MODE == 0 && res8) v += rq[e];
             if (relu) v = fmaxf(v, 0.0f);
@@ -793,6 +795,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile_c8_kernel(ConvK a) {
           float v = 0.0f;
           if (row < Cout) {
             v = acc[i][j][r] * sc[r] + sh[r];
+            if (MODE == 0 && a.y_raw) a.y_raw[colbase + (size_t)row * prow] = acc[i][j][r];
             if (has_res) v += a.residual[colbase + (size_t)row * prow];
             if (MODE == 0 && res8) v += rq[e];
             if (relu) v = fmaxf(v, 0.0f);

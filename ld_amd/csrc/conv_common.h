@@ -30,6 +30,7 @@ struct ConvK {  // kernel-side view of ld_conv_t + pointers
   int x_c8;               // x is the bf16 channel-blocked image (N, Cin/8, Pin, 8)
   void* y_c8;             // optional: also write y as (N, Cout/8, Pout, 8) bf16
   const void* res_c8;     // optional: residual as a C8 image (then residual == null)
+  float* y_raw;           // optional second output: acc (+ bias) before the affine
   unsigned x_bytes, wt_bytes;  // buffer-descriptor extents
   // MODE 1 (data-gradient of a stride-2 conv, one output-parity class per
   // launch): g.lv[].Hout/Wout/off_out describe the COMPACT grid of the class;

@@ -183,6 +183,13 @@ def set_c8(flag):
 _WGRAD_C8 = [os.environ.get('LD_CONV_WGRAD_C8', '1') == '1']
 
 
+def WGRAD_C8_ON():
+    """Whether weight gradients take C8 operand images (a conv fed by a
+    C8-only activation has no other way to get its weight gradient)."""
+    return _WGRAD_C8[0] and _C8[0] and _PRECISION[0] == 'bf16' and \
+        os.environ.get('LD_STUDENT_C8_ONLY', '1') == '1'
+
+
 def _use_c8(reduction_channels, ksize=3, stride=1, J=1 << 30, x=None):
     """Whether a conv takes the C8 image of its activation operand.  The GEMM
     itself is faster with it everywhere (profiles/r02_kernels_c8.json: head
@@ -525,6 +532,7 @@ def _epilogue(bias=None, scale=None, shift=None, residual=None, relu=False,
     ep.residual_c8 = None
     if isinstance(residual, C8Act):
         ep.residual_c8, residual = residual.buf.data_ptr(), None
+    ep.y_raw = None
     ep.bias = bias.data_ptr() if bias is not None else None
     ep.scale = scale.data_ptr() if scale is not None else None
     ep.shift = shift.data_ptr() if shift is not None else None
@@ -535,7 +543,7 @@ def _epilogue(bias=None, scale=None, shift=None, residual=None, relu=False,
 
 def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
                      shift=None, residual=None, relu=False, emit_c8=False,
-                     c8_only=False):
+                     c8_only=False, y_raw=None):
     """One implicit-GEMM launch.  Returns (y3, out_levels).  ``emit_c8``: in
     bf16 mode also write the C8 image of y from the epilogue (for a y that goes
     straight into another conv: the frozen conv+BN+ReLU chains).  ``c8_only``:
@@ -570,6 +578,12 @@ def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
         y_c8 = torch.empty(N * cout * d.Pout, dtype=torch.bfloat16,
                            device=x3.device)
     ep = _epilogue(bias, scale, shift, residual, relu, y_c8)
+    if y_raw is not None:
+        # second output: the conv result before the affine (ConvBnActFn)
+        if smallc or c8_only or tuple(y_raw.shape) != (N, cout, d.Pout):
+            raise L.LdError('conv: y_raw needs a plain fp32 output of the '
+                            'same shape')
+        ep.y_raw = y_raw.data_ptr()
     c8 = in8 or (bf16 and _use_c8(cin, kh, stride, N * d.Pout, x3))
     fn = lib.ld_conv_forward_smallc if smallc else (
         lib.ld_conv_bf16_forward_c8 if c8 else
@@ -633,6 +647,82 @@ def _emit(p):
 DIRECT_GRADS = [True]
 
 
+def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b):
+    """Data / weight / bias gradients of a conv (shared by ConvFn and the fused
+    ConvBnActFn).  x3: the saved input tensor, or -- x8 given -- its C8Act.
+    Returns (dx, dw, db); dw / db are None when they went straight into the
+    gradient arena."""
+    lib = L.get_lib()
+    if x8 is not None:
+        x3 = x8
+    stride, pad, levels, has_bias = meta
+    dy = dy.contiguous()
+    N, cin, _ = x3.shape
+    cout, _, kh, kw = w.shape
+    d, _ = conv_desc(N, cin, cout, kh, kw, stride, pad, levels)
+    st = L.stream_ptr(dy.device)
+    dx = dw = db = None
+    # bf16 + C8: the weight gradient takes both operands as C8 images
+    # (ld_conv_bf16_wgrad_c8); converting dy first lets the data gradient
+    # below use the same image
+    c8w = need_w and _PRECISION[0] == 'bf16' and \
+        _C8[0] and _WGRAD_C8[0] and cin % 32 == 0 and cout % 32 == 0
+    if c8w:
+        to_c8(dy)
+    if x8 is not None and not c8w:
+        raise L.LdError('a C8-only activation feeds this conv: its weight '
+                        'gradient needs the C8 wgrad kernel (bf16 mode, '
+                        'channel counts % 32 == 0, LD_WGRAD_C8 on)')
+    if need_x:
+        bf16 = _use_bf16(cout)  # the data gradient reduces over Cout
+        _, wt_bwd = weight_images(w, True, bf16=bf16, need_fwd=False)
+        dx = torch.empty((N, cin, d.Pin), dtype=torch.float32,
+                         device=dy.device)
+        c8 = bf16 and _use_c8(cout, kh, stride, N * d.Pin, dy)
+        tune = lib.ld_conv_bf16_tune_dgrad_c8 if c8 else \
+            lib.ld_conv_bf16_tune_dgrad if bf16 else \
+            lib.ld_conv_tune_dgrad
+        dgrad = lib.ld_conv_bf16_dgrad_c8 if c8 else \
+            lib.ld_conv_bf16_dgrad if bf16 else lib.ld_conv_dgrad
+        with _timed('conv_dgrad_bf16' if bf16 else 'conv_dgrad', d):
+            dyin = to_c8(dy) if c8 else dy
+            _tune_once('c8_dgrad' if c8 else
+                       'bf16_dgrad' if bf16 else 'dgrad', d, (),
+                       lambda: tune(C.byref(d), L.ptr(dyin),
+                                    L.ptr(wt_bwd), L.ptr(dx), st))
+            L.check(dgrad(C.byref(d), L.ptr(dyin), L.ptr(wt_bwd),
+                          L.ptr(dx), st), 'ld_conv_dgrad')
+    pw, pb = params
+    if need_w:
+        sink = _sink(pw)
+        dw = sink if sink is not None else torch.empty_like(w)
+        need = lib.ld_conv_wgrad_workspace_bytes(C.byref(d))
+        ws = workspace(dy.device, need, 'wgrad')
+        bf16 = _PRECISION[0] == 'bf16' and cin >= 16
+        wgrad = lib.ld_conv_bf16_wgrad_c8 if c8w else \
+            lib.ld_conv_bf16_wgrad if bf16 else lib.ld_conv_wgrad
+        with _timed('conv_wgrad_bf16' if bf16 else 'conv_wgrad', d):
+            xw, dyw = ((x3.buf if x8 is not None else to_c8(x3)),
+                       to_c8(dy)) if c8w else (x3, dy)
+            L.check(wgrad(C.byref(d), L.ptr(xw), L.ptr(dyw), L.ptr(dw),
+                          0 if sink is None else 1, L.ptr(ws),
+                          ws.numel(), st), 'ld_conv_wgrad')
+        if sink is not None:
+            dw = None
+            _emit(pw)
+    if has_bias and need_b:
+        sink = _sink(pb)
+        db = sink if sink is not None else \
+            torch.empty(cout, dtype=torch.float32, device=dy.device)
+        L.check(lib.ld_bias_grad(L.ptr(dy), N, cout, dy.shape[2],
+                                 L.ptr(db), 0 if sink is None else 1, st),
+                'ld_bias_grad')
+        if sink is not None:
+            db = None
+            _emit(pb)
+    return dx, dw, db
+
+
 class ConvFn(torch.autograd.Function):
     """y = conv(x, w) (+ bias).  backward = MFMA dgrad + split-K wgrad."""
 
@@ -640,7 +730,13 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x3, w, bias, stride, pad, levels):
         y3, out_levels = conv_forward_raw(x3, w, stride, pad, levels,
                                           bias=bias)
-        ctx.save_for_backward(x3, w)
+        # x3 may be a C8Act (bf16 mode: the output of the student's frozen,
+        # C8-only stages): not a tensor -- keep its bf16 image, no gradient
+        ctx.x8 = x3 if isinstance(x3, C8Act) else None
+        if ctx.x8 is not None:
+            ctx.save_for_backward(x3.buf, w)
+        else:
+            ctx.save_for_backward(x3, w)
         ctx.meta = (stride, pad, levels, bias is not None)
         ctx.params = (w, bias)
         _note_use(w, bias)
@@ -648,67 +744,11 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        lib = L.get_lib()
         x3, w = ctx.saved_tensors
-        stride, pad, levels, has_bias = ctx.meta
-        dy = dy.contiguous()
-        N, cin, _ = x3.shape
-        cout, _, kh, kw = w.shape
-        d, _ = conv_desc(N, cin, cout, kh, kw, stride, pad, levels)
-        st = L.stream_ptr(x3.device)
-        dx = dw = db = None
-        # bf16 + C8: the weight gradient takes both operands as C8 images
-        # (ld_conv_bf16_wgrad_c8); converting dy first lets the data gradient
-        # below use the same image
-        c8w = ctx.needs_input_grad[1] and _PRECISION[0] == 'bf16' and \
-            _C8[0] and _WGRAD_C8[0] and cin % 32 == 0 and cout % 32 == 0
-        if c8w:
-            to_c8(dy)
-        if ctx.needs_input_grad[0]:
-            bf16 = _use_bf16(cout)  # the data gradient reduces over Cout
-            _, wt_bwd = weight_images(w, True, bf16=bf16, need_fwd=False)
-            dx = torch.empty_like(x3)
-            c8 = bf16 and _use_c8(cout, kh, stride, N * d.Pin, dy)
-            tune = lib.ld_conv_bf16_tune_dgrad_c8 if c8 else \
-                lib.ld_conv_bf16_tune_dgrad if bf16 else \
-                lib.ld_conv_tune_dgrad
-            dgrad = lib.ld_conv_bf16_dgrad_c8 if c8 else \
-                lib.ld_conv_bf16_dgrad if bf16 else lib.ld_conv_dgrad
-            with _timed('conv_dgrad_bf16' if bf16 else 'conv_dgrad', d):
-                dyin = to_c8(dy) if c8 else dy
-                _tune_once('c8_dgrad' if c8 else
-                           'bf16_dgrad' if bf16 else 'dgrad', d, (),
-                           lambda: tune(C.byref(d), L.ptr(dyin),
-                                        L.ptr(wt_bwd), L.ptr(dx), st))
-                L.check(dgrad(C.byref(d), L.ptr(dyin), L.ptr(wt_bwd),
-                              L.ptr(dx), st), 'ld_conv_dgrad')
-        pw, pb = ctx.params
-        if ctx.needs_input_grad[1]:
-            sink = _sink(pw)
-            dw = sink if sink is not None else torch.empty_like(w)
-            need = lib.ld_conv_wgrad_workspace_bytes(C.byref(d))
-            ws = workspace(x3.device, need, 'wgrad')
-            bf16 = _PRECISION[0] == 'bf16' and cin >= 16
-            wgrad = lib.ld_conv_bf16_wgrad_c8 if c8w else \
-                lib.ld_conv_bf16_wgrad if bf16 else lib.ld_conv_wgrad
-            with _timed('conv_wgrad_bf16' if bf16 else 'conv_wgrad', d):
-                xw, dyw = (to_c8(x3), to_c8(dy)) if c8w else (x3, dy)
-                L.check(wgrad(C.byref(d), L.ptr(xw), L.ptr(dyw), L.ptr(dw),
-                              0 if sink is None else 1, L.ptr(ws),
-                              ws.numel(), st), 'ld_conv_wgrad')
-            if sink is not None:
-                dw = None
-                _emit(pw)
-        if has_bias and ctx.needs_input_grad[2]:
-            sink = _sink(pb)
-            db = sink if sink is not None else \
-                torch.empty(cout, dtype=torch.float32, device=x3.device)
-            L.check(lib.ld_bias_grad(L.ptr(dy), N, cout, dy.shape[2],
-                                     L.ptr(db), 0 if sink is None else 1, st),
-                    'ld_bias_grad')
-            if sink is not None:
-                db = None
-                _emit(pb)
+        dx, dw, db = _conv_backward(
+            x3, ctx.x8, w, dy, ctx.meta, ctx.params,
+            ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+            ctx.needs_input_grad[2])
         return dx, dw, db, None, None, None
 
 
@@ -803,38 +843,117 @@ class BnActFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        lib = L.get_lib()
         x3, y, scale, mean, rstd = ctx.saved_tensors
-        dy = dy.contiguous()
-        N, c, P = x3.shape
-        need_x = ctx.needs_input_grad[0]
-        need_g, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
-        need_res = ctx.has_res and ctx.needs_input_grad[6]
-        dx = torch.empty_like(x3) if need_x else None
-        dres = torch.empty_like(x3) if need_res else None
-        pg, pb = ctx.params
-        sg, sb = _sink(pg), _sink(pb)
-        direct = need_g and need_b and sg is not None and sb is not None
-        if direct:
-            dgamma, dbeta = sg, sb
-        else:
-            dgamma = torch.empty(c, dtype=torch.float32, device=x3.device) \
-                if need_g else None
-            dbeta = torch.empty(c, dtype=torch.float32, device=x3.device) \
-                if need_b else None
-        need = lib.ld_bn_act_backward_workspace_bytes(N, c, P)
-        ws = workspace(x3.device, need, 'bn')
-        L.check(lib.ld_bn_act_backward(
-            L.ptr(dy), L.ptr(y), L.ptr(x3), L.ptr(scale), L.ptr(mean),
-            L.ptr(rstd), N, c, P, 1 if ctx.relu else 0, L.ptr(dx),
-            L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), 1 if direct else 0,
-            L.ptr(ws), ws.numel(), L.stream_ptr(x3.device)),
-            'ld_bn_act_backward')
-        if direct:
-            dgamma = dbeta = None
-            _emit(pg)
-            _emit(pb)
+        ng = ctx.needs_input_grad
+        dx, dres, dgamma, dbeta = _bn_act_backward(
+            dy, x3, y, scale, mean, rstd, ctx.relu, ctx.params, ng[0], ng[1],
+            ng[2], ctx.has_res and ng[6])
         return dx, dgamma, dbeta, None, None, None, dres, None
+
+
+def _bn_act_backward(dy, x3, y, scale, mean, rstd, relu, params, need_x,
+                     need_g, need_b, need_res):
+    """Backward of eval-BN affine (+ residual) + ReLU (shared by BnActFn and the
+    fused ConvBnActFn): x3 = the BN input (conv output), y = its output.
+    Returns (dx, dres, dgamma, dbeta); the parameter gradients are None when
+    they went straight into the gradient arena."""
+    lib = L.get_lib()
+    dy = dy.contiguous()
+    N, c, P = x3.shape
+    dx = torch.empty_like(x3) if need_x else None
+    dres = torch.empty_like(x3) if need_res else None
+    pg, pb = params
+    sg, sb = _sink(pg), _sink(pb)
+    direct = need_g and need_b and sg is not None and sb is not None
+    if direct:
+        dgamma, dbeta = sg, sb
+    else:
+        dgamma = torch.empty(c, dtype=torch.float32, device=x3.device) \
+            if need_g else None
+        dbeta = torch.empty(c, dtype=torch.float32, device=x3.device) \
+            if need_b else None
+    need = lib.ld_bn_act_backward_workspace_bytes(N, c, P)
+    ws = workspace(x3.device, need, 'bn')
+    L.check(lib.ld_bn_act_backward(
+        L.ptr(dy), L.ptr(y), L.ptr(x3), L.ptr(scale), L.ptr(mean),
+        L.ptr(rstd), N, c, P, 1 if relu else 0, L.ptr(dx),
+        L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), 1 if direct else 0,
+        L.ptr(ws), ws.numel(), L.stream_ptr(x3.device)),
+        'ld_bn_act_backward')
+    if direct:
+        dgamma = dbeta = None
+        _emit(pg)
+        _emit(pb)
+    return dx, dres, dgamma, dbeta
+
+
+class ConvBnActFn(torch.autograd.Function):
+    """z = relu?(BN_eval(conv(x, w)) + residual) as ONE forward launch for a
+    TRAINABLE conv / norm pair (round 3; VERDICT round 2, next #1b): the conv
+    epilogue applies the folded eval-mode BN (resnet.py:639-648: norm_eval keeps
+    the running statistics, the affine stays trainable), the residual add and
+    the ReLU, and stores both z and the raw conv result (ld_conv_epilogue_t.
+    y_raw) -- what round 2 did as a conv launch + a BN launch that re-read the
+    conv output.  In bf16 mode the C8 image of z comes out of the same launch.
+    Backward = the BN backward on (dz, z, raw) followed by the conv's data /
+    weight gradients: the same kernels, in the same order, as the unfused
+    pair."""
+
+    @staticmethod
+    def forward(ctx, x3, w, gamma, beta, mean, var, eps, residual, relu, stride,
+                pad, levels):
+        scale, shift, rstd = bn_prepare(gamma, beta, mean, var, eps)
+        N = x3.shape[0]
+        cout, _, kh, kw = w.shape
+        d, _ = conv_desc(N, x3.shape[1], cout, kh, kw, stride, pad, levels)
+        raw = torch.empty((N, cout, d.Pout), dtype=torch.float32,
+                          device=w.device)
+        z, _ = conv_forward_raw(x3, w, stride, pad, levels, scale=scale,
+                                shift=shift, residual=residual, relu=relu,
+                                emit_c8=True, y_raw=raw)
+        ctx.x8 = x3 if isinstance(x3, C8Act) else None
+        ctx.save_for_backward(x3.buf if ctx.x8 is not None else x3, w, raw, z,
+                              scale, mean, rstd)
+        ctx.meta = (stride, pad, levels, False)
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        ctx.params = (w, gamma, beta)
+        _note_use(w, gamma, beta)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x3, w, raw, z, scale, mean, rstd = ctx.saved_tensors
+        pw, pg, pb = ctx.params
+        ng = ctx.needs_input_grad
+        need_conv = ng[0] or ng[1]
+        draw, dres, dgamma, dbeta = _bn_act_backward(
+            dz, raw, z, scale, mean, rstd, ctx.relu, (pg, pb), need_conv,
+            ng[2], ng[3], ctx.has_res and ng[7])
+        dx = dw = None
+        if need_conv:
+            dx, dw, _ = _conv_backward(x3, ctx.x8, w, draw, ctx.meta,
+                                       (pw, None), ng[0], ng[1], False)
+        return (dx, dw, dgamma, dbeta, None, None, None, dres, None, None,
+                None, None)
+
+
+_FUSE_CONV_BN = [os.environ.get('LD_FUSE_CONV_BN', '1') == '1']
+
+
+def conv_bn_act(x3, w, gamma, beta, mean, var, eps, stride, pad, levels,
+                residual=None, relu=True):
+    """Differentiable conv -> eval-BN (+ residual) -> ReLU.  One fused forward
+    launch (ConvBnActFn) unless LD_FUSE_CONV_BN=0 or the stem (Cin < 16, which
+    is frozen in every LD config anyway); returns (z, out_levels)."""
+    N, cin, _ = x3.shape
+    cout, _, kh, kw = w.shape
+    _, out_levels = conv_desc(N, cin, cout, kh, kw, stride, pad, levels)
+    if _FUSE_CONV_BN[0] and cin >= 16:
+        return ConvBnActFn.apply(x3, w, gamma, beta, mean, var, eps, residual,
+                                 relu, stride, pad, levels), out_levels
+    y3, _ = conv2d(x3, w, None, stride, pad, levels)
+    return bn_act(y3, gamma, beta, mean, var, eps, residual, relu), out_levels
 
 
 def bn_act(x3, gamma, beta, mean, var, eps, residual=None, relu=True):

@@ -101,7 +101,8 @@ class ConvEpilogueT(C.Structure):
     _fields_ = [('bias', C.c_void_p), ('scale', C.c_void_p),
                 ('shift', C.c_void_p), ('residual', C.c_void_p),
                 ('relu', C.c_int32), ('reserved', C.c_int32),
-                ('y_c8', C.c_void_p), ('residual_c8', C.c_void_p)]
+                ('y_c8', C.c_void_p), ('residual_c8', C.c_void_p),
+                ('y_raw', C.c_void_p)]
 
 
 class LevelsT(C.Structure):
@@ -155,7 +156,7 @@ def save_tune_table(path):
     return get_lib().ld_conv_tune_save(str(path).encode())
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 _G, _H, _M = C.POINTER(GeomT), C.POINTER(LossHpT), C.POINTER(MapsT)
 _CV, _EP, _LV = C.POINTER(ConvT), C.POINTER(ConvEpilogueT), C.POINTER(LevelsT)

@@ -132,6 +132,10 @@ class GradArena:
             for p in self.params
         ]
         self.enabled = True
+        # optional timeline (tools/profile_step.py --buckets): a HIP event on
+        # the compute stream at the moment each bucket's last gradient is
+        # produced = the earliest its all-reduce can start
+        self.trace = None
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -154,6 +158,10 @@ class GradArena:
         self._seen.add(id(p))
         b = self.bucket_of[id(p)]
         self._ready[b] += 1
+        if self.trace is not None and self._ready[b] == self.buckets[b]['n']:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.trace.append((b, ev))
         if self._ready[b] == self.buckets[b]['n'] and collectives_on():
             bk = self.buckets[b]
             self._works.append(

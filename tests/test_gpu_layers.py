@@ -157,6 +157,19 @@ def test_conv_wgrad_kernels(mode, monkeypatch):
         _close(wd.grad, wr.grad, what=f'{name} wgrad [{mode}]')
 
 
+@pytest.mark.parametrize('shape', [(2, 5, 40, 64), (1, 3, 37, 132), (2, 4, 9, 8),
+                                   (1, 2, 16, 30), (3, 1, 7, 7), (1, 64, 400, 672)])
+def test_maxpool_vector_and_scalar_paths(shape):
+    """max_pool2d(3, 2, 1): the 16-byte-load kernel (W % 4 == 0: two outputs per
+    thread, left column by lane shuffle) and the scalar fallback, bit-exact
+    against torch on CPU (a max has no rounding)."""
+    from ld_amd import layers as Y
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g)
+    got = Y.maxpool3x3s2(x.to(_dev())).cpu()
+    assert torch.equal(got, F.max_pool2d(x, 3, 2, 1))
+
+
 def test_conv_fused_epilogue_and_stem():
     from ld_amd import layers as Y
     dev = _dev()
@@ -304,3 +317,50 @@ def test_scale_levels_and_sgd():
         opt.step()
         Y.sgd_step(pd, gr.to(dev), buf, 0.01, 0.9, 1e-4)
     _close(pd, pr, rtol=1e-5, atol_rel=1e-6, what='sgd')
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('case', [  # cin, cout, k, stride, (h, w), residual, relu
+    (64, 64, 3, 1, (20, 28), False, True), (64, 256, 1, 1, (20, 28), True, True),
+    (128, 128, 3, 2, (21, 27), False, True), (256, 512, 1, 2, (16, 12), False, False),
+])
+def test_fused_conv_bn_matches_unfused_pair(mode, case):
+    """layers.ConvBnActFn (one forward launch: conv with the folded eval-BN,
+    residual and ReLU in its epilogue + the raw conv result) against the
+    round-2 pair conv2d -> bn_act on the same inputs: the same output and the
+    same gradients for x, w, gamma, beta and the residual.  Both sides run the
+    same conv / BN-backward kernels; only the forward affine moves into the conv
+    epilogue (fp32 operation order may differ by one rounding)."""
+    from ld_amd import layers as Y
+    cin, cout, k, stride, (h, w_), has_res, relu = case
+    dev = _dev()
+    g = torch.Generator().manual_seed(cin + cout + k)
+    x = torch.randn(2, cin, h * w_, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k)**0.5
+    gamma, beta = torch.rand(cout, generator=g) + .5, torch.randn(cout, generator=g)
+    mean, var = torch.randn(cout, generator=g) * .1, torch.rand(cout, generator=g) + .5
+    ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w_ + 2 * (k // 2) - k) // stride + 1
+    res = torch.randn(2, cout, ho * wo, generator=g) if has_res else None
+    go = torch.randn(2, cout, ho * wo, generator=g)
+    Y.set_precision(mode)
+    outs = []
+    try:
+        for fused in (False, True):
+            Y._FUSE_CONV_BN[0] = fused
+            leaves = [t.to(dev).requires_grad_(True) for t in (x, wt, gamma, beta)]
+            r = res.to(dev).requires_grad_(True) if has_res else None
+            z, lv = Y.conv_bn_act(leaves[0], leaves[1], leaves[2], leaves[3],
+                                  mean.to(dev), var.to(dev), 1e-5, stride, k // 2,
+                                  ((h, w_), ), r, relu)
+            assert lv == ((ho, wo), )
+            z.backward(go.to(dev))
+            outs.append([z.detach().cpu()] + [t.grad.cpu() for t in leaves] +
+                        ([r.grad.cpu()] if has_res else []))
+    finally:
+        Y._FUSE_CONV_BN[0] = True
+        Y.set_precision('fp32')
+    names = ['z', 'dx', 'dw', 'dgamma', 'dbeta', 'dres']
+    for nm, a, b in zip(names, outs[0], outs[1]):
+        sc = float(a.abs().max()) + 1e-12
+        err = float((a - b).abs().max())
+        assert err <= 2e-5 * sc, (nm, err, sc)

@@ -115,3 +115,32 @@ def test_retina_pseudo_image_views_share_memory():
     # a contiguous gradient in the pseudo layout IS the (N, 720, H, W) gradient
     g = torch.randn(N * 9, 80, 6, 5)
     assert torch.equal(g.view(N, 720, 6, 5)[1, 4 * 80 + 17], g[1 * 9 + 4, 17])
+
+
+def test_student_frozen_stages_run_c8_only_decision():
+    """bf16 mode: a training student's frozen leading stages (frozen_stages = 1)
+    run C8-only like the teacher's trunk; never in fp32 mode, under no_grad
+    (inference keeps fp32 masters), or for the teacher-flagged backbone (its
+    whole trunk already is)."""
+    import torch
+    from ld_amd import layers as Y
+    from ld_amd import model_zoo
+    from ld_amd.registry import build_backbone
+    net = build_backbone(model_zoo._backbone(50)).train()
+    assert net._frozen_c8_stages() == 0  # fp32 mode
+    Y.set_precision('bf16')
+    try:
+        assert net._frozen_c8_stages() == 1
+        with torch.no_grad():
+            assert net._frozen_c8_stages() == 0
+        net.c8_activations = True
+        assert net._frozen_c8_stages() == 0
+        net.c8_activations = False
+        r18 = build_backbone(model_zoo._backbone(18)).train()
+        # 64-channel BasicBlock stages: multiples of 32 -> eligible as well
+        assert r18._frozen_c8_stages() == 1
+        unfrozen = build_backbone(dict(model_zoo._backbone(50),
+                                       frozen_stages=-1)).train()
+        assert unfrozen._frozen_c8_stages() == 0
+    finally:
+        Y.set_precision('fp32')

@@ -1,5 +1,5 @@
 """Run one conv shape a few times (for rocprofv3 --pmc runs):
-    python tools/one_conv.py <shape> [fwd|dgrad|wgrad]
+    python tools/one_conv.py <shape> [fwd|fwd_bn_res|dgrad|wgrad]
 LD_CONV_STREAM / LD_CONV_WGRAD in the environment force a kernel shape."""
 import ctypes as C
 import os
@@ -32,7 +32,17 @@ lib = L.get_lib()
 d, out_levels = Y.conv_desc(N, cin, cout, k, k, s, p, levels)
 go = torch.randn(N, cout, d.Pout, device=dev)
 st = L.stream_ptr(dev)
-if kind == 'fwd':
+if kind == 'fwd_bn_res':
+    # the frozen teacher's bottleneck tail: conv -> folded BN -> + identity ->
+    # ReLU in one launch (resnet._conv_bn / layers.conv_bn_act_infer)
+    scale = torch.rand(cout, device=dev) + 0.5
+    shift = torch.randn(cout, device=dev) * 0.1
+    res = torch.randn(N, cout, d.Pout, device=dev)
+
+    def run():
+        Y.conv_forward_raw(x, w, s, p, levels, scale=scale, shift=shift,
+                           residual=res, relu=True)
+elif kind == 'fwd':
     def run():
         Y.conv_forward_raw(x, w, s, p, levels)
 elif kind == 'dgrad':

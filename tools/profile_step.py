@@ -21,6 +21,10 @@ def main():
     ap.add_argument('--graph', action='store_true')
     ap.add_argument('--pipeline', action='store_true',
                     help='teacher of the next batch under this step')
+    ap.add_argument('--buckets', default='',
+                    help='write the gradient-bucket timeline (when each '
+                         'bucket of the arena is complete, relative to '
+                         'backward) here')
     ap.add_argument('--layers', default='',
                     help='write the per-layer conv table (HIP events around '
                          'every conv launch, teacher on the main stream) here')
@@ -63,6 +67,49 @@ def main():
         Y.C8_STATS.update(converted=0, reused=0)
         run()
         print('C8 operand images per step:', Y.C8_STATS)
+    if args.buckets:
+        # How much of backward is left to hide each bucket's all-reduce behind.
+        # (On ONE rank RCCL launches no kernel for an in-place all-reduce --
+        # profiles/r03_overlap_trace_1rank_no_rccl_kernels.txt -- so kernel
+        # concurrency itself can only be traced on a multi-GPU node.)
+        rows = []
+        for _ in range(args.steps):
+            tr.arena.trace = []
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            tr.arena.zero_grad()
+            head = det.bbox_head
+            head.unit_upstream = True
+            losses = det(**d)
+            loss, _ = det._parse_losses(losses)
+            e0.record()
+            loss.backward()
+            e1.record()
+            head.unit_upstream = False
+            tr.arena.finish()
+            Y.sgd_step(tr.arena.flat_param, tr.arena.flat_grad,
+                       tr.flat_momentum, tr.lr, tr.momentum, tr.weight_decay)
+            e2.record()
+            torch.cuda.synchronize()
+            bw = e0.elapsed_time(e1)
+            rows.append((bw, [(b, e0.elapsed_time(ev))
+                              for b, ev in tr.arena.trace]))
+        tr.arena.trace = None
+        with open(args.buckets, 'w') as f:
+            f.write('# gradient-bucket timeline, %s, C2 step: bucket, MiB, '
+                    'ready at (ms after backward starts), backward left (ms), '
+                    'fraction of backward left\n' % args.mode)
+            bw = sorted(r[0] for r in rows)[len(rows) // 2]
+            f.write('# backward = %.2f ms (median of %d steps); ring all-reduce '
+                    'of B bytes over 8 GPUs moves 2*7/8*B per GPU: at ~300 '
+                    'GB/s effective a 32 MiB bucket needs ~0.2 ms\n'
+                    % (bw, len(rows)))
+            last = rows[-1][1]
+            for b, t in last:
+                bk = tr.arena.buckets[b]
+                mib = (bk['end'] - bk['start']) * 4 / 2**20
+                f.write('%d,%.1f,%.2f,%.2f,%.3f\n'
+                        % (b, mib, t, rows[-1][0] - t, 1 - t / rows[-1][0]))
+        print(open(args.buckets).read())
     if args.layers:
         det.use_teacher_stream = False
         tr.step(d)

@@ -24,6 +24,9 @@ def main():
     ap.add_argument('--student', type=int, default=50)
     ap.add_argument('--fresh', action='store_true',
                     help='forget the shipped table first (retune everything)')
+    ap.add_argument('--fresh-family', type=int, default=-1,
+                    help='forget only the records of this kernel family (0 = '
+                    'fp32 streaming) and retune those')
     args = ap.parse_args()
     os.environ.setdefault('LD_CONV_TUNE_LOG', '1')
     from ld_amd import layers as Y
@@ -40,6 +43,19 @@ def main():
     Y.autotune(True)
     if args.fresh:
         L.get_lib().ld_conv_tune_clear()
+    elif args.fresh_family >= 0:
+        # keep the other families' records: dump, filter, reload
+        tmp = args.out + '.keep'
+        os.makedirs(os.path.dirname(tmp), exist_ok=True)
+        L.save_tune_table(tmp)
+        keep = [ln for ln in open(tmp)
+                if ln.startswith('#') or not ln.strip() or
+                int(ln.split()[16]) != args.fresh_family]
+        with open(tmp, 'w') as f:
+            f.writelines(keep)
+        L.get_lib().ld_conv_tune_clear()
+        L.get_lib().ld_conv_tune_load(tmp.encode())
+        os.remove(tmp)
     # the teacher must not run concurrently while candidates are being timed
     det.use_teacher_stream = False
     for mode in args.modes.split(','):
