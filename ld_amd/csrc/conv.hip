@@ -689,6 +689,155 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_kernel(ConvK a) {
   }
 }
 
+// ------------------------------------ 1x1 convs: vector operand loads -------
+// PMC of the R101 teacher's 256 -> 1024 1x1 conv at 50x84 (round 3,
+// profiles/r03_pmc_teacher_1x1_256_1024.txt: 2.39 GHz, MFMA busy 43 %, TA busy
+// 59 % of the kernel): with 32x32 wave tiles the streaming kernel issues two
+// 4-byte wave loads per MFMA and each costs the texture-address unit ~9 cycles
+// -- 73 TA cycles per 64 MFMA cycles per CU: the VECTOR-MEMORY ISSUE RATE, not
+// the matrix pipe, not HBM, bounds the small-tile shapes the tuner has to pick
+// on the 50x84 / 25x42 stages.  For a 1x1, stride-1 conv the B operand has no
+// taps: the GEMM column j IS the input position, so one lane can take VEC
+// consecutive positions of a channel row in ONE 8/16-byte load and feed VEC
+// MFMA column tiles from it -- tile e of a wave = the columns {j0 + VEC*l + e}
+// (a strided set; the GEMM does not care, and the epilogue then owns VEC
+// consecutive positions per accumulator row: 8/16-byte stores and residual
+// loads, cdna_hip_programming.md T21).  Loads per k-pair and wave: TM + 1 for
+// TM*VEC MFMAs (1x1 tile before: 2 per MFMA).  Same reduction order (channel
+// ascending, one accumulator per output): same bits as the KS = 1 shapes.
+// Table code: ks = 2, tn = VEC.
+template <int VEC>
+struct VecF;
+template <>
+struct VecF<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <>
+struct VecF<4> { typedef float T __attribute__((ext_vector_type(4))); };
+
+template <int VEC>
+__device__ __forceinline__ typename VecF<VEC>::T buf_load_vec(rsrc_t r, unsigned voff,
+                                                             unsigned soff) {
+  typedef typename VecF<VEC>::T V;
+  if constexpr (VEC == 2)
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+  else
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+template <int TM, int VEC, int WVM, int D>
+__global__ __launch_bounds__(256, 2) void conv1x1_vec_kernel(ConvK a) {
+  static_assert(D * (TM + 1) < 64, "ring exceeds the 6-bit vmcnt counter");
+  typedef typename VecF<VEC>::T V;
+  constexpr int WVN = 4 / WVM;
+  constexpr int WM = TM * 32, WN = VEC * 32;
+  constexpr int BM = WVM * WM, BNT = WVN * WN;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wm = wave / WVN, wn = wave % WVN;
+  const int l31 = lane & 31, lk = lane >> 5;
+  const int mtiles = (a.Cout + BM - 1) / BM;
+  const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int m0 = (tile % mtiles) * BM + wm * WM;
+  const int n0 = (tile / mtiles) * BNT + wn * WN;
+  if (m0 >= a.Cout || n0 >= a.J) return;  // waves are independent: no barriers
+
+  const int Cin = __builtin_amdgcn_readfirstlane(a.Cin);
+  const int Cout = __builtin_amdgcn_readfirstlane(a.Cout);
+  const int P = __builtin_amdgcn_readfirstlane(a.Pin);  // == Pout
+
+  // this lane's VEC consecutive columns (P % VEC == 0: never across images)
+  const int jg = n0 + VEC * l31;
+  const bool jok = jg < a.J;
+  const int n = jok ? jg / P : 0, p = jok ? jg - (jg / P) * P : 0;
+  const unsigned vb = jok ? (unsigned)(n * Cin * P + p + lk * P) * 4u : kOOB;
+  unsigned va[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int co = m0 + i * 32 + l31;
+    va[i] = co < Cout ? (unsigned)(lk * Cout + co) * 4u : kOOB;
+  }
+  const rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  const rsrc_t rw = make_rsrc(a.wt, a.wt_bytes);
+
+  float ra[D][TM];
+  V rb[D];
+  auto load_kp = [&](int d, unsigned sa, unsigned sb) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ra[d][i] = buf_load(rw, va[i], sa);
+    rb[d] = buf_load_vec<VEC>(rx, vb, sb);
+  };
+  floatx16 acc[TM][VEC];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][e][r] = 0.0f;
+  auto mfma_kp = [&](int d) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        acc[i][e] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][i], rb[d][e], acc[i][e],
+                                                         0, 0, 0);
+  };
+  const int nchunks = Cin / (2 * D);  // host guarantees Cin % (2*D) == 0
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    load_kp(d, (unsigned)(2 * d) * Cout * 4u, (unsigned)(2 * d) * P * 4u);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int c = 1; c < nchunks; ++c) {
+    const unsigned sa = (unsigned)(c * 2 * D) * Cout * 4u;
+    const unsigned sb = (unsigned)(c * 2 * D) * P * 4u;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      mfma_kp(d);
+      __builtin_amdgcn_sched_barrier(0);
+      load_kp(d, sa + (unsigned)(2 * d) * Cout * 4u, sb + (unsigned)(2 * d) * P * 4u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) mfma_kp(d);
+
+  // ---- epilogue: VEC consecutive positions per accumulator row ---------------
+  if (!jok) return;
+  const bool has_res = a.residual != nullptr;
+  const bool relu = a.relu != 0;
+  const bool has_aff = a.scale != nullptr, has_bias = a.bias != nullptr;
+  const size_t colbase = (size_t)n * Cout * P + p;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int rbase = m0 + i * 32 + 4 * lk;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rbase + (r & 3) + 8 * (r >> 2);
+      if (row >= Cout) continue;
+      const float sc = has_aff ? a.scale[row] : 1.0f;
+      float sh = has_aff ? a.shift[row] : 0.0f;
+      if (has_bias) sh += a.bias[row];
+      const size_t o = colbase + (size_t)row * P;
+      V raw, v;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        raw[e] = acc[i][e][r];
+        v[e] = raw[e] * sc + sh;
+      }
+      if (a.y_raw) *reinterpret_cast<V*>(a.y_raw + o) = raw;
+      if (has_res) {
+        const V q = *reinterpret_cast<const V*>(a.residual + o);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] += q[e];
+      }
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.0f);
+      }
+      *reinterpret_cast<V*>(a.y + o) = v;
+    }
+  }
+}
+
 // ---------------------------------------------- the 7x7 stem, streaming ----
 // Small-Cin forward conv (the ResNet stem: 3 -> 64, 7x7, stride 2, pad 3 --
 // resnet.py:536-548) with the FLAT reduction index k = (ci, kh, kw), in the
@@ -1338,9 +1487,14 @@ struct StreamCfg {
   X(1, 1, 1, 16, 1) X(1, 1, 2, 16, 1) X(1, 1, 4, 16, 1) X(2, 1, 2, 16, 1)          \
   X(1, 2, 2, 16, 1) X(2, 1, 1, 16, 1) X(1, 1, 1, 16, 4) X(2, 1, 1, 16, 4)          \
   X(1, 2, 1, 16, 4)
+// ks = 2: conv1x1_vec_kernel (1x1 stride-1 convs only), tn = positions per lane
+#define LD_VEC_SHAPES(X)                                                           \
+  X(1, 4, 1, 8, 2) X(1, 4, 2, 8, 2) X(1, 4, 4, 8, 2) X(2, 4, 1, 8, 2)              \
+  X(2, 4, 2, 8, 2) X(1, 2, 1, 8, 2) X(1, 2, 2, 8, 2) X(1, 2, 4, 8, 2)              \
+  X(2, 2, 2, 8, 2) X(1, 4, 2, 16, 2) X(1, 4, 4, 16, 2) X(1, 2, 4, 16, 2)
 constexpr StreamCfg kStreamCfgs[] = {
 #define LD_STREAM_ROW(TM_, TN_, WVM_, D_, KS_) {TM_, TN_, WVM_, D_, KS_},
-    LD_STREAM_SHAPES(LD_STREAM_ROW)
+    LD_STREAM_SHAPES(LD_STREAM_ROW) LD_VEC_SHAPES(LD_STREAM_ROW)
 #undef LD_STREAM_ROW
 };
 constexpr int kNumStreamCfgs = sizeof(kStreamCfgs) / sizeof(kStreamCfgs[0]);
@@ -1378,8 +1532,20 @@ int launch_stream_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream,
                        dim3(nb), dim3(256), lds, stream, k);                       \
     return (int)hipGetLastError();                                                 \
   }
-  LD_STREAM_SHAPES(LD_STREAM_CASE)
+  if (c.ks != 2) {
+    LD_STREAM_SHAPES(LD_STREAM_CASE)
+  }
 #undef LD_STREAM_CASE
+  if constexpr (MODE == 0) {
+#define LD_VEC_CASE(TM_, TN_, WVM_, D_, KS_)                                       \
+  if (c.ks == 2 && c.tm == TM_ && c.tn == TN_ && c.wvm == WVM_ && c.d == D_) {     \
+    hipLaunchKernelGGL((conv1x1_vec_kernel<TM_, TN_, WVM_, D_>), dim3(nb), dim3(256), lds, \
+                       stream, k);                                                 \
+    return (int)hipGetLastError();                                                 \
+  }
+    LD_VEC_SHAPES(LD_VEC_CASE)
+#undef LD_VEC_CASE
+  }
   return LD_EUNSUPPORTED;
 }
 
@@ -1387,6 +1553,21 @@ int launch_stream_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream,
 inline bool stream_cfg_fits(const ConvK& k, const StreamCfg& c) {
   if (c.wvm < 1) return false;
   if (k.Cin % (2 * c.d) != 0) return false;
+  if (c.ks == 2) {
+    // vector 1x1 kernel: no taps, no stride, columns == input positions, and
+    // every row of x / y / residual / y_raw aligned for tn-float accesses
+    if (k.KH != 1 || k.KW != 1 || k.g.stride != 1 || k.g.pad != 0 || k.nth > 0 ||
+        k.Pin != k.Pout || k.Pout % c.tn != 0 || k.x_c8 || k.y_c8 || k.res_c8)
+      return false;
+    const uintptr_t m = (uintptr_t)(c.tn * 4 - 1);
+    if ((((uintptr_t)k.x | (uintptr_t)k.y | (uintptr_t)k.residual |
+          (uintptr_t)k.y_raw) & m) != 0)
+      return false;
+    const int bmv = c.wvm * c.tm * 32, cout32v = (k.Cout + 31) / 32 * 32;
+    if (c.wvm > 1 && bmv > cout32v) return false;
+    if (c.wvm == 1 && c.tm * 32 >= cout32v + 32) return false;
+    return true;
+  }
   if (c.d == 4 && k.Cin % 16 == 0) return false;  // the 8-deep ring covers it
   const int bm = c.wvm * c.tm * 32;
   const int cout32 = (k.Cout + 31) / 32 * 32;
@@ -1406,6 +1587,7 @@ inline int stream_cfg_model(const ConvK& k) {
   double best_t = 0;
   for (int i = 0; i < kNumStreamCfgs; ++i) {
     const StreamCfg& c = kStreamCfgs[i];
+    if (c.ks == 2) continue;  // the vector 1x1 shapes are used where TUNED
     if (!stream_cfg_fits(k, c)) continue;
     const int bm = (c.ks == 4 ? 1 : c.wvm) * c.tm * 32;
     const int bn = (c.ks == 4 ? 1 : 4 / c.wvm) * c.tn * 32;
@@ -1472,6 +1654,12 @@ int launch_stream(const ConvK& k, hipStream_t stream) {
   int cap = 0;
   const int pick = pick_stream_cfg<MODE>(k, &forced, &cap);
   if (pick == -1) return LD_EUNSUPPORTED;
+  if (pick == -2 && forced.ks == 2 && !stream_cfg_fits(k, forced)) {
+    // a forced vector-1x1 shape on a conv it cannot serve (taps, stride,
+    // alignment): the model's pick instead
+    const int m = stream_cfg_model(k);
+    return m < 0 ? LD_EUNSUPPORTED : launch_stream_cfg<MODE>(k, kStreamCfgs[m], stream);
+  }
   if (pick == -2) {
     const int rc = launch_stream_cfg<MODE>(k, forced, stream, cap);
     if (rc != LD_EUNSUPPORTED) return rc;

@@ -134,6 +134,56 @@ def test_conv_stream_shapes(shape, monkeypatch):
         _close(xd.grad, xr.grad, what=f'{name} dgrad [{shape}]')
 
 
+VEC_SHAPES = ['1x4x1x8x2', '1x4x2x8x2', '1x4x4x8x2', '2x4x1x8x2', '2x4x2x8x2',
+              '1x2x1x8x2', '1x2x2x8x2', '1x2x4x8x2', '2x2x2x8x2', '1x4x2x16x2',
+              '1x4x4x16x2', '1x2x4x16x2']
+VEC_CASES = [  # N, cin, cout, (h, w): 1x1 stride-1 convs
+    (2, 256, 1024, (50, 84)), (2, 64, 256, (20, 28)), (1, 1024, 256, (25, 42)),
+    (2, 512, 128, (13, 22)), (1, 128, 80, (9, 12)), (2, 32, 96, (7, 11)),
+]
+
+
+@pytest.mark.parametrize('shape', VEC_SHAPES)
+def test_conv1x1_vector_shapes(shape, monkeypatch):
+    """conv1x1_vec_kernel (vector operand loads, strided column tiles, 8/16-byte
+    epilogue): forward, data gradient, and the fused BN / residual / ReLU /
+    raw-output epilogue, against F.conv2d.  Cases whose position count is not a
+    multiple of the vector width (25x42, 7x11) must fall back to another shape
+    and still be right."""
+    from ld_amd import layers as Y
+    monkeypatch.setenv('LD_CONV_STREAM', shape)
+    dev = _dev()
+    for N, cin, cout, (h, w_) in VEC_CASES:
+        g = torch.Generator().manual_seed(cin + cout)
+        x = torch.randn(N, cin, h * w_, generator=g)
+        w = torch.randn(cout, cin, 1, 1, generator=g) / cin**0.5
+        xr, wr = (t.clone().requires_grad_(True) for t in (x, w))
+        ref = F.conv2d(xr.view(N, cin, h, w_), wr).reshape(N, cout, -1)
+        go = torch.randn(ref.shape, generator=g)
+        ref.backward(go)
+        xd, wd = (t.to(dev).requires_grad_(True) for t in (x, w))
+        y, _ = Y.conv2d(xd, wd, None, 1, 0, ((h, w_), ))
+        _close(y, ref, what=f'1x1 {cin}>{cout} fwd [{shape}]')
+        y.backward(go.to(dev))
+        _close(xd.grad, xr.grad, what=f'1x1 {cin}>{cout} dgrad [{shape}]')
+        # fused epilogue incl. the raw second output
+        gamma, beta = torch.rand(cout, generator=g) + .5, torch.randn(cout, generator=g)
+        mean, var = torch.randn(cout, generator=g) * .1, torch.rand(cout, generator=g) + .5
+        res = torch.randn(N, cout, h * w_, generator=g)
+        gr = gamma.clone().requires_grad_(True)
+        refz = F.relu(F.batch_norm(ref.detach().view(N, cout, h, w_), mean, var, gr,
+                                   beta, False, 0.0, 1e-5).reshape(N, cout, -1) + res)
+        refz.backward(go)
+        gd = gamma.to(dev).requires_grad_(True)
+        z, _ = Y.conv_bn_act(x.to(dev).requires_grad_(True), w.to(dev), gd,
+                             beta.to(dev), mean.to(dev), var.to(dev), 1e-5, 1, 0,
+                             ((h, w_), ), res.to(dev), True)
+        _close(z, refz, what=f'1x1 {cin}>{cout} conv+bn+res+relu [{shape}]')
+        z.backward(go.to(dev))  # d(gamma) reads the raw second output
+        _close(gd.grad, gr.grad, rtol=1e-3, atol_rel=1e-4,
+               what=f'1x1 {cin}>{cout} dgamma via y_raw [{shape}]')
+
+
 @pytest.mark.parametrize('mode', ['0', '16', '32'])
 def test_conv_wgrad_kernels(mode, monkeypatch):
     """Weight gradient under each kernel (LD_CONV_WGRAD: 0 = workgroup tiles,

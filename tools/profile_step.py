@@ -52,8 +52,26 @@ def main():
         g = GraphedStep(tr, d)
         run = g.replay
     else:
-        run = (lambda: tr.step(d, next_data=d)) if args.pipeline else \
-            (lambda: tr.step(d))  # noqa: E731
+        if args.pipeline:
+            # three DISTINCT batch tensors in rotation: step i trains on batch
+            # i and enqueues the teacher of batch i + 1 under it
+            ring = [d]
+            for sd in (77, 78):
+                bb = synthetic.synthetic_batch(2, (800, 1333), (800, 1344), 7, sd)
+                ring.append(dict(img=bb['img'].to(dev), img_metas=bb['img_metas'],
+                                 gt_bboxes=[x.to(dev) for x in bb['gt_bboxes']],
+                                 gt_labels=[x.to(dev) for x in bb['gt_labels']]))
+            state = dict(i=0)
+
+            def run():
+                i = state['i']
+                state['i'] = i + 1
+                return tr.step(ring[i % 3], next_data=ring[(i + 1) % 3])
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+        else:
+            run = lambda: tr.step(d)  # noqa: E731
     import time
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -62,7 +80,9 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     print(f'{args.mode} graph={args.graph} pipeline={args.pipeline}: '
           f'{dt * 1e3:.2f} ms/step, '
-          f'{2 / dt:.1f} img/s')
+          f'{2 / dt:.1f} img/s'
+          + (f' (teacher prefetch hits {getattr(det, "prefetch_hits", 0)})'
+             if args.pipeline else ''))
     if args.mode == 'bf16':
         Y.C8_STATS.update(converted=0, reused=0)
         run()
