@@ -106,6 +106,7 @@ def kernel_roofline(trainer, dbatch, steps, bf16=False):
         for _ in range(steps):
             trainer.step(dbatch)
     agg = prof.summary()
+    alg_bytes = prof.algorithmic_bytes()
     model.use_teacher_stream = prev
     by_kind = {k: dict(ms_per_step=v[0] / steps * 1e3,
                        tflops=v[1] / v[0] / 1e12 if v[0] else 0.0,
@@ -128,10 +129,17 @@ def kernel_roofline(trainer, dbatch, steps, bf16=False):
     out = dict(
         kernel=kernel, bound='mfma', achieved=ach, peak=peak,
         unit='TFLOP/s', frac=ach / peak,
-        traffic=None,
-        traffic_note='not measured inside bench.py; PMC passes of the conv '
-                     'kernels are under profiles/ (rocprofv3 --pmc, separate '
-                     'runs)',
+        traffic=None if bf16 else PMC_CONV_TRAFFIC_BYTES_PER_LAUNCH,
+        algorithmic_bytes_per_launch=alg_bytes / max(tot_n, 1),
+        traffic_note=(
+            'bf16: not collected' if bf16 else
+            'HBM bytes per conv launch, averaged over all 1 412 conv launches '
+            'of this very step (fwd + dgrad + wgrad): rocprofv3 --pmc '
+            'FETCH_SIZE (x 2, MI355X_MICROARCH.md) and WRITE_SIZE in separate '
+            'passes of tools/profile_step.py, '
+            'profiles/r03_pmc_traffic_conv_step_fp32.txt; '
+            'algorithmic_bytes_per_launch = both operands + the output once, '
+            'from the launches timed here; not re-measured inside bench.py'),
         launches_per_step=tot_n / steps,
         avg_launch_us=tot_t / max(tot_n, 1) * 1e6,
         conv_ms_per_step=tot_t / steps * 1e3,
@@ -203,9 +211,13 @@ def _median_launch_us(launch, warm, iters):
     return ts[len(ts) // 2], ts[0]
 
 
-# profiles/r02_pmc_traffic/pmc_traffic_regdense.txt: FETCH_SIZE 1 212 533.8 KB
-# (x 2, gfx950 correction) + WRITE_SIZE 1 120 262.4 KB per launch at 2^24 rows
-PMC_LDKL_TRAFFIC_BYTES = (2 * 1212533.8 + 1120262.4) * 1024.0
+# profiles/r03_pmc_traffic_regdense.txt (the round-3 kernel): FETCH_SIZE
+# 1 212 475.4 KB (x 2, gfx950 correction) + WRITE_SIZE 1 115 649.4 KB per launch
+# at 2^24 rows
+PMC_LDKL_TRAFFIC_BYTES = (2 * 1212475.4 + 1115649.4) * 1024.0
+# profiles/r03_pmc_traffic_conv_step_fp32.txt: per conv launch of the fp32 step,
+# averaged over 1 412 launches: FETCH_SIZE 27 172.4 KB (x 2) + WRITE_SIZE 22 754.4 KB
+PMC_CONV_TRAFFIC_BYTES_PER_LAUNCH = (2 * 27172.4 + 22754.4) * 1024.0
 
 
 def hbm_ceilings(dev):
@@ -281,9 +293,10 @@ def ldkl_roofline(dev):
                 traffic_note='HBM bytes per launch of THIS kernel at THIS size '
                              'from separate rocprofv3 --pmc passes (FETCH_SIZE '
                              'x 2 per MI355X_MICROARCH.md + WRITE_SIZE), '
-                             'profiles/r02_pmc_traffic/ (tools/pmc_traffic.sh '
-                             '+ tools/one_regdense.py): 1.05 x the algorithmic '
-                             'bytes; not re-measured inside bench.py',
+                             'profiles/r03_pmc_traffic_regdense.txt '
+                             '(tools/pmc_traffic.sh + tools/one_regdense.py): '
+                             '1.04 x the algorithmic bytes; not re-measured '
+                             'inside bench.py',
                 rows=rows, bytes_per_row=bytes_per_row, us=us, us_min=us_min,
                 us_vlr_density_0p09=us_sparse,
                 c2_rows=rows_c2, c2_us=us_c2)

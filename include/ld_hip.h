@@ -619,6 +619,16 @@ int ld_bn_act_backward(const float* dy, const float* y, const float* x,
                        float* dgamma, float* dbeta, int accumulate,
                        void* workspace, size_t workspace_bytes,
                        ld_stream_t stream);
+/* The same with the bf16 channel-blocked image of dx as a side output (bf16
+ * mode: dx feeds the conv's C8 data- / weight-gradient kernels directly, no
+ * conversion launch).  C % 8 == 0, P % 4 == 0, 16-byte aligned tensors,
+ * N * ceil(P / 1024) <= 64 partial slots; LD_EUNSUPPORTED otherwise (use the
+ * plain form + ld_conv_to_c8). */
+int ld_bn_act_backward_c8(const float* dy, const float* y, const float* x,
+                          const float* scale, const float* mean, const float* rstd,
+                          int N, int C, int P, int relu, float* dx, void* dx_c8,
+                          float* dres, float* dgamma, float* dbeta, int accumulate,
+                          void* workspace, size_t workspace_bytes, ld_stream_t stream);
 /* db[c] = sum_{n,p} dy (conv bias gradient, fpn.py / gfl_cls / gfl_reg). */
 int ld_bias_grad(const float* dy, int N, int C, int P, float* db, int accumulate,
                  ld_stream_t stream);

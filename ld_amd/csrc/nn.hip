@@ -245,7 +245,22 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(
     return;
   }
   double s = 0.0, q = 0.0;
+  // 16-byte loads on the aligned body of the slice (round 3: the scalar loop ran
+  // at 1.8 TB/s), scalar on its <= 3-cell edges
+  const bool al = ((uintptr_t)base % 16 == 0) && (lv.P % 4 == 0);
+  const int b0 = al ? min((beg + 3) & ~3, end) : end;
+  const int b1 = al ? max(end & ~3, b0) : end;
+  for (int p = b0 + 4 * (int)threadIdx.x; p < b1; p += 1024) {
+#pragma unroll 8
+    for (int ch = 0; ch < cpg; ++ch) {
+      const float4 t = *reinterpret_cast<const float4*>(base + (size_t)ch * lv.P + p);
+      const double v0 = t.x, v1 = t.y, v2 = t.z, v3 = t.w;
+      s += (v0 + v1) + (v2 + v3);
+      q += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+    }
+  }
   for (int p = beg + threadIdx.x; p < end; p += 256) {
+    if (p >= b0 && p < b1) continue;
 #pragma unroll 8
     for (int ch = 0; ch < cpg; ++ch) {
       const double v = (double)base[(size_t)ch * lv.P + p];
@@ -386,6 +401,86 @@ __global__ __launch_bounds__(256) void bn_act_fwd_c8_kernel(
   store_c8x4(y_c8 + (size_t)blk * P + p, out);
 }
 
+// backward of bn_act with the C8 image of dx as a side output (round 3): in
+// bf16 mode dx goes straight into the conv's data- and weight-gradient kernels,
+// which take C8 operands -- round 2 converted it with a separate launch per conv
+// (~42 to_c8 launches per step).  Thread = 8 channels x 4 positions; the same
+// expressions as bn_act_bwd_kernel; per-channel (sum dz, sum dz*xhat) partials
+// per workgroup, one slot per (image, position block), summed in fixed order by
+// bn_bwd_finalize_kernel.
+__global__ __launch_bounds__(256) void bn_act_bwd_c8_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y,
+    const float* __restrict__ x, const float* __restrict__ scale,
+    const float* __restrict__ mean, const float* __restrict__ rstd, int C, int P,
+    int relu, float* __restrict__ dx, float* __restrict__ dres,
+    gn_uintx4* __restrict__ dx_c8, double* __restrict__ partial, int nslots) {
+  __shared__ double red[4][16];
+  const int C8 = C >> 3;
+  const int blk = blockIdx.y;  // n * C8 + c8
+  const int c8 = blk % C8, n = blk / C8;
+  const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const bool live = p < P;
+  float out[8][4];
+  double s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c8 * 8 + e;
+    const float s = scale[c];
+    s1[e] = 0.0;
+    s2[e] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[e][k] = 0.0f;
+    if (!live) continue;
+    const size_t idx = ((size_t)n * C + c) * P + p;
+    const float4 g = *reinterpret_cast<const float4*>(dy + idx);
+    float dz[4] = {g.x, g.y, g.z, g.w};
+    if (relu) {
+      const float4 yy = *reinterpret_cast<const float4*>(y + idx);
+      if (!(yy.x > 0.f)) dz[0] = 0.f;
+      if (!(yy.y > 0.f)) dz[1] = 0.f;
+      if (!(yy.z > 0.f)) dz[2] = 0.f;
+      if (!(yy.w > 0.f)) dz[3] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[e][k] = dz[k] * s;
+    if (dx)
+      *reinterpret_cast<float4*>(dx + idx) =
+          make_float4(out[e][0], out[e][1], out[e][2], out[e][3]);
+    if (dres)
+      *reinterpret_cast<float4*>(dres + idx) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+    if (partial) {
+      const float mu = mean[c], rs = rstd[c];
+      const float4 xx = *reinterpret_cast<const float4*>(x + idx);
+      const float xv[4] = {xx.x, xx.y, xx.z, xx.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s1[e] += (double)dz[k];
+        s2[e] += (double)(dz[k] * ((xv[k] - mu) * rs));
+      }
+    }
+  }
+  if (live) store_c8x4(dx_c8 + (size_t)blk * P + p, out);
+  if (partial) {
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double a = wave_sum_d(s1[e]), b = wave_sum_d(s2[e]);
+      if ((threadIdx.x & 63) == 0) {
+        red[w][2 * e] = a;
+        red[w][2 * e + 1] = b;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      const int e = threadIdx.x >> 1, which = threadIdx.x & 1;
+      const double v = (red[0][threadIdx.x] + red[1][threadIdx.x]) +
+                       (red[2][threadIdx.x] + red[3][threadIdx.x]);
+      const int slot = n * gridDim.x + blockIdx.x;
+      partial[((size_t)(c8 * 8 + e) * nslots + slot) * 2 + which] = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void gn_apply_c8_kernel(
     const float* __restrict__ x, Levels lv, int C, int G,
     const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -510,6 +605,67 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(
   if (threadIdx.x == 0) {
     sums[(size_t)blockIdx.x * 2 + 0] = s1;
     sums[(size_t)blockIdx.x * 2 + 1] = s2;
+  }
+}
+
+// Round 3: the same sums with ONE workgroup per (n, c) row walking all levels
+// (16-byte loads on the aligned body of each level, the few edge cells scalar):
+// 512 workgroups stream 270 KB each instead of 20 480 slices of <= 2100 cells
+// whose cost was their own latency (62 us per launch, 1.5 TB/s).  Writes slice 0
+// of every (row, level) directly -- no fold launch.  Per-thread accumulation
+// order differs from the sliced kernel (fp64 sums: ~1e-16 relative).
+__global__ __launch_bounds__(256) void gn_bwd_reduce_row_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y,
+    const float* __restrict__ x, Levels lv, int C, int G,
+    const float* __restrict__ mean, const float* __restrict__ rstd, int relu,
+    double* __restrict__ sums) {
+  const int L = lv.num_levels;
+  const int row = blockIdx.x;  // n*C + c
+  const int c = row % C, n = row / C;
+  const size_t rbase = (size_t)row * lv.P;
+  for (int l = 0; l < L; ++l) {
+    const size_t o = ((size_t)n * G + c / (C / G)) * L + l;
+    const float mu = mean[o], rs = rstd[o];
+    const int p0 = lv.off[l], p1 = lv.off[l + 1];
+    // aligned body [b0, b1): rbase % 4 == 0 is guaranteed by the launcher
+    const int b0 = min((p0 + 3) & ~3, p1), b1 = max(p1 & ~3, b0);
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = b0 + 4 * (int)threadIdx.x; p < b1; p += 1024) {
+      const size_t idx = rbase + p;
+      const float4 g = *reinterpret_cast<const float4*>(dy + idx);
+      const float4 xx = *reinterpret_cast<const float4*>(x + idx);
+      float dz[4] = {g.x, g.y, g.z, g.w};
+      if (relu) {
+        const float4 yy = *reinterpret_cast<const float4*>(y + idx);
+        if (!(yy.x > 0.f)) dz[0] = 0.f;
+        if (!(yy.y > 0.f)) dz[1] = 0.f;
+        if (!(yy.z > 0.f)) dz[2] = 0.f;
+        if (!(yy.w > 0.f)) dz[3] = 0.f;
+      }
+      const float xv[4] = {xx.x, xx.y, xx.z, xx.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s1 += (double)dz[k];
+        s2 += (double)(dz[k] * ((xv[k] - mu) * rs));
+      }
+    }
+    // edges: [p0, b0) and [b1, p1), at most 3 cells each
+    const int ne = (b0 - p0) + (p1 - b1);
+    if ((int)threadIdx.x < ne) {
+      const int t = threadIdx.x;
+      const int p = t < b0 - p0 ? p0 + t : b1 + (t - (b0 - p0));
+      const size_t idx = rbase + p;
+      float dz = dy[idx];
+      if (relu && !(y[idx] > 0.f)) dz = 0.f;
+      s1 += (double)dz;
+      s2 += (double)(dz * ((x[idx] - mu) * rs));
+    }
+    block_sum2(s1, s2);
+    if (threadIdx.x == 0) {
+      const size_t at = ((size_t)row * L + l) * kGnBwdSplit * 2;
+      sums[at + 0] = s1;
+      sums[at + 1] = s2;
+    }
   }
 }
 
@@ -966,6 +1122,34 @@ extern "C" int ld_bn_act_backward(const float* dy, const float* y, const float* 
   return (int)hipGetLastError();
 }
 
+extern "C" int ld_bn_act_backward_c8(const float* dy, const float* y, const float* x,
+                                     const float* scale, const float* mean,
+                                     const float* rstd, int N, int C, int P, int relu,
+                                     float* dx, void* dx_c8, float* dres, float* dgamma,
+                                     float* dbeta, int accumulate, void* workspace,
+                                     size_t workspace_bytes, ld_stream_t stream) {
+  if (!dy || !scale || !dx_c8 || N < 1 || C < 1 || P < 1) return LD_EINVAL;
+  if (relu && !y) return LD_EINVAL;
+  const bool params = dgamma || dbeta;
+  if (params && (!x || !mean || !rstd)) return LD_EINVAL;
+  if (params && (!workspace ||
+                 workspace_bytes < ld_bn_act_backward_workspace_bytes(N, C, P)))
+    return LD_ENOSPACE;
+  const int xb = (P / 4 + 255) / 256, nslots = N * xb;
+  if (P % 4 != 0 || C % 8 != 0 || nslots > kBnSplitMax ||
+      ((uintptr_t)dy | (uintptr_t)(y ? y : dy) | (uintptr_t)(x ? x : dy) |
+       (uintptr_t)(dx ? dx : dy) | (uintptr_t)(dres ? dres : dy) | (uintptr_t)dx_c8) % 16)
+    return LD_EUNSUPPORTED;
+  hipLaunchKernelGGL(bn_act_bwd_c8_kernel, dim3(xb, N * (C / 8)), dim3(256), 0, LD_STREAM,
+                     dy, y, x, scale, mean, rstd, C, P, relu, dx, dres,
+                     (gn_uintx4*)dx_c8, params ? (double*)workspace : nullptr, nslots);
+  if (params)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0,
+                       LD_STREAM, (const double*)workspace, C, nslots, dgamma, dbeta,
+                       accumulate);
+  return (int)hipGetLastError();
+}
+
 extern "C" int ld_bias_grad(const float* dy, int N, int C, int P, float* db,
                             int accumulate, ld_stream_t stream) {
   if (!dy || !db || N < 1 || C < 1 || P < 1) return LD_EINVAL;
@@ -1062,10 +1246,17 @@ static int gn_backward_impl(const ld_levels_t* lv, const float* dy, const float*
   double* sums = (double*)workspace;
   float* gm = (float*)((char*)workspace + gn_bwd_sums_bytes(k.num_levels, N, C));
   const int rl = N * C * k.num_levels, ngl = N * G * k.num_levels;
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(rl * kGnBwdSplit), dim3(256), 0,
-                     LD_STREAM, dy, y, x, k, C, G, mean, rstd, relu, sums);
-  hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((rl + 255) / 256), dim3(256), 0,
-                     LD_STREAM, sums, rl);
+  const bool rowwise = k.P % 4 == 0 &&
+                       ((uintptr_t)dy | (uintptr_t)x | (uintptr_t)(relu ? y : x)) % 16 == 0;
+  if (rowwise) {
+    hipLaunchKernelGGL(gn_bwd_reduce_row_kernel, dim3(N * C), dim3(256), 0, LD_STREAM, dy,
+                       y, x, k, C, G, mean, rstd, relu, sums);
+  } else {
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(rl * kGnBwdSplit), dim3(256), 0,
+                       LD_STREAM, dy, y, x, k, C, G, mean, rstd, relu, sums);
+    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((rl + 255) / 256), dim3(256), 0,
+                       LD_STREAM, sums, rl);
+  }
   hipLaunchKernelGGL(gn_bwd_group_kernel, dim3((ngl + 255) / 256), dim3(256), 0,
                      LD_STREAM, sums, k, N, C, G, gamma, gm);
   const bool vec = k.P % 4 == 0 &&

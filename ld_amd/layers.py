@@ -23,6 +23,7 @@ class KernelProfile:
 
     def __init__(self):
         self.records = []  # (tag, flops, start_event, end_event, shape key)
+        self.bytes = []
 
     def __enter__(self):
         KernelProfile.active = self
@@ -38,6 +39,12 @@ class KernelProfile:
             t, f, n = agg.get(tag, (0.0, 0.0, 0))
             agg[tag] = (t + a.elapsed_time(b) * 1e-3, f + flops, n + 1)
         return agg
+
+    def algorithmic_bytes(self):
+        """Sum over the recorded launches of the bytes a conv must move: both
+        operands once + the output once, fp32 (a fused residual is not
+        counted)."""
+        return float(sum(self.bytes))
 
     def by_shape(self):
         """{(tag, shape key): (seconds, flops, launches)} -- the per-layer
@@ -70,6 +77,9 @@ class _timed:
                    f'P{d.Pout} L{d.num_levels}')
             self.prof.records.append((self.tag, _conv_flops(d), self.a, self.b,
                                       key))
+            self.prof.bytes.append(4.0 * (d.N * d.Cin * d.Pin +
+                                          d.N * d.Cout * d.Pout +
+                                          d.Cout * d.Cin * d.KH * d.KW))
 
 
 def _conv_flops(d):
@@ -851,6 +861,9 @@ class BnActFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, dres, None
 
 
+_BN_BWD_C8 = [os.environ.get('LD_BN_BWD_C8', '1') == '1']
+
+
 def _bn_act_backward(dy, x3, y, scale, mean, rstd, relu, params, need_x,
                      need_g, need_b, need_res):
     """Backward of eval-BN affine (+ residual) + ReLU (shared by BnActFn and the
@@ -874,12 +887,27 @@ def _bn_act_backward(dy, x3, y, scale, mean, rstd, relu, params, need_x,
             if need_b else None
     need = lib.ld_bn_act_backward_workspace_bytes(N, c, P)
     ws = workspace(x3.device, need, 'bn')
-    L.check(lib.ld_bn_act_backward(
-        L.ptr(dy), L.ptr(y), L.ptr(x3), L.ptr(scale), L.ptr(mean),
-        L.ptr(rstd), N, c, P, 1 if relu else 0, L.ptr(dx),
-        L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), 1 if direct else 0,
-        L.ptr(ws), ws.numel(), L.stream_ptr(x3.device)),
-        'ld_bn_act_backward')
+    # bf16 mode: dx goes into the conv's C8 data- / weight-gradient kernels --
+    # write its C8 image from this launch instead of a to_c8 launch per conv
+    dx_c8 = None
+    if need_x and _BN_BWD_C8[0] and N * ((P // 4 + 255) // 256) <= 64 and \
+            dy.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0:
+        dx_c8 = _c8_side_output(dx)
+    if dx_c8 is not None:
+        L.check(lib.ld_bn_act_backward_c8(
+            L.ptr(dy), L.ptr(y), L.ptr(x3), L.ptr(scale), L.ptr(mean),
+            L.ptr(rstd), N, c, P, 1 if relu else 0, L.ptr(dx), L.ptr(dx_c8),
+            L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), 1 if direct else 0,
+            L.ptr(ws), ws.numel(), L.stream_ptr(x3.device)),
+            'ld_bn_act_backward_c8')
+        _attach_c8(dx, dx_c8)
+    else:
+        L.check(lib.ld_bn_act_backward(
+            L.ptr(dy), L.ptr(y), L.ptr(x3), L.ptr(scale), L.ptr(mean),
+            L.ptr(rstd), N, c, P, 1 if relu else 0, L.ptr(dx),
+            L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), 1 if direct else 0,
+            L.ptr(ws), ws.numel(), L.stream_ptr(x3.device)),
+            'ld_bn_act_backward')
     if direct:
         dgamma = dbeta = None
         _emit(pg)

@@ -288,6 +288,9 @@ SIGNATURES = {
     'ld_bn_act_backward': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
                                      _i32, _i32, _vp, _vp, _vp, _vp, _i32,
                                      _vp, _sz, _vp]),
+    'ld_bn_act_backward_c8': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32,
+                                        _i32, _i32, _i32, _vp, _vp, _vp, _vp,
+                                        _vp, _i32, _vp, _sz, _vp]),
     'ld_bias_grad': (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     'ld_gn_forward_workspace_bytes': (_sz, [_LV, _i32, _i32]),
     'ld_gn_forward': (C.c_int, [_LV, _vp, _vp, _vp, _i32, _i32, _i32, _f32,

@@ -484,6 +484,50 @@ def test_bn_act_c8_side_output(bf16_mode):
     assert torch.equal(img, want)
 
 
+@pytest.mark.parametrize('relu,has_res', [(True, True), (False, False)])
+def test_bn_act_backward_c8_side_output(bf16_mode, relu, has_res):
+    """Eval-BN (+ residual) + ReLU BACKWARD with the C8 image of dx as a side
+    output (ld_bn_act_backward_c8, round 3): dx and dres bit-identical to the
+    plain kernel, the image equal to a conversion of dx, d(gamma) / d(beta)
+    equal up to the summation order (per-block fp64 partials either way)."""
+    from ld_amd import layers as Y
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    N, c, P = 2, 64, 21 * 28
+    base = [torch.randn(N, c, P, generator=g), torch.rand(c, generator=g) + 0.5,
+            torch.randn(c, generator=g), torch.randn(N, c, P, generator=g)]
+    mean = (torch.randn(c, generator=g) * 0.1).to(dev)
+    var = (torch.rand(c, generator=g) + 0.5).to(dev)
+    go = torch.randn(N, c, P, generator=g).to(dev)
+    outs = []
+    for on in (False, True):
+        Y._BN_BWD_C8[0] = on
+        try:
+            x, gamma, beta, res = (t.to(dev).requires_grad_(True) for t in base)
+            y = Y.bn_act(x, gamma, beta, mean, var, 1e-5,
+                         residual=res if has_res else None, relu=relu)
+            seen = {}
+            x.register_hook(lambda gr: seen.setdefault('dx', gr))
+            y.backward(go)
+        finally:
+            Y._BN_BWD_C8[0] = True
+        outs.append((x.grad, gamma.grad, beta.grad,
+                     res.grad if has_res else None, seen['dx']))
+    a, b = outs
+    assert torch.equal(a[0], b[0])
+    if has_res:
+        assert torch.equal(a[3], b[3])
+    for i in (1, 2):
+        sc = float(a[i].abs().max()) + 1e-12
+        assert float((a[i] - b[i]).abs().max()) <= 1e-6 * sc
+    assert Y._c8_cached(a[4]) is None
+    img = Y._c8_cached(b[4])
+    assert img is not None, 'no C8 image attached to dx'
+    want = b[0].to(torch.bfloat16).reshape(N, c // 8, 8, P).permute(
+        0, 1, 3, 2).reshape(-1)
+    assert torch.equal(img, want)
+
+
 def test_bf16_wgrad_vectorised_loads_same_bits(bf16_mode, monkeypatch):
     """The 16-byte-load variants of the wave-private bf16 weight gradient (dY
     always when Pout % 4 == 0, X too for 1x1 stride-1 convs) build the same LDS
