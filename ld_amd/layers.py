@@ -657,6 +657,43 @@ def _emit(p):
 DIRECT_GRADS = [True]
 
 
+# ---- weight gradients off the backward critical path (round 3) --------------
+# In backward only the DATA gradient of a conv feeds the next layer; its WEIGHT
+# gradient is needed by the optimizer (and the bucket's all-reduce) alone.  With
+# a gradient arena the wgrad launch (+ its split-K reduce) therefore goes to a
+# side stream, ordered after the kernels that produced its operands, and the
+# main stream continues with the dgrad / BN-backward chain: the small-layer
+# backward is a chain of 20-50 us launches at ~1 workgroup per CU, which the
+# concurrent weight gradients back-fill.  Joined (main waits for the side
+# stream) before a bucket's all-reduce is issued and before the optimizer step
+# (train.GradArena / SGDTrainer call wgrad_join).  Same kernels, same operands:
+# the result is bit-identical.  Only for gradients that go straight into the
+# arena -- a gradient handed back to autograd is consumed on the main stream.
+_WGRAD_STREAM = [os.environ.get('LD_WGRAD_STREAM', '1') == '1']
+_WGRAD_SIDE = {}
+_WGRAD_PENDING = [False]
+
+
+def _wgrad_side(device):
+    key = str(device)
+    st = _WGRAD_SIDE.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _WGRAD_SIDE[key] = st
+    return st
+
+
+def wgrad_join(device=None):
+    """Make the current stream wait for every weight gradient enqueued on the
+    side stream (no-op when none is pending)."""
+    if not _WGRAD_PENDING[0]:
+        return
+    for key, st in _WGRAD_SIDE.items():
+        if device is None or key == str(device):
+            torch.cuda.current_stream(st.device).wait_stream(st)
+    _WGRAD_PENDING[0] = False
+
+
 def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b):
     """Data / weight / bias gradients of a conv (shared by ConvFn and the fused
     ConvBnActFn).  x3: the saved input tensor, or -- x8 given -- its C8Act.
@@ -711,12 +748,40 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b):
         bf16 = _PRECISION[0] == 'bf16' and cin >= 16
         wgrad = lib.ld_conv_bf16_wgrad_c8 if c8w else \
             lib.ld_conv_bf16_wgrad if bf16 else lib.ld_conv_wgrad
+        side = None
+        # Eager bf16 steps are HOST-bound (~14 ms of enqueue per 15.5 ms step):
+        # the three extra stream calls per weight gradient cost more host time
+        # than the overlap returns (measured: 15.56 -> 17.31 ms), so there the
+        # side stream is used only while the step is being captured into a
+        # hipGraph (no host cost on replay).  fp32: 36.88 -> 35.98 ms eager.
+        # (profiles/r03_wgrad_side_stream.txt)
+        if sink is not None and _WGRAD_STREAM[0] and dy.is_cuda and \
+                KernelProfile.active is None and (
+                    _PRECISION[0] != 'bf16' or
+                    torch.cuda.is_current_stream_capturing()):
+            side = _wgrad_side(dy.device)
         with _timed('conv_wgrad_bf16' if bf16 else 'conv_wgrad', d):
+            # operand images are produced on the main stream (cached ones cost
+            # nothing); the wgrad itself may go to the side stream
             xw, dyw = ((x3.buf if x8 is not None else to_c8(x3)),
                        to_c8(dy)) if c8w else (x3, dy)
-            L.check(wgrad(C.byref(d), L.ptr(xw), L.ptr(dyw), L.ptr(dw),
-                          0 if sink is None else 1, L.ptr(ws),
-                          ws.numel(), st), 'ld_conv_wgrad')
+            if side is None:
+                L.check(wgrad(C.byref(d), L.ptr(xw), L.ptr(dyw), L.ptr(dw),
+                              0 if sink is None else 1, L.ptr(ws),
+                              ws.numel(), st), 'ld_conv_wgrad')
+            else:
+                side.wait_stream(torch.cuda.current_stream(dy.device))
+                with torch.cuda.stream(side):
+                    ws2 = workspace(dy.device, need, 'wgrad')  # per stream
+                    L.check(wgrad(C.byref(d), L.ptr(xw), L.ptr(dyw),
+                                  L.ptr(dw), 1, L.ptr(ws2), ws2.numel(),
+                                  L.stream_ptr(dy.device)), 'ld_conv_wgrad')
+                # the caching allocator must not hand these blocks to later
+                # main-stream allocations while the side stream still reads them
+                for t in (xw, dyw):
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(side)
+                _WGRAD_PENDING[0] = True
         if sink is not None:
             dw = None
             _emit(pw)

@@ -164,6 +164,8 @@ class GradArena:
             self.trace.append((b, ev))
         if self._ready[b] == self.buckets[b]['n'] and collectives_on():
             bk = self.buckets[b]
+            # weight gradients of this bucket may still run on the side stream
+            Y.wgrad_join()
             self._works.append(
                 dist.all_reduce(self.flat_grad[bk['start']:bk['end']],
                                 async_op=True))
@@ -172,6 +174,7 @@ class GradArena:
         """Wait for the in-flight bucket reductions (sums, not yet averaged).
         Buckets whose parameters received no gradient this step are reduced
         here so every rank issues the same collectives."""
+        Y.wgrad_join()
         if collectives_on():
             for b, bk in enumerate(self.buckets):
                 if self._ready[b] != bk['n']:
