@@ -589,6 +589,35 @@ def main():
                     'fresh_batch_per_replay': True,
                     'gt_per_image_cycle': [5, 11, args.num_gt]}
                 del gs
+                try:
+                    # the same with the teacher one step ahead inside the graphs
+                    # (train.PipelinedGraphedStep: two graphs over two batch slots)
+                    from ld_amd.train import PipelinedGraphedStep
+                    ps = PipelinedGraphedStep(trainer, fresh[0], fresh[1], warmup=1)
+                    for i in range(args.warmup):
+                        ps.step(fresh[(i + 1) % len(fresh)])
+                    if world > 1:
+                        dist.barrier()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(args.steps):
+                        out = ps.step(fresh[(i + 1 + args.warmup) % len(fresh)])
+                    if world > 1:
+                        dist.barrier()
+                    torch.cuda.synchronize()
+                    dtp = time.perf_counter() - t0
+                    if world > 1:
+                        tt = torch.tensor([dtp], device=dev, dtype=torch.float64)
+                        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                        dtp = float(tt)
+                    graph_res[mode]['teacher_one_step_ahead'] = {
+                        'value': args.batch_per_gpu * world * args.steps / dtp,
+                        'unit': 'images/sec', 'ms_per_step': dtp / args.steps * 1e3,
+                        'last_loss': float(out['log_vars']['loss'])}
+                    del ps
+                except Exception as e:
+                    graph_res[mode]['teacher_one_step_ahead'] = {
+                        'error': f'{type(e).__name__}: {e}'[:300]}
             except Exception as e:  # report, never lose the headline line
                 graph_res[mode] = {'error': f'{type(e).__name__}: {e}'[:300]}
         Y.set_precision('fp32')

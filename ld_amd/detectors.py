@@ -302,6 +302,14 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
                 'output_feature=False: the reference passes one argument too '
                 'few to LDHead.forward_train on that branch '
                 '(kd_one_stage.py:74-76 vs ld_head.py:73-82)')
+        forced = getattr(self, '_forced_teacher', None)
+        if forced is not None:
+            # train.PipelinedGraphedStep: the teacher outputs of THIS batch were
+            # computed by the previous graph replay into static buffers
+            teacher_x, out_teacher = forced
+            x = self.extract_feat(img)
+            return self._head_train(x, out_teacher, teacher_x, img_metas,
+                                    gt_bboxes, gt_labels, gt_bboxes_ignore)
         side = None
         queue = getattr(self, '_prefetched', None) or []
         pre = None

@@ -672,6 +672,21 @@ DIRECT_GRADS = [True]
 _WGRAD_STREAM = [os.environ.get('LD_WGRAD_STREAM', '1') == '1']
 _WGRAD_SIDE = {}
 _WGRAD_PENDING = [False]
+_WGRAD_FORCE = [False]
+
+
+class capture_warmup:
+    """Eager warm-up steps that precede a hipGraph capture must take the SAME
+    code paths the capture will take (so that every cached buffer -- workspaces,
+    operand images -- is created now, in ordinary memory, not during the capture
+    in the graph's private pool): inside this scope the weight gradients use
+    their side stream also in bf16 mode."""
+
+    def __enter__(self):
+        self.prev, _WGRAD_FORCE[0] = _WGRAD_FORCE[0], True
+
+    def __exit__(self, *exc):
+        _WGRAD_FORCE[0] = self.prev
 
 
 def _wgrad_side(device):
@@ -757,7 +772,7 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b):
         # (profiles/r03_wgrad_side_stream.txt)
         if sink is not None and _WGRAD_STREAM[0] and dy.is_cuda and \
                 KernelProfile.active is None and (
-                    _PRECISION[0] != 'bf16' or
+                    _PRECISION[0] != 'bf16' or _WGRAD_FORCE[0] or
                     torch.cuda.is_current_stream_capturing()):
             side = _wgrad_side(dy.device)
         with _timed('conv_wgrad_bf16' if bf16 else 'conv_wgrad', d):

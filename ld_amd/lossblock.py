@@ -22,7 +22,12 @@ def workspace(device, nbytes, tag='ws'):
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8,
                         device=device)
-        _WS[key] = t
+        # a buffer born while a hipGraph is being captured lives in that graph's
+        # private pool and dies with the graph: never keep it in this cache (a
+        # later capture would bake a dangling pointer -- seen in round 3 as
+        # corrupted weight gradients in the second graph test of a process)
+        if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _WS[key] = t
     return t
 
 
@@ -76,6 +81,34 @@ def _small_int_tensor(values, device):
     return t[0]
 
 
+class PinnedRing:
+    """A few pinned host staging buffers in rotation for small host -> device
+    updates that are enqueued asynchronously: the host must not rewrite a pinned
+    buffer before the copy that reads it has EXECUTED (with graph replays queued
+    ahead of it that can be a whole step later -- round 3 found exactly this
+    race: step i training with step i + 1's box counts).  Each slot carries the
+    event of its last copy; a slot is rewritten only after that event."""
+
+    def __init__(self, numel, dtype, depth=4):
+        self.bufs = [torch.zeros(numel, dtype=dtype).pin_memory()
+                     for _ in range(depth)]
+        self.events = [None] * depth
+        self.i = 0
+
+    def stage(self, dst, values):
+        """dst (device tensor) <- values (host tensor / sequence), async."""
+        k = self.i
+        self.i = (k + 1) % len(self.bufs)
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        self.bufs[k].copy_(torch.as_tensor(values, dtype=self.bufs[k].dtype)
+                           .reshape(-1))
+        dst.copy_(self.bufs[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+
+
 class StaticTargets:
     """Fixed-address ground-truth / valid-region buffers for a captured train
     step (train.GraphedStep).  A hipGraph replays launches with their pointer
@@ -99,8 +132,8 @@ class StaticTargets:
         self.gtl = torch.zeros((self.N, self.max_gt), dtype=torch.int64,
                                device=device)
         self.ng = torch.zeros(self.N, dtype=torch.int32, device=device)
-        self._ng_host = torch.zeros(self.N, dtype=torch.int32).pin_memory()
-        self.vhw = self._vhw_host = None
+        self._ng_ring = PinnedRing(self.N, torch.int32)
+        self.vhw = self._vhw_ring = None
         self.geometry = None   # (featmap_sizes, strides) the vhw buffer is for
         self.metas = None
         self.num_gt = [0] * self.N
@@ -118,9 +151,8 @@ class StaticTargets:
             if num_gt[i]:
                 self.gtb[i, :num_gt[i]].copy_(b, non_blocking=True)
                 self.gtl[i, :num_gt[i]].copy_(l, non_blocking=True)
-            self._ng_host[i] = num_gt[i]
             self.num_gt[i] = num_gt[i]
-        self.ng.copy_(self._ng_host, non_blocking=True)
+        self._ng_ring.stage(self.ng, self.num_gt)
         self.metas = [dict((k, v) for k, v in m.items()
                            if k != 'ld_static_targets') for m in img_metas]
         if self.geometry is not None:
@@ -141,10 +173,8 @@ class StaticTargets:
                                 'exist before capture (run a warm-up step)')
             self.vhw = torch.zeros(flat.numel(), dtype=torch.int32,
                                    device=self.device)
-            self._vhw_host = torch.zeros(flat.numel(),
-                                         dtype=torch.int32).pin_memory()
-        self._vhw_host.copy_(flat)
-        self.vhw.copy_(self._vhw_host, non_blocking=True)
+            self._vhw_ring = PinnedRing(flat.numel(), torch.int32)
+        self._vhw_ring.stage(self.vhw, flat)
 
     def valid_hw(self, featmap_sizes, strides):
         key = (tuple(tuple(s) for s in featmap_sizes),

@@ -213,19 +213,23 @@ class SGDTrainer:
         refreshed from ``self.lr`` ... before every eager step and before every
         ``GraphedStep.replay``; the arithmetic is bit-identical."""
         if self._hyper_dev is None:
+            from .lossblock import PinnedRing
             dev = self.arena.flat_param.device
-            self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+            self._hyper_host = PinnedRing(4, torch.float32)
             self._hyper_dev = torch.zeros(4, dtype=torch.float32, device=dev)
+            self._hyper_last = None
         self._push_hyper()
 
     def _push_hyper(self):
         if self._hyper_dev is None or \
                 torch.cuda.is_current_stream_capturing():
             return
-        h = self._hyper_host
-        h[0], h[1], h[2] = self.lr, self.momentum, self.weight_decay
-        h[3] = 1.0 / _world()
-        self._hyper_dev.copy_(h, non_blocking=True)
+        vals = (float(self.lr), float(self.momentum), float(self.weight_decay),
+                1.0 / _world())
+        if vals == self._hyper_last:
+            return  # unchanged since the last push: the device copy is current
+        self._hyper_last = vals
+        self._hyper_host.stage(self._hyper_dev, vals)
 
     # -- optimizer state in torch.optim.SGD's wire format (checkpoints) -------
     def _all_params(self):
@@ -388,8 +392,9 @@ class GraphedStep:
             # allocator / caches / weight images / the valid-region buffer
             # reach steady state on the capture stream's own key before
             # anything is recorded
-            for _ in range(warmup):
-                trainer.step(self.data)
+            with Y.capture_warmup():
+                for _ in range(max(warmup, 1)):
+                    trainer.step(self.data)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
@@ -434,4 +439,120 @@ class GraphedStep:
         return dict(loss=self._loss,
                     log_vars=LazyScalars(self._log_keys, self._log_tensor),
                     num_samples=self.num_samples)
+
+
+class PipelinedGraphedStep:
+    """GraphedStep + the teacher one step ahead, as TWO hipGraphs over two
+    static batch slots (round 3).  Graph k trains the student on slot k with
+    the teacher outputs already sitting in slot k's static buffers and, forked
+    onto the teacher stream inside the same graph, runs the frozen teacher on
+    slot 1 - k into THAT slot's buffers (the teacher forward allocates from the
+    graph's private pool; its outputs are copied to the static buffers: ~70 MB
+    per step).  Replays alternate 0, 1, 0, ...:
+
+        ps = PipelinedGraphedStep(trainer, batch0, batch1)
+        out = ps.step(batch1)   # trains on batch0, loads batch1, teacher(batch1)
+        out = ps.step(batch2)   # trains on batch1, loads batch2, teacher(batch2)
+
+    Everything GraphedStep lets a replay change (GT count per image up to
+    ``max_gt``, pad_shape, lr / momentum / weight decay) changes here too; the
+    weight gradients run on their side stream inside the graph.  The results
+    are bit-identical to eager steps on the same batch sequence
+    (tests/test_gpu_graph.py)."""
+
+    def __init__(self, trainer, first, second, warmup=1, max_gt=128):
+        from . import lossblock as LB
+        self.trainer = trainer
+        model = trainer.model
+        if not hasattr(model, 'teacher_model') or not model.eval_teacher:
+            raise ValueError('PipelinedGraphedStep needs a frozen-teacher KD '
+                             'detector')
+        if type(model.bbox_head).__name__ not in (
+                'LDHead', 'LDv2Head', 'LDATSSHead'):
+            raise NotImplementedError(
+                'static (padded) targets exist for the ATSS-assigned LD heads')
+        dev = first['img'].device
+        self.dev = dev
+        if model.teacher_stream is None:
+            model.teacher_stream = torch.cuda.Stream(device=dev)
+        max_gt = max([int(max_gt)] + [int(b.shape[0]) for d in (first, second)
+                                      for b in d['gt_bboxes']])
+        self.slots = []
+        for data in (first, second):
+            n = len(data['img_metas'])
+            st = LB.StaticTargets(n, max_gt, dev)
+            st.load(data['img_metas'], data['gt_bboxes'], data['gt_labels'])
+            metas = [dict(m) for m in data['img_metas']]
+            metas[0]['ld_static_targets'] = st
+            gtb, gtl = st.views()
+            self.slots.append(dict(
+                static=st, teacher=None,
+                data=dict(img=data['img'].clone(), img_metas=metas,
+                          gt_bboxes=gtb, gt_labels=gtl)))
+        trainer.enable_device_hyper()
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(cap):
+            with Y.capture_warmup():
+                for _ in range(max(warmup, 1)):
+                    for sl in self.slots:
+                        trainer.step(sl['data'])
+            for sl in self.slots:
+                tx, tout = model._teacher_forward(sl['data']['img'])
+                sl['teacher'] = (tuple(t.clone() for t in tx),
+                                 tuple([t.clone() for t in lvl]
+                                       for lvl in tout))
+        torch.cuda.current_stream(dev).wait_stream(cap)
+        torch.cuda.synchronize(dev)
+        self.graphs, self.outs = [], []
+        for k in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=cap):
+                out = self._one(k)
+            lv = out['log_vars']
+            self.graphs.append(g)
+            self.outs.append((out['loss'], list(lv._keys), lv._tensor,
+                              out['num_samples']))
+        self.cur = 0
+
+    def _one(self, k):
+        model = self.trainer.model
+        cur, nxt = self.slots[k], self.slots[1 - k]
+        main = torch.cuda.current_stream(self.dev)
+        side = model.teacher_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            tx, tout = model._teacher_forward(nxt['data']['img'])
+            for dst, src in zip(nxt['teacher'][0], tx):
+                dst.copy_(src)
+            for dl, sl in zip(nxt['teacher'][1], tout):
+                for dst, src in zip(dl, sl):
+                    dst.copy_(src)
+        model._forced_teacher = cur['teacher']
+        try:
+            out = self.trainer.step(cur['data'])
+        finally:
+            model._forced_teacher = None
+        main.wait_stream(side)
+        return out
+
+    def step(self, next_data):
+        """Train on the batch loaded by the previous call (the constructor's
+        ``first`` on the first call); load ``next_data`` for the following one
+        and run its teacher forward inside this replay."""
+        from .heads import LazyScalars
+        nxt = self.slots[1 - self.cur]
+        if next_data['img'].shape != nxt['data']['img'].shape:
+            raise ValueError('PipelinedGraphedStep: image shape differs from '
+                             'the captured one (capture one per shape)')
+        nxt['data']['img'].copy_(next_data['img'], non_blocking=True)
+        nxt['static'].load(next_data['img_metas'], next_data['gt_bboxes'],
+                           next_data['gt_labels'])
+        self.trainer._push_hyper()
+        self.graphs[self.cur].replay()
+        loss, keys, tensor, ns = self.outs[self.cur]
+        self.cur = 1 - self.cur
+        self.trainer.iter += 1
+        return dict(loss=loss, log_vars=LazyScalars(keys, tensor),
+                    num_samples=ns)
 
