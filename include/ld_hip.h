@@ -622,7 +622,7 @@ int ld_bn_act_backward(const float* dy, const float* y, const float* x,
 /* The same with the bf16 channel-blocked image of dx as a side output (bf16
  * mode: dx feeds the conv's C8 data- / weight-gradient kernels directly, no
  * conversion launch).  C % 8 == 0, P % 4 == 0, 16-byte aligned tensors,
- * N * ceil(P / 1024) <= 64 partial slots; LD_EUNSUPPORTED otherwise (use the
+ * N * ceil(P / 256) <= 256 partial slots; LD_EUNSUPPORTED otherwise (use the
  * plain form + ld_conv_to_c8). */
 int ld_bn_act_backward_c8(const float* dy, const float* y, const float* x,
                           const float* scale, const float* mean, const float* rstd,

@@ -408,17 +408,19 @@ __global__ __launch_bounds__(256) void bn_act_fwd_c8_kernel(
 // expressions as bn_act_bwd_kernel; per-channel (sum dz, sum dz*xhat) partials
 // per workgroup, one slot per (image, position block), summed in fixed order by
 // bn_bwd_finalize_kernel.
-__global__ __launch_bounds__(256) void bn_act_bwd_c8_kernel(
+__global__ __launch_bounds__(64) void bn_act_bwd_c8_kernel(
     const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ x, const float* __restrict__ scale,
     const float* __restrict__ mean, const float* __restrict__ rstd, int C, int P,
     int relu, float* __restrict__ dx, float* __restrict__ dres,
     gn_uintx4* __restrict__ dx_c8, double* __restrict__ partial, int nslots) {
-  __shared__ double red[4][16];
   const int C8 = C >> 3;
   const int blk = blockIdx.y;  // n * C8 + c8
   const int c8 = blk % C8, n = blk / C8;
-  const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+  // one wavefront per workgroup: 256 positions x 8 channels.  (Round 3 first
+  // ran 256-thread workgroups: 320 of them for a 256-channel 50x84 map -- 34 us
+  // against 24 us of the per-channel kernel it replaces.)
+  const int p = (blockIdx.x * 64 + threadIdx.x) * 4;
   const bool live = p < P;
   float out[8][4];
   double s1[8], s2[8];
@@ -461,22 +463,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_c8_kernel(
   }
   if (live) store_c8x4(dx_c8 + (size_t)blk * P + p, out);
   if (partial) {
-    const int w = threadIdx.x >> 6;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const double a = wave_sum_d(s1[e]), b = wave_sum_d(s2[e]);
-      if ((threadIdx.x & 63) == 0) {
-        red[w][2 * e] = a;
-        red[w][2 * e + 1] = b;
+      if (threadIdx.x == 0) {
+        const int slot = n * gridDim.x + blockIdx.x;
+        const size_t at = ((size_t)(c8 * 8 + e) * nslots + slot) * 2;
+        partial[at + 0] = a;
+        partial[at + 1] = b;
       }
-    }
-    __syncthreads();
-    if (threadIdx.x < 16) {
-      const int e = threadIdx.x >> 1, which = threadIdx.x & 1;
-      const double v = (red[0][threadIdx.x] + red[1][threadIdx.x]) +
-                       (red[2][threadIdx.x] + red[3][threadIdx.x]);
-      const int slot = n * gridDim.x + blockIdx.x;
-      partial[((size_t)(c8 * 8 + e) * nslots + slot) * 2 + which] = v;
     }
   }
 }
@@ -1004,7 +999,7 @@ int check_levels(const ld_levels_t* lv) {
   return 0;
 }
 
-constexpr int kBnSplitMax = 64;
+constexpr int kBnSplitMax = 256;
 
 int bn_splits(int N, int C, int P) {
   const long long per_c = (long long)N * P;
@@ -1135,12 +1130,12 @@ extern "C" int ld_bn_act_backward_c8(const float* dy, const float* y, const floa
   if (params && (!workspace ||
                  workspace_bytes < ld_bn_act_backward_workspace_bytes(N, C, P)))
     return LD_ENOSPACE;
-  const int xb = (P / 4 + 255) / 256, nslots = N * xb;
+  const int xb = (P / 4 + 63) / 64, nslots = N * xb;
   if (P % 4 != 0 || C % 8 != 0 || nslots > kBnSplitMax ||
       ((uintptr_t)dy | (uintptr_t)(y ? y : dy) | (uintptr_t)(x ? x : dy) |
        (uintptr_t)(dx ? dx : dy) | (uintptr_t)(dres ? dres : dy) | (uintptr_t)dx_c8) % 16)
     return LD_EUNSUPPORTED;
-  hipLaunchKernelGGL(bn_act_bwd_c8_kernel, dim3(xb, N * (C / 8)), dim3(256), 0, LD_STREAM,
+  hipLaunchKernelGGL(bn_act_bwd_c8_kernel, dim3(xb, N * (C / 8)), dim3(64), 0, LD_STREAM,
                      dy, y, x, scale, mean, rstd, C, P, relu, dx, dres,
                      (gn_uintx4*)dx_c8, params ? (double*)workspace : nullptr, nslots);
   if (params)

@@ -970,7 +970,7 @@ def _bn_act_backward(dy, x3, y, scale, mean, rstd, relu, params, need_x,
     # bf16 mode: dx goes into the conv's C8 data- / weight-gradient kernels --
     # write its C8 image from this launch instead of a to_c8 launch per conv
     dx_c8 = None
-    if need_x and _BN_BWD_C8[0] and N * ((P // 4 + 255) // 256) <= 64 and \
+    if need_x and _BN_BWD_C8[0] and N * ((P // 4 + 63) // 64) <= 256 and \
             dy.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0:
         dx_c8 = _c8_side_output(dx)
     if dx_c8 is not None:

@@ -78,7 +78,8 @@ def test_tune_table_round_trip(tmp_path):
     lib = L.get_lib()
     assert os.path.exists(L.TUNE_TABLE)
     records = [l for l in open(L.TUNE_TABLE) if l.strip() and l[0] != '#']
-    assert all(len(l.split()) == 23 for l in records)
+    # 18 key ints + tm tn wvm d ks [+ the residency cap, round 3]
+    assert all(len(l.split()) in (23, 24) for l in records)
     f = str(tmp_path / 'table.txt').encode()
     n = lib.ld_conv_tune_save(f)
     assert n >= len(records) > 50
