@@ -37,6 +37,7 @@
 //                coalesced and summed in fixed order (deterministic, no float
 //                atomics) by conv_wgrad_reduce.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -647,45 +648,107 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_kernel(ConvK a) {
   }
 
   // ---- epilogue: direct stores, 32 consecutive positions per accumulator row
+  // Round 3, after reading the ISA of the loop this replaces (r-major, plain
+  // pointers, `if (flag)` around every optional operand): the pointers of ConvK
+  // may alias as far as hipcc knows, so every affine / bias / residual load
+  // stayed behind the previous store and was waited for with vmcnt(0) -- ~2
+  // dependent round trips per output element, more cycles than the whole k-loop
+  // of a 256-deep 1x1 conv.  Now:
+  //   * buffer descriptors for every operand; an absent one has extent 0 (its
+  //     loads return 0, no memory traffic), rows >= Cout and columns >= J use
+  //     the out-of-range offset (stores dropped): no branches, no exec masks;
+  //   * a row group = 4 accumulator rows x all TN column tiles: its 12 + 4 TN
+  //     loads are in flight together, then its stores -- one round trip per
+  //     group (TM * 4 per tile) and fewer registers than the 32 affine values
+  //     the old loop held (1 x 1 tile: 76 -> 48 VGPRs, 6 -> 8 waves per SIMD);
+  //   * the residual / raw-output variants are separate straight-line copies.
+  // Same arithmetic per element as before: bit-identical results.
   const bool has_res = a.residual != nullptr;
+  const bool has_raw = MODE == 0 && a.y_raw != nullptr;
   const bool relu = a.relu != 0;
   const bool has_aff = a.scale != nullptr, has_bias = a.bias != nullptr;
+  const int prow = __builtin_amdgcn_readfirstlane(MODE == 1 ? a.Pfull : a.Pout);
+  const unsigned ybytes = (unsigned)a.N * (unsigned)Cout * (unsigned)prow * 4u;  // host: < 2 GiB
+  const rsrc_t r_y = make_rsrc(a.y, ybytes);
+  const rsrc_t r_raw = make_rsrc(a.y_raw, has_raw ? ybytes : 0u);
+  const rsrc_t r_res = make_rsrc(a.residual, has_res ? ybytes : 0u);
+  const rsrc_t r_sc = make_rsrc(a.scale, has_aff ? (unsigned)Cout * 4u : 0u);
+  const rsrc_t r_sh = make_rsrc(a.shift, has_aff ? (unsigned)Cout * 4u : 0u);
+  const rsrc_t r_bi = make_rsrc(a.bias, has_bias ? (unsigned)Cout * 4u : 0u);
+  // per column tile: byte offset of (row m0 + 4 lk, this lane's column)
+  unsigned voff[TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int rbase = m0 + i * 32 + 4 * lk;
-    float sc[16], sh[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = min(rbase + (r & 3) + 8 * (r >> 2), Cout - 1);
-      sc[r] = has_aff ? a.scale[row] : 1.0f;
-      sh[r] = has_aff ? a.shift[row] : 0.0f;
-      if (has_bias) sh[r] += a.bias[row];
+  for (int j = 0; j < TN; ++j) {
+    const int jc = n0 + j * 32 + l31;
+    const int n = jc / a.Pout;
+    int p = jc - n * a.Pout;
+    if (MODE == 1 && jc < a.J) {
+      int l, hc, wc;
+      locate_out(a.g, p, l, hc, wc);
+      p = a.foff[l] + (2 * hc + a.ph) * a.fW[l] + 2 * wc + a.pw;
     }
+    voff[j] = jc < a.J ? ((unsigned)(n * Cout + m0 + 4 * lk) * (unsigned)prow + (unsigned)p) * 4u
+                       : kOOB;
+  }
+  const unsigned prow4 = (unsigned)prow * 4u;
+  auto run = [&](auto res_c, auto raw_c) {
+    constexpr bool RES = decltype(res_c)::value, RAW = decltype(raw_c)::value;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int jc = n0 + j * 32 + l31;
-      if (jc >= a.J) continue;
-      const int n = jc / a.Pout;
-      int p = jc - n * a.Pout;
-      int prow = a.Pout;
-      if (MODE == 1) {
-        int l, hc, wc;
-        locate_out(a.g, p, l, hc, wc);
-        p = a.foff[l] + (2 * hc + a.ph) * a.fW[l] + 2 * wc + a.pw;
-        prow = a.Pfull;
+    for (int ig = 0; ig < TM * 4; ++ig) {
+      const int i = ig >> 2, g = ig & 3;
+      const int rl = i * 32 + 8 * g;  // row of the group - (m0 + 4 lk)
+      // scheduling fence: without it hipcc front-loads the loads of every group
+      // (nothing orders them any more) and the epilogue, not the k-loop, sets
+      // the kernel's register count
+      __builtin_amdgcn_sched_barrier(0);
+      float sc[4], sh[4], bi[4], rv[TN][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned ro = (unsigned)(m0 + 4 * lk + rl + e) * 4u;  // >= Cout: zeros
+        sc[e] = buf_load(r_sc, ro, 0);
+        sh[e] = buf_load(r_sh, ro, 0);
+        bi[e] = buf_load(r_bi, ro, 0);
       }
-      const size_t colbase = (size_t)n * Cout * prow + p;
+      if (RES) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rbase + (r & 3) + 8 * (r >> 2);
-        if (row >= Cout) continue;
-        float v = acc[i][j][r] * sc[r] + sh[r];
-        if (MODE == 0 && a.y_raw) a.y_raw[colbase + (size_t)row * prow] = acc[i][j][r];
-        if (has_res) v += a.residual[colbase + (size_t)row * prow];
-        if (relu) v = fmaxf(v, 0.0f);
-        a.y[colbase + (size_t)row * prow] = v;
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = m0 + 4 * lk + rl + e < Cout;
+            rv[j][e] = buf_load(r_res, ok ? voff[j] : kOOB, (unsigned)(rl + e) * prow4);
+          }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = m0 + 4 * lk + rl + e < Cout;
+        const float scale = has_aff ? sc[e] : 1.0f;
+        const float shift = sh[e] + bi[e];  // absent operands loaded as 0
+        const unsigned so = (unsigned)(rl + e) * prow4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int r = 4 * g + e;
+          const unsigned vo = ok ? voff[j] : kOOB;
+          // (a copy: __builtin_bit_cast applied to the vector ELEMENT expression
+          // acc[i][j][r] reads element 0 with this hipcc -- seen in the ISA)
+          const float av = acc[i][j][r];
+          float v = av * scale + shift;
+          if (RAW)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, av), r_raw,
+                                                  vo, so, 0);
+          if (RES) v += rv[j][e];
+          v = relu ? fmaxf(v, 0.0f) : v;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_y, vo,
+                                                so, 0);
+        }
       }
     }
+  };
+  if (has_res) {
+    if (has_raw) run(std::true_type{}, std::true_type{});
+    else run(std::true_type{}, std::false_type{});
+  } else {
+    if (has_raw) run(std::false_type{}, std::true_type{});
+    else run(std::false_type{}, std::false_type{});
   }
 }
 
@@ -806,34 +869,56 @@ __global__ __launch_bounds__(256, 2) void conv1x1_vec_kernel(ConvK a) {
   const bool relu = a.relu != 0;
   const bool has_aff = a.scale != nullptr, has_bias = a.bias != nullptr;
   const size_t colbase = (size_t)n * Cout * P + p;
+  const rsrc_t r_sc = make_rsrc(a.scale, has_aff ? (unsigned)Cout * 4u : 0u);
+  const rsrc_t r_sh = make_rsrc(a.shift, has_aff ? (unsigned)Cout * 4u : 0u);
+  const rsrc_t r_bi = make_rsrc(a.bias, has_bias ? (unsigned)Cout * 4u : 0u);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int rbase = m0 + i * 32 + 4 * lk;
+    // groups of RG rows, every load of a group before its first store (see the
+    // streaming kernel's epilogue); RG x VEC residual registers
+    constexpr int RG = 2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = rbase + (r & 3) + 8 * (r >> 2);
-      if (row >= Cout) continue;
-      const float sc = has_aff ? a.scale[row] : 1.0f;
-      float sh = has_aff ? a.shift[row] : 0.0f;
-      if (has_bias) sh += a.bias[row];
-      const size_t o = colbase + (size_t)row * P;
-      V raw, v;
+    for (int g = 0; g < 16 / RG; ++g) {
+      float sc[RG], sh[RG], bi[RG];
+      V q[RG];
+      // group fence: this group's loads stay behind the previous group's stores
+      // and none is consumed before all are issued (absent affine / bias: extent-0
+      // descriptors, loaded as 0)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        raw[e] = acc[i][e][r];
-        v[e] = raw[e] * sc + sh;
+      for (int e = 0; e < RG; ++e) {
+        const int r = RG * g + e;
+        const int row = min(rbase + (r & 3) + 8 * (r >> 2), Cout - 1);
+        sc[e] = buf_load(r_sc, (unsigned)row * 4u, 0);
+        sh[e] = buf_load(r_sh, (unsigned)row * 4u, 0);
+        bi[e] = buf_load(r_bi, (unsigned)row * 4u, 0);
+        if (has_res)
+          q[e] = *reinterpret_cast<const V*>(a.residual + colbase + (size_t)row * P);
       }
-      if (a.y_raw) *reinterpret_cast<V*>(a.y_raw + o) = raw;
-      if (has_res) {
-        const V q = *reinterpret_cast<const V*>(a.residual + o);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) v[e] += q[e];
-      }
-      if (relu) {
+      for (int e = 0; e < RG; ++e) {
+        const int r = RG * g + e;
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        if (row >= Cout) continue;
+        const size_t o = colbase + (size_t)row * P;
+        V raw, v;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.0f);
+        for (int c = 0; c < VEC; ++c) {
+          raw[c] = acc[i][c][r];
+          v[c] = raw[c] * (has_aff ? sc[e] : 1.0f) + (sh[e] + bi[e]);
+        }
+        if (a.y_raw) *reinterpret_cast<V*>(a.y_raw + o) = raw;
+        if (has_res) {
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) v[c] += q[e][c];
+        }
+        if (relu) {
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) v[c] = fmaxf(v[c], 0.0f);
+        }
+        *reinterpret_cast<V*>(a.y + o) = v;
       }
-      *reinterpret_cast<V*>(a.y + o) = v;
     }
   }
 }
@@ -1452,7 +1537,11 @@ inline TileCfg pick_tile(const ConvK& k) {
 }
 
 inline int set_extents(ConvK& k, size_t x_floats, size_t wt_floats) {
-  if (x_floats * 4 >= (size_t)kOOB || wt_floats * 4 >= (size_t)kOOB)
+  // the output (and the residual / raw output of its shape) is addressed through
+  // buffer descriptors too (round 3)
+  const size_t y_floats = (size_t)k.N * k.Cout * (size_t)max(k.Pout, k.Pfull);
+  if (x_floats * 4 >= (size_t)kOOB || wt_floats * 4 >= (size_t)kOOB ||
+      y_floats * 4 >= (size_t)kOOB)
     return LD_EUNSUPPORTED;  // 32-bit buffer offsets: tensors must be < 2 GiB
   k.x_bytes = (unsigned)(x_floats * 4);
   k.wt_bytes = (unsigned)(wt_floats * 4);
@@ -2283,6 +2372,9 @@ extern "C" size_t ld_conv_wgrad_workspace_bytes(const ld_conv_t* c) {
   int sp = wgrad_splits(c);
   if (ld_bf16_wgrad_tiled(c->Cout, c->Cin, c->Pout))
     sp = max(sp, ld_bf16_wgrad_splits(c->Cout, c->Cin, c->KH * c->KW, c->N * c->Pout));
+  if (c->Cin % 8 == 0 && c->Cout % 8 == 0 && ld_bf16_wgrad_c8_tiled(c->Cout, c->Cin))
+    sp = max(sp, ld_bf16_wgrad_c8_tile_splits(c->Cout, c->Cin, c->KH * c->KW,
+                                              c->N * c->Pout));
   return (size_t)sp * c->KH * c->KW * c->Cout * c->Cin * sizeof(float);
 }
 
@@ -2304,6 +2396,8 @@ int wgrad_run(const ld_conv_t* c, const float* x, const float* dy, float* dw,
   k.splits = wgrad_splits(c);
   if (family == 1 && ld_bf16_wgrad_tiled(c->Cout, c->Cin, c->Pout))
     k.splits = ld_bf16_wgrad_splits(c->Cout, c->Cin, c->KH * c->KW, k.J);
+  if (family == 2 && ld_bf16_wgrad_c8_tiled(c->Cout, c->Cin))
+    k.splits = ld_bf16_wgrad_c8_tile_splits(c->Cout, c->Cin, c->KH * c->KW, k.J);
   const int wmode = wgrad_mode();
   const int wbk = family >= 1 ? 32 : (wmode ? wmode : WBK);
   int jchunk = (k.J + k.splits - 1) / k.splits;

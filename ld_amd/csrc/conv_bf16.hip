@@ -263,68 +263,99 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_bf16_kernel(ConvK a) {
   const bool c8out = a.y_c8 != nullptr;
   const bool relu = a.relu != 0;
   const bool has_aff = a.scale != nullptr, has_bias = a.bias != nullptr;
+  // Loop order (round 3): row group g = 4 accumulator rows (one C8 half-row) x
+  // all TN column tiles; every load of a group -- affine, bias, fp32 / C8
+  // residual -- is issued before the group's first store.  The pointers of ConvK
+  // may alias as far as hipcc knows, so a residual load written between stores
+  // stays behind the previous store: the loop this replaces made up to 16
+  // dependent round trips per 32 x 32 tile, each waited for with vmcnt(0) (ISA
+  // reading; the 256 -> 1024 expansion convs ran at 1.2 TB/s).
+  size_t colbase[TN], c8base[TN];
+  bool jok[TN];
+  const int prow = MODE == 1 ? a.Pfull : a.Pout;
+  // per-channel operands through descriptors: an absent one has extent 0 and
+  // loads as 0 -- no flag-dependent branch inside a group's load phase
+  const rsrc_t r_sc = make_rsrc(a.scale, has_aff ? (unsigned)Cout * 4u : 0u);
+  const rsrc_t r_sh = make_rsrc(a.shift, has_aff ? (unsigned)Cout * 4u : 0u);
+  const rsrc_t r_bi = make_rsrc(a.bias, has_bias ? (unsigned)Cout * 4u : 0u);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int jc = n0 + j * 32 + l31;
+    jok[j] = jc < a.J;
+    const int n = jc / a.Pout;
+    int p = jc - n * a.Pout;
+    // C8 images (side output, residual) exist for MODE 0 only: compact p
+    c8base[j] = ((size_t)n * (Cout >> 3) * a.Pout + p) * 16;
+    if (MODE == 1 && jok[j]) {
+      int l, hc, wc;
+      locate_out(a.g, p, l, hc, wc);
+      p = a.foff[l] + (2 * hc + a.ph) * a.fW[l] + 2 * wc + a.pw;
+    }
+    colbase[j] = (size_t)n * Cout * prow + p;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int rbase = m0 + i * 32 + 4 * lk;
-    float sc[16], sh[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = min(rbase + (r & 3) + 8 * (r >> 2), Cout - 1);
-      sc[r] = has_aff ? a.scale[row] : 1.0f;
-      sh[r] = has_aff ? a.shift[row] : 0.0f;
-      if (has_bias) sh[r] += a.bias[row];
-    }
+    for (int g = 0; g < 4; ++g) {
+      const int row0 = rbase + 8 * g;  // this lane's four rows: row0 .. row0 + 3
+      // byte offset of the lane's 8-byte half of its C8 row within an image
+      const size_t c8row = (size_t)(row0 >> 3) * a.Pout * 16 + (row0 & 4) * 2;
+      float sc[4], sh[4], bi[4], rv[TN][4];
+      uintx2 rraw[TN];
+      // group fence: the loads of this group stay behind the previous group's
+      // stores and none of them is consumed before all are issued
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int jc = n0 + j * 32 + l31;
-      if (jc >= a.J) continue;
-      const int n = jc / a.Pout;
-      int p = jc - n * a.Pout;
-      int prow = a.Pout;
-      if (MODE == 1) {
-        int l, hc, wc;
-        locate_out(a.g, p, l, hc, wc);
-        p = a.foff[l] + (2 * hc + a.ph) * a.fW[l] + 2 * wc + a.pw;
-        prow = a.Pfull;
+      for (int e = 0; e < 4; ++e) {
+        const unsigned ro = (unsigned)(row0 + e) * 4u;  // >= Cout / absent: zeros
+        sc[e] = buf_load(r_sc, ro, 0);
+        sh[e] = buf_load(r_sh, ro, 0);
+        bi[e] = buf_load(r_bi, ro, 0);
       }
-      const size_t colbase = (size_t)n * Cout * prow + p;
+      if (has_res) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            rv[j][e] = (jok[j] && row0 + e < Cout)
+                           ? a.residual[colbase[j] + (size_t)(row0 + e) * prow]
+                           : 0.0f;
+      }
+      if (MODE == 0 && res8) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          rraw[j] = (jok[j] && row0 < Cout)
+                        ? *(const uintx2*)((const char*)a.res_c8 + c8base[j] + c8row)
+                        : uintx2{0u, 0u};
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (!jok[j]) continue;
         floatx4_t q;
-        // C8 residual: this lane's four channels = 8 bytes of the C8 row
         floatx4_t rq = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (MODE == 0 && res8 && rbase + 8 * g < Cout) {
-          const int row0 = rbase + 8 * g;
-          const size_t o =
-              (((size_t)n * (Cout >> 3) + (row0 >> 3)) * a.Pout + p) * 16 +
-              (row0 & 4) * 2;
-          const uintx2 raw = *(const uintx2*)((const char*)a.res_c8 + o);
-          rq = __builtin_convertvector(__builtin_bit_cast(bf16x4, raw), floatx4_t);
-        }
+        if (MODE == 0 && res8)
+          rq = __builtin_convertvector(__builtin_bit_cast(bf16x4, rraw[j]), floatx4_t);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          const int row = rbase + e + 8 * g;
+          const int row = row0 + e;
           float v = 0.0f;
           if (row < Cout) {
-            v = acc[i][j][r] * sc[r] + sh[r];
-            if (MODE == 0 && a.y_raw) a.y_raw[colbase + (size_t)row * prow] = acc[i][j][r];
-            if (has_res) v += a.residual[colbase + (size_t)row * prow];
+            v = acc[i][j][r] * (has_aff ? sc[e] : 1.0f) + (sh[e] + bi[e]);
+            if (MODE == 0 && a.y_raw)
+              a.y_raw[colbase[j] + (size_t)row * prow] = acc[i][j][r];
+            if (has_res) v += rv[j][e];
             if (MODE == 0 && res8) v += rq[e];
             if (relu) v = fmaxf(v, 0.0f);
-            if (has_y) a.y[colbase + (size_t)row * prow] = v;
+            if (has_y) a.y[colbase[j] + (size_t)row * prow] = v;
           }
           q[e] = v;
         }
         // side output: this lane's four channels = half of a 16-byte C8 row
-        if (MODE == 0 && c8out && rbase + 8 * g < Cout) {
-          const int row0 = rbase + 8 * g;
-          const size_t o =
-              (((size_t)n * (Cout >> 3) + (row0 >> 3)) * a.Pout + p) * 16 +
-              (row0 & 4) * 2;
-          *(uintx2*)((char*)a.y_c8 + o) =
+        if (MODE == 0 && c8out && row0 < Cout)
+          *(uintx2*)((char*)a.y_c8 + c8base[j] + c8row) =
               __builtin_bit_cast(uintx2, __builtin_convertvector(q, bf16x4));
-        }
       }
     }
   }
@@ -522,68 +553,99 @@ __global__ __launch_bounds__(256, 2) void conv_tile_bf16_kernel(ConvK a) {
   const bool c8out = a.y_c8 != nullptr;
   const bool relu = a.relu != 0;
   const bool has_aff = a.scale != nullptr, has_bias = a.bias != nullptr;
+  // Loop order (round 3): row group g = 4 accumulator rows (one C8 half-row) x
+  // all TN column tiles; every load of a group -- affine, bias, fp32 / C8
+  // residual -- is issued before the group's first store.  The pointers of ConvK
+  // may alias as far as hipcc knows, so a residual load written between stores
+  // stays behind the previous store: the loop this replaces made up to 16
+  // dependent round trips per 32 x 32 tile, each waited for with vmcnt(0) (ISA
+  // reading; the 256 -> 1024 expansion convs ran at 1.2 TB/s).
+  size_t colbase[TN], c8base[TN];
+  bool jok[TN];
+  const int prow = MODE == 1 ? a.Pfull : a.Pout;
+  // per-channel operands through descriptors: an absent one has extent 0 and
+  // loads as 0 -- no flag-dependent branch inside a group's load phase
+  const rsrc_t r_sc = make_rsrc(a.scale, has_aff ? (unsigned)Cout * 4u : 0u);
+  const rsrc_t r_sh = make_rsrc(a.shift, has_aff ? (unsigned)Cout * 4u : 0u);
+  const rsrc_t r_bi = make_rsrc(a.bias, has_bias ? (unsigned)Cout * 4u : 0u);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int jc = n0 + wn * (BN / 2) + j * 32 + l31;
+    jok[j] = jc < a.J;
+    const int n = jc / a.Pout;
+    int p = jc - n * a.Pout;
+    // C8 images (side output, residual) exist for MODE 0 only: compact p
+    c8base[j] = ((size_t)n * (Cout >> 3) * a.Pout + p) * 16;
+    if (MODE == 1 && jok[j]) {
+      int l, hc, wc;
+      locate_out(a.g, p, l, hc, wc);
+      p = a.foff[l] + (2 * hc + a.ph) * a.fW[l] + 2 * wc + a.pw;
+    }
+    colbase[j] = (size_t)n * Cout * prow + p;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int rbase = m0 + wm * (BM / 2) + i * 32 + 4 * lk;
-    float sc[16], sh[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = min(rbase + (r & 3) + 8 * (r >> 2), Cout - 1);
-      sc[r] = has_aff ? a.scale[row] : 1.0f;
-      sh[r] = has_aff ? a.shift[row] : 0.0f;
-      if (has_bias) sh[r] += a.bias[row];
-    }
+    for (int g = 0; g < 4; ++g) {
+      const int row0 = rbase + 8 * g;  // this lane's four rows: row0 .. row0 + 3
+      // byte offset of the lane's 8-byte half of its C8 row within an image
+      const size_t c8row = (size_t)(row0 >> 3) * a.Pout * 16 + (row0 & 4) * 2;
+      float sc[4], sh[4], bi[4], rv[TN][4];
+      uintx2 rraw[TN];
+      // group fence: the loads of this group stay behind the previous group's
+      // stores and none of them is consumed before all are issued
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int jc = n0 + wn * (BN / 2) + j * 32 + l31;
-      if (jc >= a.J) continue;
-      const int n = jc / a.Pout;
-      int p = jc - n * a.Pout;
-      int prow = a.Pout;
-      if (MODE == 1) {
-        int l, hc, wc;
-        locate_out(a.g, p, l, hc, wc);
-        p = a.foff[l] + (2 * hc + a.ph) * a.fW[l] + 2 * wc + a.pw;
-        prow = a.Pfull;
+      for (int e = 0; e < 4; ++e) {
+        const unsigned ro = (unsigned)(row0 + e) * 4u;  // >= Cout / absent: zeros
+        sc[e] = buf_load(r_sc, ro, 0);
+        sh[e] = buf_load(r_sh, ro, 0);
+        bi[e] = buf_load(r_bi, ro, 0);
       }
-      const size_t colbase = (size_t)n * Cout * prow + p;
+      if (has_res) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            rv[j][e] = (jok[j] && row0 + e < Cout)
+                           ? a.residual[colbase[j] + (size_t)(row0 + e) * prow]
+                           : 0.0f;
+      }
+      if (MODE == 0 && res8) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          rraw[j] = (jok[j] && row0 < Cout)
+                        ? *(const uintx2*)((const char*)a.res_c8 + c8base[j] + c8row)
+                        : uintx2{0u, 0u};
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (!jok[j]) continue;
         floatx4_t q;
-        // C8 residual: this lane's four channels = 8 bytes of the C8 row
         floatx4_t rq = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (MODE == 0 && res8 && rbase + 8 * g < Cout) {
-          const int row0 = rbase + 8 * g;
-          const size_t o =
-              (((size_t)n * (Cout >> 3) + (row0 >> 3)) * a.Pout + p) * 16 +
-              (row0 & 4) * 2;
-          const uintx2 raw = *(const uintx2*)((const char*)a.res_c8 + o);
-          rq = __builtin_convertvector(__builtin_bit_cast(bf16x4, raw), floatx4_t);
-        }
+        if (MODE == 0 && res8)
+          rq = __builtin_convertvector(__builtin_bit_cast(bf16x4, rraw[j]), floatx4_t);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          const int row = rbase + e + 8 * g;
+          const int row = row0 + e;
           float v = 0.0f;
           if (row < Cout) {
-            v = acc[i][j][r] * sc[r] + sh[r];
-            if (MODE == 0 && a.y_raw) a.y_raw[colbase + (size_t)row * prow] = acc[i][j][r];
-            if (has_res) v += a.residual[colbase + (size_t)row * prow];
+            v = acc[i][j][r] * (has_aff ? sc[e] : 1.0f) + (sh[e] + bi[e]);
+            if (MODE == 0 && a.y_raw)
+              a.y_raw[colbase[j] + (size_t)row * prow] = acc[i][j][r];
+            if (has_res) v += rv[j][e];
             if (MODE == 0 && res8) v += rq[e];
             if (relu) v = fmaxf(v, 0.0f);
-            if (has_y) a.y[colbase + (size_t)row * prow] = v;
+            if (has_y) a.y[colbase[j] + (size_t)row * prow] = v;
           }
           q[e] = v;
         }
         // side output: this lane's four channels = half of a 16-byte C8 row
-        if (MODE == 0 && c8out && rbase + 8 * g < Cout) {
-          const int row0 = rbase + 8 * g;
-          const size_t o =
-              (((size_t)n * (Cout >> 3) + (row0 >> 3)) * a.Pout + p) * 16 +
-              (row0 & 4) * 2;
-          *(uintx2*)((char*)a.y_c8 + o) =
+        if (MODE == 0 && c8out && row0 < Cout)
+          *(uintx2*)((char*)a.y_c8 + c8base[j] + c8row) =
               __builtin_bit_cast(uintx2, __builtin_convertvector(q, bf16x4));
-        }
       }
     }
   }
@@ -602,10 +664,21 @@ __global__ __launch_bounds__(256, 2) void conv_tile_bf16_kernel(ConvK a) {
 // wave: 4 loads, 4 ds_write_b128, 8 fragment reads, 8 MFMAs.
 // Everything else (A image, pipeline, epilogue, MODE 1 parity classes) is the
 // kernel above.
-template <int BM, int BN, int MODE, int NST>
+// BK = 64 (round 3): half the barriers and fragment-read restarts per MFMA; the
+// table's d field carries BK.
+// SCH = 1 (round 3): the LDS image of step u + 1 is written AFTER step u's
+// barrier, behind the first fragment reads and under step u's MFMAs, instead of
+// before the barrier where every wave waits for its own writes to land first.
+// One barrier per step still orders both hazards (everyone has finished reading
+// the buffer being overwritten; the writes of step u are waited for -- lgkmcnt --
+// before barrier u + 1).  The register ring then runs NST - 2 steps ahead of the
+// LDS write, so SCH = 1 needs NST = 4.  The table's cap field carries SCH.
+template <int BM, int BN, int MODE, int NST, int BK, int SCH>
 __global__ __launch_bounds__(256, 2) void conv_tile_c8_kernel(ConvK a) {
   static_assert(NST % 2 == 0, "ring length must be even (static LDS parity)");
-  constexpr int BK = 32, KB = BK / 8;
+  static_assert(BK == 32 || BK == 64, "k-step depth");
+  static_assert(SCH == 0 || NST >= 4, "write-after-barrier needs a 4-slot ring");
+  constexpr int KB = BK / 8;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_U = BM * KB / 256;  // 16-byte units of A per thread
   constexpr int CG = 256 / BN;        // k-block groups across the block
@@ -673,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile_c8_kernel(ConvK a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int csteps = Cin / BK;  // host guarantees Cin % 32 == 0
+  const int csteps = Cin / BK;  // host guarantees Cin % BK == 0
   const int nsteps = ntaps * csteps;
   uintx4 a_st[NST][A_U], b_st[NST][B_U];
   int c_step = 0, c_kh = 0, c_kw = 0, c_ci0 = 0;
@@ -710,36 +783,63 @@ __global__ __launch_bounds__(256, 2) void conv_tile_c8_kernel(ConvK a) {
     for (int q = 0; q < B_U; ++q)
       Bs[buf * KB * BN + (cg * B_U + q) * BN + bp] = rb[q];
   };
-  auto compute = [&](int buf) {
+  auto frags = [&](int buf, int s, uintx4* af, uintx4* bf) {
     const uintx4* ap = As + buf * KB * BM + wm * (BM / 2) + l31;
     const uintx4* bq = Bs + buf * KB * BN + wn * (BN / 2) + l31;
 #pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = ap[(2 * s + lk) * BM + i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[j] = bq[(2 * s + lk) * BN + j * 32];
+  };
+  auto mfmas = [&](const uintx4* af, const uintx4* bf) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]),
+            acc[i][j], 0, 0, 0);
+  };
+  auto compute = [&](int buf) {
+#pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       uintx4 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = ap[(2 * s + lk) * BM + i * 32];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = bq[(2 * s + lk) * BN + j * 32];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]),
-              acc[i][j], 0, 0, 0);
+      frags(buf, s, af, bf);
+      mfmas(af, bf);
     }
   };
 
 #pragma unroll
   for (int u = 0; u < NST - 1; ++u) load_next(a_st[u], b_st[u]);
-  for (int base = 0; base < nsteps; base += NST) {
+  if constexpr (SCH == 0) {
+    for (int base = 0; base < nsteps; base += NST) {
 #pragma unroll
-    for (int u = 0; u < NST; ++u) {
-      constexpr int ahead = NST - 1;
-      load_next(a_st[(u + ahead) % NST], b_st[(u + ahead) % NST]);
-      store_tile(u & 1, a_st[u], b_st[u]);
-      __syncthreads();
-      compute(u & 1);
+      for (int u = 0; u < NST; ++u) {
+        constexpr int ahead = NST - 1;
+        load_next(a_st[(u + ahead) % NST], b_st[(u + ahead) % NST]);
+        store_tile(u & 1, a_st[u], b_st[u]);
+        __syncthreads();
+        compute(u & 1);
+      }
+    }
+  } else {
+    store_tile(0, a_st[0], b_st[0]);
+    for (int base = 0; base < nsteps; base += NST) {
+#pragma unroll
+      for (int u = 0; u < NST; ++u) {
+        constexpr int ahead = NST - 1;
+        load_next(a_st[(u + ahead) % NST], b_st[(u + ahead) % NST]);
+        __syncthreads();  // image u complete; nobody still reads buffer (u + 1) & 1
+        uintx4 af[TM], bf[TN];
+        frags(u & 1, 0, af, bf);
+        store_tile((u + 1) & 1, a_st[(u + 1) % NST], b_st[(u + 1) % NST]);
+        mfmas(af, bf);
+#pragma unroll
+        for (int s = 1; s < BK / 16; ++s) {
+          frags(u & 1, s, af, bf);
+          mfmas(af, bf);
+        }
+      }
     }
   }
 
@@ -750,68 +850,99 @@ __global__ __launch_bounds__(256, 2) void conv_tile_c8_kernel(ConvK a) {
   const bool c8out = a.y_c8 != nullptr;
   const bool relu = a.relu != 0;
   const bool has_aff = a.scale != nullptr, has_bias = a.bias != nullptr;
+  // Loop order (round 3): row group g = 4 accumulator rows (one C8 half-row) x
+  // all TN column tiles; every load of a group -- affine, bias, fp32 / C8
+  // residual -- is issued before the group's first store.  The pointers of ConvK
+  // may alias as far as hipcc knows, so a residual load written between stores
+  // stays behind the previous store: the loop this replaces made up to 16
+  // dependent round trips per 32 x 32 tile, each waited for with vmcnt(0) (ISA
+  // reading; the 256 -> 1024 expansion convs ran at 1.2 TB/s).
+  size_t colbase[TN], c8base[TN];
+  bool jok[TN];
+  const int prow = MODE == 1 ? a.Pfull : a.Pout;
+  // per-channel operands through descriptors: an absent one has extent 0 and
+  // loads as 0 -- no flag-dependent branch inside a group's load phase
+  const rsrc_t r_sc = make_rsrc(a.scale, has_aff ? (unsigned)Cout * 4u : 0u);
+  const rsrc_t r_sh = make_rsrc(a.shift, has_aff ? (unsigned)Cout * 4u : 0u);
+  const rsrc_t r_bi = make_rsrc(a.bias, has_bias ? (unsigned)Cout * 4u : 0u);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int jc = n0 + wn * (BN / 2) + j * 32 + l31;
+    jok[j] = jc < a.J;
+    const int n = jc / a.Pout;
+    int p = jc - n * a.Pout;
+    // C8 images (side output, residual) exist for MODE 0 only: compact p
+    c8base[j] = ((size_t)n * (Cout >> 3) * a.Pout + p) * 16;
+    if (MODE == 1 && jok[j]) {
+      int l, hc, wc;
+      locate_out(a.g, p, l, hc, wc);
+      p = a.foff[l] + (2 * hc + a.ph) * a.fW[l] + 2 * wc + a.pw;
+    }
+    colbase[j] = (size_t)n * Cout * prow + p;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int rbase = m0 + wm * (BM / 2) + i * 32 + 4 * lk;
-    float sc[16], sh[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = min(rbase + (r & 3) + 8 * (r >> 2), Cout - 1);
-      sc[r] = has_aff ? a.scale[row] : 1.0f;
-      sh[r] = has_aff ? a.shift[row] : 0.0f;
-      if (has_bias) sh[r] += a.bias[row];
-    }
+    for (int g = 0; g < 4; ++g) {
+      const int row0 = rbase + 8 * g;  // this lane's four rows: row0 .. row0 + 3
+      // byte offset of the lane's 8-byte half of its C8 row within an image
+      const size_t c8row = (size_t)(row0 >> 3) * a.Pout * 16 + (row0 & 4) * 2;
+      float sc[4], sh[4], bi[4], rv[TN][4];
+      uintx2 rraw[TN];
+      // group fence: the loads of this group stay behind the previous group's
+      // stores and none of them is consumed before all are issued
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int jc = n0 + wn * (BN / 2) + j * 32 + l31;
-      if (jc >= a.J) continue;
-      const int n = jc / a.Pout;
-      int p = jc - n * a.Pout;
-      int prow = a.Pout;
-      if (MODE == 1) {
-        int l, hc, wc;
-        locate_out(a.g, p, l, hc, wc);
-        p = a.foff[l] + (2 * hc + a.ph) * a.fW[l] + 2 * wc + a.pw;
-        prow = a.Pfull;
+      for (int e = 0; e < 4; ++e) {
+        const unsigned ro = (unsigned)(row0 + e) * 4u;  // >= Cout / absent: zeros
+        sc[e] = buf_load(r_sc, ro, 0);
+        sh[e] = buf_load(r_sh, ro, 0);
+        bi[e] = buf_load(r_bi, ro, 0);
       }
-      const size_t colbase = (size_t)n * Cout * prow + p;
+      if (has_res) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            rv[j][e] = (jok[j] && row0 + e < Cout)
+                           ? a.residual[colbase[j] + (size_t)(row0 + e) * prow]
+                           : 0.0f;
+      }
+      if (MODE == 0 && res8) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          rraw[j] = (jok[j] && row0 < Cout)
+                        ? *(const uintx2*)((const char*)a.res_c8 + c8base[j] + c8row)
+                        : uintx2{0u, 0u};
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (!jok[j]) continue;
         floatx4_t q;
-        // C8 residual: this lane's four channels = 8 bytes of the C8 row
         floatx4_t rq = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (MODE == 0 && res8 && rbase + 8 * g < Cout) {
-          const int row0 = rbase + 8 * g;
-          const size_t o =
-              (((size_t)n * (Cout >> 3) + (row0 >> 3)) * a.Pout + p) * 16 +
-              (row0 & 4) * 2;
-          const uintx2 raw = *(const uintx2*)((const char*)a.res_c8 + o);
-          rq = __builtin_convertvector(__builtin_bit_cast(bf16x4, raw), floatx4_t);
-        }
+        if (MODE == 0 && res8)
+          rq = __builtin_convertvector(__builtin_bit_cast(bf16x4, rraw[j]), floatx4_t);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          const int row = rbase + e + 8 * g;
+          const int row = row0 + e;
           float v = 0.0f;
           if (row < Cout) {
-            v = acc[i][j][r] * sc[r] + sh[r];
-            if (MODE == 0 && a.y_raw) a.y_raw[colbase + (size_t)row * prow] = acc[i][j][r];
-            if (has_res) v += a.residual[colbase + (size_t)row * prow];
+            v = acc[i][j][r] * (has_aff ? sc[e] : 1.0f) + (sh[e] + bi[e]);
+            if (MODE == 0 && a.y_raw)
+              a.y_raw[colbase[j] + (size_t)row * prow] = acc[i][j][r];
+            if (has_res) v += rv[j][e];
             if (MODE == 0 && res8) v += rq[e];
             if (relu) v = fmaxf(v, 0.0f);
-            if (has_y) a.y[colbase + (size_t)row * prow] = v;
+            if (has_y) a.y[colbase[j] + (size_t)row * prow] = v;
           }
           q[e] = v;
         }
         // side output: this lane's four channels = half of a 16-byte C8 row
-        if (MODE == 0 && c8out && rbase + 8 * g < Cout) {
-          const int row0 = rbase + 8 * g;
-          const size_t o =
-              (((size_t)n * (Cout >> 3) + (row0 >> 3)) * a.Pout + p) * 16 +
-              (row0 & 4) * 2;
-          *(uintx2*)((char*)a.y_c8 + o) =
+        if (MODE == 0 && c8out && row0 < Cout)
+          *(uintx2*)((char*)a.y_c8 + c8base[j] + c8row) =
               __builtin_bit_cast(uintx2, __builtin_convertvector(q, bf16x4));
-        }
       }
     }
   }
@@ -870,6 +1001,13 @@ constexpr int WC_PITCH = 144;  // bytes per LDS row (64 channels + 16 pad)
 __device__ __forceinline__ unsigned long long lds_read_tr(unsigned addr) {
   unsigned long long v;
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+// the same read with an instruction offset (must fold to a constant)
+__device__ __forceinline__ unsigned long long lds_read_tr_off(unsigned addr, int off) {
+  unsigned long long v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off) : "memory");
   return v;
 }
 
@@ -992,19 +1130,22 @@ __global__ __launch_bounds__(64, 2) void conv_wgrad_c8_kernel(WgradK a) {
     return base + (unsigned)(s * 16 * WC_PITCH + tile * 64);
   };
 
+  // The ring loads are UNCONDITIONAL (positions past jend resolve to the
+  // descriptor's out-of-range zero, no memory traffic): with `if (step + ahead <
+  // nsteps)` around them hipcc merged the two paths' counters and waited
+  // vmcnt(0) before every LDS write -- each step paid the full latency of the
+  // loads it had just issued and the ring hid nothing (round-3 ISA reading).
   const int nsteps = (jend - jbeg + WC_J - 1) / WC_J;
 #pragma unroll
-  for (int u = 0; u < NR - 1; ++u)
-    if (u < nsteps) load_tile(jbeg + u * WC_J, a_st[u], b_st[u]);
+  for (int u = 0; u < NR - 1; ++u) load_tile(jbeg + u * WC_J, a_st[u], b_st[u]);
   for (int base = 0; base < nsteps; base += NR) {
 #pragma unroll
     for (int u = 0; u < NR; ++u) {
       const int step = base + u;
       if (step >= nsteps) break;
       constexpr int ahead = NR - 1;
-      if (step + ahead < nsteps)
-        load_tile(jbeg + (step + ahead) * WC_J, a_st[(u + ahead) % NR],
-                  b_st[(u + ahead) % NR]);
+      load_tile(jbeg + (step + ahead) * WC_J, a_st[(u + ahead) % NR],
+                b_st[(u + ahead) % NR]);
       store_tile(a_st[u], b_st[u]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -1063,6 +1204,234 @@ __global__ __launch_bounds__(64, 2) void conv_wgrad_c8_kernel(WgradK a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (co < Cout) slab[(size_t)co * Cin + ci] = acc[i][j][r];
+      }
+  }
+}
+
+// ------------------------------ wgrad, workgroup-tiled, C8 operands (round 3) --
+// The wave-private kernel above gives every wavefront its own 64 x 64 tile: 32
+// flops per operand byte, and the (co tile, ci tile, tap) waves of a split all
+// walk the same positions at the same time -- the 256-channel head layer pulls
+// 1.65 GB through L2 -> L1 per launch (11.5 TB/s for 145 us), ~3 500 cycles per
+// 32-position step at two waves per SIMD with the matrix pipe ~15 % busy.  Here
+// four wavefronts (2 x 2) share a 128(co) x 128(ci) tile: each staged 16-byte
+// unit feeds two waves (half the requests, 4 loads + 4 ds_write_b128 per lane
+// and step instead of 16), and the LDS image of step u + 1 is written after
+// step u's barrier, behind its transpose reads and under its MFMAs.
+//   LDS image per operand: [32 positions][128 channels] bf16 = 256-byte rows, no
+// padding; the 16-byte unit `ub` of row r sits at unit ub ^ 4 (r & 3) ^ ((r >> 2)
+// & 3): the 32 lanes a ds_read_b64_tr_b16 services together (4 rows x one
+// aligned group of 4 units) then cover all 64 banks once, and the 8 rows of a
+// ds_write_b128 lane group land on 4 distinct bank groups (2-way).
+// Same bf16 operands and the same per-wave MFMA order as the wave-private
+// kernel for equal split boundaries.
+constexpr int WT_PITCH = 256;
+
+__device__ __forceinline__ unsigned wt_swz(int row) {
+  return (unsigned)((4 * (row & 3)) ^ ((row >> 2) & 3));
+}
+
+template <int NR>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_c8_tile_kernel(WgradK a) {
+  static_assert(NR >= 3, "the ring runs NR - 2 steps ahead of the LDS write");
+  constexpr int TB = 128;
+  constexpr int U = 2;  // 16-byte units per thread and operand: 32 x 16 / 256
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * WC_J * WT_PITCH];
+  __shared__ int s_geo[LD_MAX_LEVELS * 6];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int Cin = __builtin_amdgcn_readfirstlane(a.Cin);
+  const int Cout = __builtin_amdgcn_readfirstlane(a.Cout);
+  const int Pin = __builtin_amdgcn_readfirstlane(a.Pin);
+  const int Pout = __builtin_amdgcn_readfirstlane(a.Pout);
+  const int nlev = __builtin_amdgcn_readfirstlane(a.g.num_levels);
+  const int stride = __builtin_amdgcn_readfirstlane(a.g.stride);
+  const int pad = __builtin_amdgcn_readfirstlane(a.g.pad);
+  const int mt = (Cout + TB - 1) / TB, nt = (Cin + TB - 1) / TB;
+  const int ntaps = a.KH * a.KW;
+  int b = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int ntile = b % nt;
+  b /= nt;
+  const int mtile = b % mt;
+  b /= mt;
+  const int tap = b % ntaps;
+  const int split = b / ntaps;
+  const int m0 = mtile * TB, c0 = ntile * TB;
+  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int jbeg = split * a.jchunk;
+  const int jend = min(a.J, jbeg + a.jchunk);
+
+  if (t < LD_MAX_LEVELS) {
+    const ld_conv_level_t lv = a.g.lv[t];
+    s_geo[t * 6 + 0] = lv.Hin;
+    s_geo[t * 6 + 1] = lv.Win;
+    s_geo[t * 6 + 2] = lv.Hout;
+    s_geo[t * 6 + 3] = lv.Wout;
+    s_geo[t * 6 + 4] = lv.off_in;
+    s_geo[t * 6 + 5] = lv.off_out;
+  }
+  __syncthreads();
+
+  // load side: lane = (position kq of the step, C8 block cb of the tile); unit
+  // i of the thread is C8 block cb + 8 i
+  const int kq = lane & (WC_J - 1);
+  const int cb = 2 * wave + (lane >> 5);
+  const int Co8 = Cout >> 3, Ci8 = Cin >> 3;
+  const rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  const rsrc_t ry = make_rsrc(a.dy, a.dy_bytes);
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  uintx4 a_st[NR][U], b_st[NR][U];
+  auto load_tile = [&](int j0, uintx4* ra, uintx4* rb) {
+    const int j = j0 + kq;
+    unsigned vy = kOOB, vx = kOOB;
+    if (j < jend) {
+      const int n = j / Pout, p = j - n * Pout;
+      int l = 0;
+      for (int i = 1; i < nlev; ++i)
+        if (p >= s_geo[i * 6 + 5]) l = i;
+      const int Hin = s_geo[l * 6 + 0], Win = s_geo[l * 6 + 1];
+      const int Wout = s_geo[l * 6 + 3];
+      const int r = p - s_geo[l * 6 + 5];
+      const int ho = r / Wout, wo = r - ho * Wout;
+      const int hi = ho * stride - pad + kh, wi = wo * stride - pad + kw;
+      vy = (unsigned)((n * Co8 + (m0 >> 3) + cb) * Pout + p) * 16u;
+      if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win)
+        vx = (unsigned)((n * Ci8 + (c0 >> 3) + cb) * Pin + s_geo[l * 6 + 4] +
+                        hi * Win + wi) * 16u;
+    }
+    // C8 blocks past the channel count (ragged last tile) read zeros
+    const unsigned da = 8u * (unsigned)Pout * 16u, db = 8u * (unsigned)Pin * 16u;
+    const int na = (Co8 - (m0 >> 3) - cb + 7) / 8, nb = (Ci8 - (c0 >> 3) - cb + 7) / 8;
+    unsigned sa = 0, sb = 0;
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      ra[i] = buf_load16(ry, i < na ? vy : kOOB, sa);
+      rb[i] = buf_load16(rx, i < nb ? vx : kOOB, sb);
+      sa += da;
+      sb += db;
+    }
+  };
+  const unsigned st_off0 = (unsigned)(kq * WT_PITCH) + (((unsigned)cb ^ wt_swz(kq)) << 4);
+  const unsigned st_off1 =
+      (unsigned)(kq * WT_PITCH) + (((unsigned)(cb + 8) ^ wt_swz(kq)) << 4);
+  auto store_tile = [&](int buf, const uintx4* ra, const uintx4* rb) {
+    unsigned char* As = lds + buf * 2 * WC_J * WT_PITCH;
+    unsigned char* Bs = As + WC_J * WT_PITCH;
+    *(uintx4*)(As + st_off0) = ra[0];
+    *(uintx4*)(As + st_off1) = ra[1];
+    *(uintx4*)(Bs + st_off0) = rb[0];
+    *(uintx4*)(Bs + st_off1) = rb[1];
+  };
+  // fragment read (the wave-private kernel's lane map): lane l = (g = l >> 4,
+  // t = l & 15) passes the address of the 8-byte piece at row 8 (g >> 1) + (t >>
+  // 2) (+ 4 for the second read, + 16 per k16 step), channels 16 (g & 1) +
+  // 4 (t & 3) (+ 32 per column tile, + 64 for the wave's half of the tile)
+  const int g4 = lane >> 4, t16 = lane & 15;
+  const int frow = 8 * (g4 >> 1) + (t16 >> 2);
+  const unsigned fub = (unsigned)(2 * (g4 & 1) + ((t16 & 3) >> 1));  // unit in its group of 4
+  const unsigned fhalf = (unsigned)((t16 & 3) & 1) * 8u;
+  // row & 3 = t16 >> 2 for every read of this lane; (row >> 2) & 3 = 2 (g4 >> 1)
+  // + h (h = second read)
+  const unsigned sw0 = wt_swz(frow), sw1 = wt_swz(frow + 4);
+  // eight per-lane addresses (operand, column tile, first / second read); the LDS
+  // buffer (16 KB) and the k16 step (16 rows) are instruction offsets
+  auto frag_base = [&](int op, int half64, int tile, int h) -> unsigned {
+    const unsigned ub = (unsigned)(8 * half64 + 4 * tile) + fub;
+    const unsigned row = (unsigned)(frow + 4 * h);
+    return (unsigned)(size_t)lds + (unsigned)(op * WC_J * WT_PITCH) + row * WT_PITCH +
+           ((ub ^ (h ? sw1 : sw0)) << 4) + fhalf;
+  };
+  unsigned fad[2][2][2];  // [operand][tile][h]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      fad[0][i][h] = frag_base(0, wm, i, h);
+      fad[1][i][h] = frag_base(1, wn, i, h);
+    }
+
+  const int nsteps = (jend - jbeg + WC_J - 1) / WC_J;
+  // unconditional ring loads and LDS writes (past jend: zeros) -- see the
+  // wave-private kernel: a branch around them costs the counted vmcnt waits
+#pragma unroll
+  for (int u = 0; u < NR - 1; ++u) load_tile(jbeg + u * WC_J, a_st[u], b_st[u]);
+  store_tile(0, a_st[0], b_st[0]);
+  constexpr int UN = NR % 2 == 0 ? NR : 2 * NR;  // ring slot and LDS parity both static
+  for (int base = 0; base < nsteps; base += UN) {
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int step = base + u;
+      if (step >= nsteps) break;
+      constexpr int ahead = NR - 1;
+      load_tile(jbeg + (step + ahead) * WC_J, a_st[(u + ahead) % NR],
+                b_st[(u + ahead) % NR]);
+      __syncthreads();  // image `step` complete; nobody still reads buffer (u + 1) & 1
+      unsigned long long fa[2][2][2], fb[2][2][2];  // [k16 step][tile][half]
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          constexpr int kBuf = 2 * WC_J * WT_PITCH, kS2 = 16 * WT_PITCH;
+          const int off = (u & 1) * kBuf + s2 * kS2;  // compile-time after unrolling
+          fa[s2][i][0] = lds_read_tr_off(fad[0][i][0], off);
+          fa[s2][i][1] = lds_read_tr_off(fad[0][i][1], off);
+          fb[s2][i][0] = lds_read_tr_off(fad[1][i][0], off);
+          fb[s2][i][1] = lds_read_tr_off(fad[1][i][1], off);
+        }
+      // image step + 1 (zeros past the end), behind the reads, under the MFMAs
+      store_tile((u + 1) & 1, a_st[(u + 1) % NR], b_st[(u + 1) % NR]);
+      // LDS operations complete in order: at most the 4 newest (the writes
+      // just issued) outstanding = all 16 transpose reads have landed
+      asm volatile("s_waitcnt lgkmcnt(4)"
+                   : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]),
+                     "+v"(fa[0][1][1]), "+v"(fa[1][0][0]), "+v"(fa[1][0][1]),
+                     "+v"(fa[1][1][0]), "+v"(fa[1][1][1]), "+v"(fb[0][0][0]),
+                     "+v"(fb[0][0][1]), "+v"(fb[0][1][0]), "+v"(fb[0][1][1]),
+                     "+v"(fb[1][0][0]), "+v"(fb[1][0][1]), "+v"(fb[1][1][0]),
+                     "+v"(fb[1][1][1])
+                   :
+                   : "memory");
+      bf16x8 af[2][2], bfr[2][2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          af[s2][i] = __builtin_bit_cast(bf16x8, fa[s2][i]);
+          bfr[s2][i] = __builtin_bit_cast(bf16x8, fb[s2][i]);
+        }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s2][i], bfr[s2][j],
+                                                                acc[i][j], 0, 0, 0);
+    }
+  }
+  // slab store: [split][tap][co][ci], ci fastest (= lane & 31)
+  const int l31 = lane & 31, lk = lane >> 5;
+  float* slab = a.slabs + ((size_t)split * ntaps + tap) * Cout * Cin;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ci = c0 + wn * 64 + j * 32 + l31;
+    if (ci >= Cin) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (co < Cout) slab[(size_t)co * Cin + ci] = acc[i][j][r];
       }
   }
@@ -1516,6 +1885,7 @@ __global__ __launch_bounds__(256) void conv_weight_transform_bf16_batch_kernel(
 // ---- shape dispatch ---------------------------------------------------------
 struct StreamCfg {
   int tm, tn, wvm, d, ks;
+  int sch = 0;  // C8 tiled family: 1 = LDS image written after the barrier
 };
 // Ring depth is bounded by the 6-bit vmcnt counter: D * (TM + 8 * TN) loads are
 // in flight per wavefront and must stay below 64 (2x2 tiles: D = 2, 36 loads).
@@ -1528,12 +1898,18 @@ struct StreamCfg {
 // (NST = register stages of the load ring; the ks field carries it)
 #define LD_BF16_TILE_SHAPES(X)                                                     \
   X(128, 128, 2) X(128, 128, 4) X(64, 128, 4) X(128, 64, 4) X(128, 64, 2)
-// C8-input tiled kernel shapes (family 2): (BM, BN, NST)
+// C8-input tiled kernel shapes (family 2): (BM, BN, NST, BK, SCH)
 #define LD_C8_TILE_SHAPES(X)                                                       \
-  X(128, 128, 2) X(128, 128, 4) X(64, 128, 4) X(128, 64, 4) X(64, 64, 4)           \
-  X(64, 128, 2) X(128, 64, 2) X(64, 64, 2) X(128, 256, 2) X(64, 256, 2)
+  X(128, 128, 2, 32, 0) X(128, 128, 4, 32, 0) X(64, 128, 4, 32, 0)                 \
+  X(128, 64, 4, 32, 0) X(64, 64, 4, 32, 0) X(64, 128, 2, 32, 0)                    \
+  X(128, 64, 2, 32, 0) X(64, 64, 2, 32, 0) X(128, 256, 2, 32, 0)                   \
+  X(64, 256, 2, 32, 0)                                                             \
+  X(128, 128, 2, 64, 0) X(64, 128, 2, 64, 0) X(128, 64, 2, 64, 0)                  \
+  X(64, 64, 2, 64, 0) X(64, 64, 4, 64, 0) X(64, 128, 4, 64, 0)                     \
+  X(128, 128, 4, 32, 1) X(64, 128, 4, 32, 1) X(128, 64, 4, 32, 1)                  \
+  X(64, 64, 4, 32, 1) X(64, 64, 4, 64, 1) X(64, 128, 4, 64, 1)
 constexpr StreamCfg kC8Cfgs[] = {
-#define LD_ROW(BM_, BN_, NST_) {BM_ / 32, BN_ / 32, 0, 32, NST_},
+#define LD_ROW(BM_, BN_, NST_, BK_, SCH_) {BM_ / 32, BN_ / 32, 0, BK_, NST_, SCH_},
     LD_C8_TILE_SHAPES(LD_ROW)
 #undef LD_ROW
 };
@@ -1555,12 +1931,12 @@ inline int mode_taps(const ConvK& k) {
 template <int MODE>
 int launch_c8_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream) {
   const int BM = c.tm * 32, BN = c.tn * 32;
-  if (k.Cin % 32 != 0) return LD_EUNSUPPORTED;
+  if (c.d < 32 || k.Cin % c.d != 0) return LD_EUNSUPPORTED;
   const int nb = ((k.Cout + BM - 1) / BM) * ((k.J + BN - 1) / BN);
-#define LD_CASE(BM_, BN_, NST_)                                                    \
-  if (BM == BM_ && BN == BN_ && c.ks == NST_) {                                    \
-    hipLaunchKernelGGL((conv_tile_c8_kernel<BM_, BN_, MODE, NST_>), dim3(nb),      \
-                       dim3(256), 0, stream, k);                                   \
+#define LD_CASE(BM_, BN_, NST_, BK_, SCH_)                                         \
+  if (BM == BM_ && BN == BN_ && c.ks == NST_ && c.d == BK_ && c.sch == SCH_) {     \
+    hipLaunchKernelGGL((conv_tile_c8_kernel<BM_, BN_, MODE, NST_, BK_, SCH_>),     \
+                       dim3(nb), dim3(256), 0, stream, k);                         \
     return (int)hipGetLastError();                                                 \
   }
   LD_C8_TILE_SHAPES(LD_CASE)
@@ -1569,7 +1945,7 @@ int launch_c8_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream) {
 }
 
 inline bool c8_cfg_fits(const ConvK& k, const StreamCfg& c) {
-  if (k.Cin % 32 != 0) return false;
+  if (c.d < 32 || k.Cin % c.d != 0) return false;
   const int BM = c.tm * 32;
   const int cout32 = (k.Cout + 31) / 32 * 32;
   return BM <= cout32 + 32;
@@ -1582,7 +1958,8 @@ inline int c8_cfg_model(const ConvK& k) {
   double best_t = 0;
   for (int i = 0; i < kNumC8Cfgs; ++i) {
     const StreamCfg& c = kC8Cfgs[i];
-    if (!c8_cfg_fits(k, c)) continue;
+    // 64-deep steps and the write-after-barrier schedule: by table only
+    if (c.d != 32 || c.sch != 0 || !c8_cfg_fits(k, c)) continue;
     const long nb = (long)((k.Cout + c.tm * 32 - 1) / (c.tm * 32)) *
                     ((k.J + c.tn * 32 - 1) / (c.tn * 32));
     const double rounds = nb <= 512 ? (double)((nb + 255) / 256) : (double)nb / 256.0;
@@ -1700,7 +2077,7 @@ inline int cfg_index(const LdTuneCfg& c) {
 inline int c8_cfg_index(const LdTuneCfg& c) {
   for (int i = 0; i < kNumC8Cfgs; ++i)
     if (kC8Cfgs[i].tm == c.tm && kC8Cfgs[i].tn == c.tn && kC8Cfgs[i].ks == c.ks &&
-        c.wvm == 0)
+        kC8Cfgs[i].d == c.d && kC8Cfgs[i].sch == c.cap && c.wvm == 0)
       return i;
   return -1;
 }
@@ -1708,9 +2085,11 @@ inline int c8_cfg_index(const LdTuneCfg& c) {
 template <int MODE>
 int launch_c8(const ConvK& k, hipStream_t stream) {
   if (k.Cin % 32 != 0) return LD_EUNSUPPORTED;
-  if (const char* env = getenv("LD_CONV_C8_SHAPE")) {  // "4x4x2": BM/32 x BN/32 x NST
-    StreamCfg c{0, 0, 0, 32, 0};
-    if (sscanf(env, "%dx%dx%d", &c.tm, &c.tn, &c.ks) == 3 && c8_cfg_fits(k, c)) {
+  // "4x4x2", "4x4x2x64" or "4x4x4x32x1": BM/32 x BN/32 x NST [x BK [x SCH]]
+  if (const char* env = getenv("LD_CONV_C8_SHAPE")) {
+    StreamCfg c{0, 0, 0, 32, 0, 0};
+    if (sscanf(env, "%dx%dx%dx%dx%d", &c.tm, &c.tn, &c.ks, &c.d, &c.sch) >= 3 &&
+        c8_cfg_fits(k, c)) {
       const int rc = launch_c8_cfg<MODE>(k, c, stream);
       if (rc != LD_EUNSUPPORTED) return rc;
     }
@@ -1770,12 +2149,12 @@ int tune_c8(const ConvK& k, hipStream_t stream) {
       const double fl = 2.0 * k.J * k.Cout * k.Cin * mode_taps(k);
       fprintf(stderr,
               "[ld_conv c8] mode %d Cin %d Cout %d k %dx%d s%d J %d lv %d -> "
-              "%dx%dx%d  %.1f TFLOP/s\n",
+              "%dx%dx%d bk%d sch%d  %.1f TFLOP/s\n",
               MODE, k.Cin, k.Cout, k.KH, k.KW, k.g.stride, k.J, k.g.num_levels,
-              c.tm * 32, c.tn * 32, c.ks,
+              c.tm * 32, c.tn * 32, c.ks, c.d, c.sch,
               best_ms > 0 ? fl / (best_ms * 1e-3 / kReps) / 1e12 : 0.0);
     }
-  if (best_ms > 0.0f) ld_tune_store(key, LdTuneCfg{c.tm, c.tn, 0, c.d, c.ks});
+  if (best_ms > 0.0f) ld_tune_store(key, LdTuneCfg{c.tm, c.tn, 0, c.d, c.ks, c.sch});
   return 0;
 }
 
@@ -1898,10 +2277,54 @@ int ld_bf16_wgrad_splits(int Cout, int Cin, int ntaps, int J) {
   return sp;
 }
 
+// C8 weight gradient: the workgroup-tiled kernel (128 x 128 tiles) whenever both
+// channel counts fill a tile; LD_CONV_WGRAD_C8_KERNEL=wave / tile forces one.
+bool ld_bf16_wgrad_c8_tiled(int Cout, int Cin) {
+  if (const char* env = getenv("LD_CONV_WGRAD_C8_KERNEL")) {
+    if (env[0] == 'w') return false;
+    if (env[0] == 't') return true;
+  }
+  return Cout >= 128 && Cin >= 128;
+}
+
+// j-split count of the tiled kernel: whole rounds of the 2 workgroups per CU its
+// registers allow, at least 8 steps of 32 positions per split
+int ld_bf16_wgrad_c8_tile_splits(int Cout, int Cin, int ntaps, int J) {
+  const int tiles = ((Cout + 127) / 128) * ((Cin + 127) / 128) * ntaps;
+  const int slots = 512;     // two workgroups per CU (190 VGPRs)
+  const double fixed = 6.0;  // prologue + slab store, in steps
+  const size_t wbytes = (size_t)ntaps * Cout * Cin * sizeof(float);
+  int best = 1;
+  double best_cost = 0;
+  for (int sp = 1; sp <= 128; ++sp) {
+    if (sp > 1 && sp * wbytes > ((size_t)256 << 20)) break;  // slab budget
+    int jchunk = (J + sp - 1) / sp;
+    jchunk = (jchunk + WC_J - 1) / WC_J * WC_J;
+    if (sp > 1 && (long)(sp - 1) * jchunk >= J) continue;  // empty last split
+    const int steps = jchunk / WC_J;
+    if (sp > 1 && steps < 8) break;
+    const long blocks = (long)tiles * sp;
+    const double rounds = (double)((blocks + slots - 1) / slots);
+    const double cost = rounds * (steps + fixed) + 1e-3 * sp;
+    if (sp == 1 || cost < best_cost) {
+      best = sp;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
+
 // both operands as C8 images (k.x / k.dy point at them; extents in bytes)
 int ld_bf16_wgrad_c8_launch(const WgradK& k, hipStream_t stream) {
   if (k.Cin % 8 != 0 || k.Cout % 8 != 0) return LD_EUNSUPPORTED;
   const int ntaps = k.KH * k.KW;
+  if (ld_bf16_wgrad_c8_tiled(k.Cout, k.Cin)) {
+    const int blocks =
+        ((k.Cout + 127) / 128) * ((k.Cin + 127) / 128) * ntaps * k.splits;
+    hipLaunchKernelGGL(conv_wgrad_c8_tile_kernel<4>, dim3(blocks), dim3(256), 0, stream,
+                       k);
+    return (int)hipGetLastError();
+  }
   const int blocks = ((k.Cout + 63) / 64) * ((k.Cin + 63) / 64) * ntaps * k.splits;
   const char* env = getenv("LD_CONV_WGRAD_C8_RING");
   if (env && env[0] == '2')

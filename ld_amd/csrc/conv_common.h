@@ -59,6 +59,8 @@ struct WgradK {
 // (mode 0 = conv, 1 = stride-2 dgrad parity class), wave-private bf16 wgrad.
 int ld_bf16_stream_launch(int mode, const ConvK& k, hipStream_t stream);
 int ld_bf16_wgrad_c8_launch(const WgradK& k, hipStream_t stream);
+bool ld_bf16_wgrad_c8_tiled(int Cout, int Cin);  // 128 x 128 workgroup tiles?
+int ld_bf16_wgrad_c8_tile_splits(int Cout, int Cin, int ntaps, int J);
 int ld_bf16_stream_tune(int mode, const ConvK& k, hipStream_t stream);
 int ld_bf16_wgrad_launch(const WgradK& k, hipStream_t stream);
 bool ld_bf16_wgrad_tiled(int Cout, int Cin, int Pout);     // which bf16 wgrad kernel

@@ -64,12 +64,17 @@ def test_bf16_layout_identity(bf16_mode):
     assert torch.equal(y.reshape(ref.shape).cpu(), ref)
 
 
-@pytest.mark.parametrize('wgrad', ['wave', 'tile'])
+@pytest.mark.parametrize('wgrad', ['wave', 'tile', 'c8tile'])
 @pytest.mark.parametrize('case', BF16_CASES, ids=[c[0] for c in BF16_CASES])
 def test_bf16_conv_fwd_bwd(case, wgrad, bf16_mode, monkeypatch):
     from ld_amd import layers as Y
-    # both weight-gradient kernels (the workgroup-tiled one is opt-in)
-    monkeypatch.setenv('LD_CONV_BF16_WGRAD', wgrad)
+    # both fp32-operand weight-gradient kernels (the workgroup-tiled one is
+    # opt-in) with the wave-private C8 kernel where the operands are C8 images;
+    # 'c8tile': the workgroup-tiled C8 kernel on EVERY case it accepts (ragged
+    # 128-channel tiles included), not only where the dispatch rule picks it
+    monkeypatch.setenv('LD_CONV_BF16_WGRAD', 'wave' if wgrad == 'c8tile' else wgrad)
+    monkeypatch.setenv('LD_CONV_WGRAD_C8_KERNEL',
+                       'tile' if wgrad == 'c8tile' else 'wave')
     dev = _dev()
     name, N, cin, cout, k, stride, pad, levels = case
     import zlib
@@ -203,7 +208,13 @@ def test_bf16_train_step_vs_fp32_golden(golden, bf16_mode):
 
 
 C8_SHAPES = ['4x4x2', '4x4x4', '2x4x4', '4x2x4', '2x2x4', '2x4x2', '4x2x2',
-             '2x2x2', '4x8x2', '2x8x2']
+             '2x2x2', '4x8x2', '2x8x2',
+             # 64-deep k-steps (BM/32 x BN/32 x NST x BK)
+             '4x4x2x64', '2x4x2x64', '4x2x2x64', '2x2x2x64', '2x2x4x64',
+             '2x4x4x64',
+             # LDS image written after the barrier (... x BK x SCH)
+             '4x4x4x32x1', '2x4x4x32x1', '4x2x4x32x1', '2x2x4x32x1',
+             '2x2x4x64x1', '2x4x4x64x1']
 
 
 def test_to_c8_layout():
@@ -234,6 +245,9 @@ def test_c8_kernel_bit_identical_to_fp32_input_tile_kernel(shape, monkeypatch,
         name, N, cin, cout, k, stride, pad, levels = case
         if cin % 32 or cout % 32:
             continue
+        bk = int((shape.split('x') + ['32'])[3])
+        if cin % bk or cout % bk:
+            continue  # forward needs Cin % BK == 0, the data gradient Cout
         ran += 1
         g = torch.Generator().manual_seed(len(name) * 3 + cout)
         P = sum(h * w for h, w in levels)
