@@ -556,3 +556,92 @@ class PipelinedGraphedStep:
         return dict(loss=loss, log_vars=LazyScalars(keys, tensor),
                     num_samples=ns)
 
+class AutoStepper:
+    """How a train step is enqueued, chosen per precision mode (VERDICT round 2,
+    #8: the hipGraph path is the DEFAULT in bf16 mode, where the eager step is
+    host-bound -- DESIGN.md section 5):
+
+        stepper = AutoStepper(trainer)            # mode=None: by precision
+        for data, nxt in pairs(loader):           # nxt = the following batch
+            out = stepper.step(data, next_data=nxt)
+
+    ``step`` has the meaning of ``SGDTrainer.step``: ONE optimizer update on
+    ``data``; the results are bit-identical in every mode.
+      * ``'eager'`` (fp32 default, every CPU run): ``trainer.step`` with the
+        frozen teacher of ``next_data`` one step ahead on its own stream;
+      * ``'graph'`` (bf16 default on a GPU): one ``GraphedStep`` per padded
+        image shape (the reference's GroupSampler yields two aspect-ratio
+        groups, mmdet/datasets/samplers/group_sampler.py), captured the first
+        time a shape is seen.  The capture's warm-up steps are real steps on
+        that batch, so the trainable state (flat parameters, momentum,
+        iteration counter) is saved before and restored after: the first
+        replay IS the batch's one update;
+      * ``'pipelined'``: ``PipelinedGraphedStep`` (two graphs, teacher one step
+        ahead inside the graph) for fixed-shape training: needs ``next_data`` on
+        every call and one padded shape throughout.
+    """
+
+    def __init__(self, trainer, mode=None, warmup=1, max_gt=128):
+        if mode is None:
+            on_gpu = next(trainer.model.parameters()).is_cuda
+            mode = 'graph' if (on_gpu and Y.get_precision() == 'bf16') else 'eager'
+        if mode not in ('eager', 'graph', 'pipelined'):
+            raise ValueError(f'AutoStepper: unknown mode {mode!r}')
+        self.trainer, self.mode = trainer, mode
+        self.warmup, self.max_gt = int(warmup), int(max_gt)
+        self._graphs = {}
+        self._pipe = None
+        self._pipe_loaded = None  # the batch object the pipeline holds for its next step
+        self.captures = 0
+
+    def _saved_state(self):
+        tr = self.trainer
+        return (tr.arena.flat_param.clone(), tr.flat_momentum.clone(), tr.iter)
+
+    def _restore_state(self, st):
+        tr = self.trainer
+        tr.arena.flat_param.copy_(st[0])
+        tr.flat_momentum.copy_(st[1])
+        tr.iter = st[2]
+        # the GEMM weight images / folded BN coefficients are refreshed AFTER
+        # each optimizer launch (layers.sgd_step), for the next forward: the
+        # cached ones belong to the warm-up's parameters.  Recompute them (into
+        # the same buffers the captured graph reads) for the restored ones.
+        Y.bump_param_generation()
+        Y.refresh_params(st[0].device)
+
+    def step(self, data, next_data=None):
+        if self.mode == 'eager':
+            return self.trainer.step(data, next_data=next_data)
+        if self.mode == 'graph':
+            key = (tuple(data['img'].shape), len(data['img_metas']))
+            g = self._graphs.get(key)
+            if g is None:
+                st = self._saved_state()
+                g = GraphedStep(self.trainer, data, warmup=self.warmup,
+                                max_gt=self.max_gt)
+                torch.cuda.synchronize(data['img'].device)
+                self._restore_state(st)
+                self._graphs[key] = g
+                self.captures += 1
+            g.copy_inputs(data)
+            return g.replay()
+        # pipelined: the graph of this step runs the teacher of next_data
+        if next_data is None:
+            raise ValueError("AutoStepper('pipelined') needs next_data on every "
+                             "call (pass the last batch again at the end)")
+        if self._pipe is None:
+            st = self._saved_state()
+            self._pipe = PipelinedGraphedStep(self.trainer, data, next_data,
+                                              warmup=self.warmup,
+                                              max_gt=self.max_gt)
+            torch.cuda.synchronize(data['img'].device)
+            self._restore_state(st)
+            self._pipe_loaded = data
+            self.captures += 1
+        if self._pipe_loaded is not data:
+            raise ValueError("AutoStepper('pipelined'): this call's data must be "
+                             "the previous call's next_data")
+        out = self._pipe.step(next_data)
+        self._pipe_loaded = next_data
+        return out

@@ -178,3 +178,80 @@ def test_teacher_prefetch_bit_identical():
     # twice per step); announcements that never arrive are never consumed
     assert hits['pipelined'] == len(batches) - 1, hits
     assert hits['stale'] == 0 and hits['plain'] == 0, hits
+
+
+def _batch_hw(seed, num_gt, dev, hw):
+    from ld_amd import synthetic
+    b = synthetic.synthetic_batch(2, (hw[0] - 8, hw[1] - 10), hw, num_gt, seed)
+    return dict(img=b['img'].to(dev), img_metas=b['img_metas'],
+                gt_bboxes=[x.to(dev) for x in b['gt_bboxes']],
+                gt_labels=[x.to(dev) for x in b['gt_labels']])
+
+
+def test_auto_stepper_graph_is_the_bf16_default_and_equals_eager():
+    """train.AutoStepper: in bf16 mode on a GPU the per-shape hipGraph path is
+    the default; a sequence that alternates between two
+    padded shapes (the GroupSampler's two aspect groups) with different GT
+    counts and a moving lr gives the SAME parameters as plain eager steps, bit
+    for bit -- the capture's warm-up steps leave no trace (state saved /
+    restored around them), so every batch is exactly one update."""
+    from ld_amd import layers as Y
+    from ld_amd.train import AutoStepper
+    dev = torch.device('cuda:0')
+    Y.set_precision('bf16')
+    try:
+        wide, tall = (128, 160), (160, 128)
+        seq = [_batch_hw(41, [3, 2], dev, wide), _batch_hw(42, [5, 1], dev, tall),
+               _batch_hw(43, [2, 6], dev, wide), _batch_hw(44, [1, 1], dev, wide),
+               _batch_hw(45, [4, 3], dev, tall)]
+        lrs = [0.01, 0.01, 0.006, 0.02, 0.01]
+        eager = _trainer(dev)
+        outs_e = []
+        for d, lr in zip(seq, lrs):
+            eager.lr = lr
+            outs_e.append(float(eager.step(d)['loss']))
+        torch.cuda.synchronize()
+        tr = _trainer(dev)
+        st = AutoStepper(tr, max_gt=16)
+        assert st.mode == 'graph'
+        outs_g = []
+        for k, (d, lr) in enumerate(zip(seq, lrs)):
+            tr.lr = lr
+            nxt = seq[k + 1] if k + 1 < len(seq) else None
+            outs_g.append(st.step(d, next_data=nxt)['loss'].clone())
+        torch.cuda.synchronize()
+        assert st.captures == 2  # one graph per padded shape
+        assert tr.iter == eager.iter == len(seq)
+        assert [float(l) for l in outs_g] == outs_e
+        assert torch.equal(tr.arena.flat_param, eager.arena.flat_param)
+        assert torch.equal(tr.flat_momentum, eager.flat_momentum)
+    finally:
+        Y.set_precision('fp32')
+    # fp32: eager with the teacher one step ahead is the default
+    assert AutoStepper(_trainer(dev)).mode == 'eager'
+
+
+def test_auto_stepper_pipelined_equals_eager():
+    from ld_amd import layers as Y
+    from ld_amd.train import AutoStepper
+    dev = torch.device('cuda:0')
+    Y.set_precision('bf16')
+    try:
+        seq = [_batch_g(51, [3, 2], dev), _batch_g(52, [5, 1], dev),
+               _batch_g(53, [2, 7], dev), _batch_g(54, [4, 4], dev)]
+        eager = _trainer(dev)
+        outs_e = [float(eager.step(d)['loss']) for d in seq]
+        torch.cuda.synchronize()
+        tr = _trainer(dev)
+        st = AutoStepper(tr, mode='pipelined', max_gt=16)
+        outs = []
+        for k, d in enumerate(seq):
+            nxt = seq[min(k + 1, len(seq) - 1)]
+            outs.append(st.step(d, next_data=nxt)['loss'].clone())
+        torch.cuda.synchronize()
+        assert [float(l) for l in outs] == outs_e
+        assert torch.equal(tr.arena.flat_param, eager.arena.flat_param)
+        with pytest.raises(ValueError):
+            st.step(seq[0], next_data=seq[1])  # not the batch the pipeline holds
+    finally:
+        Y.set_precision('fp32')
