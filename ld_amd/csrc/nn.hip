@@ -235,29 +235,49 @@ __device__ __forceinline__ int level_of_pos(const Levels& lv, int p) {
 //   stage 1  kGnSplit blocks per (n, g, l) -> partial (sum, sumsq) in fp64
 //   stage 2  one thread per (n, g, l) adds the partials in fixed order
 constexpr int kGnSplit = 32;
+// positions per slice of a level with A positions, and how many slices hold any
+__host__ __device__ __forceinline__ int gn_slice_len(int A) {
+  const int per = (A + kGnSplit - 1) / kGnSplit;
+  return per > 1024 ? per : 1024;
+}
+__host__ __device__ __forceinline__ int gn_slices(int A) {
+  const int per = gn_slice_len(A);
+  return A > 0 ? (A + per - 1) / per : 0;
+}
 
 __global__ __launch_bounds__(256) void gn_stats_partial_kernel(
     const float* __restrict__ x, Levels lv, int C, int G,
     double* __restrict__ partial) {
+  // Only the slices that own positions are launched (gn_slices(): 26 of the
+  // 5 x 32 per (n, group) at the C2 pyramid).  Round 3 first launched all of
+  // them and let the empty ones return at once: 10 240 workgroups, 8 576 of them
+  // empty, cost more to dispatch than the 1 664 real ones to run (27 us per
+  // launch for 46 MB).
   const int L = lv.num_levels;
-  const int sp = blockIdx.x % kGnSplit;
-  const int ngl = blockIdx.x / kGnSplit;
-  const int l = ngl % L, g = (ngl / L) % G, n = ngl / (L * G);
+  int per_ng = 0;
+#pragma unroll
+  for (int i = 0; i < LD_MAX_LEVELS; ++i)
+    if (i < L) per_ng += gn_slices(lv.off[i + 1] - lv.off[i]);
+  const int ng = blockIdx.x / per_ng;
+  int sp = blockIdx.x - ng * per_ng, l = 0;
+#pragma unroll
+  for (int i = 0; i < LD_MAX_LEVELS - 1; ++i) {
+    const int c = i < L ? gn_slices(lv.off[i + 1] - lv.off[i]) : 0;
+    if (l == i && i + 1 < L && sp >= c) {
+      sp -= c;
+      l = i + 1;
+    }
+  }
+  const int g = ng % G, n = ng / G;
+  const int ngl = (n * G + g) * L + l;
   const int cpg = C / G, A = lv.off[l + 1] - lv.off[l];
   const float* base = x + ((size_t)n * C + (size_t)g * cpg) * lv.P + lv.off[l];
   // split sp owns positions [beg, end) of the level in every channel of the
-  // group: coalesced rows, no per-element index arithmetic
-  // at least 1024 positions per slice: the small levels collapse onto one
-  // workgroup each and the other slices return at once
-  const int per = max((A + kGnSplit - 1) / kGnSplit, 1024);
+  // group: coalesced rows, no per-element index arithmetic; at least 1024
+  // positions per slice (the small levels are one workgroup each)
+  const int per = gn_slice_len(A);
   const int beg = sp * per, end = min(A, beg + per);
-  if (beg >= end) {
-    if (threadIdx.x == 0) {
-      partial[(size_t)blockIdx.x * 2 + 0] = 0.0;
-      partial[(size_t)blockIdx.x * 2 + 1] = 0.0;
-    }
-    return;
-  }
+  double* const slot = partial + ((size_t)ngl * kGnSplit + sp) * 2;
   double s = 0.0, q = 0.0;
   // 16-byte loads on the aligned body of the slice (round 3: the scalar loop ran
   // at 1.8 TB/s), scalar on its <= 3-cell edges
@@ -284,8 +304,8 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(
   }
   block_sum2(s, q);
   if (threadIdx.x == 0) {
-    partial[(size_t)blockIdx.x * 2 + 0] = s;
-    partial[(size_t)blockIdx.x * 2 + 1] = q;
+    slot[0] = s;
+    slot[1] = q;
   }
 }
 
@@ -299,7 +319,8 @@ __global__ void gn_stats_final_kernel(const double* __restrict__ partial, Levels
   const int l = ngl % L;
   const double total = (double)(C / G) * (lv.off[l + 1] - lv.off[l]);
   double s = 0.0, q = 0.0;
-  for (int k = 0; k < kGnSplit; ++k) {
+  const int nk = gn_slices(lv.off[l + 1] - lv.off[l]);  // the slices that were written
+  for (int k = 0; k < nk; ++k) {
     s += partial[((size_t)ngl * kGnSplit + k) * 2 + 0];
     q += partial[((size_t)ngl * kGnSplit + k) * 2 + 1];
   }
@@ -1186,7 +1207,9 @@ static int gn_forward_impl(const ld_levels_t* lv, const float* x, const float* g
     return LD_ENOSPACE;
   const Levels k = make_levels(lv);
   const int ngl = N * G * k.num_levels;
-  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(ngl * kGnSplit), dim3(256), 0,
+  int per_ng = 0;
+  for (int l = 0; l < k.num_levels; ++l) per_ng += gn_slices(k.off[l + 1] - k.off[l]);
+  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(N * G * per_ng), dim3(256), 0,
                      LD_STREAM, x, k, C, G, (double*)workspace);
   hipLaunchKernelGGL(gn_stats_final_kernel, dim3((ngl + 255) / 256), dim3(256), 0,
                      LD_STREAM, (const double*)workspace, k, N, C, G, eps, mean,
