@@ -46,3 +46,28 @@ def test_c8_tiled_forward_rings_prefetch(bf16_rows):
         assert min(hist) >= 2, (name, hist)
         seen += 1
     assert seen >= 40  # 22 shapes x 2 modes
+
+
+@pytest.fixture(scope='module')
+def fp32_rows():
+    import isa_lint
+    src = os.path.join(REPO, 'ld_amd', 'csrc', 'conv.hip')
+    if not os.path.exists(isa_lint.os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')):
+        pytest.skip('hipcc not available')
+    return isa_lint.lint(isa_lint.device_asm(src))
+
+
+def test_fp32_stream_kernel_loop_and_epilogue(fp32_rows):
+    """The fp32 streaming conv: counted waits in the k-loop, and an epilogue
+    that is not a chain of dependent loads.  The r-major epilogue over may-alias
+    pointers this round replaced had ~155 `vmcnt(0)` per kernel (one per affine
+    / residual load); the grouped, descriptor-based one has a few per row group
+    and variant."""
+    seen = 0
+    for name, hist, outside0 in fp32_rows:
+        if 'conv_stream_kernel' not in name or not hist:
+            continue
+        seen += 1
+        assert 0 not in hist or hist[0] <= 1, (name, hist)
+        assert outside0 <= 48, (name, outside0)
+    assert seen >= 50
