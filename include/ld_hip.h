@@ -494,10 +494,20 @@ int ld_conv_tune_load(const char* path);
 int ld_conv_tune_save(const char* path);
 int ld_conv_tune_clear(void);
 size_t ld_conv_wgrad_workspace_bytes(const ld_conv_t* c);
-/* dw (Cout,Cin,KH,KW): overwritten, or += if accumulate != 0. */
+/* dw (Cout,Cin,KH,KW): overwritten, or += if accumulate != 0.  Deterministic:
+ * the j-reduction is split in a fixed pattern (per wave, per k-group, per
+ * workgroup) and every partial sum is combined in index order -- by a second
+ * launch, or inside the launch by the last-arriving workgroup of a tile (no
+ * float atomics either way).  Launches that may run concurrently must not share
+ * a workspace. */
 int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy, float* dw,
                   int accumulate, void* workspace, size_t workspace_bytes,
                   ld_stream_t stream);
+/* Times the fp32 weight-gradient kernels / split shapes of this geometry on the
+ * caller's buffers (dw is overwritten) and records the winner in the shape
+ * table (key MODE 2).  Same rules and return values as ld_conv_tune_forward. */
+int ld_conv_tune_wgrad(const ld_conv_t* c, const float* x, const float* dy, float* dw,
+                       void* workspace, size_t workspace_bytes, ld_stream_t stream);
 
 /* ---- convolution, bf16 matrix operands (BASELINE.json config 3) -----------
  * The same three GEMMs on v_mfma_f32_32x32x16_bf16 (16x the f32-MFMA rate).

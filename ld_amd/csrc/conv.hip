@@ -42,7 +42,9 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <string>
 #include <unordered_map>
+#include <vector>
 
 #include "conv_common.h"
 
@@ -2403,17 +2405,94 @@ static int wgrad_splits(const ld_conv_t* c) {
   return best;
 }
 
+// ---- which fp32 weight-gradient kernel, and how it is split (round 4) ---------
+// kind 1 = conv_wgrad_tile_kernel (conv_wgrad.hip: 128 x 128 workgroup tiles, kg
+// k-groups, bk columns per slice, `splits` workgroups per tile, fused = splits
+// combined inside the launch), kind 0 = the wave-private kernel above with its
+// own split model.  Order: LD_CONV_WGRAD_CFG="kind,kg,bk,splits,fused" (tools),
+// the tuning table (key MODE 2, family 0; ld_conv_tune_wgrad), else a model
+// that is a pure function of the geometry -- all ranks pick the same.
+struct WgCfg {
+  int kind, kg, bk, splits, fused;
+};
+
+static LdTuneKey wgrad_tune_key(const ld_conv_t* c) {
+  return LdTuneKey{{2, c->Cin, c->Cout, c->KH, c->KW, c->stride, c->pad, c->N * c->Pout,
+                    c->num_levels, c->lv[0].Hin, c->lv[0].Win, 0, 0, 0, 0, 0, 0, 0}};
+}
+
+// most splits a tile config may use: >= 2 slices per workgroup, <= 128 MB of partials
+static int wgrad_tile_max_splits(const ld_conv_t* c, int bk) {
+  const int J = c->N * c->Pout;
+  const int ntaps = c->KH * c->KW;
+  int by_k = J / (2 * bk);
+  if (by_k < 1) by_k = 1;
+  int sp = by_k < 64 ? by_k : 64;
+  while (sp > 1 && ld_f32_wgrad_tile_workspace(c->Cout, c->Cin, ntaps, sp) > ((size_t)128 << 20))
+    --sp;
+  return sp;
+}
+
+static WgCfg wgrad_model(const ld_conv_t* c) {
+  WgCfg g{0, 0, 0, 0, 0};
+  // narrow outputs (the 68 / 80-channel predictors) would multiply half a tile
+  // of padding: wave-private 64 x 64 tiles
+  if (c->Cout < 96 || c->Cin < 96) return g;
+  g.kind = 1;
+  g.kg = 2;
+  g.bk = 32;
+  g.fused = 1;
+  const int ntaps = c->KH * c->KW;
+  const int tiles = ((c->Cout + 127) / 128) * ((c->Cin + 127) / 128) * ntaps;
+  const int slots = ld_f32_wgrad_tile_slots(g.kg, g.bk);
+  int sp = slots / tiles;
+  if (sp < 1) sp = 1;
+  const int mx = wgrad_tile_max_splits(c, g.bk);
+  g.splits = sp < mx ? sp : mx;
+  return g;
+}
+
+static WgCfg wgrad_pick(const ld_conv_t* c) {
+  if (const char* env = getenv("LD_CONV_WGRAD_CFG")) {
+    WgCfg g{0, 0, 0, 0, 0};
+    if (sscanf(env, "%d,%d,%d,%d,%d", &g.kind, &g.kg, &g.bk, &g.splits, &g.fused) >= 1) {
+      if (g.kind == 0) return g;
+      if (ld_f32_wgrad_tile_cfg_ok(g.kg, g.bk)) {
+        const int mx = wgrad_tile_max_splits(c, g.bk);
+        if (g.splits < 1) g.splits = 1;
+        if (g.splits > mx) g.splits = mx;
+        return g;
+      }
+    }
+  }
+  LdTuneCfg t;
+  if (ld_tune_lookup(wgrad_tune_key(c), &t)) {
+    WgCfg g{t.tm, t.tn, t.wvm, t.d, t.ks};
+    if (g.kind == 0) return g;
+    if (ld_f32_wgrad_tile_cfg_ok(g.kg, g.bk)) {
+      const int mx = wgrad_tile_max_splits(c, g.bk);
+      if (g.splits < 1) g.splits = 1;
+      if (g.splits > mx) g.splits = mx;
+      return g;
+    }
+  }
+  return wgrad_model(c);
+}
+
 extern "C" size_t ld_conv_wgrad_workspace_bytes(const ld_conv_t* c) {
   if (check_conv(c) != 0) return 0;
-  // one size for both kernel families (the bf16 workgroup-tiled wgrad picks its
-  // own split count)
+  // one size for all kernel families and for every candidate ld_conv_tune_wgrad
+  // times (the bf16 workgroup-tiled wgrad picks its own split count)
   int sp = wgrad_splits(c);
   if (ld_bf16_wgrad_tiled(c->Cout, c->Cin, c->Pout))
     sp = max(sp, ld_bf16_wgrad_splits(c->Cout, c->Cin, c->KH * c->KW, c->N * c->Pout));
   if (c->Cin % 8 == 0 && c->Cout % 8 == 0 && ld_bf16_wgrad_c8_tiled(c->Cout, c->Cin))
     sp = max(sp, ld_bf16_wgrad_c8_tile_splits(c->Cout, c->Cin, c->KH * c->KW,
                                               c->N * c->Pout));
-  return (size_t)sp * c->KH * c->KW * c->Cout * c->Cin * sizeof(float);
+  size_t need = (size_t)sp * c->KH * c->KW * c->Cout * c->Cin * sizeof(float);
+  const size_t tile = ld_f32_wgrad_tile_workspace(c->Cout, c->Cin, c->KH * c->KW,
+                                                  wgrad_tile_max_splits(c, 32));
+  return need > tile ? need : tile;
 }
 
 namespace {
@@ -2456,6 +2535,9 @@ int wgrad_run(const ld_conv_t* c, const float* x, const float* dy, float* dw,
     if (int e = ld_bf16_wgrad_c8_launch(k, stream)) return e;
   } else if (family == 1) {
     if (int e = ld_bf16_wgrad_launch(k, stream)) return e;
+  } else if (const WgCfg cfg = wgrad_pick(c); cfg.kind == 1) {
+    return ld_f32_wgrad_tile_launch(k, cfg.kg, cfg.bk, cfg.splits, cfg.fused, dw,
+                                    accumulate, workspace, workspace_bytes, stream);
   } else if (wmode) {
     const int blocks = ((c->Cout + 63) / 64) * ((c->Cin + 63) / 64) * ntaps * k.splits;
     if (wmode == 32)
@@ -2493,6 +2575,106 @@ extern "C" int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy
                              float* dw, int accumulate, void* workspace,
                              size_t workspace_bytes, ld_stream_t stream) {
   return wgrad_run(c, x, dy, dw, accumulate, workspace, workspace_bytes, stream, 0);
+}
+
+// Explicit tuning of the fp32 weight gradient (the counterpart of
+// ld_conv_tune_forward): times the wave-private kernel and every (kg, bk, splits,
+// fused) instance of the workgroup-tiled kernel that fits the geometry on the
+// caller's buffers (dw is overwritten with the same result by every candidate)
+// and records the winner.  Synchronises; not on a capturing stream.
+extern "C" int ld_conv_tune_wgrad(const ld_conv_t* c, const float* x, const float* dy,
+                                  float* dw, void* workspace, size_t workspace_bytes,
+                                  ld_stream_t stream_) {
+  if (int e = check_conv(c)) return e;
+  if (!x || !dy || !dw || !workspace) return LD_EINVAL;
+  if (workspace_bytes < ld_conv_wgrad_workspace_bytes(c)) return LD_ENOSPACE;
+  const LdTuneKey key = wgrad_tune_key(c);
+  LdTuneCfg have;
+  if (ld_tune_lookup(key, &have)) return 1;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(stream, &cap);
+  if (cap != hipStreamCaptureStatusNone) return LD_EUNSUPPORTED;
+  (void)hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  // candidates: the wave-private kernel, then the tile instances
+  std::vector<WgCfg> cands;
+  cands.push_back(WgCfg{0, 0, 0, 0, 0});
+  if (c->Cout >= 48 && c->Cin >= 48) {
+    static const int kShapes[][2] = {{1, 32}, {2, 32}, {4, 32}, {2, 64}, {4, 64}};
+    const int ntaps = c->KH * c->KW;
+    const int tiles = ((c->Cout + 127) / 128) * ((c->Cin + 127) / 128) * ntaps;
+    for (const auto& sh : kShapes) {
+      const int slots = ld_f32_wgrad_tile_slots(sh[0], sh[1]);
+      const int mx = wgrad_tile_max_splits(c, sh[1]);
+      int last = 0;
+      // whole rounds of the device and the steps between them
+      const int tries[] = {slots / tiles, (slots + tiles - 1) / tiles, slots / (2 * tiles),
+                           (3 * slots) / (4 * tiles), 2 * slots / tiles, 1};
+      std::vector<int> seen;
+      for (int sp : tries) {
+        if (sp < 1) sp = 1;
+        if (sp > mx) sp = mx;
+        bool dup = false;
+        for (int v : seen) dup |= v == sp;
+        if (dup) continue;
+        seen.push_back(sp);
+        cands.push_back(WgCfg{1, sh[0], sh[1], sp, 0});
+        if (sp > 1) cands.push_back(WgCfg{1, sh[0], sh[1], sp, 1});
+      }
+      (void)last;
+    }
+  }
+  float best_ms = -1.0f;
+  WgCfg best = cands[0];
+  char envbuf[64];
+  const char* saved = getenv("LD_CONV_WGRAD_CFG");
+  std::string saved_s = saved ? saved : "";
+  for (const WgCfg& g : cands) {
+    snprintf(envbuf, sizeof(envbuf), "%d,%d,%d,%d,%d", g.kind, g.kg, g.bk, g.splits, g.fused);
+    setenv("LD_CONV_WGRAD_CFG", envbuf, 1);
+    if (wgrad_run(c, x, dy, dw, 0, workspace, workspace_bytes, stream_, 0) != 0) continue;
+    float ms = -1.0f;
+    for (int trial = 0; trial < 2; ++trial) {
+      (void)hipEventRecord(e0, stream);
+      for (int rep = 0; rep < kTuneReps; ++rep)
+        wgrad_run(c, x, dy, dw, 0, workspace, workspace_bytes, stream_, 0);
+      (void)hipEventRecord(e1, stream);
+      if (hipEventSynchronize(e1) != hipSuccess) break;
+      float t = 0.0f;
+      (void)hipEventElapsedTime(&t, e0, e1);
+      if (ms < 0.0f || t < ms) ms = t;
+    }
+    if (const char* lg = getenv("LD_CONV_TUNE_LOG"))
+      if (lg[0] == '2')
+        fprintf(stderr, "[ld_conv]   wgrad cand %s  %.1f us\n", envbuf,
+                ms * 1e3 / kTuneReps);
+    if (ms >= 0.0f && (best_ms < 0.0f || ms < best_ms)) {
+      best_ms = ms;
+      best = g;
+    }
+  }
+  if (saved)
+    setenv("LD_CONV_WGRAD_CFG", saved_s.c_str(), 1);
+  else
+    unsetenv("LD_CONV_WGRAD_CFG");
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (const char* lg = getenv("LD_CONV_TUNE_LOG"))
+    if (lg[0] == '1' || lg[0] == '2') {
+      const double fl = 2.0 * c->N * c->Pout * (double)c->Cout * c->Cin * c->KH * c->KW;
+      fprintf(stderr,
+              "[ld_conv] wgrad Cin %d Cout %d k %dx%d s%d J %d lv %d -> kind %d kg %d bk %d "
+              "splits %d fused %d  %.1f TFLOP/s\n",
+              c->Cin, c->Cout, c->KH, c->KW, c->stride, c->N * c->Pout, c->num_levels,
+              best.kind, best.kg, best.bk, best.splits, best.fused,
+              best_ms > 0 ? fl / (best_ms * 1e-3 / kTuneReps) / 1e12 : 0.0);
+    }
+  if (best_ms > 0.0f)
+    ld_tune_store(key, LdTuneCfg{best.kind, best.kg, best.bk, best.splits, best.fused, 0});
+  return 0;
 }
 
 // bf16-MFMA weight gradient: fp32 x / dy / dw, operands rounded to bf16 on the

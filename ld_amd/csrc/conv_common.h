@@ -65,6 +65,16 @@ int ld_bf16_stream_tune(int mode, const ConvK& k, hipStream_t stream);
 int ld_bf16_wgrad_launch(const WgradK& k, hipStream_t stream);
 bool ld_bf16_wgrad_tiled(int Cout, int Cin, int Pout);     // which bf16 wgrad kernel
 int ld_bf16_wgrad_splits(int Cout, int Cin, int ntaps, int J);  // its j-split count
+// conv_wgrad.hip: fp32 workgroup-tiled weight gradient (128 x 128 tiles, kg
+// k-groups of four waves, bk columns per staged slice, `splits` workgroups per
+// tile; fused = combine the splits inside the launch).  Sets k.splits / k.jchunk
+// itself; issues the slab reduce launch when the combination is not fused.
+bool ld_f32_wgrad_tile_cfg_ok(int kg, int bk);
+int ld_f32_wgrad_tile_slots(int kg, int bk);  // workgroups resident on the device
+size_t ld_f32_wgrad_tile_workspace(int Cout, int Cin, int ntaps, int splits);
+int ld_f32_wgrad_tile_launch(const WgradK& k, int kg, int bk, int splits, int fused,
+                             float* dw, int accumulate, void* workspace,
+                             size_t workspace_bytes, hipStream_t stream);
 // conv.hip: fixed-order sum of the wgrad slabs into dW (shared by both families)
 int ld_wgrad_reduce_launch(const float* slabs, int splits, int ntaps, int Cout,
                            int Cin, float* dw, int accumulate, hipStream_t stream);

@@ -775,6 +775,14 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b):
                     _PRECISION[0] != 'bf16' or _WGRAD_FORCE[0] or
                     torch.cuda.is_current_stream_capturing()):
             side = _wgrad_side(dy.device)
+        if not bf16 and not c8w:
+            # explicit tuning writes its result with accumulate = 0: into a
+            # scratch dW, never into the gradient arena
+            _tune_once('wgrad', d, (),
+                       lambda: lib.ld_conv_tune_wgrad(
+                           C.byref(d), L.ptr(x3), L.ptr(dy),
+                           L.ptr(torch.empty_like(w)), L.ptr(ws), ws.numel(),
+                           st))
         with _timed('conv_wgrad_bf16' if bf16 else 'conv_wgrad', d):
             # operand images are produced on the main stream (cached ones cost
             # nothing); the wgrad itself may go to the side stream

@@ -207,6 +207,129 @@ def test_conv_wgrad_kernels(mode, monkeypatch):
         _close(wd.grad, wr.grad, what=f'{name} wgrad [{mode}]')
 
 
+WGRAD_TILE_CFGS = ['1,1,32,1,0', '1,1,32,3,0', '1,1,32,3,1', '1,2,32,1,0', '1,2,32,2,1',
+                   '1,2,32,5,0', '1,2,32,5,1', '1,4,32,1,0', '1,4,32,3,1', '1,2,64,2,1',
+                   '1,2,64,3,0', '1,4,64,1,0', '1,4,64,2,1', '1,4,64,4,0']
+
+
+@pytest.mark.parametrize('cfg', WGRAD_TILE_CFGS)
+def test_conv_wgrad_tile_configs(cfg, monkeypatch):
+    """The workgroup-tiled fp32 weight gradient (conv_wgrad.hip) under every
+    (k-groups, slice width) instance, with 1..5 workgroups per tile combined by
+    the slab reduce launch and inside the launch (last-arriving workgroup),
+    against autograd of F.conv2d.  Covers ragged 128-channel tiles (68 / 80 /
+    64 channels), strides, the level-concatenated head maps and reductions
+    shorter than one slice per split."""
+    from ld_amd import layers as Y
+    monkeypatch.setenv('LD_CONV_WGRAD_CFG', cfg)
+    dev = _dev()
+    for case in CONV_CASES:
+        name, N, cin, cout, k, stride, pad, levels = case
+        g = torch.Generator().manual_seed(len(name) * 13 + cout)
+        P = sum(h * w for h, w in levels)
+        x = torch.randn(N, cin, P, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k)**0.5
+        xr, wr = (t.clone().requires_grad_(True) for t in (x, w))
+        ref = _ref_conv_levels(xr, wr, None, stride, pad, levels)
+        go = torch.randn(ref.shape, generator=g)
+        ref.backward(go)
+        xd, wd = (t.to(dev).requires_grad_(True) for t in (x, w))
+        y, _ = Y.conv2d(xd, wd, None, stride, pad, levels)
+        y.backward(go.to(dev))
+        _close(wd.grad, wr.grad, what=f'{name} wgrad tile [{cfg}]')
+
+
+def _wgrad_call(lib, d, x, dy, dw, ws, acc, st):
+    import ctypes as C
+    from ld_amd import lib as L
+    L.check(lib.ld_conv_wgrad(C.byref(d), L.ptr(x), L.ptr(dy), L.ptr(dw), acc,
+                              L.ptr(ws), ws.numel(), st), 'ld_conv_wgrad')
+
+
+@pytest.mark.parametrize('shape', [(256, 256, 3, 1, 1, ((50, 84), )),
+                                   (1024, 256, 1, 1, 0, ((50, 84), )),
+                                   (256, 80, 3, 1, 1, ((20, 28), (10, 14), (5, 7)))])
+def test_conv_wgrad_fused_equals_slab_reduce(shape, monkeypatch):
+    """In-launch combination of the split partials == the fixed-order slab
+    reduce launch, BIT FOR BIT, overwrite and accumulate, and stays so over
+    repeated launches on one workspace with alternating operands while another
+    stream keeps the device busy (the hand-off under load: a stale partial or a
+    missed ticket shows as a differing word; every word is compared)."""
+    import ctypes as C
+    from ld_amd import layers as Y
+    from ld_amd import lib as L
+    dev = _dev()
+    lib = L.get_lib()
+    cin, cout, k, stride, pad, levels = shape
+    N = 2
+    d, _ = Y.conv_desc(N, cin, cout, k, k, stride, pad, levels)
+    g = torch.Generator().manual_seed(cin + cout)
+    xs = [torch.randn(N, cin, d.Pin, generator=g).to(dev) for _ in range(2)]
+    dys = [torch.randn(N, cout, d.Pout, generator=g).to(dev) for _ in range(2)]
+    ws = torch.zeros(lib.ld_conv_wgrad_workspace_bytes(C.byref(d)),
+                     dtype=torch.uint8, device=dev)
+    st = L.stream_ptr(dev)
+    base = torch.randn(cout, cin, k, k, generator=g).to(dev)
+    for kg, bk, sp in ((2, 32, 6), (1, 32, 4), (4, 64, 3)):
+        refs = []
+        monkeypatch.setenv('LD_CONV_WGRAD_CFG', f'1,{kg},{bk},{sp},0')
+        for x, dy in zip(xs, dys):
+            dw = torch.empty(cout, cin, k, k, device=dev)
+            _wgrad_call(lib, d, x, dy, dw, ws, 0, st)
+            dwa = base.clone()
+            _wgrad_call(lib, d, x, dy, dwa, ws, 1, st)
+            refs.append((dw, dwa))
+        torch.cuda.synchronize()
+        monkeypatch.setenv('LD_CONV_WGRAD_CFG', f'1,{kg},{bk},{sp},1')
+        side = torch.cuda.Stream()
+        busy = torch.randn(4096, 4096, device=dev)
+        for it in range(24):
+            with torch.cuda.stream(side):  # uneven load on the other queue
+                for _ in range(1 + it % 3):
+                    busy = busy * 1.0001 + 0.5
+            x, dy = xs[it % 2], dys[it % 2]
+            dw = torch.full((cout, cin, k, k), float('nan'), device=dev)
+            _wgrad_call(lib, d, x, dy, dw, ws, 0, st)
+            dwa = base.clone()
+            _wgrad_call(lib, d, x, dy, dwa, ws, 1, st)
+            torch.cuda.synchronize()
+            assert torch.equal(dw, refs[it % 2][0]), (kg, bk, sp, it, 'overwrite')
+            assert torch.equal(dwa, refs[it % 2][1]), (kg, bk, sp, it, 'accumulate')
+
+
+def test_conv_tune_wgrad_records_a_pick(tmp_path):
+    """ld_conv_tune_wgrad times the candidates on the caller's buffers, stores
+    the winner under the MODE 2 key, and the next launch uses it (result still
+    equal to the wave-private kernel's within fp32 summation-order noise)."""
+    import ctypes as C
+    from ld_amd import layers as Y
+    from ld_amd import lib as L
+    dev = _dev()
+    lib = L.get_lib()
+    d, _ = Y.conv_desc(2, 128, 256, 3, 3, 1, 1, ((30, 44), ))
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 128, d.Pin, generator=g).to(dev)
+    dy = torch.randn(2, 256, d.Pout, generator=g).to(dev)
+    ws = torch.zeros(lib.ld_conv_wgrad_workspace_bytes(C.byref(d)),
+                     dtype=torch.uint8, device=dev)
+    st = L.stream_ptr(dev)
+    dw = torch.empty(256, 128, 3, 3, device=dev)
+    rc = lib.ld_conv_tune_wgrad(C.byref(d), L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(ws),
+                                ws.numel(), st)
+    assert rc == 0
+    assert lib.ld_conv_tune_wgrad(C.byref(d), L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(ws),
+                                  ws.numel(), st) == 1
+    f = str(tmp_path / 't.txt')
+    L.save_tune_table(f)
+    mine = [ln.split() for ln in open(f) if ln.split()[:5] == ['2', '128', '256', '3', '3']]
+    assert len(mine) == 1 and len(mine[0]) == 24
+    _wgrad_call(lib, d, x, dy, dw, ws, 0, st)
+    ref = torch.nn.grad.conv2d_weight(
+        x.reshape(2, 128, 30, 44).cpu().double(), (256, 128, 3, 3),
+        dy.reshape(2, 256, 30, 44).cpu().double(), padding=1)
+    _close(dw, ref, what='tuned wgrad')
+
+
 @pytest.mark.parametrize('shape', [(2, 5, 40, 64), (1, 3, 37, 132), (2, 4, 9, 8),
                                    (1, 2, 16, 30), (3, 1, 7, 7), (1, 64, 400, 672)])
 def test_maxpool_vector_and_scalar_paths(shape):
