@@ -2427,22 +2427,35 @@ static int wgrad_tile_max_splits(const ld_conv_t* c, int bk) {
   const int ntaps = c->KH * c->KW;
   int by_k = J / (2 * bk);
   if (by_k < 1) by_k = 1;
-  int sp = by_k < 64 ? by_k : 64;
+  int sp = by_k < 256 ? by_k : 256;
   while (sp > 1 && ld_f32_wgrad_tile_workspace(c->Cout, c->Cin, ntaps, sp) > ((size_t)128 << 20))
     --sp;
   return sp;
 }
 
 static WgCfg wgrad_model(const ld_conv_t* c) {
+  // Untuned geometries; the rules are the pattern of the round-4 sweep on the C2
+  // shapes (profiles/r04_wgrad_sweep.json).  In-launch combination of the splits
+  // (fused) measured slower than the slab reduce launch everywhere: off.
   WgCfg g{0, 0, 0, 0, 0};
-  // narrow outputs (the 68 / 80-channel predictors) would multiply half a tile
-  // of padding: wave-private 64 x 64 tiles
-  if (c->Cout < 96 || c->Cin < 96) return g;
+  if (c->Cout < 48 || c->Cin < 48) return g;  // stem-like: wave-private 64 x 64 tiles
+  const int J = c->N * c->Pout;
+  const int ntaps = c->KH * c->KW;
+  if (c->KH == 3 && c->KW == 3) {
+    // three kw taps per workgroup when a workgroup still gets >= ~1000 columns
+    const int tiles3 = ((c->Cout + 127) / 128) * ((c->Cin + 127) / 128) * 3;
+    if ((long)J * tiles3 >= 256L * 1000) {
+      g.kind = 2;
+      int sp = 256 / tiles3;
+      if (sp < 1) sp = 1;
+      const int mx = wgrad_tile_max_splits(c, 32);
+      g.splits = sp < mx ? sp : mx;
+      return g;
+    }
+  }
   g.kind = 1;
   g.kg = 2;
-  g.bk = 32;
-  g.fused = 1;
-  const int ntaps = c->KH * c->KW;
+  g.bk = 64;
   const int tiles = ((c->Cout + 127) / 128) * ((c->Cin + 127) / 128) * ntaps;
   const int slots = ld_f32_wgrad_tile_slots(g.kg, g.bk);
   int sp = slots / tiles;
@@ -2457,6 +2470,11 @@ static WgCfg wgrad_pick(const ld_conv_t* c) {
     WgCfg g{0, 0, 0, 0, 0};
     if (sscanf(env, "%d,%d,%d,%d,%d", &g.kind, &g.kg, &g.bk, &g.splits, &g.fused) >= 1) {
       if (g.kind == 0) return g;
+      if (g.kind == 2 && c->KH == 3 && c->KW == 3) {
+        const int mx = wgrad_tile_max_splits(c, 32);
+        g.splits = g.splits < 1 ? 1 : (g.splits > mx ? mx : g.splits);
+        return g;
+      }
       if (ld_f32_wgrad_tile_cfg_ok(g.kg, g.bk)) {
         const int mx = wgrad_tile_max_splits(c, g.bk);
         if (g.splits < 1) g.splits = 1;
@@ -2469,6 +2487,11 @@ static WgCfg wgrad_pick(const ld_conv_t* c) {
   if (ld_tune_lookup(wgrad_tune_key(c), &t)) {
     WgCfg g{t.tm, t.tn, t.wvm, t.d, t.ks};
     if (g.kind == 0) return g;
+    if (g.kind == 2 && c->KH == 3 && c->KW == 3) {
+      const int mx = wgrad_tile_max_splits(c, 32);
+      g.splits = g.splits < 1 ? 1 : (g.splits > mx ? mx : g.splits);
+      return g;
+    }
     if (ld_f32_wgrad_tile_cfg_ok(g.kg, g.bk)) {
       const int mx = wgrad_tile_max_splits(c, g.bk);
       if (g.splits < 1) g.splits = 1;
@@ -2538,6 +2561,9 @@ int wgrad_run(const ld_conv_t* c, const float* x, const float* dy, float* dw,
   } else if (const WgCfg cfg = wgrad_pick(c); cfg.kind == 1) {
     return ld_f32_wgrad_tile_launch(k, cfg.kg, cfg.bk, cfg.splits, cfg.fused, dw,
                                     accumulate, workspace, workspace_bytes, stream);
+  } else if (cfg.kind == 2) {
+    return ld_f32_wgrad_tap3_launch(k, cfg.splits, dw, accumulate, workspace,
+                                    workspace_bytes, stream);
   } else if (wmode) {
     const int blocks = ((c->Cout + 63) / 64) * ((c->Cin + 63) / 64) * ntaps * k.splits;
     if (wmode == 32)
@@ -2625,6 +2651,23 @@ extern "C" int ld_conv_tune_wgrad(const ld_conv_t* c, const float* x, const floa
         if (sp > 1) cands.push_back(WgCfg{1, sh[0], sh[1], sp, 1});
       }
       (void)last;
+    }
+  }
+  if (c->KH == 3 && c->KW == 3 && c->Cout >= 48 && c->Cin >= 48) {
+    // the three kw taps of a kernel row per workgroup, one workgroup per CU
+    const int tiles3 = ((c->Cout + 127) / 128) * ((c->Cin + 127) / 128) * 3;
+    const int mx = wgrad_tile_max_splits(c, 32);
+    std::vector<int> seen;
+    const int tries[] = {256 / tiles3, (256 + tiles3 - 1) / tiles3, 128 / tiles3,
+                         192 / tiles3, 384 / tiles3, 512 / tiles3, 1};
+    for (int sp : tries) {
+      if (sp < 1) sp = 1;
+      if (sp > mx) sp = mx;
+      bool dup = false;
+      for (int v : seen) dup |= v == sp;
+      if (dup) continue;
+      seen.push_back(sp);
+      cands.push_back(WgCfg{2, 0, 0, sp, 0});
     }
   }
   float best_ms = -1.0f;

@@ -75,6 +75,8 @@ size_t ld_f32_wgrad_tile_workspace(int Cout, int Cin, int ntaps, int splits);
 int ld_f32_wgrad_tile_launch(const WgradK& k, int kg, int bk, int splits, int fused,
                              float* dw, int accumulate, void* workspace,
                              size_t workspace_bytes, hipStream_t stream);
+int ld_f32_wgrad_tap3_launch(const WgradK& k, int splits, float* dw, int accumulate,
+                             void* workspace, size_t workspace_bytes, hipStream_t stream);
 // conv.hip: fixed-order sum of the wgrad slabs into dW (shared by both families)
 int ld_wgrad_reduce_launch(const float* slabs, int splits, int ntaps, int Cout,
                            int Cin, float* dw, int accumulate, hipStream_t stream);

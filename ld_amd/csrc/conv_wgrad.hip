@@ -64,7 +64,10 @@ constexpr int wgrad_tile_occ(int kg, int bk) {
   return wgs * kg > 4 ? 4 : wgs * kg;
 }
 
-template <int KG, int BK, bool ML>
+// DBG (timing attribution only, results are wrong when non-zero; LD_WGRAD_DBG in
+// tools/): 1 = no barrier in the main loop, 2 = no global loads, 4 = no LDS
+// writes, 8 = no per-slice position decode, 16 = no fragment reads.
+template <int KG, int BK, bool ML, int DBG = 0>
 __global__ __launch_bounds__(256 * KG, wgrad_tile_occ(KG, BK)) void conv_wgrad_tile_kernel(
     WgradK a, WgradTileOut o) {
   constexpr int TB = 128;            // tile edge (co and ci)
@@ -165,6 +168,12 @@ __global__ __launch_bounds__(256 * KG, wgrad_tile_occ(KG, BK)) void conv_wgrad_t
   };
 
   float sta[NP], stb[NP];  // the slice in flight: dY rows, X rows
+  float sta2[NP], stb2[NP];            // DBG & 64 only
+#pragma unroll
+  for (int i = 0; i < NP; ++i) sta2[i] = stb2[i] = 0.0f;
+  floatx4 sta4[NP / 4], stb4[NP / 4];  // DBG & 32 only
+#pragma unroll
+  for (int i = 0; i < NP / 4; ++i) sta4[i] = stb4[i] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
   unsigned vy = kOOB, vx = kOOB;
   // LDS write position of pass 0 (floats): image row r0, column kq
   const int wr0 = r0 * LDA + kq;
@@ -222,8 +231,8 @@ __global__ __launch_bounds__(256 * KG, wgrad_tile_occ(KG, BK)) void conv_wgrad_t
       if (step >= nsteps) break;
       const float* cur = lds + u * STAGE;
       float* nxt = lds + (u ^ 1) * STAGE;
-      unsigned vy2, vx2;
-      decode(jbeg + (step + 2) * BK, vy2, vx2);
+      unsigned vy2 = vy, vx2 = vx;
+      if (!(DBG & 8)) decode(jbeg + (step + 2) * BK, vy2, vx2);
       floatx2 fa[2][2], fb[2][2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(256 * KG, wgrad_tile_occ(KG, BK)) void conv_wgrad_t
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int c = q & 1;
-        if (q + 1 < NQ) {
+        if (q + 1 < NQ && !(DBG & 16)) {
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             fa[c ^ 1][i] = *reinterpret_cast<const floatx2*>(cur + fa0 + i * 32 * LDA +
@@ -243,15 +252,44 @@ __global__ __launch_bounds__(256 * KG, wgrad_tile_occ(KG, BK)) void conv_wgrad_t
                                                             4 * (q + 1));
           }
         }
-        // staging slots 2q, 2q + 1 of both operands: slice step + 1 -> LDS, then
-        // the same registers take slice step + 2
+        if constexpr ((DBG & 32) != 0) {
+          // timing experiment: the same bytes as 16-byte loads (8 rows x 128 B per
+          // wave instruction), taps' border masks ignored
+          constexpr int NP4 = NP / 4;
+          const int row4 = t / 8, quad = t % 8;
+          const bool isb = q >= NP4;
+          const int i4 = isb ? q - NP4 : q;
+          float* dst = nxt + (isb ? OPF : 0) + (row4 + i4 * (NT / 8)) * LDA + 4 * quad;
+          floatx4& reg = isb ? stb4[i4] : sta4[i4];
+          if (!(DBG & 4)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[e] = reg[e];
+          }
+          const unsigned vb = isb ? vx2 - (unsigned)(r0 * Pin + kq) * 4u +
+                                        (unsigned)(row4 * Pin + 4 * quad) * 4u
+                                  : vy2 - (unsigned)(r0 * Pout + kq) * 4u +
+                                        (unsigned)(row4 * Pout + 4 * quad) * 4u;
+          const unsigned so = (unsigned)i4 * (unsigned)(NT / 8) * (unsigned)(isb ? Pin : Pout) * 4u;
+          if (!(DBG & 2))
+            reg = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  isb ? rx : ry, vb + so, 0, 0));
+        } else
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int i = 2 * q + h;
-          nxt[wr0 + i * RPASS * LDA] = sta[i];
-          nxt[OPF + wr0 + i * RPASS * LDA] = stb[i];
-          sta[i] = buf_load(ry, vy2 + sa, 0);
-          stb[i] = buf_load(rx, vx2 + sb, 0);
+          if (!(DBG & 4)) {
+            nxt[wr0 + i * RPASS * LDA] = sta[i];
+            nxt[OPF + wr0 + i * RPASS * LDA] = stb[i];
+          }
+          if constexpr ((DBG & 64) != 0) {  // timing: one more slice of load distance
+            sta[i] = sta2[i];
+            stb[i] = stb2[i];
+            sta2[i] = buf_load(ry, vy2 + sa, 0);
+            stb2[i] = buf_load(rx, vx2 + sb, 0);
+          } else if (!(DBG & 2)) {
+            sta[i] = buf_load(ry, vy2 + sa, 0);
+            stb[i] = buf_load(rx, (DBG & 128) ? kOOB : vx2 + sb, 0);
+          }
           sa += da;
           sb += db;
         }
@@ -265,7 +303,7 @@ __global__ __launch_bounds__(256 * KG, wgrad_tile_occ(KG, BK)) void conv_wgrad_t
                                                                acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      __syncthreads();  // slice step + 1 complete; nobody still reads buffer u
+      if (!(DBG & 1)) __syncthreads();  // slice step + 1 complete; nobody still reads buffer u
     }
   }
 
@@ -437,6 +475,249 @@ __global__ __launch_bounds__(256 * KG, wgrad_tile_occ(KG, BK)) void conv_wgrad_t
     __hip_atomic_store(o.tickets + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- 3x3 convs: the three kw taps of a kernel row in ONE workgroup ------------
+// What the timing attribution of the kernel above shows (head-tower shape,
+// profiles/r04_wgrad_attribution.txt): MFMAs alone 369 us, everything but the
+// global loads 376 us, the full kernel 460 us; with the X loads returning nothing
+// 405 us; one more slice of load distance changes nothing -- the cost is
+// proportional to the BYTES that miss L1 (8 B / clk / CU at 128 x 128 tiles),
+// not to latency, barriers or LDS work.  The nine tap workgroups of a (co, ci)
+// tile all read the same dY rows and -- shifted by one position -- the same X
+// rows; spread over different CUs each of them misses L1 on its own.  Here the
+// three kw taps of one kernel row share a workgroup of 12 wavefronts: the dY
+// image is staged once for all three (a third of its L1 misses) and the three X
+// images are loaded back to back by the same CU (the shifted segments are the
+// same cache lines: L1 hits for two of the three).  Each 4-wave tap group owns
+// its X image, its tap and its 128 x 128 accumulators; nothing is reduced across
+// groups.  LDS per slice: dY 144 rows (18 passes of 8, so that the three groups
+// stage six passes each -- rows 128..143 are loaded and never read) + 3 x 128
+// X rows, pitch 34 floats: 71.8 KB, two buffers, one workgroup per CU, three
+// waves per SIMD.
+template <bool ML>
+__global__ __launch_bounds__(768, 3) void conv_wgrad_tap3_kernel(WgradK a, WgradTileOut o) {
+  constexpr int TB = 128, BK = 32, LDA = BK + 2;
+  constexpr int DYR = 144;              // dY image rows (18 passes x 8)
+  constexpr int NPX = 16, NPY = 6;      // load passes per lane: X image, dY share
+  constexpr int XOFF = DYR * LDA;       // first X image (floats)
+  constexpr int XIMG = TB * LDA;        // one X image
+  constexpr int STAGE = XOFF + 3 * XIMG;
+  constexpr int NQ = BK / 4;            // 8 fragment quads per slice
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+  __shared__ int s_geo[LD_MAX_LEVELS * 6];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int g = wave >> 2, w4 = wave & 3;  // tap group (= kw), wave position
+  const int wm = w4 >> 1, wn = w4 & 1;
+  const int l31 = lane & 31, lk = lane >> 5;
+  const int Cin = __builtin_amdgcn_readfirstlane(a.Cin);
+  const int Cout = __builtin_amdgcn_readfirstlane(a.Cout);
+  const int Pin = __builtin_amdgcn_readfirstlane(a.Pin);
+  const int Pout = __builtin_amdgcn_readfirstlane(a.Pout);
+  const int nlev = __builtin_amdgcn_readfirstlane(a.g.num_levels);
+  const int stride = __builtin_amdgcn_readfirstlane(a.g.stride);
+  const int pad = __builtin_amdgcn_readfirstlane(a.g.pad);
+  const int mt = (Cout + TB - 1) / TB, nt = (Cin + TB - 1) / TB;
+  const int ntiles = mt * nt * 3;
+  int b = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tile_id = b % ntiles;
+  const int split = b / ntiles;
+  const int ntile = tile_id % nt;
+  const int mtile = (tile_id / nt) % mt;
+  const int kh = tile_id / (nt * mt);
+  const int kw = g;
+  const int tap = kh * 3 + kw;
+  const int m0 = mtile * TB, c0 = ntile * TB;
+  const int jbeg = split * a.jchunk;
+  const int jend = min(a.J, jbeg + a.jchunk);
+
+  if (ML) {
+    if (t < LD_MAX_LEVELS) {
+      const ld_conv_level_t lv = a.g.lv[t];
+      s_geo[t * 6 + 0] = lv.Hin;
+      s_geo[t * 6 + 1] = lv.Win;
+      s_geo[t * 6 + 2] = lv.Hout;
+      s_geo[t * 6 + 3] = lv.Wout;
+      s_geo[t * 6 + 4] = lv.off_in;
+      s_geo[t * 6 + 5] = lv.off_out;
+    }
+    __syncthreads();
+  }
+  const int Hin0 = __builtin_amdgcn_readfirstlane(a.g.lv[0].Hin);
+  const int Win0 = __builtin_amdgcn_readfirstlane(a.g.lv[0].Win);
+  const int Wout0 = __builtin_amdgcn_readfirstlane(a.g.lv[0].Wout);
+
+  // load side: the group's 256 lanes = (column kq of the slice, first row r0)
+  const int tl = t & 255;
+  const int kq = tl & 31, r0 = tl >> 5;
+  const int ry0 = r0 + 48 * g;  // first dY row of this lane: passes 6g .. 6g + 5
+  const rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  const rsrc_t ry = make_rsrc(a.dy, a.dy_bytes);
+  const unsigned da = 8u * (unsigned)Pout * 4u, db = 8u * (unsigned)Pin * 4u;
+
+  auto decode = [&](int j0, unsigned& vy, unsigned& vx) {
+    const int j = j0 + kq;
+    const int n = j / Pout, p = j - n * Pout;
+    int Hin = Hin0, Win = Win0, Wout = Wout0, off_in = 0, off_out = 0;
+    if (ML) {
+      int l = 0;
+      for (int i = 1; i < nlev; ++i)
+        if (p >= s_geo[i * 6 + 5]) l = i;
+      Hin = s_geo[l * 6 + 0];
+      Win = s_geo[l * 6 + 1];
+      Wout = s_geo[l * 6 + 3];
+      off_in = s_geo[l * 6 + 4];
+      off_out = s_geo[l * 6 + 5];
+    }
+    const int r = p - off_out;
+    const int ho = r / Wout, wo = r - ho * Wout;
+    const int hi = ho * stride - pad + kh, wi = wo * stride - pad + kw;
+    const bool jok = j < jend;
+    const bool xok = jok && hi >= 0 && hi < Hin && wi >= 0 && wi < Win;
+    // dY rows past Cout (the image's rows 128..143, ragged tiles): range-checked
+    // voffset -> the next image's rows or zero, never stored (see the kernel above)
+    vy = jok ? (unsigned)((n * Cout + m0 + ry0) * Pout + p) * 4u : kOOB;
+    vx = xok ? (unsigned)((n * Cin + c0 + r0) * Pin + off_in + hi * Win + wi) * 4u
+             : kOOB;
+  };
+
+  float sty[NPY], stx[NPX];
+  unsigned vy = kOOB, vx = kOOB;
+  const int wry = ry0 * LDA + kq;                   // dY image, pass 0
+  const int wrx = XOFF + g * XIMG + r0 * LDA + kq;  // this group's X image, pass 0
+  const int fa0 = (wm * 64 + l31) * LDA + 2 * lk;
+  const int fb0 = XOFF + g * XIMG + (wn * 64 + l31) * LDA + 2 * lk;
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int nsteps = (jend - jbeg + BK - 1) / BK;
+  {
+    decode(jbeg, vy, vx);
+    unsigned sa = 0, sb = 0;
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      stx[i] = buf_load(rx, vx + sb, 0);
+      sb += db;
+      if (i < NPY) {
+        sty[i] = buf_load(ry, vy + sa, 0);
+        sa += da;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      lds[wrx + i * 8 * LDA] = stx[i];
+      if (i < NPY) lds[wry + i * 8 * LDA] = sty[i];
+    }
+    decode(jbeg + BK, vy, vx);
+    sa = 0;
+    sb = 0;
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      stx[i] = buf_load(rx, vx + sb, 0);
+      sb += db;
+      if (i < NPY) {
+        sty[i] = buf_load(ry, vy + sa, 0);
+        sa += da;
+      }
+    }
+  }
+  __syncthreads();
+
+  for (int base = 0; base < nsteps; base += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int step = base + u;
+      if (step >= nsteps) break;
+      const float* cur = lds + u * STAGE;
+      float* nxt = lds + (u ^ 1) * STAGE;
+      unsigned vy2, vx2;
+      decode(jbeg + (step + 2) * BK, vy2, vx2);
+      floatx2 fa[2][2], fb[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[0][i] = *reinterpret_cast<const floatx2*>(cur + fa0 + i * 32 * LDA);
+        fb[0][i] = *reinterpret_cast<const floatx2*>(cur + fb0 + i * 32 * LDA);
+      }
+      unsigned sa = 0, sb = 0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int c = q & 1;
+        if (q + 1 < NQ) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            fa[c ^ 1][i] = *reinterpret_cast<const floatx2*>(cur + fa0 + i * 32 * LDA +
+                                                            4 * (q + 1));
+            fb[c ^ 1][i] = *reinterpret_cast<const floatx2*>(cur + fb0 + i * 32 * LDA +
+                                                            4 * (q + 1));
+          }
+        }
+        // X slots 2q, 2q + 1 and (q < 6) dY slot q: slice step + 1 -> LDS, the
+        // registers take slice step + 2
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int i = 2 * q + h;
+          nxt[wrx + i * 8 * LDA] = stx[i];
+          stx[i] = buf_load(rx, vx2 + sb, 0);
+          sb += db;
+        }
+        if (q < NPY) {
+          nxt[wry + q * 8 * LDA] = sty[q];
+          sty[q] = buf_load(ry, vy2 + sa, 0);
+          sa += da;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][e], fb[c][j][e],
+                                                               acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- output: every tap group stores its own tile ---------------------------
+  if (o.out_mode == 0) {
+    float* slab = a.slabs + ((size_t)split * 9 + tap) * Cout * Cin;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ci = c0 + wn * 64 + j * 32 + l31;
+      if (ci >= Cin) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (co < Cout) slab[(size_t)co * Cin + ci] = acc[i][j][r];
+        }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ci = c0 + wn * 64 + j * 32 + l31;
+      if (ci >= Cin) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (co >= Cout) continue;
+          const size_t idx = ((size_t)co * Cin + ci) * 9 + tap;
+          o.dw[idx] = o.accumulate ? o.dw[idx] + acc[i][j][r] : acc[i][j][r];
+        }
+    }
+  }
+}
+
 // ---- host side --------------------------------------------------------------
 constexpr size_t kTicketSlots = 4096;  // counters per workspace (tiles per launch)
 constexpr size_t kTicketPools = 256;   // distinct workspaces served per device
@@ -483,8 +764,35 @@ unsigned* ticket_slice(const void* workspace, hipStream_t stream) {
   return p.base + idx * kTicketSlots;
 }
 
+template <int DBG>
+void launch_tile_dbg(const WgradK& k, const WgradTileOut& o, int blocks, hipStream_t stream) {
+  hipLaunchKernelGGL((conv_wgrad_tile_kernel<1, 32, true, DBG>), dim3(blocks), dim3(256), 0,
+                     stream, k, o);
+}
+
 template <int KG, int BK>
 void launch_tile(const WgradK& k, const WgradTileOut& o, int blocks, hipStream_t stream) {
+  if (KG == 1 && BK == 32) {
+    if (const char* env = getenv("LD_WGRAD_DBG")) {
+      switch (atoi(env)) {
+        case 1: return launch_tile_dbg<1>(k, o, blocks, stream);
+        case 2: return launch_tile_dbg<2>(k, o, blocks, stream);
+        case 4: return launch_tile_dbg<4>(k, o, blocks, stream);
+        case 6: return launch_tile_dbg<6>(k, o, blocks, stream);
+        case 8: return launch_tile_dbg<8>(k, o, blocks, stream);
+        case 14: return launch_tile_dbg<14>(k, o, blocks, stream);
+        case 15: return launch_tile_dbg<15>(k, o, blocks, stream);
+        case 16: return launch_tile_dbg<16>(k, o, blocks, stream);
+        case 30: return launch_tile_dbg<30>(k, o, blocks, stream);
+        case 31: return launch_tile_dbg<31>(k, o, blocks, stream);
+        case 32: return launch_tile_dbg<32>(k, o, blocks, stream);
+        case 33: return launch_tile_dbg<33>(k, o, blocks, stream);
+        case 64: return launch_tile_dbg<64>(k, o, blocks, stream);
+        case 128: return launch_tile_dbg<128>(k, o, blocks, stream);
+        default: break;
+      }
+    }
+  }
   if (k.g.num_levels > 1)
     hipLaunchKernelGGL((conv_wgrad_tile_kernel<KG, BK, true>), dim3(blocks), dim3(256 * KG),
                        0, stream, k, o);
@@ -497,6 +805,42 @@ void launch_tile(const WgradK& k, const WgradTileOut& o, int blocks, hipStream_t
 
 bool ld_f32_wgrad_tile_cfg_ok(int kg, int bk) {
   return (bk == 32 && (kg == 1 || kg == 2 || kg == 4)) || (bk == 64 && (kg == 2 || kg == 4));
+}
+
+// 3 x 3 convs only: conv_wgrad_tap3_kernel (one workgroup = the three kw taps of a
+// kernel row of a 128 x 128 tile).  256 workgroups fill the device.
+int ld_f32_wgrad_tap3_launch(const WgradK& k_in, int splits, float* dw, int accumulate,
+                             void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (k_in.KH != 3 || k_in.KW != 3) return LD_EUNSUPPORTED;
+  WgradK k = k_in;
+  const int ntiles = ((k.Cout + 127) / 128) * ((k.Cin + 127) / 128) * 3;
+  if (splits < 1) splits = 1;
+  int jchunk = (k.J + splits - 1) / splits;
+  jchunk = (jchunk + 31) / 32 * 32;
+  splits = (k.J + jchunk - 1) / jchunk;
+  k.splits = splits;
+  k.jchunk = jchunk;
+  if (splits > 1 &&
+      workspace_bytes < (size_t)splits * 9 * k.Cout * k.Cin * sizeof(float))
+    return LD_ENOSPACE;
+  WgradTileOut o;
+  o.dw = dw;
+  o.accumulate = accumulate;
+  o.part = nullptr;
+  o.tickets = nullptr;
+  o.out_mode = splits == 1 ? 1 : 0;
+  k.slabs = (float*)workspace;
+  const int blocks = ntiles * splits;
+  if (k.g.num_levels > 1)
+    hipLaunchKernelGGL((conv_wgrad_tap3_kernel<true>), dim3(blocks), dim3(768), 0, stream, k,
+                       o);
+  else
+    hipLaunchKernelGGL((conv_wgrad_tap3_kernel<false>), dim3(blocks), dim3(768), 0, stream, k,
+                       o);
+  if (hipError_t e = hipGetLastError()) return (int)e;
+  if (o.out_mode == 0)
+    return ld_wgrad_reduce_launch(k.slabs, splits, 9, k.Cout, k.Cin, dw, accumulate, stream);
+  return 0;
 }
 
 // workgroups the device holds at once for a (kg, bk) instance: LDS (2 buffers of

@@ -279,6 +279,21 @@ def grad_probe(n, seed):
     return h.astype(np.float64) / 4294967296.0 - 0.5
 
 
+def grad_sample_idx(n, k=256, seed=7):
+    """k deterministic flat indices into a gradient of n elements (all of them
+    when n <= k): integer hash, exact on every platform, so the fixture and the
+    test address the same elements without storing the indices."""
+    import numpy as np
+    if n <= k:
+        return np.arange(n, dtype=np.int64)
+    i = np.arange(k, dtype=np.uint64)
+    h = (i * np.uint64(2246822519) + np.uint64(seed * 3266489917 % (1 << 32))) & \
+        np.uint64(0xFFFFFFFF)
+    h = (h ^ (h >> np.uint64(16))) * np.uint64(2654435761) & np.uint64(0xFFFFFFFF)
+    h = h ^ (h >> np.uint64(13))
+    return (h % np.uint64(n)).astype(np.int64)
+
+
 VOTING_CASES = [
     # name, pad, img_shapes, scale factors, seed, nms_pre, clustered
     ('v_small', (128, 160), [(128, 160, 3), (120, 150, 3)],

@@ -770,6 +770,59 @@ def gen_e2e_v2_r3(cases=None):
     print('e2e_v2_r3.npz')
 
 
+def gen_grad_samples(cases=None):
+    """Round 4: whole-step parameter gradients of the
+    REFERENCE at the BASELINE config-2 size, ELEMENT-WISE -- for every trainable
+    parameter 256 sampled elements (synthetic.grad_sample_idx: a fixed integer
+    hash of the element count) and the gradient's max |g|.  Their own file
+    (grad_samples.npz): the earlier fixtures stay byte-identical.  The step is
+    exactly gen_e2e's / gen_e2e_v2_r3's (same seeds, same batch)."""
+    d = {}
+    path = os.path.join(OUT, 'grad_samples.npz')
+    if os.path.exists(path) and cases:
+        d = dict(np.load(path))
+    todo = [(n, c, p, i, g, b, None) for n, c, p, i, g, b in E2E_CASES
+            if n in ('small_r50', 'c2_r50')]
+    todo += [c for c in E2E_V2_R3_CASES if c[0] == 'v2_c2_r50']
+    for name, cfg_path, pad, img_shape, num_gt, bseed, teacher in todo:
+        if cases and name not in cases:
+            continue
+        torch.manual_seed(0)
+        det = build_reference_detector(cfg_path, imitation_method='finegrained')
+        det.load_state_dict(
+            synthetic.seeded_state_dict(det.state_dict(), seed=1))
+        det.teacher_model.load_state_dict(
+            synthetic.seeded_state_dict(det.teacher_model.state_dict(), seed=2))
+        det.train()
+        batch = synthetic.synthetic_batch(
+            num_imgs=len(num_gt), img_shape=img_shape, pad_shape=pad,
+            num_gt=num_gt, seed=bseed)
+        t0 = time.time()
+        losses = det.forward_train(batch['img'], batch['img_metas'],
+                                   batch['gt_bboxes'], batch['gt_labels'])
+        loss, log_vars = det._parse_losses(losses)
+        loss.backward()
+        names, vals, amax = [], [], []
+        for k, p in det.named_parameters():
+            if p.grad is None:
+                continue
+            gflat = p.grad.reshape(-1)
+            idx = synthetic.grad_sample_idx(gflat.numel())
+            v = np.zeros(256, dtype=np.float32)
+            v[:idx.size] = gflat[torch.from_numpy(idx)].numpy()
+            names.append(k)
+            vals.append(v)
+            amax.append(float(gflat.abs().max()))
+        d[name + '_grad_names'] = np.array(names)
+        d[name + '_grad_samples'] = np.stack(vals)
+        d[name + '_grad_absmax'] = np.array(amax)
+        d[name + '_loss'] = np.array(float(loss.detach()))
+        print(f'  grad samples {name}: {time.time() - t0:.1f}s, {len(names)} '
+              f'parameters, loss {float(loss.detach()):.6f}')
+    np.savez_compressed(path, **d)
+    print('grad_samples.npz')
+
+
 RESNEXT_CASES = [
     # name, depth, input (N, H, W), seed, sample step of the stored features
     ('x101_small', 101, (2, 64, 96), 31, 1),
@@ -1606,6 +1659,8 @@ def main():
         gen_resnext()
     if 'e2e_v2_r3' in only:
         gen_e2e_v2_r3([c for c in args.e2e_cases.split(',') if c])
+    if 'grad_samples' in only:
+        gen_grad_samples([c for c in args.e2e_cases.split(',') if c])
 
 
 if __name__ == '__main__':

@@ -209,7 +209,8 @@ def test_conv_wgrad_kernels(mode, monkeypatch):
 
 WGRAD_TILE_CFGS = ['1,1,32,1,0', '1,1,32,3,0', '1,1,32,3,1', '1,2,32,1,0', '1,2,32,2,1',
                    '1,2,32,5,0', '1,2,32,5,1', '1,4,32,1,0', '1,4,32,3,1', '1,2,64,2,1',
-                   '1,2,64,3,0', '1,4,64,1,0', '1,4,64,2,1', '1,4,64,4,0']
+                   '1,2,64,3,0', '1,4,64,1,0', '1,4,64,2,1', '1,4,64,4,0',
+                   '2,0,0,1,0', '2,0,0,3,0', '2,0,0,8,0']
 
 
 @pytest.mark.parametrize('cfg', WGRAD_TILE_CFGS)

@@ -165,3 +165,16 @@ def test_ldv2_step_vs_reference_r3(golden, name):
             if abs(gp - want) > 1e-2 * r + 1e-6:
                 bad.append((k, f'proj{sd}', gp, want))
     assert not bad, f'{len(bad)} gradient checks off, first: {bad[:5]}'
+    if name == 'v2_c2_r50':
+        # ... and element-wise against the reference's own gradients (round 4)
+        import os
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from _gradcheck import check_grad_samples
+        worst = check_grad_samples(golden, name, params)
+        print(name, 'worst err/tol ratios:', [(round(r, 3), k) for r, k, _, _ in worst[:5]])
+        off = [(k, float(params[k].grad.double().norm()), float(r))
+               for k, r in zip(names, g[name + '_grad_norms'])
+               if not np.isclose(float(params[k].grad.double().norm()), r, rtol=1e-3,
+                                 atol=1e-7)]
+        assert not off, f'{len(off)} grad norms off at 1e-3, first: {off[:5]}'

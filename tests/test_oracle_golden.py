@@ -231,3 +231,38 @@ def test_net_oracle_vs_golden(golden, name, sdepth):
         got = float(res['grads'][k].double().norm())
         np.testing.assert_allclose(got, ref, rtol=2e-3, atol=1e-7,
                                    err_msg=k)
+
+
+def test_net_oracle_gradient_elements_vs_reference(golden):
+    """Round 4: the oracle's whole-step gradients, ELEMENT-WISE against the
+    reference's own (256 sampled elements per parameter,
+    tests/golden/grad_samples.npz): pins the checker the GPU element-wise tests
+    of the small cases rely on.  Both sides are torch-CPU fp32, so the band is
+    the summation-order noise of the convolutions."""
+    import net_oracle as NO
+    import torch
+    from ld_amd import build_detector, model_zoo
+    g, gs = golden['e2e'], golden['grad_samples']
+    name = 'small_r50'
+    cfg = g[name + '_cfg']
+    pad, img_shape, bseed = tuple(cfg[:2]), tuple(cfg[2:4]), int(cfg[4])
+    num_gt = [int(x) for x in g[name + '_num_gt']]
+    batch = synthetic.synthetic_batch(len(num_gt), img_shape, pad, num_gt, bseed)
+    det = build_detector(model_zoo.ld_detector(50, 101))
+    ssd = synthetic.seeded_state_dict(det.state_dict(), seed=1)
+    tsd = synthetic.seeded_state_dict(det.teacher_model.state_dict(), seed=2)
+    torch.set_num_threads(8)
+    res = NO.ld_train_step(ssd, tsd, batch, 50, 101, None)
+    names = [str(k) for k in gs[name + '_grad_names']]
+    assert sorted(names) == sorted(res['grads'])
+    worst = 0.0
+    for k, ref, am in zip(names, gs[name + '_grad_samples'], gs[name + '_grad_absmax']):
+        flat = res['grads'][k].reshape(-1)
+        idx = synthetic.grad_sample_idx(flat.numel())
+        got = flat[torch.from_numpy(idx)].double().numpy()
+        ref = ref[:idx.size].astype(np.float64)
+        tol = 2e-4 * np.abs(ref) + 2e-6 * am
+        ratio = float((np.abs(got - ref) / (tol + 1e-30)).max())
+        worst = max(worst, ratio)
+        assert ratio <= 1.0, (k, ratio)
+    print('worst err/tol', worst)

@@ -21,6 +21,12 @@ def main():
     ap.add_argument('--graph', action='store_true')
     ap.add_argument('--pipeline', action='store_true',
                     help='teacher of the next batch under this step')
+    ap.add_argument('--serial', action='store_true',
+                    help='ONE stream: teacher inside the step on the main '
+                         'stream, weight gradients on the main stream -- no two '
+                         'kernels overlap, so a rocprofv3 --kernel-trace --stats '
+                         'of this run sums to the serialised conv time that '
+                         'bench.py\'s roofline.conv_ms_per_step reports')
     ap.add_argument('--buckets', default='',
                     help='write the gradient-bucket timeline (when each '
                          'bucket of the arena is complete, relative to '
@@ -39,7 +45,11 @@ def main():
         torch.cuda.set_device(dev)
         dist.init_process_group('nccl', device_id=dev)
     Y.set_precision(args.mode)
+    if args.serial:
+        Y._WGRAD_STREAM[0] = False
     det = model_zoo.build_seeded_ld_detector(50, 101, dev)
+    if args.serial:
+        det.use_teacher_stream = False
     tr = SGDTrainer(det, lr=model_zoo.OPTIMIZER['lr'])
     b = synthetic.synthetic_batch(2, (800, 1333), (800, 1344), 7, 1234)
     d = dict(img=b['img'].to(dev), img_metas=b['img_metas'],

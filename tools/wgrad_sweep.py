@@ -60,12 +60,12 @@ def slots(kg, bk):
     return 256 * max(per_cu, 1)
 
 
-def candidates(cin, cout, k, J, quick):
+def candidates(cin, cout, k, J, quick, fused=False):
     out = [(0, 0, 0, 0, 0)]
     tiles = -(-cout // 128) * -(-cin // 128) * k * k
     for kg, bk in TILE_SHAPES:
         sl = slots(kg, bk)
-        mx = max(1, min(64, J // (2 * bk)))
+        mx = max(1, min(256, J // (2 * bk)))
         base = sl / tiles
         mults = (1.0, ) if quick else (0.25, 0.5, 0.75, 1.0, 1.5, 2.0)
         seen = set()
@@ -76,10 +76,20 @@ def candidates(cin, cout, k, J, quick):
                     continue
                 seen.add(sp)
                 out.append((1, kg, bk, sp, 0))
-                if sp > 1:
+                if sp > 1 and fused:
                     out.append((1, kg, bk, sp, 1))
         if 1 not in seen:
             out.append((1, kg, bk, 1, 0))
+    if k == 3:  # the three kw taps of a kernel row per workgroup, one workgroup per CU
+        tiles3 = -(-cout // 128) * -(-cin // 128) * 3
+        mx = max(1, min(256, J // 64))
+        seen = set()
+        for m in ((1.0, ) if quick else (0.25, 0.5, 0.75, 1.0, 1.5, 2.0, 3.0)):
+            for sp in {int(256 / tiles3 * m), -(-int(256 / tiles3 * m * 1000) // 1000)}:
+                sp = max(1, min(mx, sp))
+                if sp not in seen:
+                    seen.add(sp)
+                    out.append((2, 0, 0, sp, 0))
     return out
 
 
@@ -91,6 +101,7 @@ def main():
     ap.add_argument('--quick', action='store_true')
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--only', default='')
+    ap.add_argument('--fused', action='store_true', help='also time the in-launch combination')
     args = ap.parse_args()
     from ld_amd import layers as Y
     from ld_amd import lib as L
@@ -118,7 +129,7 @@ def main():
                                       acc, L.ptr(ws), ws.numel(), st), 'wgrad')
         ref = None
         best = None
-        for cand in candidates(cin, cout, k, J, args.quick):
+        for cand in candidates(cin, cout, k, J, args.quick, args.fused):
             os.environ['LD_CONV_WGRAD_CFG'] = ','.join(str(v) for v in cand)
             dw.fill_(float('nan'))
             try:
