@@ -11,6 +11,13 @@ import torch
 from . import lib as L
 
 _WS = {}
+# Buffers a larger one superseded.  They are kept alive for the life of the
+# process: a hipGraph captured earlier has the old pointer baked into its
+# launches (the wgrad side stream and the teacher stream are shared by every
+# GraphedStep), and replaying it after the buffer was freed would write split-K
+# slabs into memory the allocator has handed to someone else.  Sizes
+# only grow, so the list stays short.
+_WS_RETIRED = []
 
 
 def workspace(device, nbytes, tag='ws'):
@@ -20,6 +27,8 @@ def workspace(device, nbytes, tag='ws'):
     key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
+        if t is not None:
+            _WS_RETIRED.append(t)
         t = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8,
                         device=device)
         # a buffer born while a hipGraph is being captured lives in that graph's

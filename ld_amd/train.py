@@ -35,11 +35,30 @@ def _world():
     return 1
 
 
+_SUSPENDED = [0]
+
+
+class suspend_collectives:
+    """``with suspend_collectives():`` -- no gradient / scalar collective is
+    issued inside (collectives_on() is False).  For steps whose result is
+    thrown away on THIS rank only: the warm-up steps of a lazily captured
+    hipGraph (AutoStepper).  Ranks see different padded shapes at the same
+    iteration (DistributedGroupSampler), so one rank may be warming up a capture
+    while its peers replay: collectives issued by the warm-up would have no
+    partner."""
+
+    def __enter__(self):
+        _SUSPENDED[0] += 1
+
+    def __exit__(self, *exc):
+        _SUSPENDED[0] -= 1
+
+
 def collectives_on():
     """True when gradient / scalar collectives must be issued.  With
     LD_FORCE_COLLECTIVES=1 they are issued even in a 1-rank group, which lets
     the RCCL code path be exercised on a single-GPU box."""
-    if not (dist.is_available() and dist.is_initialized()):
+    if _SUSPENDED[0] or not (dist.is_available() and dist.is_initialized()):
         return False
     return dist.get_world_size() > 1 or \
         os.environ.get('LD_FORCE_COLLECTIVES', '0') == '1'
@@ -359,11 +378,17 @@ class GraphedStep:
     Every launch entry point of libldhip.so only enqueues (no timing, no
     synchronisation: include/ld_hip.h), which is what makes the step capturable;
     shape tuning must have happened before (ld_conv_tune_* refuse a capturing
-    stream).  With world_size > 1 the bucketed RCCL all-reduces are captured
-    like any other launch.
+    stream).  With world_size > 1 the bucketed RCCL all-reduces are issued on
+    the capturing stream like any other launch; this has been exercised only
+    through a forced-collective ONE-rank group (tests/test_gpu_rccl.py) -- a
+    multi-GPU node was never available to this build, so bench.py keeps the
+    graph leg off for N > 1 unless asked (--graph-multi).  ``warmup_collectives
+    = False`` runs the warm-up steps without collectives (see
+    ``suspend_collectives``): for captures that only this rank performs.
     """
 
-    def __init__(self, trainer, data, warmup=2, max_gt=128):
+    def __init__(self, trainer, data, warmup=2, max_gt=128,
+                 warmup_collectives=True):
         from . import lossblock as LB
         self.trainer = trainer
         dev = data['img'].device
@@ -394,7 +419,11 @@ class GraphedStep:
             # anything is recorded
             with Y.capture_warmup():
                 for _ in range(max(warmup, 1)):
-                    trainer.step(self.data)
+                    if warmup_collectives:
+                        trainer.step(self.data)
+                    else:  # a capture only THIS rank performs (AutoStepper)
+                        with suspend_collectives():
+                            trainer.step(self.data)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
@@ -581,7 +610,7 @@ class AutoStepper:
         every call and one padded shape throughout.
     """
 
-    def __init__(self, trainer, mode=None, warmup=1, max_gt=128):
+    def __init__(self, trainer, mode=None, warmup=1, max_gt=128, max_graphs=6):
         if mode is None:
             on_gpu = next(trainer.model.parameters()).is_cuda
             mode = 'graph' if (on_gpu and Y.get_precision() == 'bf16') else 'eager'
@@ -589,7 +618,19 @@ class AutoStepper:
             raise ValueError(f'AutoStepper: unknown mode {mode!r}')
         self.trainer, self.mode = trainer, mode
         self.warmup, self.max_gt = int(warmup), int(max_gt)
-        self._graphs = {}
+        # one graph per padded shape, at most max_graphs of them (least recently
+        # used evicted: each holds a private pool with a whole step's
+        # activations, and the reference's Resize(keep_ratio) + Pad(32) pipeline
+        # produces dozens of padded shapes on COCO -- ADVICE r3)
+        import collections
+        self._graphs = collections.OrderedDict()
+        self.max_graphs = max(1, int(max_graphs))
+        self.evictions = 0
+        if collectives_on() and mode != 'eager':
+            # RCCL sets its communicator up lazily on the first collective: do
+            # that here, eagerly and on every rank, never inside a capture
+            t = torch.zeros(1, device=next(trainer.model.parameters()).device)
+            dist.all_reduce(t)
         self._pipe = None
         self._pipe_loaded = None  # the batch object the pipeline holds for its next step
         self.captures = 0
@@ -617,13 +658,20 @@ class AutoStepper:
             key = (tuple(data['img'].shape), len(data['img_metas']))
             g = self._graphs.get(key)
             if g is None:
+                while len(self._graphs) >= self.max_graphs:
+                    self._graphs.popitem(last=False)  # frees that graph's pool
+                    self.evictions += 1
                 st = self._saved_state()
+                # the warm-up's result is discarded (state restored below) and
+                # only THIS rank captures now: no collectives in it
                 g = GraphedStep(self.trainer, data, warmup=self.warmup,
-                                max_gt=self.max_gt)
+                                max_gt=self.max_gt, warmup_collectives=False)
                 torch.cuda.synchronize(data['img'].device)
                 self._restore_state(st)
                 self._graphs[key] = g
                 self.captures += 1
+            else:
+                self._graphs.move_to_end(key)
             g.copy_inputs(data)
             return g.replay()
         # pipelined: the graph of this step runs the teacher of next_data

@@ -770,6 +770,70 @@ def gen_e2e_v2_r3(cases=None):
     print('e2e_v2_r3.npz')
 
 
+def _two_rank_worker(rank, world, port, cases, ret):
+    """One rank of the REFERENCE under a real gloo group: LDHead.loss on this
+    rank's case (its own reduce_mean all-reduces, ld_head.py:338-341,362-365) and
+    BaseDetector._parse_losses (base.py:185-218) with its per-key all-reduce."""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from mmdet.models.detectors.base import BaseDetector
+        name, pad, img_shape, num_gt, bseed, hseed, _ = \
+            [c for c in LOSSBLOCK_CASES if c[0] == cases[rank]][0]
+        head = _ld_head()
+        batch = synthetic.synthetic_batch(num_imgs=len(num_gt), img_shape=img_shape,
+                                          pad_shape=pad, num_gt=num_gt, seed=bseed)
+        sizes = synthetic.level_shapes(pad)
+        hi = synthetic.synthetic_head_inputs(len(num_gt), sizes, seed=hseed)
+        losses = head.loss(hi['cls'], hi['reg'], batch['gt_bboxes'],
+                           batch['gt_labels'], (hi['t_cls'], hi['t_reg']),
+                           hi['x'], hi['t_x'], batch['img_metas'])
+        table = np.stack(
+            [np.array([float(v.detach()) for v in losses[k]]) for k in LOSS_KEYS])
+        loss, log_vars = BaseDetector._parse_losses(None, losses)
+        ret[rank] = dict(table=table, loss=float(loss.detach()),
+                         log_vars=[log_vars[k] for k in LOSS_KEYS + ['loss']])
+    finally:
+        dist.destroy_process_group()
+
+
+def gen_lossblock_2rank():
+    """Round 4: the reference's own cross-rank arithmetic.
+    Two gloo ranks execute LDHead.loss on DIFFERENT lossblock cases; the tables
+    each rank gets (QFL divided by max(mean_ranks(num_total_pos), 1), GIoU / DFL
+    by mean_ranks(sum weight_targets + 1e-6)) and the rank-averaged log_vars are
+    the fixture (tests/golden/lossblock_2rank.npz)."""
+    import socket
+    import torch.multiprocessing as mp
+    d = {}
+    for tag, cases in (('small_pair', ('small', 'small_crowd')),
+                       ('c2_pair', ('c2', 'c2_crowd'))):
+        so = socket.socket()
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+        so.close()
+        ctx = mp.get_context('spawn')
+        ret = ctx.Manager().dict()
+        procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, cases, ret))
+                 for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(600)
+            assert p.exitcode == 0
+        d[tag + '_cases'] = np.array(cases)
+        for r in range(2):
+            d[f'{tag}_r{r}_losses'] = ret[r]['table'].astype(np.float64)
+            d[f'{tag}_r{r}_loss'] = np.array(ret[r]['loss'])
+            d[f'{tag}_r{r}_log_vars'] = np.array(ret[r]['log_vars'], dtype=np.float64)
+        print(f'  2-rank {tag}: loss', ret[0]['loss'], ret[1]['loss'], 'log loss',
+              ret[0]['log_vars'][-1])
+    np.savez_compressed(os.path.join(OUT, 'lossblock_2rank.npz'), **d)
+    print('lossblock_2rank.npz')
+
+
 def gen_grad_samples(cases=None):
     """Round 4: whole-step parameter gradients of the
     REFERENCE at the BASELINE config-2 size, ELEMENT-WISE -- for every trainable
@@ -1659,6 +1723,8 @@ def main():
         gen_resnext()
     if 'e2e_v2_r3' in only:
         gen_e2e_v2_r3([c for c in args.e2e_cases.split(',') if c])
+    if 'lossblock_2rank' in only:
+        gen_lossblock_2rank()
     if 'grad_samples' in only:
         gen_grad_samples([c for c in args.e2e_cases.split(',') if c])
 

@@ -6,7 +6,9 @@
  (iii) _parse_losses' single packed all-reduce equals per-key means, and
  (iv) ranks that were initialised with DIFFERENT seeds hold rank 0's
      parameters, frozen parameters and buffers after GradArena's constructor
-     (the broadcast MMDistributedDataParallel does, apis/train.py:74-84)."""
+     (the broadcast MMDistributedDataParallel does, apis/train.py:74-84), and
+ (v) a step that only one rank performs under suspend_collectives (the warm-up
+     of a lazily captured hipGraph) issues no collective."""
 import os
 import socket
 
@@ -56,6 +58,31 @@ def _worker(rank, world, port, ret):
             for p, r in zip(model.parameters(), ref):
                 got = p.grad / world  # SGD kernel folds 1/world in
                 assert torch.allclose(got, r, rtol=1e-5, atol=1e-6), step
+        # (v) a step only ONE rank performs (the warm-up of a lazily captured
+        # hipGraph, AutoStepper): under suspend_collectives it issues no
+        # collective, so the peer -- which does nothing meanwhile -- is not left
+        # with an unmatched all-reduce, and the next real step still reduces
+        from ld_amd.train import collectives_on, suspend_collectives
+        if rank == 0:
+            with suspend_collectives():
+                assert not collectives_on()
+                arena.zero_grad()
+                ((model(full_x[:4]) - full_y[:4])**2).sum(1).mean().backward()
+                arena.finish()
+                local = [p.grad.clone() for p in model.parameters()]
+            lm = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(),
+                                     torch.nn.Linear(32, 8), torch.nn.Linear(8, 4))
+            lm.load_state_dict(model.state_dict())
+            ((lm(full_x[:4]) - full_y[:4])**2).sum(1).mean().backward()
+            for a, b in zip(local, lm.parameters()):
+                assert torch.allclose(a, b.grad, rtol=1e-5, atol=1e-6)
+        assert collectives_on()
+        arena.zero_grad()
+        sl = slice(rank * 4, rank * 4 + 4)
+        ((model(full_x[sl]) - full_y[sl])**2).sum(1).mean().backward()
+        arena.finish()
+        for p, r in zip(model.parameters(), ref):
+            assert torch.allclose(p.grad / world, r, rtol=1e-5, atol=1e-6)
         # (ii) normaliser reduction
         red = GFLHead._norm_reducer()
         norm = torch.tensor([3.0 + rank, 1.5 * (rank + 1), 0., 0.])
