@@ -10,6 +10,7 @@ import torch.nn as nn
 
 from .config import Config, ConfigDict
 from .heads import LazyScalars
+from .layers import side_stream as _side_stream
 from .registry import (DETECTORS, build_backbone, build_detector, build_head,
                        build_neck)
 
@@ -271,7 +272,7 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
         if not (self.use_teacher_stream and img.is_cuda and self.eval_teacher):
             return False
         if self.teacher_stream is None:
-            self.teacher_stream = torch.cuda.Stream(device=img.device)
+            self.teacher_stream = _side_stream(img.device, 'teacher')
         main = torch.cuda.current_stream(img.device)
         side = self.teacher_stream
         side.wait_stream(main)  # the batch (and all earlier work) is ready
@@ -339,7 +340,7 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
                                     gt_bboxes, gt_labels, gt_bboxes_ignore)
         if self.use_teacher_stream and img.is_cuda:
             if self.teacher_stream is None:
-                self.teacher_stream = torch.cuda.Stream(device=img.device)
+                self.teacher_stream = _side_stream(img.device, 'teacher')
             main = torch.cuda.current_stream(img.device)
             side = self.teacher_stream
             side.wait_stream(main)

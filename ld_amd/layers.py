@@ -669,6 +669,20 @@ DIRECT_GRADS = [True]
 # (train.GradArena / SGDTrainer call wgrad_join).  Same kernels, same operands:
 # the result is bit-identical.  Only for gradients that go straight into the
 # arena -- a gradient handed back to autograd is consumed on the main stream.
+def side_stream(device, role):
+    """A side stream of the train step ('teacher': the frozen teacher's forward
+    one step ahead; 'wgrad': weight gradients, off the backward critical path).
+    LD_SIDE_STREAM_PRIORITY = an integer gives them that HIP stream priority
+    (lower number = higher priority; the main stream has 0): with a positive
+    value the dispatcher prefers the critical path's kernels and lets the side
+    streams fill what is left."""
+    pr = os.environ.get('LD_SIDE_STREAM_PRIORITY_' + role.upper(),
+                        os.environ.get('LD_SIDE_STREAM_PRIORITY'))
+    if pr is None:
+        return torch.cuda.Stream(device=device)
+    return torch.cuda.Stream(device=device, priority=int(pr))
+
+
 _WGRAD_STREAM = [os.environ.get('LD_WGRAD_STREAM', '1') == '1']
 _WGRAD_SIDE = {}
 _WGRAD_PENDING = [False]
@@ -693,7 +707,7 @@ def _wgrad_side(device):
     key = str(device)
     st = _WGRAD_SIDE.get(key)
     if st is None:
-        st = torch.cuda.Stream(device=device)
+        st = side_stream(device, 'wgrad')
         _WGRAD_SIDE[key] = st
     return st
 

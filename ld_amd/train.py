@@ -503,7 +503,7 @@ class PipelinedGraphedStep:
         dev = first['img'].device
         self.dev = dev
         if model.teacher_stream is None:
-            model.teacher_stream = torch.cuda.Stream(device=dev)
+            model.teacher_stream = Y.side_stream(dev, 'teacher')
         max_gt = max([int(max_gt)] + [int(b.shape[0]) for d in (first, second)
                                       for b in d['gt_bboxes']])
         self.slots = []

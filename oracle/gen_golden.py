@@ -887,6 +887,57 @@ def gen_grad_samples(cases=None):
     print('grad_samples.npz')
 
 
+def gen_grad_truth64(cases=('small_r50', 'c2_r50')):
+    """How well fp32 DEFINES these gradients (round 4): the same steps with the
+    nets evaluated in float64 (oracle/net_oracle.py on float64 state_dicts and
+    images; the loss block stays the fp32 numpy oracle), sampled at the elements
+    of grad_samples.npz, plus the REFERENCE's own deviation from it per
+    parameter.  On small_r50 the reference's fp32 CPU gradients differ from the
+    float64 evaluation by up to 4e-4 of max|g| (median 4e-5): that, not 1e-5, is
+    the floor any fp32 implementation can be held to element-wise.  This fixture
+    is produced by the ORACLE, not by the reference (the reference is fp32-only
+    here); the oracle is pinned on the reference element-wise in
+    tests/test_oracle_golden.py."""
+    import net_oracle as NO
+    from ld_amd import build_detector, model_zoo
+    gs = np.load(os.path.join(OUT, 'grad_samples.npz'))
+    ge = np.load(os.path.join(OUT, 'e2e.npz'))
+    d = {}
+    for name in cases:
+        cfg = ge[name + '_cfg']
+        pad, img_shape, bseed = tuple(cfg[:2]), tuple(cfg[2:4]), int(cfg[4])
+        num_gt = [int(x) for x in ge[name + '_num_gt']]
+        batch = synthetic.synthetic_batch(len(num_gt), img_shape, pad, num_gt, bseed)
+        det = build_detector(model_zoo.ld_detector(50, 101))
+        ssd = synthetic.seeded_state_dict(det.state_dict(), seed=1)
+        tsd = synthetic.seeded_state_dict(det.teacher_model.state_dict(), seed=2)
+        to64 = lambda sd: {k: (v.double() if v.is_floating_point() else v)  # noqa: E731
+                           for k, v in sd.items()}
+        b64 = dict(batch)
+        b64['img'] = batch['img'].double()
+        t0 = time.time()
+        res = NO.ld_train_step(to64(ssd), to64(tsd), b64, 50, 101, None)
+        names = [str(k) for k in gs[name + '_grad_names']]
+        vals, referr = [], []
+        for k, ref, am in zip(names, gs[name + '_grad_samples'],
+                              gs[name + '_grad_absmax']):
+            flat = res['grads'][k].reshape(-1)
+            idx = synthetic.grad_sample_idx(flat.numel())
+            v = np.zeros(256, dtype=np.float64)
+            v[:idx.size] = flat[torch.from_numpy(idx)].double().numpy()
+            vals.append(v)
+            referr.append(float(np.abs(ref[:idx.size] - v[:idx.size]).max()))
+        d[name + '_grad_names'] = np.array(names)
+        d[name + '_grad_truth64'] = np.stack(vals)
+        d[name + '_ref_abs_err'] = np.array(referr)
+        rel = np.array(referr) / np.maximum(gs[name + '_grad_absmax'], 1e-30)
+        print(f'  truth64 {name}: {time.time() - t0:.1f}s; reference vs float64, '
+              f'max|err| / max|g| per parameter: median {np.median(rel):.2e}, '
+              f'max {rel.max():.2e}')
+    np.savez_compressed(os.path.join(OUT, 'grad_truth64.npz'), **d)
+    print('grad_truth64.npz')
+
+
 RESNEXT_CASES = [
     # name, depth, input (N, H, W), seed, sample step of the stored features
     ('x101_small', 101, (2, 64, 96), 31, 1),
@@ -1725,6 +1776,8 @@ def main():
         gen_e2e_v2_r3([c for c in args.e2e_cases.split(',') if c])
     if 'lossblock_2rank' in only:
         gen_lossblock_2rank()
+    if 'grad_truth64' in only:
+        gen_grad_truth64()
     if 'grad_samples' in only:
         gen_grad_samples([c for c in args.e2e_cases.split(',') if c])
 

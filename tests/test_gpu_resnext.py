@@ -172,7 +172,7 @@ def test_ldv2_step_vs_reference_r3(golden, name):
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         from _gradcheck import check_grad_samples
         worst = check_grad_samples(golden, name, params)
-        print(name, 'worst err/tol ratios:', [(round(r, 3), k) for r, k, _, _ in worst[:5]])
+        print(name, 'vs reference, max|err|/max|g| top 5:', [(f'{r:.1e}', k) for r, k in worst[:5]])
         off = [(k, float(params[k].grad.double().norm()), float(r))
                for k, r in zip(names, g[name + '_grad_norms'])
                if not np.isclose(float(params[k].grad.double().norm()), r, rtol=1e-3,
