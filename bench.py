@@ -57,6 +57,11 @@ def parse():
     ap.add_argument('--profile-steps', type=int, default=2)
     ap.add_argument('--no-graph', action='store_true',
                     help='skip the hipGraph-replay leg')
+    ap.add_argument('--graph-multi', action='store_true',
+                    help='run the hipGraph-replay leg with N > 1 ranks too (RCCL '
+                    'all-reduces issued on the capturing stream: exercised only '
+                    'through a forced-collective 1-rank group so far, off by '
+                    'default so that an untested path cannot hang a scaling run)')
     ap.add_argument('--no-bf16', action='store_true',
                     help='skip the bf16 (BASELINE config 3) leg')
     ap.add_argument('--no-prefetch', action='store_true',
@@ -126,8 +131,9 @@ def kernel_roofline(trainer, dbatch, steps, bf16=False):
                   'operand images, conv_bf16.hip)')
     else:
         main, rest, peak = agg, {}, PEAK_FP32_MFMA_TFLOPS
-        kernel = ('conv (fp32 MFMA 32x32x2 implicit GEMM: streaming fwd/dgrad '
-                  '+ wave-private wgrad)')
+        kernel = ('conv (fp32 MFMA 32x32x2 implicit GEMM: streaming fwd/dgrad, '
+                  'workgroup-tiled / three-taps-per-workgroup wgrad with '
+                  'in-workgroup k-groups, conv.hip + conv_wgrad.hip)')
     tot_t = sum(v[0] for v in main.values())
     tot_f = sum(v[1] for v in main.values())
     tot_n = sum(v[2] for v in main.values())
@@ -662,7 +668,7 @@ def main():
     # ~750 launches of a step cost ~13 ms of Python + ctypes on the host, which
     # binds once the kernels are faster than that).  Reported beside the eager
     # numbers; `value` stays the eager fp32 step.
-    if not args.no_graph and world == 1:
+    if not args.no_graph and (world == 1 or args.graph_multi):
         from ld_amd import layers as Y
         from ld_amd.train import GraphedStep
         graph_res = {}

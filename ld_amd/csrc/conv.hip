@@ -463,7 +463,10 @@ __global__ __launch_bounds__(64 * WVM * WVN * KG) void conv_igemm_kernel(ConvK a
 // (J = 8400 / 2100 stages) lose up to half the machine to the rounding of
 // tiles-per-SIMD; quartering the work unit brings that back (8.2 -> 9 instead
 // of 2.05 -> 3).  The per-element summation order differs from KS = 1.
-template <int TM, int TN, int WVM, int MODE, int D, int OCC, int KS>
+// DBG (timing attribution only, LD_STREAM_DBG, results wrong when non-zero): 1 = the
+// ring is never refilled after the prologue, 2 = pixel (B) loads read nothing,
+// 4 = weight (A) loads read nothing, 8 = no epilogue stores / epilogue loads.
+template <int TM, int TN, int WVM, int MODE, int D, int OCC, int KS, int DBG = 0>
 __global__ __launch_bounds__(256, OCC) void conv_stream_kernel(ConvK a) {
   static_assert(KS == 1 || (KS == 4 && WVM == 1), "KS is 1 or 4");
   static_assert(D * (TM + TN) < 64, "ring exceeds the 6-bit vmcnt counter");
@@ -548,9 +551,9 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_kernel(ConvK a) {
   float ra[D][TM], rb[D][TN];
   auto load_kp = [&](int d, unsigned sa, unsigned sb) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) ra[d][i] = buf_load(rw, va[i], sa);
+    for (int i = 0; i < TM; ++i) ra[d][i] = buf_load(rw, (DBG & 4) ? kOOB : va[i], sa);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) rb[d][j] = buf_load(rx, vb[j], sb);
+    for (int j = 0; j < TN; ++j) rb[d][j] = buf_load(rx, (DBG & 2) ? kOOB : vb[j], sb);
   };
 
   floatx16 acc[TM][TN];
@@ -608,8 +611,9 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_kernel(ConvK a) {
         // refills below the MFMAs and the prefetch distance collapses to zero
         mfma_kp(d);
         __builtin_amdgcn_sched_barrier(0);
-        load_kp(d, sa + (unsigned)(2 * d) * Cout * 4u,
-                sb + (unsigned)(2 * d) * Pin * 4u);
+        if (!(DBG & 1))
+          load_kp(d, sa + (unsigned)(2 * d) * Cout * 4u,
+                  sb + (unsigned)(2 * d) * Pin * 4u);
         __builtin_amdgcn_sched_barrier(0);
       }
       advance(KS);
@@ -665,6 +669,17 @@ __global__ __launch_bounds__(256, OCC) void conv_stream_kernel(ConvK a) {
   //     the old loop held (1 x 1 tile: 76 -> 48 VGPRs, 6 -> 8 waves per SIMD);
   //   * the residual / raw-output variants are separate straight-line copies.
   // Same arithmetic per element as before: bit-identical results.
+  if (DBG & 8) {  // keep the accumulators alive without the epilogue's traffic
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    if (s == 1.2345e-30f) a.y[0] = s;
+    return;
+  }
   const bool has_res = a.residual != nullptr;
   const bool has_raw = MODE == 0 && a.y_raw != nullptr;
   const bool relu = a.relu != 0;
@@ -1650,6 +1665,23 @@ inline unsigned cap_lds_bytes(int cap, int static_bytes) {
 template <int MODE>
 int launch_stream_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream,
                       int cap = 0) {
+  if (const char* env = getenv("LD_STREAM_DBG")) {
+    // timing attribution (tools/stream_dbg.py): the 1x1x1 d16 ks4 / ks1 shapes only
+    const int dbg = atoi(env);
+    if (MODE == 0 && dbg && c.tm == 1 && c.tn == 1 && c.wvm == 1 && c.d == 16) {
+      const int bm = 32, bn = 32;
+      const int nb = ((k.Cout + bm - 1) / bm) * ((k.J + bn - 1) / bn);
+#define LD_DBG_CASE(V_)                                                                  \
+  if (dbg == V_ && c.ks == 4) {                                                          \
+    hipLaunchKernelGGL((conv_stream_kernel<1, 1, 1, 0, 16, 4, 4, V_>), dim3(nb), dim3(256), \
+                       0, stream, k);                                                    \
+    return (int)hipGetLastError();                                                       \
+  }
+      LD_DBG_CASE(1) LD_DBG_CASE(2) LD_DBG_CASE(4) LD_DBG_CASE(6) LD_DBG_CASE(8) LD_DBG_CASE(9)
+      LD_DBG_CASE(14)
+#undef LD_DBG_CASE
+    }
+  }
   const int bm = (c.ks == 4 ? 1 : c.wvm) * c.tm * 32;
   const int bn = (c.ks == 4 ? 1 : 4 / c.wvm) * c.tn * 32;
   const int nb = ((k.Cout + bm - 1) / bm) * ((k.J + bn - 1) / bn);
