@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256 * KG, wgrad_tile_occ(KG, BK)) void conv_wgrad_t
 // stage six passes each -- rows 128..143 are loaded and never read) + 3 x 128
 // X rows, pitch 34 floats: 71.8 KB, two buffers, one workgroup per CU, three
 // waves per SIMD.
-template <bool ML>
+template <bool ML, int DBG = 0>
 __global__ __launch_bounds__(768, 3) void conv_wgrad_tap3_kernel(WgradK a, WgradTileOut o) {
   constexpr int TB = 128, BK = 32, LDA = BK + 2;
   constexpr int DYR = 144;              // dY image rows (18 passes x 8)
@@ -663,7 +663,9 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_tap3_kernel(WgradK a, Wgrad
         for (int h = 0; h < 2; ++h) {
           const int i = 2 * q + h;
           nxt[wrx + i * 8 * LDA] = stx[i];
-          stx[i] = buf_load(rx, vx2 + sb, 0);
+          // DBG 1 (timing only): only tap group 0 reads X -- the traffic of ONE
+          // shared X image
+          stx[i] = buf_load(rx, (DBG == 1 && g != 0) ? kOOB : vx2 + sb, 0);
           sb += db;
         }
         if (q < NPY) {
@@ -831,7 +833,10 @@ int ld_f32_wgrad_tap3_launch(const WgradK& k_in, int splits, float* dw, int accu
   o.out_mode = splits == 1 ? 1 : 0;
   k.slabs = (float*)workspace;
   const int blocks = ntiles * splits;
-  if (k.g.num_levels > 1)
+  if (k.g.num_levels > 1 && getenv("LD_WGRAD_DBG") && atoi(getenv("LD_WGRAD_DBG")) == 1)
+    hipLaunchKernelGGL((conv_wgrad_tap3_kernel<true, 1>), dim3(blocks), dim3(768), 0, stream,
+                       k, o);
+  else if (k.g.num_levels > 1)
     hipLaunchKernelGGL((conv_wgrad_tap3_kernel<true>), dim3(blocks), dim3(768), 0, stream, k,
                        o);
   else

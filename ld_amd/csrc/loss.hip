@@ -1192,7 +1192,11 @@ inline int im_chunk(int ch) { return max(32, (ch + kZMax - 1) / kZMax); }
 // SIMD) | bits 8-15 KiB of dynamic LDS per workgroup (an occupancy throttle for
 // experiments) | bit 16 (with bit 5) the 4 sides of a chunk on one XCD; < 0 =
 // the round-2 kernel.
-// Default = the measured best of profiles/r03_ldkl_variants.json.
+// Default = the measured best of profiles/r03_ldkl_variants.json.  FAST replaces
+// the correctly rounded expf / division of the KL rows by v_exp_f32 / v_rcp_f32
+// (1 ulp each): the loss tables stay within 1e-6 of the reference's (bar 1e-4,
+// tests/test_gpu_lossblock.py) and the gradient rows within 2.6e-7 of the scale;
+// ld_loss_set_reg_variant(LD_REG_VARIANT_DEFAULT & ~16) restores the exact forms.
 // vec 1, NT loads + stores, hardware exp, side-fast: 568-571 us at 2^24 rows =
 // 0.76 of 8 TB/s (round-2 kernel: 665-743 us), 11.2 us at the C2 step size
 #define LD_REG_VARIANT_DEFAULT (0 | 4 | 8 | 16 | 32)
@@ -1357,8 +1361,16 @@ extern "C" int ld_loss_main_parts(
                        bm, split ? *kd_s : *cls, split ? *kd_t : *t_cls, *reg, labels,
                        bbox_targets, weight_targets, score, norm, upstream, posrec,
                        partial);
+  // the lean kernel addresses a level's 68 channel planes through ONE 32-bit
+  // buffer descriptor extent (stride_c * 68 * 4 bytes): a level map that large
+  // (>= 15.8 M positions) takes the round-2 kernel instead of wrapping
+  bool extent_ok = true;
+  for (int l = 0; l < geom->num_levels; ++l)
+    extent_ok &= reg->stride_c[l] * 272 < ((int64_t)1 << 32) &&
+                 t_reg->stride_c[l] * 272 < ((int64_t)1 << 32) &&
+                 grad_reg->stride_c[l] * 272 < ((int64_t)1 << 32);
   const bool lean_ok = !(hp->flags & LD_LOSS_RETINA) && hp->T_ld == hp->T_ld_vlr &&
-                       g_reg_variant >= 0;
+                       g_reg_variant >= 0 && extent_ok;
   if ((parts & LD_LOSS_PART_REG) && lean_ok) {
     const size_t bytes = (size_t)geom->num_imgs * geom->num_anchors * 68 * 4 * 3;
     const bool big = bytes > ((size_t)192 << 20);

@@ -992,8 +992,11 @@ def _bn_act_backward(dy, x3, y, scale, mean, rstd, relu, params, need_x,
     # bf16 mode: dx goes into the conv's C8 data- / weight-gradient kernels --
     # write its C8 image from this launch instead of a to_c8 launch per conv
     dx_c8 = None
-    if need_x and _BN_BWD_C8[0] and N * ((P // 4 + 63) // 64) <= 256 and \
-            dy.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0:
+    # every tensor ld_bn_act_backward_c8 takes 16 bytes at a time must be 16-byte
+    # aligned (a saved conv output or residual that is an offset view is not):
+    # otherwise the plain kernel + a to_c8 launch where needed
+    al16 = all(t is None or t.data_ptr() % 16 == 0 for t in (dy, y, x3, dx, dres))
+    if need_x and _BN_BWD_C8[0] and N * ((P // 4 + 63) // 64) <= 256 and al16:
         dx_c8 = _c8_side_output(dx)
     if dx_c8 is not None:
         L.check(lib.ld_bn_act_backward_c8(

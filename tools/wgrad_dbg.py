@@ -25,6 +25,30 @@ NAMES = {0: 'full', 1: '-barrier', 2: '-gloads', 4: '-ldswrites', 6: '-gloads-ld
          16: '-fragreads', 30: 'mfma+barrier only', 31: 'mfma only',
          32: 'x4 loads (timing only)', 33: 'x4 loads -barrier',
          64: 'loads two slices ahead', 128: 'X loads read nothing'}
+if os.environ.get('WGRAD_DBG_TAP3'):
+    os.environ['LD_CONV_WGRAD_CFG'] = '2,0,0,21,0'
+    for dbg in (0, 1, 0, 1):
+        os.environ['LD_WGRAD_DBG'] = str(dbg)
+
+        def run():
+            L.check(lib.ld_conv_wgrad(C.byref(d), L.ptr(x), L.ptr(dy), L.ptr(dw), 0,
+                                      L.ptr(ws), ws.numel(), st), 'wgrad')
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+            e0.record()
+            for _ in range(10):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 100
+            best = us if best is None else min(best, us)
+        print(f'tap3 dbg {dbg} ({"only group 0 reads X" if dbg else "full"}) {best:8.1f} us '
+              f'{flop / best / 1e6:6.1f} TF', flush=True)
+    sys.exit(0)
 for splits in (14, ):
     os.environ['LD_CONV_WGRAD_CFG'] = f'1,1,32,{splits},0'
     for dbg in (0, 64, 128, 0, 64, 128, 2):
