@@ -145,13 +145,19 @@ def kernel_roofline(trainer, dbatch, steps, bf16=False):
         algorithmic_bytes_per_launch=alg_bytes / max(tot_n, 1),
         traffic_note=(
             'bf16: not collected' if bf16 else
-            'HBM bytes per conv launch, averaged over all 1 412 conv launches '
-            'of this very step (fwd + dgrad + wgrad): rocprofv3 --pmc '
-            'FETCH_SIZE (x 2, MI355X_MICROARCH.md) and WRITE_SIZE in separate '
-            'passes of tools/profile_step.py, '
-            'profiles/r03_pmc_traffic_conv_step_fp32.txt; '
-            'algorithmic_bytes_per_launch = both operands + the output once, '
-            'from the launches timed here; not re-measured inside bench.py'),
+            'fabric-side bytes per GEMM launch (requests leaving the XCD L2s, '
+            'Infinity-Cache hits included), averaged over the 324 forward / '
+            'dgrad / wgrad launches of this very step: rocprofv3 --pmc '
+            'FETCH_SIZE (x 2: calibrated on a known-size copy at 4 B and 16 B '
+            'per lane, profiles/r04_pmc_calib_copy_*) and WRITE_SIZE in '
+            'separate passes of tools/profile_step.py --serial, '
+            'profiles/r04_pmc_traffic_conv_step_fp32_by_kernel.txt = 1.79 x '
+            'algorithmic_bytes_per_launch (both operands + the output once): '
+            'every XCD fetches its own copy of the operands it works on; the '
+            'kernels are MFMA-bound, but the bytes through the L1 miss path are '
+            'what the time above the MFMA floor is made of '
+            '(profiles/r04_wgrad_attribution.txt); not re-measured inside '
+            'bench.py'),
         launches_per_step=tot_n / steps,
         avg_launch_us=tot_t / max(tot_n, 1) * 1e6,
         conv_ms_per_step=tot_t / steps * 1e3,
@@ -227,9 +233,17 @@ def _median_launch_us(launch, warm, iters):
 # 1 212 475.4 KB (x 2, gfx950 correction) + WRITE_SIZE 1 115 649.4 KB per launch
 # at 2^24 rows
 PMC_LDKL_TRAFFIC_BYTES = (2 * 1212475.4 + 1115649.4) * 1024.0
-# profiles/r03_pmc_traffic_conv_step_fp32.txt: per conv launch of the fp32 step,
-# averaged over 1 412 launches: FETCH_SIZE 27 172.4 KB (x 2) + WRITE_SIZE 22 754.4 KB
-PMC_CONV_TRAFFIC_BYTES_PER_LAUNCH = (2 * 27172.4 + 22754.4) * 1024.0
+# profiles/r04_pmc_traffic_conv_step_fp32_by_kernel.txt (round 4, the serialised
+# fp32 step, 6 steps): the GEMM kernels (forward / dgrad streaming shapes + the
+# weight-gradient kernels; 324 launches per step incl. the stride-2 dgrad parity
+# classes) move FETCH_SIZE 2 x 11.66 GB + WRITE_SIZE 9.62 GB = 32.96 GB per step
+# = 101.7 MB per launch.  FETCH_SIZE x 2 is CALIBRATED for this access width:
+# a 1 GiB copy reports exactly half its read bytes at 4 B per lane and at 16 B
+# per lane (profiles/r04_pmc_calib_copy_*): the counter tallies 128-byte fabric
+# requests at 64 bytes.  It counts requests LEAVING an XCD's L2, Infinity-Cache
+# hits included.  (The slab reduce launches add 1.65 GB, the weight transforms
+# 1.72 GB per step; not part of `traffic`.)
+PMC_CONV_TRAFFIC_BYTES_PER_LAUNCH = 32.96e9 / 324.0
 
 
 def hbm_ceilings(dev):
