@@ -1,7 +1,8 @@
-"""Worker of tests/test_gpu_rccl.py::test_two_ranks_on_one_gpu_match_single_process:
-two torch.distributed.run ranks that share cuda:0, each stepping on its own
-half of a 4-image batch over RCCL.  Rank r saves its parameter arena to
-$LD_RCCL_OUT/rank{r}.npy."""
+"""Worker of tests/test_gpu_rccl.py::test_two_ranks_on_one_gpu_match_single_process
+(two torch.distributed.run ranks that share cuda:0) and ::test_multi_gpu_ranks_
+match_single_process (LD_RCCL_MULTI_GPU=1: `world` ranks, one GPU each): every
+rank steps on its own 2 images of a 2 * world-image batch over RCCL and saves
+its parameter arena to $LD_RCCL_OUT/rank{r}.npy."""
 import os
 import sys
 
@@ -17,11 +18,13 @@ sys.path.insert(0, os.path.join(REPO, 'tests'))
 def main():
     rank = int(os.environ['RANK'])
     world = int(os.environ['WORLD_SIZE'])
-    dev = torch.device('cuda:0')
+    multi = os.environ.get('LD_RCCL_MULTI_GPU') == '1'
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)) if multi else 0)
     torch.cuda.set_device(dev)
-    dist.init_process_group('nccl', rank=rank, world_size=world)
+    dist.init_process_group('nccl', rank=rank, world_size=world,
+                            **(dict(device_id=dev) if multi else {}))
     from test_gpu_rccl import _batch, _one_step
-    data = _batch(4, 33, dev, lo=2 * rank, hi=2 * rank + 2)
+    data = _batch(2 * world, 33, dev, lo=2 * rank, hi=2 * rank + 2)
     tr, _ = _one_step(dev, data, steps=1)
     np.save(os.path.join(os.environ['LD_RCCL_OUT'], f'rank{rank}.npy'),
             tr.arena.flat_param.detach().cpu().numpy())

@@ -38,7 +38,7 @@ def _free_port():
 def _batch(n_img, seed, dev, lo=0, hi=None):
     from ld_amd import synthetic
     b = synthetic.synthetic_batch(n_img, (128, 150), (128, 160),
-                                  [3, 2, 4, 1][:n_img], seed)
+                                  ([3, 2, 4, 1] * 4)[:n_img], seed)
     hi = n_img if hi is None else hi
     return dict(img=b['img'][lo:hi].to(dev), img_metas=b['img_metas'][lo:hi],
                 gt_bboxes=[x.to(dev) for x in b['gt_bboxes'][lo:hi]],
@@ -133,4 +133,36 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     got = [np.load(tmp_path / f'rank{i}.npy') for i in range(2)]
     assert np.array_equal(got[0], got[1]), 'ranks diverged'
     # fp32 reassociation between (2+2 averaged) and one 4-image batch
+    np.testing.assert_allclose(got[0], ref, rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_multi_gpu_ranks_match_single_process(world, tmp_path):
+    """`world` ranks, ONE GPU EACH (a multi-GPU node: skipped on the 1-GPU box),
+    2 images per rank over RCCL / xGMI, against one process stepping on all 2 *
+    world images: equal parameters on every rank, and equal to the single-process
+    update within fp32 reassociation (the reference's MMDistributedDataParallel
+    contract, mmdet/apis/train.py:74-82; cross-rank loss normalisers included:
+    ld_head.py:338-341, 362-365)."""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f'needs {world} GPUs on this node, '
+                    f'{torch.cuda.device_count()} visible')
+    dev = torch.device('cuda:0')
+    tr, _ = _one_step(dev, _batch(2 * world, 33, dev), steps=1)
+    ref = tr.arena.flat_param.detach().cpu().numpy()
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY='0', LD_RCCL_OUT=str(tmp_path),
+               LD_RCCL_MULTI_GPU='1')
+    env.pop('LD_FORCE_COLLECTIVES', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(port),
+           os.path.join(REPO, 'tests', '_rccl_two_rank.py')]
+    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (r.stderr or r.stdout)[-1500:]
+    got = [np.load(tmp_path / f'rank{i}.npy') for i in range(world)]
+    for g in got[1:]:
+        assert np.array_equal(got[0], g), 'ranks diverged'
     np.testing.assert_allclose(got[0], ref, rtol=2e-4, atol=2e-6)
