@@ -6,7 +6,18 @@ Importing the package registers every component under its mmdet ``type``
 name; nothing here runs on the CPU -- ops raise ``LdError`` when handed a
 non-HIP tensor or when libldhip.so has not been built.
 """
-from . import registry  # noqa: F401
+import os as _os
+
+# Three HIP streams carry the train step (student, teacher one step ahead,
+# weight gradients) and RCCL adds its own; the ROCm runtime multiplexes streams
+# onto 4 hardware queues by default, and with a process group present two of the
+# step's streams share one queue (measured: 36.8 vs 35.1 ms per step, DESIGN.md
+# section 6).  The runtime reads this when it initialises (the first HIP call),
+# so it is set at import unless the application chose a value itself;
+# ld_amd.train warns when a process group exists and it came too late.
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+from . import registry  # noqa: F401,E402
 from .config import Config, ConfigDict  # noqa: F401
 from .lib import LdError  # noqa: F401
 from . import core, losses, resnet, fpn, heads, detectors  # noqa: F401,E402

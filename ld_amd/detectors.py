@@ -163,8 +163,8 @@ class SingleStageDetector(nn.Module):
             loss = key_sums.index_select(
                 0, _device_index(tuple(sel), key_sums.device)).sum()
         logged = torch.cat([key_sums.detach(), loss.detach().reshape(1)])
-        from .train import collectives_on
-        if collectives_on():
+        from .train import _diag_skip, collectives_on
+        if collectives_on() and not _diag_skip('logs'):
             logged = logged.clone()
             dist.all_reduce(logged.div_(dist.get_world_size()))
         log_vars = LazyScalars(names + ['loss'], logged)

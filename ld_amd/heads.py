@@ -349,8 +349,8 @@ class GFLHead(nn.Module):
         side all-reduce instead of the reference's two reduce_mean(...).item()
         host syncs (ld_head.py:338-341,362-363)."""
         import torch.distributed as dist
-        from .train import collectives_on
-        if not collectives_on():
+        from .train import _diag_skip, collectives_on
+        if not collectives_on() or _diag_skip('norm'):
             return None
         ws = float(dist.get_world_size())
 

@@ -712,6 +712,18 @@ def _wgrad_side(device):
     return st
 
 
+def wgrad_pending_stream(device):
+    """The weight-gradient side stream of ``device`` when gradients are still
+    queued on it, else None.  A bucket's all-reduce is issued FROM that stream
+    (after it has waited for the main stream): the collective then follows the
+    bucket's last weight gradient without making the MAIN stream -- the data
+    gradient chain, i.e. the critical path of backward -- wait for the side
+    stream's backlog at every bucket boundary."""
+    if not _WGRAD_PENDING[0]:
+        return None
+    return _WGRAD_SIDE.get(str(device))
+
+
 def wgrad_join(device=None):
     """Make the current stream wait for every weight gradient enqueued on the
     side stream (no-op when none is pending)."""

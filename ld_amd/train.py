@@ -54,6 +54,15 @@ class suspend_collectives:
         _SUSPENDED[0] -= 1
 
 
+def _diag_skip(kind):
+    """LD_COLLECTIVES_SKIP=buckets,norm,logs -- timing diagnostics of the forced
+    1-rank group only (tools/sessions): honoured when the group has ONE rank, where
+    skipping a collective cannot change a result."""
+    v = os.environ.get('LD_COLLECTIVES_SKIP')
+    return bool(v) and kind in v.split(',') and dist.is_initialized() and \
+        dist.get_world_size() == 1
+
+
 def collectives_on():
     """True when gradient / scalar collectives must be issued.  With
     LD_FORCE_COLLECTIVES=1 they are issued even in a 1-rank group, which lets
@@ -181,20 +190,34 @@ class GradArena:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             self.trace.append((b, ev))
-        if self._ready[b] == self.buckets[b]['n'] and collectives_on():
+        if self._ready[b] == self.buckets[b]['n'] and collectives_on() and \
+                not _diag_skip('buckets'):
             bk = self.buckets[b]
-            # weight gradients of this bucket may still run on the side stream
-            Y.wgrad_join()
-            self._works.append(
-                dist.all_reduce(self.flat_grad[bk['start']:bk['end']],
-                                async_op=True))
+            grad = self.flat_grad[bk['start']:bk['end']]
+            # Weight gradients of this bucket may still run on the side stream.
+            # Round 3 made the MAIN stream wait for them here (wgrad_join) -- at
+            # every bucket boundary the data-gradient chain stalled behind the
+            # side stream's backlog: 56.7 -> 54.1 img/s with the collectives
+            # forced in a 1-rank group (profiles/r04_bench_torchrun_1rank_
+            # forced_collectives.json), a loss every rank of an N-GPU job pays.
+            # Now the all-reduce is issued from the SIDE stream once that has
+            # caught up with the main stream: RCCL's stream waits for the
+            # stream the collective is issued from, the main stream for nobody.
+            side = Y.wgrad_pending_stream(grad.device) if grad.is_cuda else None
+            if side is not None and os.environ.get('LD_BUCKET_FROM_SIDE', '1') == '1':
+                side.wait_stream(torch.cuda.current_stream(grad.device))
+                with torch.cuda.stream(side):
+                    self._works.append(dist.all_reduce(grad, async_op=True))
+            else:
+                Y.wgrad_join()
+                self._works.append(dist.all_reduce(grad, async_op=True))
 
     def finish(self):
         """Wait for the in-flight bucket reductions (sums, not yet averaged).
         Buckets whose parameters received no gradient this step are reduced
         here so every rank issues the same collectives."""
         Y.wgrad_join()
-        if collectives_on():
+        if collectives_on() and not _diag_skip('buckets'):
             for b, bk in enumerate(self.buckets):
                 if self._ready[b] != bk['n']:
                     self._works.append(
@@ -206,12 +229,37 @@ class GradArena:
         self._works = []
 
 
+_HWQ_CHECKED = [False]
+
+
+def _check_hw_queues():
+    """With a process group the step's three streams + RCCL's need more than the
+    runtime's default of 4 hardware queues (ld_amd/__init__.py sets 8 at import;
+    an application that initialised HIP before importing ld_amd, or exported a
+    smaller value, loses the teacher / weight-gradient overlap: -4.6 % measured)."""
+    if _HWQ_CHECKED[0] or not collectives_on():
+        return
+    _HWQ_CHECKED[0] = True
+    try:
+        q = int(os.environ.get('GPU_MAX_HW_QUEUES', '4'))
+    except ValueError:
+        q = 4
+    if q < 8:
+        import warnings
+        warnings.warn(
+            f'GPU_MAX_HW_QUEUES={q}: with a process group the train step\'s '
+            'streams share hardware queues and stop overlapping; export '
+            'GPU_MAX_HW_QUEUES=8 before the first HIP call (importing ld_amd '
+            'first does it)')
+
+
 class SGDTrainer:
     """One LD training iteration = forward_train -> _parse_losses -> backward
     (with overlapped gradient all-reduce) -> SGD step."""
 
     def __init__(self, model, lr, momentum=0.9, weight_decay=1e-4,
                  bucket_bytes=32 << 20, tail_bytes=8 << 20):
+        _check_hw_queues()
         self.model = model
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         frozen = [p for p in model.parameters() if not p.requires_grad]
