@@ -40,10 +40,15 @@ sys.path.insert(0, REPO)
 # gradients) and RCCL adds its own.  The ROCm runtime multiplexes streams onto 4
 # hardware queues by default: once a process group exists two of the step's
 # streams land on ONE queue and the teacher overlap is gone (measured with the
-# collectives forced in a 1-rank group: 36.8 ms per step at the default, 35.1 ms
-# with 8 queues = the figure without a process group).  Read
-# by the runtime when it initialises, i.e. at the first HIP call: set it before.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# collectives forced in a 1-rank group: 36.8 ms per step at the default, 35.1-35.5
+# with 5 / 6 / 8 queues = the figure without a process group).  But a hipGraph
+# replay is far SLOWER with more than 4 queues (bf16: 15.2 -> 26-28 ms), so the
+# value is raised only for a multi-process job, whose steps are enqueued eagerly
+# (profiles/r04_process_group_stream_overlap.txt).  The
+# runtime reads it when it initialises, at the first HIP call: set it before.
+if int(os.environ.get('WORLD_SIZE', '1')) > 1 or \
+        os.environ.get('LD_FORCE_COLLECTIVES') == '1':
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -11,11 +11,15 @@ import os as _os
 # Three HIP streams carry the train step (student, teacher one step ahead,
 # weight gradients) and RCCL adds its own; the ROCm runtime multiplexes streams
 # onto 4 hardware queues by default, and with a process group present two of the
-# step's streams share one queue (measured: 36.8 vs 35.1 ms per step, DESIGN.md
-# section 6).  The runtime reads this when it initialises (the first HIP call),
-# so it is set at import unless the application chose a value itself;
-# ld_amd.train warns when a process group exists and it came too late.
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# step's streams share one queue (measured: 36.8 vs 35.1 ms per step).  More
+# queues fix that -- but make hipGraph replays much slower (bf16 15.2 -> 26 ms),
+# so the value is raised only in a multi-process job (WORLD_SIZE > 1), whose
+# steps AutoStepper enqueues eagerly.  The runtime reads it
+# when it initialises (the first HIP call): set at import, unless the
+# application chose a value itself; ld_amd.train warns when it came too late.
+if int(_os.environ.get('WORLD_SIZE', '1') or 1) > 1 or \
+        _os.environ.get('LD_FORCE_COLLECTIVES') == '1':
+    _os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 from . import registry  # noqa: F401,E402
 from .config import Config, ConfigDict  # noqa: F401

@@ -646,7 +646,7 @@ class AutoStepper:
     ``data``; the results are bit-identical in every mode.
       * ``'eager'`` (fp32 default, every CPU run): ``trainer.step`` with the
         frozen teacher of ``next_data`` one step ahead on its own stream;
-      * ``'graph'`` (bf16 default on a GPU): one ``GraphedStep`` per padded
+      * ``'graph'`` (bf16 default on a GPU in a single-process job): one ``GraphedStep`` per padded
         image shape (the reference's GroupSampler yields two aspect-ratio
         groups, mmdet/datasets/samplers/group_sampler.py), captured the first
         time a shape is seen.  The capture's warm-up steps are real steps on
@@ -661,7 +661,13 @@ class AutoStepper:
     def __init__(self, trainer, mode=None, warmup=1, max_gt=128, max_graphs=6):
         if mode is None:
             on_gpu = next(trainer.model.parameters()).is_cuda
-            mode = 'graph' if (on_gpu and Y.get_precision() == 'bf16') else 'eager'
+            # a multi-process job enqueues eagerly: it needs more than the default
+            # 4 hardware queues for its streams to overlap next to RCCL's, and
+            # with more than 4 a graph replay is much slower than the eager step
+            # (profiles/r04_process_group_stream_overlap.txt); RCCL inside a
+            # capture is also unverified beyond one rank
+            mode = 'graph' if (on_gpu and Y.get_precision() == 'bf16' and
+                               not collectives_on()) else 'eager'
         if mode not in ('eager', 'graph', 'pipelined'):
             raise ValueError(f'AutoStepper: unknown mode {mode!r}')
         self.trainer, self.mode = trainer, mode
