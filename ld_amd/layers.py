@@ -676,11 +676,27 @@ def side_stream(device, role):
     (lower number = higher priority; the main stream has 0): with a positive
     value the dispatcher prefers the critical path's kernels and lets the side
     streams fill what is left."""
+    if os.environ.get('LD_SHARE_SIDE_STREAMS', '1') == '1':
+        # ONE background stream for the teacher's forward and the weight
+        # gradients (round 4): the critical path has a hardware queue to itself
+        # and the two background jobs take turns instead of competing with it
+        # and with each other.  Measured (profiles/r04_process_group_stream_
+        # overlap.txt): fp32 eager 34.9 -> 34.65 ms, one hipGraph 36.7 -> 36.3 ms,
+        # under a process group with 8 queues 35.05 -> 34.78 ms; with the
+        # runtime held to TWO hardware queues the separate streams gave the same
+        # figure (34.55) -- two lanes is what the step wants.
+        key = str(device)
+        if key not in _SHARED_SIDE:
+            _SHARED_SIDE[key] = torch.cuda.Stream(device=device)
+        return _SHARED_SIDE[key]
     pr = os.environ.get('LD_SIDE_STREAM_PRIORITY_' + role.upper(),
                         os.environ.get('LD_SIDE_STREAM_PRIORITY'))
     if pr is None:
         return torch.cuda.Stream(device=device)
     return torch.cuda.Stream(device=device, priority=int(pr))
+
+
+_SHARED_SIDE = {}
 
 
 _WGRAD_STREAM = [os.environ.get('LD_WGRAD_STREAM', '1') == '1']
