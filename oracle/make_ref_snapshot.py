@@ -37,13 +37,18 @@ def make(reference_root='/root/reference'):
                     files.append(os.path.relpath(os.path.join(root, n),
                                                  reference_root))
     files.sort()
+    import gzip
     buf = io.BytesIO()
-    with tarfile.open(fileobj=buf, mode='w:gz') as tar:
-        for rel in files:
-            info = tar.gettarinfo(os.path.join(reference_root, rel), arcname=rel)
-            info.mtime = 0  # reproducible archive
-            with open(os.path.join(reference_root, rel), 'rb') as f:
-                tar.addfile(info, f)
+    # reproducible archive: no timestamps in the gzip header or the members
+    with gzip.GzipFile(fileobj=buf, mode='wb', mtime=0) as gz:
+        with tarfile.open(fileobj=gz, mode='w') as tar:
+            for rel in files:
+                info = tar.gettarinfo(os.path.join(reference_root, rel), arcname=rel)
+                info.mtime = 0
+                info.uid = info.gid = 0
+                info.uname = info.gname = ''
+                with open(os.path.join(reference_root, rel), 'rb') as f:
+                    tar.addfile(info, f)
     data = buf.getvalue()
     with open(ARCHIVE, 'wb') as f:
         f.write(data)
