@@ -1665,8 +1665,9 @@ inline unsigned cap_lds_bytes(int cap, int static_bytes) {
 template <int MODE>
 int launch_stream_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream,
                       int cap = 0) {
-  if (const char* env = getenv("LD_STREAM_DBG")) {
-    // timing attribution (tools/stream_dbg.py): the 1x1x1 d16 ks4 / ks1 shapes only
+  if (const char* env = getenv("LD_ALLOW_WRONG_RESULTS") ? getenv("LD_STREAM_DBG") : nullptr) {
+    // timing attribution (tools/stream_dbg.py; the variants compute WRONG results,
+    // hence the second variable): the 1x1x1 d16 ks4 shape only
     const int dbg = atoi(env);
     if (MODE == 0 && dbg && c.tm == 1 && c.tn == 1 && c.wvm == 1 && c.d == 16) {
       const int bm = 32, bn = 32;

@@ -775,7 +775,9 @@ void launch_tile_dbg(const WgradK& k, const WgradTileOut& o, int blocks, hipStre
 template <int KG, int BK>
 void launch_tile(const WgradK& k, const WgradTileOut& o, int blocks, hipStream_t stream) {
   if (KG == 1 && BK == 32) {
-    if (const char* env = getenv("LD_WGRAD_DBG")) {
+    // timing-attribution variants compute WRONG results: both variables needed
+    const char* env = getenv("LD_ALLOW_WRONG_RESULTS") ? getenv("LD_WGRAD_DBG") : nullptr;
+    if (env) {
       switch (atoi(env)) {
         case 1: return launch_tile_dbg<1>(k, o, blocks, stream);
         case 2: return launch_tile_dbg<2>(k, o, blocks, stream);
@@ -833,7 +835,8 @@ int ld_f32_wgrad_tap3_launch(const WgradK& k_in, int splits, float* dw, int accu
   o.out_mode = splits == 1 ? 1 : 0;
   k.slabs = (float*)workspace;
   const int blocks = ntiles * splits;
-  if (k.g.num_levels > 1 && getenv("LD_WGRAD_DBG") && atoi(getenv("LD_WGRAD_DBG")) == 1)
+  if (k.g.num_levels > 1 && getenv("LD_ALLOW_WRONG_RESULTS") && getenv("LD_WGRAD_DBG") &&
+      atoi(getenv("LD_WGRAD_DBG")) == 1)
     hipLaunchKernelGGL((conv_wgrad_tap3_kernel<true, 1>), dim3(blocks), dim3(768), 0, stream,
                        k, o);
   else if (k.g.num_levels > 1)

@@ -11,6 +11,7 @@ from ld_amd import layers as Y  # noqa: E402
 from ld_amd import lib as L  # noqa: E402
 
 HEAD = ((100, 168), (50, 84), (25, 42), (13, 21), (7, 11))
+os.environ['LD_ALLOW_WRONG_RESULTS'] = '1'  # the variants timed here compute wrong results by design
 dev = torch.device('cuda:0')
 lib = L.get_lib()
 d, _ = Y.conv_desc(2, 256, 256, 3, 3, 1, 1, HEAD)
