@@ -503,6 +503,12 @@ size_t ld_conv_wgrad_workspace_bytes(const ld_conv_t* c);
 int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy, float* dw,
                   int accumulate, void* workspace, size_t workspace_bytes,
                   ld_stream_t stream);
+/* The plan ld_conv_wgrad would follow for this geometry, without touching the
+ * device: out[0..4] = kind (0 wave-private 64 x 64 tiles, 1 workgroup tiles, 2
+ * three kw taps per workgroup), k-groups, columns per slice, splits along the
+ * reduction, in-launch combination.  Order of precedence: LD_CONV_WGRAD_CFG, the
+ * shape table (MODE 2), a model that is a pure function of the geometry. */
+int ld_conv_wgrad_plan(const ld_conv_t* c, int* out);
 /* Times the fp32 weight-gradient kernels / split shapes of this geometry on the
  * caller's buffers (dw is overwritten) and records the winner in the shape
  * table (key MODE 2).  Same rules and return values as ld_conv_tune_forward. */

@@ -2636,6 +2636,20 @@ extern "C" int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy
   return wgrad_run(c, x, dy, dw, accumulate, workspace, workspace_bytes, stream, 0);
 }
 
+// Which kernel / split a launch of ld_conv_wgrad would use for this geometry
+// (host logic only, no device work): out = {kind, kg, bk, splits, fused}.
+extern "C" int ld_conv_wgrad_plan(const ld_conv_t* c, int* out) {
+  if (int e = check_conv(c)) return e;
+  if (!out) return LD_EINVAL;
+  const WgCfg g = wgrad_pick(c);
+  out[0] = g.kind;
+  out[1] = g.kg;
+  out[2] = g.bk;
+  out[3] = g.kind == 0 ? wgrad_splits(c) : g.splits;
+  out[4] = g.fused;
+  return 0;
+}
+
 // Explicit tuning of the fp32 weight gradient (the counterpart of
 // ld_conv_tune_forward): times the wave-private kernel and every (kg, bk, splits,
 // fused) instance of the workgroup-tiled kernel that fits the geometry on the

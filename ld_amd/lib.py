@@ -156,7 +156,7 @@ def save_tune_table(path):
     return get_lib().ld_conv_tune_save(str(path).encode())
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 _G, _H, _M = C.POINTER(GeomT), C.POINTER(LossHpT), C.POINTER(MapsT)
 _CV, _EP, _LV = C.POINTER(ConvT), C.POINTER(ConvEpilogueT), C.POINTER(LevelsT)
@@ -279,6 +279,7 @@ SIGNATURES = {
     'ld_conv_wgrad_workspace_bytes': (_sz, [_CV]),
     'ld_conv_wgrad': (C.c_int, [_CV, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     'ld_conv_tune_wgrad': (C.c_int, [_CV, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'ld_conv_wgrad_plan': (C.c_int, [_CV, C.POINTER(C.c_int)]),
     'ld_bn_prepare': (C.c_int, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp,
                                 _vp]),
     'ld_bn_act_forward_c8': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32,

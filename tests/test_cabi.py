@@ -88,3 +88,44 @@ def test_tune_table_round_trip(tmp_path):
     assert lib.ld_conv_tune_load(f) == n
     assert lib.ld_conv_tune_load(b'/nonexistent/table') == -1
     assert lib.ld_conv_tune_load(None) == -1
+
+
+def test_wgrad_plan_host_logic(monkeypatch):
+    """Round 4: which fp32 weight-gradient kernel / split a geometry gets is host
+    logic (ld_conv_wgrad_plan, no device work): the shipped MODE 2 records for
+    the C2 shapes, the geometry model for an untuned shape, the tool override,
+    and a workspace that covers every plan the tuner may time."""
+    import ctypes as C
+    from ld_amd import layers as Y
+    from ld_amd import lib as L
+    lib = L.get_lib()
+    monkeypatch.delenv('LD_CONV_WGRAD_CFG', raising=False)
+    out = (C.c_int * 5)()
+
+    def plan(N, cin, cout, k, s, p, levels):
+        d, _ = Y.conv_desc(N, cin, cout, k, k, s, p, levels)
+        assert lib.ld_conv_wgrad_plan(C.byref(d), out) == 0
+        return d, tuple(out)
+    head = ((100, 168), (50, 84), (25, 42), (13, 21), (7, 11))
+    # shipped table: the head tower takes the three-taps kernel, the 50 x 84 1x1
+    # layers the workgroup tiles with two k-groups; nothing is fused
+    d, pl = plan(2, 256, 256, 3, 1, 1, head)
+    assert pl[0] == 2 and pl[3] == 21 and pl[4] == 0
+    assert lib.ld_conv_wgrad_workspace_bytes(C.byref(d)) >= pl[3] * 9 * 256 * 256 * 4
+    _, pl = plan(2, 1024, 256, 1, 1, 0, ((50, 84), ))
+    assert pl[:3] == (1, 2, 64) and pl[3] == 16
+    # an untuned geometry: the model (pure function of the geometry)
+    _, a = plan(2, 384, 384, 3, 1, 1, ((40, 60), ))
+    _, b = plan(2, 384, 384, 3, 1, 1, ((40, 60), ))
+    assert a == b and a[0] in (1, 2) and a[3] >= 1 and a[4] == 0
+    # stem-like channel counts stay on the wave-private kernel
+    _, pl = plan(2, 3, 64, 7, 2, 3, ((64, 64), ))
+    assert pl[0] == 0 and pl[3] >= 1
+    # tools override; a three-taps request on a 1x1 conv is ignored
+    monkeypatch.setenv('LD_CONV_WGRAD_CFG', '1,4,64,3,1')
+    _, pl = plan(2, 256, 256, 3, 1, 1, head)
+    assert pl == (1, 4, 64, 3, 1)
+    monkeypatch.setenv('LD_CONV_WGRAD_CFG', '2,0,0,5,0')
+    _, pl = plan(2, 1024, 256, 1, 1, 0, ((50, 84), ))
+    assert pl[0] == 1
+    assert lib.ld_conv_wgrad_plan(None, out) == -1
