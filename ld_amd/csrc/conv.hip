@@ -2554,7 +2554,7 @@ extern "C" size_t ld_conv_wgrad_workspace_bytes(const ld_conv_t* c) {
 namespace {
 int wgrad_run(const ld_conv_t* c, const float* x, const float* dy, float* dw,
               int accumulate, void* workspace, size_t workspace_bytes,
-              ld_stream_t stream_, int family) {
+              ld_stream_t stream_, int family, const WgCfg* forced = nullptr) {
   if (int e = check_conv(c)) return e;
   if (!x || !dy || !dw) return LD_EINVAL;
   if (!workspace || workspace_bytes < ld_conv_wgrad_workspace_bytes(c))
@@ -2591,7 +2591,7 @@ int wgrad_run(const ld_conv_t* c, const float* x, const float* dy, float* dw,
     if (int e = ld_bf16_wgrad_c8_launch(k, stream)) return e;
   } else if (family == 1) {
     if (int e = ld_bf16_wgrad_launch(k, stream)) return e;
-  } else if (const WgCfg cfg = wgrad_pick(c); cfg.kind == 1) {
+  } else if (const WgCfg cfg = forced ? *forced : wgrad_pick(c); cfg.kind == 1) {
     return ld_f32_wgrad_tile_launch(k, cfg.kg, cfg.bk, cfg.splits, cfg.fused, dw,
                                     accumulate, workspace, workspace_bytes, stream);
   } else if (cfg.kind == 2) {
@@ -2719,18 +2719,13 @@ extern "C" int ld_conv_tune_wgrad(const ld_conv_t* c, const float* x, const floa
   }
   float best_ms = -1.0f;
   WgCfg best = cands[0];
-  char envbuf[64];
-  const char* saved = getenv("LD_CONV_WGRAD_CFG");
-  std::string saved_s = saved ? saved : "";
   for (const WgCfg& g : cands) {
-    snprintf(envbuf, sizeof(envbuf), "%d,%d,%d,%d,%d", g.kind, g.kg, g.bk, g.splits, g.fused);
-    setenv("LD_CONV_WGRAD_CFG", envbuf, 1);
-    if (wgrad_run(c, x, dy, dw, 0, workspace, workspace_bytes, stream_, 0) != 0) continue;
+    if (wgrad_run(c, x, dy, dw, 0, workspace, workspace_bytes, stream_, 0, &g) != 0) continue;
     float ms = -1.0f;
     for (int trial = 0; trial < 2; ++trial) {
       (void)hipEventRecord(e0, stream);
       for (int rep = 0; rep < kTuneReps; ++rep)
-        wgrad_run(c, x, dy, dw, 0, workspace, workspace_bytes, stream_, 0);
+        wgrad_run(c, x, dy, dw, 0, workspace, workspace_bytes, stream_, 0, &g);
       (void)hipEventRecord(e1, stream);
       if (hipEventSynchronize(e1) != hipSuccess) break;
       float t = 0.0f;
@@ -2739,17 +2734,13 @@ extern "C" int ld_conv_tune_wgrad(const ld_conv_t* c, const float* x, const floa
     }
     if (const char* lg = getenv("LD_CONV_TUNE_LOG"))
       if (lg[0] == '2')
-        fprintf(stderr, "[ld_conv]   wgrad cand %s  %.1f us\n", envbuf,
-                ms * 1e3 / kTuneReps);
+        fprintf(stderr, "[ld_conv]   wgrad cand %d,%d,%d,%d,%d  %.1f us\n", g.kind, g.kg, g.bk,
+                g.splits, g.fused, ms * 1e3 / kTuneReps);
     if (ms >= 0.0f && (best_ms < 0.0f || ms < best_ms)) {
       best_ms = ms;
       best = g;
     }
   }
-  if (saved)
-    setenv("LD_CONV_WGRAD_CFG", saved_s.c_str(), 1);
-  else
-    unsetenv("LD_CONV_WGRAD_CFG");
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (const char* lg = getenv("LD_CONV_TUNE_LOG"))
