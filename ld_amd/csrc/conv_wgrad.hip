@@ -760,7 +760,11 @@ unsigned* ticket_slice(const void* workspace, hipStream_t stream) {
   if (it != p.slice.end()) {
     idx = it->second;
   } else {
-    idx = p.next++ % kTicketPools;
+    // a slice is never handed to a second workspace (two live workspaces on one
+    // slice could run concurrently): past the pool's capacity the caller takes
+    // the slab path
+    if (p.next >= kTicketPools) return nullptr;
+    idx = p.next++;
     p.slice[workspace] = idx;
   }
   return p.base + idx * kTicketSlots;
