@@ -359,7 +359,7 @@ def _host_cpu():
     return model, phys, os.cpu_count() or 1
 
 
-def cpu_baseline_reference(threads, reps=2, timeout_s=600):
+def cpu_baseline_reference(threads, reps=3, timeout_s=600):
     """The REFERENCE'S OWN train step on the host cores:
     KnowledgeDistillationSingleStageDetector.forward_train -> _parse_losses ->
     backward -> SGD.step, imported unmodified from the archive
@@ -398,7 +398,7 @@ def cpu_baseline(batch, sdepth=50, tdepth=101, reps=3):
     """BASELINE.md section 3 on the GPU box's host cores, on the SAME synthetic
     batch shape and seeded weights as the device run.  kind "reference": the
     reference's own code (cpu_baseline_reference above), 1 warm-up + the median
-    of 2 steps, per-stage split.  When the archive is absent (a tree that was
+    of 3 steps, per-stage split.  When the archive is absent (a tree that was
     never built next to /root/reference) the CPU oracle "port" (torch-CPU fp32
     nets with the reference's layer sequence + the numpy loss block) is timed
     instead and labelled so; the port was measured at 0.82 x the reference's
@@ -604,6 +604,22 @@ def main():
 
     dt, t_enq, loss_val = timed(args.warmup, args.steps)
     hits0 = getattr(det, 'prefetch_hits', 0)
+
+    def synced_median(n):
+        # the median of individually synchronised steps, reported
+        # beside the K-step mean (a synchronised step cannot overlap its tail
+        # with the next step's head, so this figure is the larger one)
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            one_step()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2] * 1e3
+
+    ms_sync_median = synced_median(min(max(args.steps, 3), 11))
     dt_plain = None
     if prefetch:  # the same K steps with the teacher inside each step, for the record
         prefetch = False
@@ -630,6 +646,7 @@ def main():
                 'optimizer': 'SGD(momentum 0.9, wd 1e-4), step included',
                 'last_loss': loss_val,
                 'host_enqueue_ms_per_step': t_enq / args.steps * 1e3,
+                'ms_per_step_synchronised_median': ms_sync_median,
                 'prime_steps': 1,
                 'teacher_prefetch': bool(prefetch),
                 'teacher_prefetch_note': (

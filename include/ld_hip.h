@@ -476,6 +476,17 @@ int ld_conv_forward(const ld_conv_t* c, const float* x, const float* wt_fwd,
 /* dx (N,Cin,Pin) fully overwritten. */
 int ld_conv_dgrad(const ld_conv_t* c, const float* dy, const float* wt_bwd,
                   float* dx, ld_stream_t stream);
+/* dx = conv_transpose(dy) + addend, the sum formed in the GEMM epilogue.  addend
+ * is (N,Cin,Pin) fp32 and may be dx itself.  Replaces the separate elementwise
+ * add autograd issues wherever an activation has two consumers: the block input
+ * of a residual block (mmdet/models/backbones/resnet.py:260-299: `out +=
+ * identity`), a backbone stage output read by the next stage and the FPN lateral
+ * (necks/fpn.py:170-176), an FPN level read by both head towers
+ * (dense_heads/gfl_head.py:164-172).  Same tile shape (shape-table record) as
+ * ld_conv_dgrad.  ld_conv_bf16_dgrad_acc / ld_conv_bf16_dgrad_c8_acc: the bf16
+ * families. */
+int ld_conv_dgrad_acc(const ld_conv_t* c, const float* dy, const float* wt_bwd,
+                      const float* addend, float* dx, ld_stream_t stream);
 /* ---- shape tuning (explicit; cudnn.benchmark's role, kept OUT of the launch
  * path).  ld_conv_tune_* time every candidate tile shape of the geometry by
  * launching the (idempotent) kernel on the caller's buffers -- y / dx must not
@@ -493,7 +504,12 @@ int ld_conv_tune_dgrad(const ld_conv_t* c, const float* dy, const float* wt_bwd,
 int ld_conv_tune_load(const char* path);
 int ld_conv_tune_save(const char* path);
 int ld_conv_tune_clear(void);
+/* Workspace of the plan a launch of this geometry actually follows (one size for
+ * ld_conv_wgrad / ld_conv_bf16_wgrad / ld_conv_bf16_wgrad_c8).
+ * ld_conv_tune_wgrad_workspace_bytes: the worst case over every candidate
+ * ld_conv_tune_wgrad times (<= 128 MB), needed by that call only. */
 size_t ld_conv_wgrad_workspace_bytes(const ld_conv_t* c);
+size_t ld_conv_tune_wgrad_workspace_bytes(const ld_conv_t* c);
 /* dw (Cout,Cin,KH,KW): overwritten, or += if accumulate != 0.  Deterministic:
  * the j-reduction is split in a fixed pattern (per wave, per k-group, per
  * workgroup) and every partial sum is combined in index order -- by a second
@@ -511,7 +527,8 @@ int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy, float* dw
 int ld_conv_wgrad_plan(const ld_conv_t* c, int* out);
 /* Times the fp32 weight-gradient kernels / split shapes of this geometry on the
  * caller's buffers (dw is overwritten) and records the winner in the shape
- * table (key MODE 2).  Same rules and return values as ld_conv_tune_forward. */
+ * table (key MODE 2).  Same rules and return values as ld_conv_tune_forward;
+ * workspace_bytes >= ld_conv_tune_wgrad_workspace_bytes(c). */
 int ld_conv_tune_wgrad(const ld_conv_t* c, const float* x, const float* dy, float* dw,
                        void* workspace, size_t workspace_bytes, ld_stream_t stream);
 
@@ -569,6 +586,10 @@ int ld_conv_bf16_tune_forward_c8(const ld_conv_t* c, const void* x_c8,
                                  float* y, ld_stream_t stream);
 int ld_conv_bf16_dgrad_c8(const ld_conv_t* c, const void* dy_c8, const void* wt_bwd,
                           float* dx, ld_stream_t stream);
+int ld_conv_bf16_dgrad_acc(const ld_conv_t* c, const float* dy, const void* wt_bwd,
+                           const float* addend, float* dx, ld_stream_t stream);
+int ld_conv_bf16_dgrad_c8_acc(const ld_conv_t* c, const void* dy_c8, const void* wt_bwd,
+                              const float* addend, float* dx, ld_stream_t stream);
 int ld_conv_bf16_tune_dgrad_c8(const ld_conv_t* c, const void* dy_c8,
                                const void* wt_bwd, float* dx, ld_stream_t stream);
 /* Weight gradient with BOTH operands as C8 images (Cin, Cout multiples of 8):

@@ -2243,8 +2243,15 @@ extern "C" int ld_conv_forward_smallc(const ld_conv_t* c, const float* x,
 // classes; each class sees only the taps of matching parity (1, 2, 2 or 4 of
 // the 9 for a 3x3), so no MFMA work is spent on the dilation zeros.
 namespace {
+// addend (round 5): optional (N, Cin, Pin) tensor added in the epilogue -- dx =
+// conv_transpose(dy) + addend, addend == dx allowed (every element is read and
+// written by the same lane).  It is what autograd would otherwise do in a
+// separate elementwise launch wherever a tensor has two consumers (the block
+// input of a residual block: conv1 and the identity path; an FPN level feeding
+// both head towers).  The launch uses the shape-table record of the plain dgrad.
 int dgrad_walk(const ld_conv_t* c, const float* dy, const void* wt_bwd, float* dx,
-               ld_stream_t stream_, bool tune, int family = 0) {
+               ld_stream_t stream_, bool tune, int family = 0,
+               const float* addend = nullptr) {
   if (int e = check_conv(c)) return e;
   if (!dy || !wt_bwd || !dx) return LD_EINVAL;
   if (c->KH != c->KW) return LD_EUNSUPPORTED;
@@ -2254,7 +2261,9 @@ int dgrad_walk(const ld_conv_t* c, const float* dy, const void* wt_bwd, float* d
   k.x = dy;
   k.wt = (const float*)wt_bwd;
   k.y = dx;
-  k.bias = k.scale = k.shift = k.residual = nullptr;
+  k.bias = k.scale = k.shift = nullptr;
+  k.residual = addend;
+  k.tune_plain = 1;
   k.relu = 0;
   k.N = c->N; k.Cin = c->Cout; k.Cout = c->Cin; k.KH = c->KH; k.KW = c->KW;
   k.g.stride = 1;
@@ -2302,8 +2311,13 @@ int dgrad_walk(const ld_conv_t* c, const float* dy, const void* wt_bwd, float* d
     if (k0 >= c->KH) any_empty = true;
   }
   if (any_empty && !tune) {
-    hipError_t err = hipMemsetAsync(
-        dx, 0, (size_t)c->N * c->Cin * c->Pin * sizeof(float), stream);
+    // ... or, with an addend, start from the addend (nothing to do in place)
+    const size_t bytes = (size_t)c->N * c->Cin * c->Pin * sizeof(float);
+    hipError_t err = hipSuccess;
+    if (!addend)
+      err = hipMemsetAsync(dx, 0, bytes, stream);
+    else if (addend != dx)
+      err = hipMemcpyAsync(dx, addend, bytes, hipMemcpyDeviceToDevice, stream);
     if (err) return (int)err;
   }
   for (int ph = 0; ph < 2; ++ph)
@@ -2348,6 +2362,24 @@ int dgrad_walk(const ld_conv_t* c, const float* dy, const void* wt_bwd, float* d
 extern "C" int ld_conv_dgrad(const ld_conv_t* c, const float* dy,
                              const float* wt_bwd, float* dx, ld_stream_t stream) {
   return dgrad_walk(c, dy, wt_bwd, dx, stream, false);
+}
+
+extern "C" int ld_conv_dgrad_acc(const ld_conv_t* c, const float* dy,
+                                 const float* wt_bwd, const float* addend, float* dx,
+                                 ld_stream_t stream) {
+  return dgrad_walk(c, dy, wt_bwd, dx, stream, false, 0, addend);
+}
+
+extern "C" int ld_conv_bf16_dgrad_acc(const ld_conv_t* c, const float* dy,
+                                      const void* wt_bwd, const float* addend,
+                                      float* dx, ld_stream_t stream) {
+  return dgrad_walk(c, dy, wt_bwd, dx, stream, false, 1, addend);
+}
+
+extern "C" int ld_conv_bf16_dgrad_c8_acc(const ld_conv_t* c, const void* dy_c8,
+                                         const void* wt_bwd, const float* addend,
+                                         float* dx, ld_stream_t stream) {
+  return dgrad_walk(c, (const float*)dy_c8, wt_bwd, dx, stream, false, 2, addend);
 }
 
 extern "C" int ld_conv_tune_dgrad(const ld_conv_t* c, const float* dy,
@@ -2535,17 +2567,46 @@ static WgCfg wgrad_pick(const ld_conv_t* c) {
   return wgrad_model(c);
 }
 
+// Workspace of the plan a launch of this geometry ACTUALLY uses (round 4
+// returned the tuner's worst case for every family, ~250 MB of device memory more
+// than the shipped plans need): per kernel family the split count that family's
+// launch picks; family 0 = ld_conv_wgrad (the record of the shape table, else the
+// model), 1 = ld_conv_bf16_wgrad, 2 = ld_conv_bf16_wgrad_c8.
+static size_t wgrad_need(const ld_conv_t* c, int family, const WgCfg* forced) {
+  const int ntaps = c->KH * c->KW;
+  const size_t per = (size_t)ntaps * c->Cout * c->Cin * sizeof(float);
+  if (family == 2 && ld_bf16_wgrad_c8_tiled(c->Cout, c->Cin))
+    return per * ld_bf16_wgrad_c8_tile_splits(c->Cout, c->Cin, ntaps, c->N * c->Pout);
+  if (family == 1 && ld_bf16_wgrad_tiled(c->Cout, c->Cin, c->Pout))
+    return per * ld_bf16_wgrad_splits(c->Cout, c->Cin, ntaps, c->N * c->Pout);
+  if (family >= 1) return per * wgrad_splits(c);
+  const WgCfg g = forced ? *forced : wgrad_pick(c);
+  if (g.kind == 0) return per * wgrad_splits(c);
+  const size_t tile = ld_f32_wgrad_tile_workspace(c->Cout, c->Cin, ntaps, g.splits);
+  return tile > per ? tile : per;
+}
+
+// One size that serves whichever of the three launch entry points the caller
+// takes for this geometry (the host keeps one buffer per stream).
 extern "C" size_t ld_conv_wgrad_workspace_bytes(const ld_conv_t* c) {
   if (check_conv(c) != 0) return 0;
-  // one size for all kernel families and for every candidate ld_conv_tune_wgrad
-  // times (the bf16 workgroup-tiled wgrad picks its own split count)
-  int sp = wgrad_splits(c);
-  if (ld_bf16_wgrad_tiled(c->Cout, c->Cin, c->Pout))
-    sp = max(sp, ld_bf16_wgrad_splits(c->Cout, c->Cin, c->KH * c->KW, c->N * c->Pout));
-  if (c->Cin % 8 == 0 && c->Cout % 8 == 0 && ld_bf16_wgrad_c8_tiled(c->Cout, c->Cin))
-    sp = max(sp, ld_bf16_wgrad_c8_tile_splits(c->Cout, c->Cin, c->KH * c->KW,
-                                              c->N * c->Pout));
-  size_t need = (size_t)sp * c->KH * c->KW * c->Cout * c->Cin * sizeof(float);
+  size_t need = wgrad_need(c, 0, nullptr);
+  if (c->Cin >= 16) {
+    const size_t b = wgrad_need(c, 1, nullptr);
+    need = b > need ? b : need;
+  }
+  if (c->Cin % 8 == 0 && c->Cout % 8 == 0) {
+    const size_t b = wgrad_need(c, 2, nullptr);
+    need = b > need ? b : need;
+  }
+  return need;
+}
+
+// ld_conv_tune_wgrad times every candidate plan on the caller's workspace: the
+// worst case over them (capped at 128 MB by wgrad_tile_max_splits).
+extern "C" size_t ld_conv_tune_wgrad_workspace_bytes(const ld_conv_t* c) {
+  if (check_conv(c) != 0) return 0;
+  const size_t need = ld_conv_wgrad_workspace_bytes(c);
   const size_t tile = ld_f32_wgrad_tile_workspace(c->Cout, c->Cin, c->KH * c->KW,
                                                   wgrad_tile_max_splits(c, 32));
   return need > tile ? need : tile;
@@ -2557,8 +2618,7 @@ int wgrad_run(const ld_conv_t* c, const float* x, const float* dy, float* dw,
               ld_stream_t stream_, int family, const WgCfg* forced = nullptr) {
   if (int e = check_conv(c)) return e;
   if (!x || !dy || !dw) return LD_EINVAL;
-  if (!workspace || workspace_bytes < ld_conv_wgrad_workspace_bytes(c))
-    return LD_ENOSPACE;
+  if (!workspace || workspace_bytes < wgrad_need(c, family, forced)) return LD_ENOSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   WgradK k;
   k.x = x; k.dy = dy; k.slabs = (float*)workspace;
@@ -2660,7 +2720,7 @@ extern "C" int ld_conv_tune_wgrad(const ld_conv_t* c, const float* x, const floa
                                   ld_stream_t stream_) {
   if (int e = check_conv(c)) return e;
   if (!x || !dy || !dw || !workspace) return LD_EINVAL;
-  if (workspace_bytes < ld_conv_wgrad_workspace_bytes(c)) return LD_ENOSPACE;
+  if (workspace_bytes < ld_conv_tune_wgrad_workspace_bytes(c)) return LD_ENOSPACE;
   const LdTuneKey key = wgrad_tune_key(c);
   LdTuneCfg have;
   if (ld_tune_lookup(key, &have)) return 1;

@@ -38,6 +38,7 @@ struct ConvK {  // kernel-side view of ld_conv_t + pointers
   // (j < ntw) reach it; input row = hc + ch0 + i, col = wc + cw0 + j.
   int ph, pw, kh0, kw0, nth, ntw, ch0, cw0;
   int Pfull;                       // positions per (n, c) row of the output
+  int tune_plain;                  // shape-table key ignores the residual (dgrad + addend)
   int fW[LD_MAX_LEVELS], foff[LD_MAX_LEVELS];  // full output row length/offset
   Geo g;
 };
@@ -179,6 +180,6 @@ namespace {
 inline LdTuneKey make_tune_key(int mode, int family, const ConvK& k) {
   return LdTuneKey{{mode, k.Cin, k.Cout, k.KH, k.KW, k.g.stride, k.g.pad, k.J,
                     k.g.num_levels, k.g.lv[0].Hin, k.g.lv[0].Win, k.ph, k.pw, k.relu,
-                    k.residual != nullptr, k.scale != nullptr, family, 0}};
+                    k.residual != nullptr && !k.tune_plain, k.scale != nullptr, family, 0}};
 }
 }  // namespace

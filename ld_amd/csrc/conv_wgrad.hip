@@ -753,7 +753,15 @@ unsigned* ticket_slice(const void* workspace, hipStream_t stream) {
       p.base = nullptr;
       return nullptr;
     }
-    if (hipMemset(p.base, 0, bytes) != hipSuccess) return nullptr;
+    // zeroed ON the launching stream (a null-stream memset is not
+    // ordered before a kernel on a non-blocking side stream); a pool that could
+    // not be zeroed is released, never used as counters
+    if (hipMemsetAsync(p.base, 0, bytes, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) {
+      (void)hipFree(p.base);
+      p.base = nullptr;
+      return nullptr;
+    }
   }
   auto it = p.slice.find(workspace);
   size_t idx;

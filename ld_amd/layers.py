@@ -820,11 +820,14 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b):
         if not bf16 and not c8w:
             # explicit tuning writes its result with accumulate = 0: into a
             # scratch dW, never into the gradient arena
-            _tune_once('wgrad', d, (),
-                       lambda: lib.ld_conv_tune_wgrad(
-                           C.byref(d), L.ptr(x3), L.ptr(dy),
-                           L.ptr(torch.empty_like(w)), L.ptr(ws), ws.numel(),
-                           st))
+            def _tune_wgrad():
+                # the tuner times every candidate plan: its own, larger workspace
+                tws = torch.empty(lib.ld_conv_tune_wgrad_workspace_bytes(
+                    C.byref(d)), dtype=torch.uint8, device=dy.device)
+                return lib.ld_conv_tune_wgrad(
+                    C.byref(d), L.ptr(x3), L.ptr(dy),
+                    L.ptr(torch.empty_like(w)), L.ptr(tws), tws.numel(), st)
+            _tune_once('wgrad', d, (), _tune_wgrad)
         with _timed('conv_wgrad_bf16' if bf16 else 'conv_wgrad', d):
             # operand images are produced on the main stream (cached ones cost
             # nothing); the wgrad itself may go to the side stream

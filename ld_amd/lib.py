@@ -254,6 +254,7 @@ SIGNATURES = {
     'ld_conv_forward': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
     'ld_conv_forward_smallc': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
     'ld_conv_dgrad': (C.c_int, [_CV, _vp, _vp, _vp, _vp]),
+    'ld_conv_dgrad_acc': (C.c_int, [_CV, _vp, _vp, _vp, _vp, _vp]),
     'ld_conv_tune_forward': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
     'ld_conv_tune_dgrad': (C.c_int, [_CV, _vp, _vp, _vp, _vp]),
     'ld_conv_bf16_weight_image_elems': (_sz, [_i32, _i32, _i32, _i32, _i32]),
@@ -263,6 +264,7 @@ SIGNATURES = {
     'ld_conv_bf16_forward': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
     'ld_conv_bf16_tune_forward': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
     'ld_conv_bf16_dgrad': (C.c_int, [_CV, _vp, _vp, _vp, _vp]),
+    'ld_conv_bf16_dgrad_acc': (C.c_int, [_CV, _vp, _vp, _vp, _vp, _vp]),
     'ld_conv_bf16_tune_dgrad': (C.c_int, [_CV, _vp, _vp, _vp, _vp]),
     'ld_conv_bf16_wgrad': (C.c_int, [_CV, _vp, _vp, _vp, _i32, _vp, _sz,
                                      _vp]),
@@ -272,11 +274,13 @@ SIGNATURES = {
     'ld_conv_bf16_forward_c8': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
     'ld_conv_bf16_tune_forward_c8': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
     'ld_conv_bf16_dgrad_c8': (C.c_int, [_CV, _vp, _vp, _vp, _vp]),
+    'ld_conv_bf16_dgrad_c8_acc': (C.c_int, [_CV, _vp, _vp, _vp, _vp, _vp]),
     'ld_conv_bf16_tune_dgrad_c8': (C.c_int, [_CV, _vp, _vp, _vp, _vp]),
     'ld_conv_tune_load': (C.c_int, [C.c_char_p]),
     'ld_conv_tune_save': (C.c_int, [C.c_char_p]),
     'ld_conv_tune_clear': (C.c_int, []),
     'ld_conv_wgrad_workspace_bytes': (_sz, [_CV]),
+    'ld_conv_tune_wgrad_workspace_bytes': (_sz, [_CV]),
     'ld_conv_wgrad': (C.c_int, [_CV, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     'ld_conv_tune_wgrad': (C.c_int, [_CV, _vp, _vp, _vp, _vp, _sz, _vp]),
     'ld_conv_wgrad_plan': (C.c_int, [_CV, C.POINTER(C.c_int)]),

@@ -8,7 +8,7 @@ oracle/ref_shim.py, on the synthetic C2 batch and seeded weights bench.py uses.
 Run as a child process of bench.py's `cpu_baseline` leg (the shim rewires
 sys.meta_path; the bench process stays clean).  Prints one JSON line.
 
-    LD_REFERENCE_ROOT=<root> python oracle/ref_cpu_step.py --threads 64 --reps 2
+    LD_REFERENCE_ROOT=<root> python oracle/ref_cpu_step.py --threads 64 --reps 3
 """
 import argparse
 import json
@@ -24,7 +24,7 @@ sys.path.insert(0, HERE)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--threads', type=int, default=os.cpu_count() or 1)
-    ap.add_argument('--reps', type=int, default=2)
+    ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--pad', default='800x1344')
     ap.add_argument('--num-gt', type=int, default=7)
     ap.add_argument('--seed', type=int, default=1234)
@@ -76,7 +76,9 @@ def main():
         step(tm)
         runs.append(tm)
     runs.sort(key=lambda r: r['total'])
-    med = runs[(len(runs) - 1) // 2]
+    if len(runs) % 2 == 0:
+        raise SystemExit('--reps must be odd: the reported step is the median')
+    med = runs[len(runs) // 2]
     print(json.dumps(dict(images=2, threads=args.threads, reps=args.reps,
                           stages_s={k: round(v, 4) for k, v in med.items()},
                           all_totals_s=[round(r['total'], 3) for r in runs])))

@@ -20,19 +20,24 @@ is 3.6e-4 of max|g| off the float64 value, 10x its typical error).  The checks
 therefore bound the BULK tightly and the few outliers loosely:
   (1) against the reference, per element:
           |got - ref| <= RTOL |ref| + ATOL_REL max|g|      (1e-3, 1e-3)
-      for all but at most MAX_OUTLIERS parameters, and 1e-2 max|g| for those
-      -- 5x tighter than round 3's 5e-3 NORM band and element-wise: a dropped
-      term, a sign or layout error in any sampled element shows;
+      for all but at most MAX_OUTLIERS parameters, and OUTLIER_REL max|g| for
+      those -- element-wise: a dropped term, a sign or layout error in any
+      sampled element shows.  Round 5 sized both constants to what was MEASURED
+      (profiles/r04_grad_outliers_c2.txt: no parameter left this band under
+      either forward summation order; the worst element 6.3e-4 of max|g|):
+      OUTLIER_REL 1e-2 -> 2e-3, MAX_OUTLIERS 8 -> 5;
   (2) against float64, per parameter: our worst sampled error is at most
           3 x the reference's own worst error + 5e-5 max|g|
-      for all but MAX_OUTLIERS parameters, and our MEDIAN error over the
+      for all but MAX_OUTLIERS_T64 parameters (measured: 5 under both
+      summation orders tried, a different five each time), and our MEDIAN error over the
       parameters is within 2x the reference's median: we are as close to the
       exact gradient as the reference is."""
 import numpy as np
 
 RTOL, ATOL_REL = 1e-3, 1e-3
-MAX_OUTLIERS = 8     # parameters (of ~175) allowed outside the tight band
-OUTLIER_REL = 1e-2   # ... but never further than this fraction of max|g|
+MAX_OUTLIERS = 5      # parameters (of ~175) allowed outside the tight band (1)
+MAX_OUTLIERS_T64 = 6  # ... outside band (2): 5 measured, which five moves with the rounding
+OUTLIER_REL = 2e-3    # ... but never further than this fraction of max|g| (worst seen 6.3e-4)
 
 
 def _sampled(p, synthetic):
@@ -86,10 +91,10 @@ def check_grad_truth64(golden, name, params, factor=3.0, floor_rel=5e-5):
         if err > factor * float(referr) + floor_rel * am + 1e-30:
             bad.append((k, err, float(referr), am))
     rows.sort(reverse=True)
-    assert len(bad) <= MAX_OUTLIERS, (
+    assert len(bad) <= MAX_OUTLIERS_T64, (
         f'{name}: {len(bad)} of {len(names)} parameter gradients are further from '
         f'the float64 evaluation than {factor} x the reference itself (+ {floor_rel} '
-        f'max|g|; at most {MAX_OUTLIERS} outliers allowed); (name, our max err, '
+        f'max|g|; at most {MAX_OUTLIERS_T64} outliers allowed); (name, our max err, '
         f'reference max err, max|g|): {bad[:6]}')
     ours = float(np.median([a for a, _, _ in rows]))
     theirs = float(np.median([b for _, b, _ in rows]))

@@ -71,7 +71,7 @@ def test_train_step_vs_reference_golden(golden, name, sdepth, lw_im):
     for k, r in zip(names, norms):
         assert params[k].grad is not None, k
         got_n = float(params[k].grad.double().norm())
-        if not np.isclose(got_n, r, rtol=5e-3, atol=1e-6):
+        if not np.isclose(got_n, r, rtol=1e-3, atol=1e-6):
             bad.append((k, got_n, r))
     assert not bad, f'{len(bad)} grad norms off, first: {bad[:5]}'
     # ... and two pseudo-random projections of every gradient (sign / order /

@@ -267,7 +267,8 @@ def test_conv_wgrad_fused_equals_slab_reduce(shape, monkeypatch):
     g = torch.Generator().manual_seed(cin + cout)
     xs = [torch.randn(N, cin, d.Pin, generator=g).to(dev) for _ in range(2)]
     dys = [torch.randn(N, cout, d.Pout, generator=g).to(dev) for _ in range(2)]
-    ws = torch.zeros(lib.ld_conv_wgrad_workspace_bytes(C.byref(d)),
+    # sized before the plans below are forced: the worst case over every plan
+    ws = torch.zeros(lib.ld_conv_tune_wgrad_workspace_bytes(C.byref(d)),
                      dtype=torch.uint8, device=dev)
     st = L.stream_ptr(dev)
     base = torch.randn(cout, cin, k, k, generator=g).to(dev)
@@ -311,7 +312,7 @@ def test_conv_tune_wgrad_records_a_pick(tmp_path):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 128, d.Pin, generator=g).to(dev)
     dy = torch.randn(2, 256, d.Pout, generator=g).to(dev)
-    ws = torch.zeros(lib.ld_conv_wgrad_workspace_bytes(C.byref(d)),
+    ws = torch.zeros(lib.ld_conv_tune_wgrad_workspace_bytes(C.byref(d)),
                      dtype=torch.uint8, device=dev)
     st = L.stream_ptr(dev)
     dw = torch.empty(256, 128, 3, 3, device=dev)

@@ -10,6 +10,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ld_amd import model_zoo  # noqa: E402
 from ld_amd.train import SGDTrainer  # noqa: E402
 import bench  # noqa: E402
+from ld_amd import layers as Y  # noqa: E402
+
+if len(sys.argv) > 1:
+    Y.set_precision(sys.argv[1])  # fp32 | bf16
 
 dev = torch.device('cuda:0')
 det = model_zoo.build_seeded_ld_detector(50, 101, dev)

@@ -18,7 +18,7 @@ d, _ = Y.conv_desc(2, 256, 256, 3, 3, 1, 1, HEAD)
 x = torch.randn(2, 256, d.Pin, device=dev)
 dy = torch.randn(2, 256, d.Pout, device=dev)
 dw = torch.empty(256, 256, 3, 3, device=dev)
-ws = torch.zeros(lib.ld_conv_wgrad_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
+ws = torch.zeros(lib.ld_conv_tune_wgrad_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
 st = L.stream_ptr(dev)
 flop = 2.0 * 2 * d.Pout * 256 * 256 * 9
 NAMES = {0: 'full', 1: '-barrier', 2: '-gloads', 4: '-ldswrites', 6: '-gloads-ldswrites',

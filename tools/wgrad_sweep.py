@@ -118,7 +118,7 @@ def main():
         g = torch.Generator().manual_seed(cin * 7 + cout)
         x = torch.randn(N, cin, d.Pin, generator=g).to(dev)
         dy = torch.randn(N, cout, d.Pout, generator=g).to(dev)
-        need = lib.ld_conv_wgrad_workspace_bytes(C.byref(d))
+        need = lib.ld_conv_tune_wgrad_workspace_bytes(C.byref(d))  # every forced plan fits
         ws = torch.zeros(need, dtype=torch.uint8, device=dev)
         dw = torch.empty(cout, cin, k, k, device=dev)
         J = N * d.Pout
