@@ -709,6 +709,20 @@ int ld_upsample_add_forward(const float* fine, const float* coarse, int rows,
                             ld_stream_t stream);
 int ld_upsample_add_backward(const float* dout, int rows, int Hf, int Wf, int Hc,
                              int Wc, float* dcoarse, ld_stream_t stream);
+/* ... + addend (the gradient the coarse map already holds from its other
+ * consumer, the level's output conv; may be NULL; may be dcoarse itself). */
+int ld_upsample_add_backward_acc(const float* dout, int rows, int Hf, int Wf, int Hc,
+                                 int Wc, const float* addend, float* dcoarse,
+                                 ld_stream_t stream);
+/* Level packing for the shared head towers (gfl_head.py:164-172 applies the same
+ * convs to every FPN level; here they run on ONE level-concatenated (N, C, P)
+ * tensor): levels[l] = contiguous (rows, H_l*W_l) fp32, x3 = (rows, P), rows = N*C.
+ * pack copies the levels into x3, unpack is its inverse (the backward): one
+ * launch for all levels. */
+int ld_pack_levels(const ld_levels_t* lv, const float* const* levels, int rows,
+                   float* x3, ld_stream_t stream);
+int ld_unpack_levels(const ld_levels_t* lv, const float* x3, int rows,
+                     float* const* levels, ld_stream_t stream);
 /* mmcv Scale per level (gfl_head.py:182): y = x * scales[level]. */
 int ld_scale_levels_forward(const ld_levels_t* lv, const float* x,
                             const float* scales, int rows, float* y,

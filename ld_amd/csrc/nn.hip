@@ -888,9 +888,12 @@ __global__ __launch_bounds__(256) void upsample_add_fwd_kernel(
 }
 
 // dcoarse[q] = sum over fine cells mapping to q of dout
+// addend (optional, round 5): the gradient the coarse map already received from
+// its other consumer (the level's 3x3 output conv) -- summed here instead of by
+// an elementwise launch of the autograd engine
 __global__ __launch_bounds__(256) void upsample_add_bwd_kernel(
     const float* __restrict__ dout, int Hf, int Wf, int Hc, int Wc,
-    float* __restrict__ dcoarse) {
+    const float* addend, float* dcoarse) {
   const int row = blockIdx.y;
   const int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= Hc * Wc) return;
@@ -907,7 +910,29 @@ __global__ __launch_bounds__(256) void upsample_add_bwd_kernel(
       acc += dout[(size_t)row * Hf * Wf + hf * Wf + wf];
     }
   }
-  dcoarse[(size_t)row * Hc * Wc + r] = acc;
+  const size_t o = (size_t)row * Hc * Wc + r;
+  dcoarse[o] = addend ? acc + addend[o] : acc;
+}
+
+// (N*C, P) level-concatenated rows <-> per-level contiguous (N*C, H_l*W_l)
+// tensors, all levels in one launch (pack = what torch.cat(dim=2) did for the head
+// input, gfl_head.py:164-172 runs the shared towers on every level; unpack = its
+// backward).  16-byte accesses where the level length allows.
+struct LevelPtrs {
+  float* p[LD_MAX_LEVELS];
+};
+template <bool PACK>
+__global__ __launch_bounds__(256) void pack_levels_kernel(Levels lv, LevelPtrs lp,
+                                                          float* __restrict__ x3) {
+  const int row = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= lv.P) return;
+  const int l = level_of_pos(lv, p);
+  const int len = lv.off[l + 1] - lv.off[l];
+  float* a = lp.p[l] + (size_t)row * len + (p - lv.off[l]);
+  float* b = x3 + (size_t)row * lv.P + p;
+  if (PACK) *b = *a;
+  else *a = *b;
 }
 
 // ------------------------------------------------------------- Scale layer --
@@ -1365,14 +1390,48 @@ extern "C" int ld_upsample_add_forward(const float* fine, const float* coarse,
   return (int)hipGetLastError();
 }
 
-extern "C" int ld_upsample_add_backward(const float* dout, int rows, int Hf, int Wf,
-                                        int Hc, int Wc, float* dcoarse,
-                                        ld_stream_t stream) {
+extern "C" int ld_upsample_add_backward_acc(const float* dout, int rows, int Hf, int Wf,
+                                            int Hc, int Wc, const float* addend,
+                                            float* dcoarse, ld_stream_t stream) {
   if (!dout || !dcoarse || rows < 1 || Hf < 1 || Wf < 1 || Hc < 1 || Wc < 1)
     return LD_EINVAL;
   hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3((Hc * Wc + 255) / 256, rows),
-                     dim3(256), 0, LD_STREAM, dout, Hf, Wf, Hc, Wc, dcoarse);
+                     dim3(256), 0, LD_STREAM, dout, Hf, Wf, Hc, Wc, addend, dcoarse);
   return (int)hipGetLastError();
+}
+
+extern "C" int ld_upsample_add_backward(const float* dout, int rows, int Hf, int Wf,
+                                        int Hc, int Wc, float* dcoarse,
+                                        ld_stream_t stream) {
+  return ld_upsample_add_backward_acc(dout, rows, Hf, Wf, Hc, Wc, nullptr, dcoarse, stream);
+}
+
+namespace {
+template <bool PACK>
+int pack_levels_run(const ld_levels_t* lv, float* const* levels, int rows, float* x3,
+                    ld_stream_t stream) {
+  if (int e = check_levels(lv)) return e;
+  if (!levels || !x3 || rows < 1) return LD_EINVAL;
+  LevelPtrs lp{};
+  for (int l = 0; l < lv->num_levels; ++l) {
+    if (!levels[l]) return LD_EINVAL;
+    lp.p[l] = levels[l];
+  }
+  const Levels k = make_levels(lv);
+  hipLaunchKernelGGL(pack_levels_kernel<PACK>, dim3((k.P + 255) / 256, rows), dim3(256), 0,
+                     LD_STREAM, k, lp, x3);
+  return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int ld_pack_levels(const ld_levels_t* lv, const float* const* levels, int rows,
+                              float* x3, ld_stream_t stream) {
+  return pack_levels_run<true>(lv, const_cast<float* const*>(levels), rows, x3, stream);
+}
+
+extern "C" int ld_unpack_levels(const ld_levels_t* lv, const float* x3, int rows,
+                                float* const* levels, ld_stream_t stream) {
+  return pack_levels_run<false>(lv, levels, rows, const_cast<float*>(x3), stream);
 }
 
 extern "C" int ld_scale_levels_forward(const ld_levels_t* lv, const float* x,

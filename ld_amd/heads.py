@@ -260,7 +260,7 @@ class GFLHead(nn.Module):
         """feats: tuple of per-level (N, C, H, W) -> (cls_scores, bbox_preds)
         lists (gfl_head.py:145-183), all levels in one launch per layer."""
         assert len(feats) == len(self.scales)
-        x3, levels = Y.pack_levels(feats)
+        x3, levels = self._pack(feats)
         cls_feat = reg_feat = x3
         for m in self.cls_convs:
             cls_feat, _ = m.forward3(cls_feat, levels)
@@ -271,6 +271,27 @@ class GFLHead(nn.Module):
         scales = torch.stack([s.scale for s in self.scales])
         reg3 = Y.scale_levels(reg3, scales, levels)
         return Y.split_levels(cls3, levels), Y.split_levels(reg3, levels)
+
+    _wants_packed_feats = False  # LDHead / LDv2Head: their loss reads the features
+
+    def _pack(self, feats):
+        """The level-concatenated head input; remembered for ``_loss_feats``
+        while a gradient is wanted."""
+        x3, levels = Y.pack_levels(feats)
+        self._packed = (x3, levels) if self._wants_packed_feats and \
+            torch.is_grad_enabled() and x3.requires_grad and \
+            len(feats) > 1 else None
+        return x3, levels
+
+    def _loss_feats(self, x):
+        """The neck features the LD loss block reads (ld_head.py:284-375: ``x``
+        for the imitation term): the level VIEWS of the packed head input --
+        the same values as ``x``, but the imitation gradient then re-enters the
+        graph at the packed tensor, where the first tower conv's data gradient
+        sums it in its epilogue (layers.fan_*), instead of five per-level
+        elementwise adds at the neck outputs."""
+        pk, self._packed = getattr(self, '_packed', None), None
+        return x if pk is None else Y.split_levels(*pk)
 
     def forward_single(self, x, scale):
         raise NotImplementedError(
@@ -446,6 +467,7 @@ class GFLHead(nn.Module):
 @HEADS.register_module()
 class LDHead(GFLHead):
     """ld_head.py:43-637."""
+    _wants_packed_feats = True
 
     def __init__(self, num_classes, in_channels,
                  loss_ld=dict(type='KnowledgeDistillationKLDivLoss',
@@ -480,8 +502,8 @@ class LDHead(GFLHead):
         outs = self(x)
         if gt_labels is None:
             raise NotImplementedError('LDHead needs gt_labels')
-        losses = self.loss(*outs, gt_bboxes, gt_labels, out_teacher, x,
-                           teacher_x, img_metas,
+        losses = self.loss(*outs, gt_bboxes, gt_labels, out_teacher,
+                           self._loss_feats(x), teacher_x, img_metas,
                            gt_bboxes_ignore=gt_bboxes_ignore)
         if proposal_cfg is not None:
             raise NotImplementedError('get_bboxes (inference) is a "next" row '
@@ -594,7 +616,7 @@ class ATSSGFLHead(GFLHead):
     def forward(self, feats):
         """atss_gfl_head.py:139-183, all levels in one launch per layer."""
         assert len(feats) == len(self.scales)
-        x3, levels = Y.pack_levels(feats)
+        x3, levels = self._pack(feats)
         cls_feat = reg_feat = x3
         for m in self.cls_convs:
             cls_feat, _ = m.forward3(cls_feat, levels)
@@ -1265,7 +1287,7 @@ class GFocalHead(GFLHead):
         """gfocal_head.py:160-217, all levels per launch: towers, predictors,
         per-level Scale, then the fused quality kernel."""
         assert len(feats) == len(self.scales)
-        x3, levels = Y.pack_levels(feats)
+        x3, levels = self._pack(feats)
         cls_feat = reg_feat = x3
         for m in self.cls_convs:
             cls_feat, _ = m.forward3(cls_feat, levels)
@@ -1342,6 +1364,7 @@ class LDv2Head(GFocalHead):
     sigmoid, QFL on probabilities over 81 channels, KD on the raw cls_feat of
     student and teacher (``soft_teacher`` = (cls_score, bbox_pred, cls_feat),
     of which the first is ignored)."""
+    _wants_packed_feats = True
 
     def __init__(self, num_classes, in_channels,
                  loss_ld=dict(type='KnowledgeDistillationKLDivLoss',
@@ -1371,8 +1394,8 @@ class LDv2Head(GFocalHead):
             raise NotImplementedError('LDv2Head needs gt_labels')
         if proposal_cfg is not None:
             raise NotImplementedError('proposal_cfg')
-        return self.loss(*outs, gt_bboxes, gt_labels, out_teacher, x,
-                         teacher_x, img_metas,
+        return self.loss(*outs, gt_bboxes, gt_labels, out_teacher,
+                         self._loss_feats(x), teacher_x, img_metas,
                          gt_bboxes_ignore=gt_bboxes_ignore)
 
     def loss(self, cls_scores, bbox_preds, cls_feat, gt_bboxes, gt_labels,

@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .lossblock import workspace
+from .lossblock import alloc_level_views, level_views, workspace  # noqa: F401
 
 _PARAM_GEN = [0]
 
@@ -751,7 +751,118 @@ def wgrad_join(device=None):
     _WGRAD_PENDING[0] = False
 
 
-def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b):
+# ---- fan-out gradients: summed by the consumers' kernels (round 5) ------------
+# Wherever an activation has several consumers (the input of a residual block:
+# conv1 and the identity path, resnet.py:260-299; a stage output read by the next
+# stage and an FPN lateral, fpn.py:170-176; the packed FPN levels read by both head
+# towers and the loss block) the autograd engine sums the consumers' gradients
+# with one elementwise ATen launch per extra consumer: 37 launches and ~0.4 ms per
+# C2 step, 100-140 MB each on the big maps.  The consumers below hand their
+# gradient over through this protocol instead:
+#   forward   c = fan_in(ctx, i, t)      register as a participating consumer of t
+#   backward  a = fan_take(c)            whatever earlier participants deposited
+#             g = kernel(..., addend=a)  (conv data gradient: summed in the GEMM
+#                                        epilogue, ld_conv_dgrad_acc; FPN upsample
+#                                        backward: ld_upsample_add_backward_acc)
+#             return fan_give(c, g)      None while participants are outstanding
+#                                        (g is deposited on t), the total otherwise
+# Consumers that are not participants keep going through autograd's own sum, so
+# mixing is safe.  State lives on the tensor object (it dies with the graph); a
+# reshape-view of a tensor resolves to its base, so x3.view(n, c, h, w) handed to
+# the neck and x3 handed to the next block are one fan.  A deposit nobody
+# collected by the end of the backward pass raises (a consumer's branch did not
+# take part in this backward: the gradient would be silently incomplete).
+_FAN_ON = [os.environ.get('LD_FAN_FUSE', '1') == '1']
+_FAN_OPEN = []
+FAN_STATS = dict(fused=0, fallback_adds=0)
+
+
+def _fan_canon(t):
+    b = t._base
+    if b is not None and b.numel() == t.numel() and \
+            b.data_ptr() == t.data_ptr() and b.is_contiguous() and \
+            t.is_contiguous():
+        return b
+    return t
+
+
+def fan_in(ctx, idx, t):
+    """Register autograd Function ``ctx``'s input number ``idx`` (= ``t``) as a
+    participant; call from ``forward`` (grad mode is off in there: whether a
+    gradient is wanted is ``ctx.needs_input_grad``)."""
+    if not _FAN_ON[0] or not isinstance(t, torch.Tensor) or \
+            not ctx.needs_input_grad[idx] or t.grad_fn is None or \
+            not t.is_contiguous():
+        return None  # leaves (user inputs, parameters) stay with autograd
+    c = _fan_canon(t)
+    c._ld_fan = getattr(c, '_ld_fan', 0) + 1
+    return c
+
+
+def fan_take(c):
+    if c is None:
+        return None
+    s = getattr(c, '_ld_stash', None)
+    if s is not None:
+        c._ld_stash = None
+        FAN_STATS['fused'] += 1
+    return s
+
+
+def _fan_add(a, b):
+    """a + b for two contiguous tensors of one size as the library's affine
+    launch with the identity affine (a participant that could not fuse the
+    deposit into its own kernel: rare paths only)."""
+    FAN_STATS['fallback_adds'] += 1
+    key = (str(a.device), 1)
+    c = _RELU_CONSTS.get(key)
+    if c is None:
+        c = (torch.ones(1, device=a.device), torch.zeros(1, device=a.device))
+        _RELU_CONSTS[key] = c
+    out = torch.empty_like(a)
+    n = a.numel()
+    L.check(L.get_lib().ld_bn_act_forward(
+        L.ptr(a), L.ptr(b.contiguous()), L.ptr(c[0]), L.ptr(c[1]), 1, 1, n, 0,
+        L.ptr(out), L.stream_ptr(a.device)), 'ld_bn_act_forward')
+    return out
+
+
+def _fan_verify():
+    bad = [c for c in _FAN_OPEN if getattr(c, '_ld_stash', None) is not None]
+    for c in _FAN_OPEN:
+        c._ld_stash = None
+        c._ld_fan = 0
+    del _FAN_OPEN[:]
+    if bad:
+        raise RuntimeError(
+            f'{len(bad)} activation gradient(s) were deposited for a consumer '
+            'whose backward never ran in this pass (shapes '
+            f'{[tuple(c.shape) for c in bad[:4]]}): a partial backward through a '
+            'fan-out; set LD_FAN_FUSE=0 for such graphs')
+
+
+def fan_give(c, g):
+    if c is None or g is None:
+        if c is not None:
+            c._ld_fan -= 1
+        return g
+    c._ld_fan -= 1
+    s = getattr(c, '_ld_stash', None)
+    if s is not None:  # a deposit this participant could not fuse
+        g = _fan_add(g, s.view(g.shape))
+        c._ld_stash = None
+    if c._ld_fan > 0:
+        c._ld_stash = g
+        if not _FAN_OPEN:
+            torch.autograd.Variable._execution_engine.queue_callback(
+                _fan_verify)
+        _FAN_OPEN.append(c)
+        return None
+    return g
+
+
+def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b,
+                   addend=None):
     """Data / weight / bias gradients of a conv (shared by ConvFn and the fused
     ConvBnActFn).  x3: the saved input tensor, or -- x8 given -- its C8Act.
     Returns (dx, dw, db); dw / db are None when they went straight into the
@@ -788,14 +899,25 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b):
             lib.ld_conv_tune_dgrad
         dgrad = lib.ld_conv_bf16_dgrad_c8 if c8 else \
             lib.ld_conv_bf16_dgrad if bf16 else lib.ld_conv_dgrad
+        dgrad_acc = lib.ld_conv_bf16_dgrad_c8_acc if c8 else \
+            lib.ld_conv_bf16_dgrad_acc if bf16 else lib.ld_conv_dgrad_acc
         with _timed('conv_dgrad_bf16' if bf16 else 'conv_dgrad', d):
             dyin = to_c8(dy) if c8 else dy
             _tune_once('c8_dgrad' if c8 else
                        'bf16_dgrad' if bf16 else 'dgrad', d, (),
                        lambda: tune(C.byref(d), L.ptr(dyin),
                                     L.ptr(wt_bwd), L.ptr(dx), st))
-            L.check(dgrad(C.byref(d), L.ptr(dyin), L.ptr(wt_bwd),
-                          L.ptr(dx), st), 'ld_conv_dgrad')
+            if addend is not None:
+                # the other consumers' gradient of this input, summed in the
+                # GEMM epilogue (fan protocol above)
+                if addend.numel() != dx.numel() or not addend.is_contiguous():
+                    raise L.LdError('conv dgrad: addend shape mismatch')
+                L.check(dgrad_acc(C.byref(d), L.ptr(dyin), L.ptr(wt_bwd),
+                                  L.ptr(addend), L.ptr(dx), st),
+                        'ld_conv_dgrad_acc')
+            else:
+                L.check(dgrad(C.byref(d), L.ptr(dyin), L.ptr(wt_bwd),
+                              L.ptr(dx), st), 'ld_conv_dgrad')
     pw, pb = params
     if need_w:
         sink = _sink(pw)
@@ -882,6 +1004,7 @@ class ConvFn(torch.autograd.Function):
             ctx.save_for_backward(x3, w)
         ctx.meta = (stride, pad, levels, bias is not None)
         ctx.params = (w, bias)
+        ctx.fan = fan_in(ctx, 0, x3) if ctx.x8 is None else None
         _note_use(w, bias)
         return y3
 
@@ -891,8 +1014,8 @@ class ConvFn(torch.autograd.Function):
         dx, dw, db = _conv_backward(
             x3, ctx.x8, w, dy, ctx.meta, ctx.params,
             ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-            ctx.needs_input_grad[2])
-        return dx, dw, db, None, None, None
+            ctx.needs_input_grad[2], addend=fan_take(ctx.fan))
+        return fan_give(ctx.fan, dx), dw, db, None, None, None
 
 
 def conv2d(x3, w, bias, stride, pad, levels):
@@ -981,6 +1104,7 @@ class BnActFn(torch.autograd.Function):
         ctx.relu = relu
         ctx.has_res = residual is not None
         ctx.params = (gamma, beta)
+        ctx.fan_res = fan_in(ctx, 6, residual)
         _note_use(gamma, beta)
         return y
 
@@ -991,7 +1115,8 @@ class BnActFn(torch.autograd.Function):
         dx, dres, dgamma, dbeta = _bn_act_backward(
             dy, x3, y, scale, mean, rstd, ctx.relu, ctx.params, ng[0], ng[1],
             ng[2], ctx.has_res and ng[6])
-        return dx, dgamma, dbeta, None, None, None, dres, None
+        return (dx, dgamma, dbeta, None, None, None,
+                fan_give(ctx.fan_res, dres), None)
 
 
 _BN_BWD_C8 = [os.environ.get('LD_BN_BWD_C8', '1') == '1']
@@ -1082,6 +1207,8 @@ class ConvBnActFn(torch.autograd.Function):
         ctx.relu = relu
         ctx.has_res = residual is not None
         ctx.params = (w, gamma, beta)
+        ctx.fan = fan_in(ctx, 0, x3) if ctx.x8 is None else None
+        ctx.fan_res = fan_in(ctx, 7, residual)
         _note_use(w, gamma, beta)
         return z
 
@@ -1094,12 +1221,17 @@ class ConvBnActFn(torch.autograd.Function):
         draw, dres, dgamma, dbeta = _bn_act_backward(
             dz, raw, z, scale, mean, rstd, ctx.relu, (pg, pb), need_conv,
             ng[2], ng[3], ctx.has_res and ng[7])
+        # the identity path's gradient: deposited on the block input, where
+        # conv1's data gradient (it runs later) sums it in its epilogue
+        dres = fan_give(ctx.fan_res, dres)
         dx = dw = None
         if need_conv:
             dx, dw, _ = _conv_backward(x3, ctx.x8, w, draw, ctx.meta,
-                                       (pw, None), ng[0], ng[1], False)
-        return (dx, dw, dgamma, dbeta, None, None, None, dres, None, None,
-                None, None)
+                                       (pw, None), ng[0], ng[1], False,
+                                       addend=fan_take(ctx.fan) if ng[0]
+                                       else None)
+        return (fan_give(ctx.fan, dx), dw, dgamma, dbeta, None, None, None,
+                dres, None, None, None, None)
 
 
 _FUSE_CONV_BN = [os.environ.get('LD_FUSE_CONV_BN', '1') == '1']
@@ -1312,6 +1444,7 @@ class UpsampleAddFn(torch.autograd.Function):
                                             L.stream_ptr(fine.device)),
                 'ld_upsample_add_forward')
         ctx.shapes = (N, c, hf, wf, hc, wc)
+        ctx.fan_f, ctx.fan_c = fan_in(ctx, 0, fine), fan_in(ctx, 1, coarse)
         return out
 
     @staticmethod
@@ -1323,11 +1456,15 @@ class UpsampleAddFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dcoarse = torch.empty((N, c, hc, wc), dtype=torch.float32,
                                   device=dout.device)
-            L.check(lib.ld_upsample_add_backward(L.ptr(dout), N * c, hf, wf,
-                                                 hc, wc, L.ptr(dcoarse),
-                                                 L.stream_ptr(dout.device)),
-                    'ld_upsample_add_backward')
-        return (dout if ctx.needs_input_grad[0] else None), dcoarse
+            # the coarse map's other consumer (its 3x3 output conv) ran first
+            # and deposited its gradient: summed here
+            addend = fan_take(ctx.fan_c)
+            L.check(lib.ld_upsample_add_backward_acc(
+                L.ptr(dout), N * c, hf, wf, hc, wc, L.ptr(addend),
+                L.ptr(dcoarse), L.stream_ptr(dout.device)),
+                'ld_upsample_add_backward_acc')
+        dfine = dout if ctx.needs_input_grad[0] else None
+        return fan_give(ctx.fan_f, dfine), fan_give(ctx.fan_c, dcoarse)
 
 
 def upsample_add(fine, coarse):
@@ -1530,21 +1667,110 @@ def sgd_step(params_flat, grads_flat, momentum_flat, lr, momentum,
 
 
 # ---------------------------------------------------------------------------
-# level packing (device-side copies only: plumbing)
+# level packing: the shared head towers run on ONE level-concatenated tensor
 # ---------------------------------------------------------------------------
+def _level_ptrs(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def _pack_launch(feats, levels):
+    f0 = feats[0]
+    N, c = int(f0.shape[0]), int(f0.shape[1])
+    P = sum(h * w for h, w in levels)
+    x3 = torch.empty((N, c, P), dtype=torch.float32, device=f0.device)
+    fs = [_dev_f32(f, 'level map') for f in feats]
+    lv = levels_desc(levels)
+    L.check(L.get_lib().ld_pack_levels(C.byref(lv), _level_ptrs(fs), N * c,
+                                       L.ptr(x3), L.stream_ptr(f0.device)),
+            'ld_pack_levels')
+    return x3
+
+
+class PackLevelsFn(torch.autograd.Function):
+    """tuple of (N, C, H_l, W_l) -> (N, C, P): one launch each way (torch.cat
+    forward and five strided-slice copies backward before)."""
+
+    @staticmethod
+    def forward(ctx, levels, *feats):
+        ctx.levels = levels
+        ctx.fans = [fan_in(ctx, 1 + i, f) for i, f in enumerate(feats)]
+        ctx.shape = tuple(feats[0].shape[:2])
+        return _pack_launch(feats, levels)
+
+    @staticmethod
+    def backward(ctx, dx3):
+        N, c = ctx.shape
+        dx3 = dx3.contiguous()
+        outs = [torch.empty((N, c, h, w), dtype=torch.float32,
+                            device=dx3.device) for h, w in ctx.levels]
+        lv = levels_desc(ctx.levels)
+        L.check(L.get_lib().ld_unpack_levels(
+            C.byref(lv), L.ptr(dx3), N * c, _level_ptrs(outs),
+            L.stream_ptr(dx3.device)), 'ld_unpack_levels')
+        return (None, ) + tuple(fan_give(f, o)
+                                for f, o in zip(ctx.fans, outs))
+
+
 def pack_levels(feats):
     """tuple of (N, C, H_l, W_l) -> (N, C, P) level-concatenated tensor."""
     levels = tuple((int(f.shape[2]), int(f.shape[3])) for f in feats)
     if len(feats) == 1:
         return feats[0].reshape(feats[0].shape[0], feats[0].shape[1], -1), levels
-    return torch.cat([f.flatten(2) for f in feats], dim=2), levels
+    if any(not f.is_contiguous() for f in feats):
+        return torch.cat([f.flatten(2) for f in feats], dim=2), levels
+    if torch.is_grad_enabled() and any(f.requires_grad for f in feats):
+        return PackLevelsFn.apply(levels, *feats), levels
+    return _pack_launch(feats, levels), levels
+
+
+def _common_buffer(gs, levels, N, c):
+    """The (N, C, P) tensor the per-level gradients ``gs`` are views of, or
+    None."""
+    P = sum(h * w for h, w in levels)
+    g0 = gs[0]
+    if g0 is None or g0.dtype != torch.float32:
+        return None
+    st0, off = g0.untyped_storage().data_ptr(), 0
+    base = g0.storage_offset()
+    for g, (h, w) in zip(gs, levels):
+        if g is None or tuple(g.shape) != (N, c, h, w) or \
+                g.untyped_storage().data_ptr() != st0 or \
+                g.stride() != (c * P, P, w, 1) or \
+                g.storage_offset() != base + off:
+            return None
+        off += h * w
+    return torch.as_strided(g0, (N, c, P), (c * P, P, 1), base)
+
+
+class SplitLevelsFn(torch.autograd.Function):
+    """(N, C, P) -> per-level (N, C, H_l, W_l) VIEWS.  Backward: when the
+    incoming gradients are the level views of one (N, C, P) buffer (the loss
+    block writes them that way) that buffer IS the gradient -- autograd's own
+    slice backward allocated a zero-filled full-size tensor per level and summed
+    the five (10 fills + 10 copies + 8 adds of 12-14 MB per step)."""
+
+    @staticmethod
+    def forward(ctx, x3, levels):
+        ctx.levels, ctx.shape = levels, tuple(x3.shape)
+        ctx.fan = fan_in(ctx, 0, x3)
+        return tuple(level_views(x3, levels))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        N, c, P = ctx.shape
+        buf = _common_buffer(gs, ctx.levels, N, c)
+        if buf is None:
+            ref = next(g for g in gs if g is not None)
+            full = [g.contiguous() if g is not None else
+                    torch.zeros((N, c, h, w), dtype=torch.float32,
+                                device=ref.device)
+                    for g, (h, w) in zip(gs, ctx.levels)]
+            buf = _pack_launch(full, ctx.levels)
+        return fan_give(ctx.fan, buf), None
 
 
 def split_levels(x3, levels):
     """(N, C, P) -> list of (N, C, H_l, W_l) views (no copies)."""
-    N, c, _ = x3.shape
-    outs, off = [], 0
-    for h, w in levels:
-        outs.append(x3[:, :, off:off + h * w].view(N, c, h, w))
-        off += h * w
-    return outs
+    if torch.is_grad_enabled() and x3.requires_grad and x3.is_contiguous():
+        return list(SplitLevelsFn.apply(x3, tuple(levels)))
+    return level_views(x3, levels)

@@ -40,6 +40,30 @@ def workspace(device, nbytes, tag='ws'):
     return t
 
 
+def level_views(x3, levels):
+    """(N, C, P) -> list of (N, C, H_l, W_l) views (no copies, no autograd)."""
+    N, c, _ = x3.shape
+    outs, off = [], 0
+    for h, w in levels:
+        outs.append(x3[:, :, off:off + h * w].view(N, c, h, w))
+        off += h * w
+    return outs
+
+
+def alloc_level_views(like):
+    """Per-level (N, C, H_l, W_l) tensors that are views of ONE new (N, C, P)
+    buffer (the loss block's gradient maps: SplitLevelsFn.backward then hands
+    the buffer on without touching it)."""
+    N, c = like[0].shape[:2]
+    levels = tuple((int(t.shape[2]), int(t.shape[3])) for t in like)
+    if any(tuple(t.shape[:2]) != (N, c) for t in like):
+        return [torch.empty_like(t, memory_format=torch.contiguous_format)
+                for t in like]
+    buf = torch.empty((N, c, sum(h * w for h, w in levels)),
+                      dtype=like[0].dtype, device=like[0].device)
+    return level_views(buf, levels)
+
+
 def make_hp(num_classes=80, reg_max=16, topk=9, feat_channels=256, lw_cls=1.0,
             qfl_beta=2.0, lw_bbox=2.0, giou_eps=1e-6, lw_dfl=0.25, lw_ld=0.25,
             T_ld=10.0, lw_ld_vlr=0.25, T_ld_vlr=10.0, lw_kd=10.0, T_kd=2.0,
@@ -417,19 +441,18 @@ def loss_block_forward(hp, targets, cls, reg, t_cls, t_reg, x, t_x,
     m_cls, m_reg = L.make_maps(cls), L.make_maps(reg)
     m_tcls, m_treg = L.make_maps(t_cls), L.make_maps(t_reg)
     m_x, m_tx = L.make_maps(x), L.make_maps(t_x)
-    g_cls = [torch.empty_like(t, memory_format=torch.contiguous_format)
-             for t in cls]
-    g_reg = [torch.empty_like(t, memory_format=torch.contiguous_format)
-             for t in reg]
-    g_x = [torch.empty_like(t, memory_format=torch.contiguous_format)
-           for t in x]
+    # gradient maps = the level views of ONE (N, C, P) buffer each: what
+    # layers.SplitLevelsFn hands back to the level-concatenated head tensors
+    # without a copy
+    g_cls = alloc_level_views(cls)
+    g_reg = alloc_level_views(reg)
+    g_x = alloc_level_views(x)
     mg_cls, mg_reg, mg_x = L.make_maps(g_cls), L.make_maps(g_reg), \
         L.make_maps(g_x)
     split = kd_s is not None
     g_kd = m_kds = m_kdt = mg_kd = None
     if split:
-        g_kd = [torch.empty_like(t, memory_format=torch.contiguous_format)
-                for t in kd_s]
+        g_kd = alloc_level_views(kd_s)
         m_kds, m_kdt, mg_kd = (L.make_maps(kd_s), L.make_maps(kd_t),
                                L.make_maps(g_kd))
     wt = torch.empty((N, A), dtype=torch.float32, device=device)
@@ -467,8 +490,7 @@ def loss_block_forward(hp, targets, cls, reg, t_cls, t_reg, x, t_x,
     if hp.flags & L.LD_LOSS_ATSS:
         if ctr is None:
             raise L.LdError('LD_LOSS_ATSS needs the centerness maps')
-        g_ctr = [torch.empty_like(t, memory_format=torch.contiguous_format)
-                 for t in ctr]
+        g_ctr = alloc_level_views(ctr)
         L.check(lib.ld_loss_centerness(
             C.byref(geom), C.byref(hp), C.byref(L.make_maps(ctr)),
             L.ptr(targets['labels']), L.ptr(score), L.ptr(norm), L.ptr(up),
