@@ -41,14 +41,15 @@ sys.path.insert(0, REPO)
 # hardware queues by default: once a process group exists two of the step's
 # streams land on ONE queue and the teacher overlap is gone (measured with the
 # collectives forced in a 1-rank group: 36.8 ms per step at the default, 35.1-35.5
-# with 5 / 6 / 8 queues = the figure without a process group).  But a hipGraph
-# replay is far SLOWER with more than 4 queues (bf16: 15.2 -> 26-28 ms), so the
-# value is raised only for a multi-process job, whose steps are enqueued eagerly
-# (profiles/r04_process_group_stream_overlap.txt).  The
-# runtime reads it when it initialises, at the first HIP call: set it before.
+# with 5 / 6 / 8 queues = the figure without a process group).  hipGraph replays
+# need DEBUG_HIP_FORCE_GRAPH_QUEUES=2 next to it (the graph executor's internal
+# streams must not each get a hardware queue of their own: bf16 replay 28 ms vs
+# 15.2, profiles/r05_graph_queues_s1.jsonl; ld_amd/__init__.py, DESIGN.md section
+# 6).  The runtime reads both when it initialises, at the first HIP call.
 if int(os.environ.get('WORLD_SIZE', '1')) > 1 or \
         os.environ.get('LD_FORCE_COLLECTIVES') == '1':
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+    os.environ.setdefault('DEBUG_HIP_FORCE_GRAPH_QUEUES', '2')
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -519,6 +519,28 @@ size_t ld_conv_tune_wgrad_workspace_bytes(const ld_conv_t* c);
 int ld_conv_wgrad(const ld_conv_t* c, const float* x, const float* dy, float* dw,
                   int accumulate, void* workspace, size_t workspace_bytes,
                   ld_stream_t stream);
+/* Deferred reduction (round 5): a parameter gradient is needed when its bucket is
+ * reduced across ranks / the optimizer runs, not when its layer's backward runs.
+ * ld_conv_wgrad_partial computes only the split partials of a weight gradient --
+ * family 0 = the fp32 kernels of ld_conv_wgrad, 1 = ld_conv_bf16_wgrad, 2 =
+ * ld_conv_bf16_wgrad_c8 (x / dy as C8 images) -- into `slabs` (>=
+ * ld_conv_wgrad_workspace_bytes(c), owned by this weight until the batch ran) and
+ * fills job->slabs / splits / ntaps / Cout / Cin; the caller sets dw, accumulate
+ * and first_block and uploads the jobs of a bucket once.  ld_wgrad_reduce_batch
+ * sums every job of a table in ONE launch (block b serves 1024 consecutive
+ * [tap][co][ci] elements of job block_job[b]; a job owns ceil(ntaps*Cout*Cin /
+ * 1024) consecutive blocks from first_block): the same additions in the same
+ * order as the per-layer reduce launch it replaces, 53 launches per step fewer. */
+typedef struct {
+  const float* slabs; /* [splits][ntaps][Cout][Cin] */
+  float* dw;          /* (Cout, Cin, KH, KW) */
+  int32_t splits, ntaps, Cout, Cin, accumulate, first_block;
+} ld_wgrad_job_t;
+int ld_conv_wgrad_partial(const ld_conv_t* c, int family, const void* x, const void* dy,
+                          void* slabs, size_t slab_bytes, ld_wgrad_job_t* job,
+                          ld_stream_t stream);
+int ld_wgrad_reduce_batch(const ld_wgrad_job_t* jobs, const int32_t* block_job,
+                          int nblocks, ld_stream_t stream);
 /* The plan ld_conv_wgrad would follow for this geometry, without touching the
  * device: out[0..4] = kind (0 wave-private 64 x 64 tiles, 1 workgroup tiles, 2
  * three kw taps per workgroup), k-groups, columns per slice, splits along the
@@ -666,6 +688,25 @@ int ld_bn_act_backward_c8(const float* dy, const float* y, const float* x,
                           int N, int C, int P, int relu, float* dx, void* dx_c8,
                           float* dres, float* dgamma, float* dbeta, int accumulate,
                           void* workspace, size_t workspace_bytes, ld_stream_t stream);
+/* Deferred finalisation (round 5, see ld_wgrad_reduce_batch): with accumulate ==
+ * LD_GRAD_DEFER the two BN backward entry points above write only their
+ * per-workgroup fp64 partials ([C][nsplit] pairs (sum dz, sum dz*xhat), nsplit =
+ * ld_bn_act_backward_nsplit(N, C, P, c8)) into `workspace` -- which the caller
+ * then owns until ld_bn_bwd_finalize_batch has summed every job of a bucket in ONE
+ * launch (16 channels per block, a job owns ceil(C / 16) blocks from first_block;
+ * the arithmetic of the per-layer finalize launch: 37 launches per step fewer).
+ * dgamma / dbeta must be non-NULL in the deferring call (they request the
+ * partials) and are not written by it. */
+#define LD_GRAD_DEFER 2
+typedef struct {
+  const double* partial;
+  float* dgamma;
+  float* dbeta;
+  int32_t C, nsplit, accumulate, first_block;
+} ld_bn_fin_job_t;
+int ld_bn_act_backward_nsplit(int N, int C, int P, int c8);
+int ld_bn_bwd_finalize_batch(const ld_bn_fin_job_t* jobs, const int32_t* block_job,
+                             int nblocks, ld_stream_t stream);
 /* db[c] = sum_{n,p} dy (conv bias gradient, fpn.py / gfl_cls / gfl_reg). */
 int ld_bias_grad(const float* dy, int N, int C, int P, float* db, int accumulate,
                  ld_stream_t stream);

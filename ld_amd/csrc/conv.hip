@@ -2613,11 +2613,15 @@ extern "C" size_t ld_conv_tune_wgrad_workspace_bytes(const ld_conv_t* c) {
 }
 
 namespace {
+// defer != nullptr (round 5): only the split partials are computed, as slabs in
+// `workspace` (which the caller keeps until ld_wgrad_reduce_batch has run), and
+// *defer receives the reduction job; dw / accumulate are not touched.
 int wgrad_run(const ld_conv_t* c, const float* x, const float* dy, float* dw,
               int accumulate, void* workspace, size_t workspace_bytes,
-              ld_stream_t stream_, int family, const WgCfg* forced = nullptr) {
+              ld_stream_t stream_, int family, const WgCfg* forced = nullptr,
+              ld_wgrad_job_t* defer = nullptr) {
   if (int e = check_conv(c)) return e;
-  if (!x || !dy || !dw) return LD_EINVAL;
+  if (!x || !dy || (!dw && !defer)) return LD_EINVAL;
   if (!workspace || workspace_bytes < wgrad_need(c, family, forced)) return LD_ENOSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   WgradK k;
@@ -2645,6 +2649,15 @@ int wgrad_run(const ld_conv_t* c, const float* x, const float* dy, float* dw,
     k.dy_bytes = (unsigned)(yf * 4);
   }
   const int ntaps = c->KH * c->KW;
+  int nslabs = k.splits;
+  auto deferred = [&]() -> int {
+    defer->slabs = (const float*)workspace;
+    defer->splits = nslabs;
+    defer->ntaps = ntaps;
+    defer->Cout = c->Cout;
+    defer->Cin = c->Cin;
+    return 0;
+  };
   if (family == 2) {  // x / dy are bf16 C8 images: half the bytes
     k.x_bytes = (unsigned)((size_t)c->N * c->Cin * c->Pin * 2);
     k.dy_bytes = (unsigned)((size_t)c->N * c->Cout * c->Pout * 2);
@@ -2652,11 +2665,15 @@ int wgrad_run(const ld_conv_t* c, const float* x, const float* dy, float* dw,
   } else if (family == 1) {
     if (int e = ld_bf16_wgrad_launch(k, stream)) return e;
   } else if (const WgCfg cfg = forced ? *forced : wgrad_pick(c); cfg.kind == 1) {
-    return ld_f32_wgrad_tile_launch(k, cfg.kg, cfg.bk, cfg.splits, cfg.fused, dw,
-                                    accumulate, workspace, workspace_bytes, stream);
+    const int e = ld_f32_wgrad_tile_launch(k, cfg.kg, cfg.bk, cfg.splits, cfg.fused, dw,
+                                           accumulate, workspace, workspace_bytes, stream,
+                                           defer ? &nslabs : nullptr);
+    return e || !defer ? e : deferred();
   } else if (cfg.kind == 2) {
-    return ld_f32_wgrad_tap3_launch(k, cfg.splits, dw, accumulate, workspace,
-                                    workspace_bytes, stream);
+    const int e = ld_f32_wgrad_tap3_launch(k, cfg.splits, dw, accumulate, workspace,
+                                           workspace_bytes, stream,
+                                           defer ? &nslabs : nullptr);
+    return e || !defer ? e : deferred();
   } else if (wmode) {
     const int blocks = ((c->Cout + 63) / 64) * ((c->Cin + 63) / 64) * ntaps * k.splits;
     if (wmode == 32)
@@ -2670,10 +2687,83 @@ int wgrad_run(const ld_conv_t* c, const float* x, const float* dy, float* dw,
         ((c->Cout + 127) / 128) * ((c->Cin + 127) / 128) * ntaps * k.splits;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(blocks), dim3(kThreads), 0, stream, k);
   }
+  if (defer) {
+    if (hipError_t e = hipGetLastError()) return (int)e;
+    return deferred();
+  }
   return ld_wgrad_reduce_launch(k.slabs, k.splits, ntaps, c->Cout, c->Cin, dw,
                                 accumulate, stream);
 }
+
+// dW (+)= sum_split slab, every job of the table in ONE launch: block b serves
+// 1024 consecutive [tap][co][ci] elements of job block_job[b].  Per element the
+// splits are added in index order, exactly as conv_wgrad_reduce(4)_kernel does.
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_batch_kernel(
+    const ld_wgrad_job_t* __restrict__ jobs, const int32_t* __restrict__ block_job) {
+  const ld_wgrad_job_t j = jobs[block_job[blockIdx.x]];
+  const size_t per = (size_t)j.ntaps * j.Cout * j.Cin;
+  const size_t i = ((size_t)(blockIdx.x - j.first_block) * 256 + threadIdx.x) * 4;
+  if (i >= per) return;
+  const bool vec = j.Cin % 4 == 0 && ((uintptr_t)j.slabs & 15) == 0 &&
+                   (j.ntaps > 1 || ((uintptr_t)j.dw & 15) == 0);
+  if (vec) {
+    const int ci = (int)(i % j.Cin);
+    const size_t q = i / j.Cin;
+    const int co = (int)(q % j.Cout), tap = (int)(q / j.Cout);
+    floatx4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+    int k = 0;
+    for (; k + 8 <= j.splits; k += 8) {
+      floatx4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = *reinterpret_cast<const floatx4*>(j.slabs + (size_t)(k + u) * per + i);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < j.splits; ++k)
+      s += *reinterpret_cast<const floatx4*>(j.slabs + (size_t)k * per + i);
+    if (j.ntaps == 1) {
+      float* o = j.dw + (size_t)co * j.Cin + ci;
+      if (j.accumulate) s += *reinterpret_cast<const floatx4*>(o);
+      *reinterpret_cast<floatx4*>(o) = s;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const size_t o = ((size_t)co * j.Cin + ci + e) * j.ntaps + tap;
+        j.dw[o] = j.accumulate ? j.dw[o] + s[e] : s[e];
+      }
+    }
+    return;
+  }
+  for (int e = 0; e < 4 && i + e < per; ++e) {
+    const size_t ie = i + e;
+    const int ci = (int)(ie % j.Cin);
+    const size_t q = ie / j.Cin;
+    const int co = (int)(q % j.Cout), tap = (int)(q / j.Cout);
+    float s = 0.0f;
+    for (int k = 0; k < j.splits; ++k) s += j.slabs[(size_t)k * per + ie];
+    const size_t o = ((size_t)co * j.Cin + ci) * j.ntaps + tap;
+    j.dw[o] = j.accumulate ? j.dw[o] + s : s;
+  }
+}
 }  // namespace
+
+extern "C" int ld_conv_wgrad_partial(const ld_conv_t* c, int family, const void* x,
+                                     const void* dy, void* slabs, size_t slab_bytes,
+                                     ld_wgrad_job_t* job, ld_stream_t stream) {
+  if (!job || family < 0 || family > 2) return LD_EINVAL;
+  if (family == 2 && c && (c->Cin % 8 != 0 || c->Cout % 8 != 0)) return LD_EUNSUPPORTED;
+  return wgrad_run(c, (const float*)x, (const float*)dy, nullptr, 0, slabs, slab_bytes,
+                   stream, family, nullptr, job);
+}
+
+extern "C" int ld_wgrad_reduce_batch(const ld_wgrad_job_t* jobs, const int32_t* block_job,
+                                     int nblocks, ld_stream_t stream) {
+  if (!jobs || !block_job || nblocks < 1) return LD_EINVAL;
+  hipLaunchKernelGGL(conv_wgrad_reduce_batch_kernel, dim3(nblocks), dim3(256), 0,
+                     (hipStream_t)stream, jobs, block_job);
+  return (int)hipGetLastError();
+}
 
 int ld_wgrad_reduce_launch(const float* slabs, int splits, int ntaps, int Cout, int Cin,
                            float* dw, int accumulate, hipStream_t stream) {

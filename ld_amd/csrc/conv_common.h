@@ -73,11 +73,16 @@ int ld_bf16_wgrad_splits(int Cout, int Cin, int ntaps, int J);  // its j-split c
 bool ld_f32_wgrad_tile_cfg_ok(int kg, int bk);
 int ld_f32_wgrad_tile_slots(int kg, int bk);  // workgroups resident on the device
 size_t ld_f32_wgrad_tile_workspace(int Cout, int Cin, int ntaps, int splits);
+// slabs_only (round 5, deferred reduction): write the split partials as slabs
+// [split][tap][Cout][Cin] into the workspace even for one split, issue NO reduce
+// launch, and report the number of slabs written through *slabs_only.
 int ld_f32_wgrad_tile_launch(const WgradK& k, int kg, int bk, int splits, int fused,
                              float* dw, int accumulate, void* workspace,
-                             size_t workspace_bytes, hipStream_t stream);
+                             size_t workspace_bytes, hipStream_t stream,
+                             int* slabs_only = nullptr);
 int ld_f32_wgrad_tap3_launch(const WgradK& k, int splits, float* dw, int accumulate,
-                             void* workspace, size_t workspace_bytes, hipStream_t stream);
+                             void* workspace, size_t workspace_bytes, hipStream_t stream,
+                             int* slabs_only = nullptr);
 // conv.hip: fixed-order sum of the wgrad slabs into dW (shared by both families)
 int ld_wgrad_reduce_launch(const float* slabs, int splits, int ntaps, int Cout,
                            int Cin, float* dw, int accumulate, hipStream_t stream);

@@ -826,7 +826,8 @@ bool ld_f32_wgrad_tile_cfg_ok(int kg, int bk) {
 // 3 x 3 convs only: conv_wgrad_tap3_kernel (one workgroup = the three kw taps of a
 // kernel row of a 128 x 128 tile).  256 workgroups fill the device.
 int ld_f32_wgrad_tap3_launch(const WgradK& k_in, int splits, float* dw, int accumulate,
-                             void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                             void* workspace, size_t workspace_bytes, hipStream_t stream,
+                             int* slabs_only) {
   if (k_in.KH != 3 || k_in.KW != 3) return LD_EUNSUPPORTED;
   WgradK k = k_in;
   const int ntiles = ((k.Cout + 127) / 128) * ((k.Cin + 127) / 128) * 3;
@@ -836,7 +837,7 @@ int ld_f32_wgrad_tap3_launch(const WgradK& k_in, int splits, float* dw, int accu
   splits = (k.J + jchunk - 1) / jchunk;
   k.splits = splits;
   k.jchunk = jchunk;
-  if (splits > 1 &&
+  if ((splits > 1 || slabs_only) &&
       workspace_bytes < (size_t)splits * 9 * k.Cout * k.Cin * sizeof(float))
     return LD_ENOSPACE;
   WgradTileOut o;
@@ -844,7 +845,7 @@ int ld_f32_wgrad_tap3_launch(const WgradK& k_in, int splits, float* dw, int accu
   o.accumulate = accumulate;
   o.part = nullptr;
   o.tickets = nullptr;
-  o.out_mode = splits == 1 ? 1 : 0;
+  o.out_mode = splits == 1 && !slabs_only ? 1 : 0;
   k.slabs = (float*)workspace;
   const int blocks = ntiles * splits;
   if (k.g.num_levels > 1 && getenv("LD_ALLOW_WRONG_RESULTS") && getenv("LD_WGRAD_DBG") &&
@@ -858,6 +859,10 @@ int ld_f32_wgrad_tap3_launch(const WgradK& k_in, int splits, float* dw, int accu
     hipLaunchKernelGGL((conv_wgrad_tap3_kernel<false>), dim3(blocks), dim3(768), 0, stream, k,
                        o);
   if (hipError_t e = hipGetLastError()) return (int)e;
+  if (slabs_only) {
+    *slabs_only = splits;
+    return 0;
+  }
   if (o.out_mode == 0)
     return ld_wgrad_reduce_launch(k.slabs, splits, 9, k.Cout, k.Cin, dw, accumulate, stream);
   return 0;
@@ -888,7 +893,7 @@ size_t ld_f32_wgrad_tile_workspace(int Cout, int Cin, int ntaps, int splits) {
 // pool is unavailable.
 int ld_f32_wgrad_tile_launch(const WgradK& k_in, int kg, int bk, int splits, int fused,
                              float* dw, int accumulate, void* workspace,
-                             size_t workspace_bytes, hipStream_t stream) {
+                             size_t workspace_bytes, hipStream_t stream, int* slabs_only) {
   if (!ld_f32_wgrad_tile_cfg_ok(kg, bk)) return LD_EUNSUPPORTED;
   WgradK k = k_in;
   const int ntaps = k.KH * k.KW;
@@ -900,16 +905,16 @@ int ld_f32_wgrad_tile_launch(const WgradK& k_in, int kg, int bk, int splits, int
   k.splits = splits;
   k.jchunk = jchunk;
   if (workspace_bytes < ld_f32_wgrad_tile_workspace(k.Cout, k.Cin, ntaps, splits) &&
-      splits > 1)
+      (splits > 1 || slabs_only))
     return LD_ENOSPACE;
   WgradTileOut o;
   o.dw = dw;
   o.accumulate = accumulate;
   o.part = (float*)workspace;
   o.tickets = nullptr;
-  o.out_mode = splits == 1 ? 1 : 0;
+  o.out_mode = splits == 1 && !slabs_only ? 1 : 0;
   k.slabs = (float*)workspace;
-  if (splits > 1 && fused && (size_t)ntiles <= kTicketSlots) {
+  if (splits > 1 && fused && !slabs_only && (size_t)ntiles <= kTicketSlots) {
     o.tickets = ticket_slice(workspace, stream);
     if (o.tickets) o.out_mode = 2;
   }
@@ -923,6 +928,10 @@ int ld_f32_wgrad_tile_launch(const WgradK& k_in, int kg, int bk, int splits, int
   LD_WT_CASE(4, 64)
 #undef LD_WT_CASE
   if (hipError_t e = hipGetLastError()) return (int)e;
+  if (slabs_only) {
+    *slabs_only = splits;
+    return 0;
+  }
   if (o.out_mode == 0)
     return ld_wgrad_reduce_launch(k.slabs, splits, ntaps, k.Cout, k.Cin, dw, accumulate,
                                   stream);

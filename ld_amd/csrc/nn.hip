@@ -1170,7 +1170,7 @@ extern "C" int ld_bn_act_backward(const float* dy, const float* y, const float* 
     hipLaunchKernelGGL((bn_act_bwd_kernel<false>), dim3(C, ns), dim3(256), 0,
                        LD_STREAM, dy, y, x, scale, mean, rstd, N, C, P, relu, dx, dres,
                        params ? (double*)workspace : nullptr);
-  if (params)
+  if (params && accumulate != LD_GRAD_DEFER)
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0,
                        LD_STREAM, (const double*)workspace, C, ns, dgamma, dbeta,
                        accumulate);
@@ -1198,10 +1198,53 @@ extern "C" int ld_bn_act_backward_c8(const float* dy, const float* y, const floa
   hipLaunchKernelGGL(bn_act_bwd_c8_kernel, dim3(xb, N * (C / 8)), dim3(64), 0, LD_STREAM,
                      dy, y, x, scale, mean, rstd, C, P, relu, dx, dres,
                      (gn_uintx4*)dx_c8, params ? (double*)workspace : nullptr, nslots);
-  if (params)
+  if (params && accumulate != LD_GRAD_DEFER)
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0,
                        LD_STREAM, (const double*)workspace, C, nslots, dgamma, dbeta,
                        accumulate);
+  return (int)hipGetLastError();
+}
+
+// How many partial slots per channel ld_bn_act_backward (c8 == 0) /
+// ld_bn_act_backward_c8 (c8 != 0) write for this geometry (host logic).
+extern "C" int ld_bn_act_backward_nsplit(int N, int C, int P, int c8) {
+  if (N < 1 || C < 1 || P < 1) return 0;
+  return c8 ? N * ((P / 4 + 63) / 64) : bn_splits(N, C, P);
+}
+
+// every job of the table in ONE launch: block b finalises 16 channels of job
+// block_job[b] with bn_bwd_finalize_kernel's own arithmetic (16 lanes per channel
+// over the slots, fixed butterfly)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_batch_kernel(
+    const ld_bn_fin_job_t* __restrict__ jobs, const int32_t* __restrict__ block_job) {
+  const ld_bn_fin_job_t jb = jobs[block_job[blockIdx.x]];
+  const int j = threadIdx.x & 15;
+  const int c = (blockIdx.x - jb.first_block) * 16 + (threadIdx.x >> 4);
+  double s1 = 0.0, s2 = 0.0;
+  if (c < jb.C) {
+    const double2* row = reinterpret_cast<const double2*>(jb.partial) + (size_t)c * jb.nsplit;
+    for (int k = j; k < jb.nsplit; k += 16) {
+      const double2 v = row[k];
+      s1 += v.x;
+      s2 += v.y;
+    }
+  }
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) {
+    s1 += __shfl_xor(s1, m, 16);
+    s2 += __shfl_xor(s2, m, 16);
+  }
+  if (c >= jb.C || j != 0) return;
+  if (jb.dbeta) jb.dbeta[c] = jb.accumulate ? jb.dbeta[c] + (float)s1 : (float)s1;
+  if (jb.dgamma) jb.dgamma[c] = jb.accumulate ? jb.dgamma[c] + (float)s2 : (float)s2;
+}
+
+extern "C" int ld_bn_bwd_finalize_batch(const ld_bn_fin_job_t* jobs,
+                                        const int32_t* block_job, int nblocks,
+                                        ld_stream_t stream) {
+  if (!jobs || !block_job || nblocks < 1) return LD_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_finalize_batch_kernel, dim3(nblocks), dim3(256), 0, LD_STREAM,
+                     jobs, block_job);
   return (int)hipGetLastError();
 }
 

@@ -705,6 +705,100 @@ _WGRAD_PENDING = [False]
 _WGRAD_FORCE = [False]
 
 
+# ---- parameter gradients finalised per BUCKET, not per layer (round 5) ---------
+# A parameter gradient is needed when its bucket is all-reduced / the optimizer
+# runs -- not when its layer's backward runs.  With a gradient arena the
+# cross-workgroup finalisation of the two big families is therefore deferred:
+#   * weight gradients: the conv launch writes only its split partials (slabs,
+#     into a buffer the weight owns), the fixed-order sum of EVERY pending weight
+#     gradient runs as one ld_wgrad_reduce_batch launch when a bucket completes
+#     (53 conv_wgrad_reduce launches per C2 step before, 5 now);
+#   * eval-BN affine gradients: the backward launch writes its per-workgroup fp64
+#     partials into a buffer the layer owns, one ld_bn_bwd_finalize_batch per bucket
+#     (42 finalize launches before).
+# Same additions in the same order: bit-identical gradients.  The job tables live
+# on the device and are cached by content, so a steady-state step uploads nothing.
+_DEFER_ON = [os.environ.get('LD_DEFER_GRADS', '1') == '1']
+_DEFER_W, _DEFER_B = [], []
+_DEFER_TABLES = {}
+DEFER_STATS = dict(wgrad_jobs=0, bn_jobs=0, flushes=0, tables_built=0)
+
+
+def _defer_buffer(owner, attr, nbytes, device):
+    """A persistent scratch buffer owned by a parameter (slabs / partials live
+    from the layer's backward to the bucket's flush; never shrinks).  A buffer
+    born during a hipGraph capture belongs to that graph's pool: not cached."""
+    t = getattr(owner, attr, None)
+    if t is None or t.numel() < nbytes or t.device != device:
+        t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+            try:
+                setattr(owner, attr, t)
+            except AttributeError:
+                pass
+    return t
+
+
+def _defer_table(jobs, blocks_of, device):
+    key = (str(device), bytes(b''.join(bytes(j) for j in jobs)))
+    hit = _DEFER_TABLES.get(key)
+    if hit is None:
+        if len(_DEFER_TABLES) > 256:
+            _DEFER_TABLES.clear()
+        structs = [type(j).from_buffer_copy(bytes(j)) for j in jobs]
+        hit = _job_table(structs, blocks_of, device)
+        DEFER_STATS['tables_built'] += 1
+        if not torch.cuda.is_current_stream_capturing():
+            _DEFER_TABLES[key] = hit
+    return hit
+
+
+def flush_deferred(device=None):
+    """Sum every pending deferred parameter gradient into the arena: one launch
+    per family, on the CURRENT stream (the caller has ordered it after the
+    launches that produced the partials)."""
+    if not (_DEFER_W or _DEFER_B):
+        return
+    lib = L.get_lib()
+    for pending, fn, what, per_block in (
+            (_DEFER_W, lib.ld_wgrad_reduce_batch, 'ld_wgrad_reduce_batch', 0),
+            (_DEFER_B, lib.ld_bn_bwd_finalize_batch, 'ld_bn_bwd_finalize_batch',
+             16)):
+        if not pending:
+            continue
+        jobs = [j for j, _ in pending]
+        dev = pending[0][1]
+        if per_block:
+            blocks = [(j.C + 15) // 16 for j in jobs]
+        else:
+            blocks = [(j.ntaps * j.Cout * j.Cin + 1023) // 1024 for j in jobs]
+        for j in jobs:
+            j.first_block = 0  # set by the table builder; part of the cache key
+        tab, bmap, nb = _defer_table(jobs, blocks, dev)
+        prof = KernelProfile.active if not per_block else None
+        if prof is not None:  # the sum belongs to the weight gradients' time
+            a = torch.cuda.Event(enable_timing=True)
+            b = torch.cuda.Event(enable_timing=True)
+            a.record()
+        L.check(fn(L.ptr(tab), L.ptr(bmap), nb, L.stream_ptr(dev)), what)
+        if prof is not None:
+            b.record()
+            prof.records.append((
+                'conv_wgrad_bf16' if _PRECISION[0] == 'bf16' else 'conv_wgrad',
+                0.0, a, b, f'deferred reduce of {len(jobs)} weight gradients'))
+        del pending[:]
+    DEFER_STATS['flushes'] += 1
+
+
+def deferred_pending():
+    return bool(_DEFER_W or _DEFER_B)
+
+
+def drop_deferred():
+    del _DEFER_W[:]
+    del _DEFER_B[:]
+
+
 class capture_warmup:
     """Eager warm-up steps that precede a hipGraph capture must take the SAME
     code paths the capture will take (so that every cached buffer -- workspaces,
@@ -923,7 +1017,8 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b,
         sink = _sink(pw)
         dw = sink if sink is not None else torch.empty_like(w)
         need = lib.ld_conv_wgrad_workspace_bytes(C.byref(d))
-        ws = workspace(dy.device, need, 'wgrad')
+        ws = None if sink is not None and _DEFER_ON[0] else \
+            workspace(dy.device, need, 'wgrad')
         bf16 = _PRECISION[0] == 'bf16' and cin >= 16
         wgrad = lib.ld_conv_bf16_wgrad_c8 if c8w else \
             lib.ld_conv_bf16_wgrad if bf16 else lib.ld_conv_wgrad
@@ -950,22 +1045,42 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b,
                     C.byref(d), L.ptr(x3), L.ptr(dy),
                     L.ptr(torch.empty_like(w)), L.ptr(tws), tws.numel(), st)
             _tune_once('wgrad', d, (), _tune_wgrad)
+        # with a gradient arena only the split partials are computed here; their
+        # sum runs once per bucket (flush_deferred)
+        defer = sink is not None and _DEFER_ON[0]
+        if defer and any(j.dw == sink.data_ptr() for j, _ in _DEFER_W):
+            flush_deferred()  # a weight used twice: its slabs are still pending
+        family = 2 if c8w else 1 if bf16 else 0
+
+        def _launch(ws_, stream_ptr):
+            if not defer:
+                L.check(wgrad(C.byref(d), L.ptr(xw), L.ptr(dyw), L.ptr(dw),
+                              0 if sink is None else 1, L.ptr(ws_),
+                              ws_.numel(), stream_ptr), 'ld_conv_wgrad')
+                return
+            slabs = _defer_buffer(pw, '_ld_slabs', need, dy.device)
+            job = L.WgradJobT()
+            L.check(lib.ld_conv_wgrad_partial(
+                C.byref(d), family, L.ptr(xw), L.ptr(dyw), L.ptr(slabs),
+                slabs.numel(), C.byref(job), stream_ptr),
+                'ld_conv_wgrad_partial')
+            job.dw, job.accumulate = sink.data_ptr(), 1
+            _DEFER_W.append((job, dy.device))
+            DEFER_STATS['wgrad_jobs'] += 1
+
         with _timed('conv_wgrad_bf16' if bf16 else 'conv_wgrad', d):
             # operand images are produced on the main stream (cached ones cost
             # nothing); the wgrad itself may go to the side stream
             xw, dyw = ((x3.buf if x8 is not None else to_c8(x3)),
                        to_c8(dy)) if c8w else (x3, dy)
             if side is None:
-                L.check(wgrad(C.byref(d), L.ptr(xw), L.ptr(dyw), L.ptr(dw),
-                              0 if sink is None else 1, L.ptr(ws),
-                              ws.numel(), st), 'ld_conv_wgrad')
+                _launch(ws, st)
             else:
                 side.wait_stream(torch.cuda.current_stream(dy.device))
                 with torch.cuda.stream(side):
-                    ws2 = workspace(dy.device, need, 'wgrad')  # per stream
-                    L.check(wgrad(C.byref(d), L.ptr(xw), L.ptr(dyw),
-                                  L.ptr(dw), 1, L.ptr(ws2), ws2.numel(),
-                                  L.stream_ptr(dy.device)), 'ld_conv_wgrad')
+                    ws2 = ws if defer else workspace(dy.device, need,
+                                                     'wgrad')  # per stream
+                    _launch(ws2, L.stream_ptr(dy.device))
                 # the caching allocator must not hand these blocks to later
                 # main-stream allocations while the side stream still reads them
                 for t in (xw, dyw):
@@ -1144,7 +1259,12 @@ def _bn_act_backward(dy, x3, y, scale, mean, rstd, relu, params, need_x,
         dbeta = torch.empty(c, dtype=torch.float32, device=x3.device) \
             if need_b else None
     need = lib.ld_bn_act_backward_workspace_bytes(N, c, P)
-    ws = workspace(x3.device, need, 'bn')
+    defer = direct and _DEFER_ON[0]
+    if defer and any(j.dgamma == sg.data_ptr() for j, _ in _DEFER_B):
+        flush_deferred()  # a norm used twice: its partials are still pending
+    ws = _defer_buffer(pg, '_ld_bn_partial', need, x3.device) if defer else \
+        workspace(x3.device, need, 'bn')
+    acc = L.LD_GRAD_DEFER if defer else 1 if direct else 0
     # bf16 mode: dx goes into the conv's C8 data- / weight-gradient kernels --
     # write its C8 image from this launch instead of a to_c8 launch per conv
     dx_c8 = None
@@ -1158,7 +1278,7 @@ def _bn_act_backward(dy, x3, y, scale, mean, rstd, relu, params, need_x,
         L.check(lib.ld_bn_act_backward_c8(
             L.ptr(dy), L.ptr(y), L.ptr(x3), L.ptr(scale), L.ptr(mean),
             L.ptr(rstd), N, c, P, 1 if relu else 0, L.ptr(dx), L.ptr(dx_c8),
-            L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), 1 if direct else 0,
+            L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), acc,
             L.ptr(ws), ws.numel(), L.stream_ptr(x3.device)),
             'ld_bn_act_backward_c8')
         _attach_c8(dx, dx_c8)
@@ -1166,9 +1286,18 @@ def _bn_act_backward(dy, x3, y, scale, mean, rstd, relu, params, need_x,
         L.check(lib.ld_bn_act_backward(
             L.ptr(dy), L.ptr(y), L.ptr(x3), L.ptr(scale), L.ptr(mean),
             L.ptr(rstd), N, c, P, 1 if relu else 0, L.ptr(dx),
-            L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), 1 if direct else 0,
+            L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), acc,
             L.ptr(ws), ws.numel(), L.stream_ptr(x3.device)),
             'ld_bn_act_backward')
+    if defer:
+        job = L.BnFinJobT()
+        job.partial, job.dgamma, job.dbeta = (ws.data_ptr(), sg.data_ptr(),
+                                              sb.data_ptr())
+        job.C, job.accumulate = c, 1
+        job.nsplit = lib.ld_bn_act_backward_nsplit(
+            N, c, P, 1 if dx_c8 is not None else 0)
+        _DEFER_B.append((job, x3.device))
+        DEFER_STATS['bn_jobs'] += 1
     if direct:
         dgamma = dbeta = None
         _emit(pg)

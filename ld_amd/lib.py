@@ -82,6 +82,22 @@ class WtJobT(C.Structure):  # ld_wt_job_t
                 ('first_block', C.c_int32)]
 
 
+class WgradJobT(C.Structure):  # ld_wgrad_job_t
+    _fields_ = [('slabs', C.c_void_p), ('dw', C.c_void_p),
+                ('splits', C.c_int32), ('ntaps', C.c_int32),
+                ('Cout', C.c_int32), ('Cin', C.c_int32),
+                ('accumulate', C.c_int32), ('first_block', C.c_int32)]
+
+
+class BnFinJobT(C.Structure):  # ld_bn_fin_job_t
+    _fields_ = [('partial', C.c_void_p), ('dgamma', C.c_void_p),
+                ('dbeta', C.c_void_p), ('C', C.c_int32), ('nsplit', C.c_int32),
+                ('accumulate', C.c_int32), ('first_block', C.c_int32)]
+
+
+LD_GRAD_DEFER = 2
+
+
 class BnJobT(C.Structure):  # ld_bn_job_t
     _fields_ = [('gamma', C.c_void_p), ('beta', C.c_void_p),
                 ('mean', C.c_void_p), ('var', C.c_void_p),
@@ -280,6 +296,11 @@ SIGNATURES = {
     'ld_conv_tune_save': (C.c_int, [C.c_char_p]),
     'ld_conv_tune_clear': (C.c_int, []),
     'ld_conv_wgrad_workspace_bytes': (_sz, [_CV]),
+    'ld_conv_wgrad_partial': (C.c_int, [_CV, _i32, _vp, _vp, _vp, _sz,
+                                        C.POINTER(WgradJobT), _vp]),
+    'ld_wgrad_reduce_batch': (C.c_int, [_vp, _vp, _i32, _vp]),
+    'ld_bn_act_backward_nsplit': (C.c_int, [_i32, _i32, _i32, _i32]),
+    'ld_bn_bwd_finalize_batch': (C.c_int, [_vp, _vp, _i32, _vp]),
     'ld_conv_tune_wgrad_workspace_bytes': (_sz, [_CV]),
     'ld_conv_wgrad': (C.c_int, [_CV, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     'ld_conv_tune_wgrad': (C.c_int, [_CV, _vp, _vp, _vp, _vp, _sz, _vp]),

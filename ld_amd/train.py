@@ -166,6 +166,7 @@ class GradArena:
         self.trace = None
 
     def zero_grad(self):
+        Y.drop_deferred()  # partials of a step that did not finish
         self.flat_grad.zero_()
         for p, o in zip(self.order, self.offsets):
             if p.grad is None or p.grad.data_ptr() != \
@@ -190,33 +191,43 @@ class GradArena:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             self.trace.append((b, ev))
-        if self._ready[b] == self.buckets[b]['n'] and collectives_on() and \
-                not _diag_skip('buckets'):
+        if self._ready[b] == self.buckets[b]['n']:
             bk = self.buckets[b]
             grad = self.flat_grad[bk['start']:bk['end']]
-            # Weight gradients of this bucket may still run on the side stream.
-            # Round 3 made the MAIN stream wait for them here (wgrad_join) -- at
-            # every bucket boundary the data-gradient chain stalled behind the
-            # side stream's backlog: 56.7 -> 54.1 img/s with the collectives
-            # forced in a 1-rank group (profiles/r04_bench_torchrun_1rank_
-            # forced_collectives.json), a loss every rank of an N-GPU job pays.
-            # Now the all-reduce is issued from the SIDE stream once that has
-            # caught up with the main stream: RCCL's stream waits for the
-            # stream the collective is issued from, the main stream for nobody.
+            reduce = collectives_on() and not _diag_skip('buckets')
+            if not (reduce or Y.deferred_pending()):
+                return
+            # The bucket is complete: sum the deferred partials of its weight /
+            # norm gradients (layers.flush_deferred: one launch per family for
+            # everything pending) and, in a multi-process job, issue its
+            # all-reduce.  Weight gradients of this bucket may still run on the
+            # side stream.  Round 3 made the MAIN stream wait for them here
+            # (wgrad_join) -- at every bucket boundary the data-gradient chain
+            # stalled behind the side stream's backlog: 56.7 -> 54.1 img/s with the
+            # collectives forced in a 1-rank group (profiles/r04_bench_torchrun_
+            # 1rank_forced_collectives.json), a loss every rank of an N-GPU job
+            # pays.  So both are issued from the SIDE stream once that has caught
+            # up with the main stream: RCCL's stream waits for the stream the
+            # collective is issued from, the main stream for nobody.
             side = Y.wgrad_pending_stream(grad.device) if grad.is_cuda else None
             if side is not None and os.environ.get('LD_BUCKET_FROM_SIDE', '1') == '1':
                 side.wait_stream(torch.cuda.current_stream(grad.device))
                 with torch.cuda.stream(side):
-                    self._works.append(dist.all_reduce(grad, async_op=True))
+                    Y.flush_deferred()
+                    if reduce:
+                        self._works.append(dist.all_reduce(grad, async_op=True))
             else:
                 Y.wgrad_join()
-                self._works.append(dist.all_reduce(grad, async_op=True))
+                Y.flush_deferred()
+                if reduce:
+                    self._works.append(dist.all_reduce(grad, async_op=True))
 
     def finish(self):
         """Wait for the in-flight bucket reductions (sums, not yet averaged).
         Buckets whose parameters received no gradient this step are reduced
         here so every rank issues the same collectives."""
         Y.wgrad_join()
+        Y.flush_deferred()  # parameters whose bucket never completed this step
         if collectives_on() and not _diag_skip('buckets'):
             for b, bk in enumerate(self.buckets):
                 if self._ready[b] != bk['n']:
@@ -251,6 +262,35 @@ def _check_hw_queues():
             'streams share hardware queues and stop overlapping; export '
             'GPU_MAX_HW_QUEUES=8 before the first HIP call (importing ld_amd '
             'first does it)')
+
+
+def graph_queues_ok():
+    """Whether a hipGraph replay of the step runs at its normal speed under the
+    runtime configuration of this process: the graph executor spreads the
+    captured branches over DEBUG_HIP_FORCE_GRAPH_QUEUES internal streams (4 unless
+    set); with more than 4 hardware queues each gets its own queue and every
+    fork / join edge of the step turns into a cross-queue dependency (bf16 replay
+    15.2 -> 28 ms).  Fine with <= 4 hardware queues, or <= 2 graph streams
+    (profiles/r05_graph_queues_s1.jsonl; 1 crashes the runtime, never use it)."""
+    def _int(name, default):
+        try:
+            return int(os.environ.get(name, default))
+        except ValueError:
+            return default
+    return _int('GPU_MAX_HW_QUEUES', 4) <= 4 or \
+        _int('DEBUG_HIP_FORCE_GRAPH_QUEUES', 4) == 2
+
+
+def _warn_graph_queues(what):
+    if not graph_queues_ok():
+        import warnings
+        warnings.warn(
+            f'{what}: GPU_MAX_HW_QUEUES={os.environ.get("GPU_MAX_HW_QUEUES")} '
+            'without DEBUG_HIP_FORCE_GRAPH_QUEUES=2 -- hipGraph replays of the '
+            'train step run ~1.8x slower in this configuration (each internal '
+            'graph stream lands on its own hardware queue); export '
+            'DEBUG_HIP_FORCE_GRAPH_QUEUES=2 before the first HIP call (importing '
+            'ld_amd first does it in a multi-process job)')
 
 
 class SGDTrainer:
@@ -426,18 +466,21 @@ class GraphedStep:
     Every launch entry point of libldhip.so only enqueues (no timing, no
     synchronisation: include/ld_hip.h), which is what makes the step capturable;
     shape tuning must have happened before (ld_conv_tune_* refuse a capturing
-    stream).  With world_size > 1 the bucketed RCCL all-reduces are issued on
-    the capturing stream like any other launch; this has been exercised only
-    through a forced-collective ONE-rank group (tests/test_gpu_rccl.py) -- a
-    multi-GPU node was never available to this build, so bench.py keeps the
-    graph leg off for N > 1 unless asked (--graph-multi).  ``warmup_collectives
-    = False`` runs the warm-up steps without collectives (see
-    ``suspend_collectives``): for captures that only this rank performs.
+    stream).  Under a process group the bucketed RCCL all-reduces are issued on
+    the capturing streams like any other launch and become graph nodes:
+    tests/test_gpu_graph_pg.py captures the step under an RCCL group (one rank,
+    collectives forced -- the only form a one-GPU box admits) with 8 hardware
+    queues and replays it bit-identical to the eager steps; a multi-GPU node was
+    never available to this build, so bench.py keeps the graph leg off for N > 1
+    unless asked (--graph-multi).  ``warmup_collectives = False`` runs the
+    warm-up steps without collectives (see ``suspend_collectives``): for captures
+    that only this rank performs.
     """
 
     def __init__(self, trainer, data, warmup=2, max_gt=128,
                  warmup_collectives=True):
         from . import lossblock as LB
+        _warn_graph_queues('GraphedStep')
         self.trainer = trainer
         dev = data['img'].device
         n = len(data['img_metas'])
@@ -539,6 +582,7 @@ class PipelinedGraphedStep:
 
     def __init__(self, trainer, first, second, warmup=1, max_gt=128):
         from . import lossblock as LB
+        _warn_graph_queues('PipelinedGraphedStep')
         self.trainer = trainer
         model = trainer.model
         if not hasattr(model, 'teacher_model') or not model.eval_teacher:
@@ -661,13 +705,15 @@ class AutoStepper:
     def __init__(self, trainer, mode=None, warmup=1, max_gt=128, max_graphs=6):
         if mode is None:
             on_gpu = next(trainer.model.parameters()).is_cuda
-            # a multi-process job enqueues eagerly: it needs more than the default
-            # 4 hardware queues for its streams to overlap next to RCCL's, and
-            # with more than 4 a graph replay is much slower than the eager step
-            # (profiles/r04_process_group_stream_overlap.txt); RCCL inside a
-            # capture is also unverified beyond one rank
+            # bf16: the graph path, also in a multi-process job (BASELINE config
+            # 3's form) -- a process group needs 8 hardware queues for the step's
+            # streams to overlap next to RCCL's, and with DEBUG_HIP_FORCE_GRAPH_
+            # QUEUES=2 beside it a replay keeps its speed (round 4 had to fall
+            # back to the eager step here; tests/test_gpu_graph_pg.py replays a
+            # step captured WITH its bucket all-reduces under an RCCL group bit
+            # for bit).  A runtime configured otherwise enqueues eagerly.
             mode = 'graph' if (on_gpu and Y.get_precision() == 'bf16' and
-                               not collectives_on()) else 'eager'
+                               graph_queues_ok()) else 'eager'
         if mode not in ('eager', 'graph', 'pipelined'):
             raise ValueError(f'AutoStepper: unknown mode {mode!r}')
         self.trainer, self.mode = trainer, mode
@@ -688,6 +734,13 @@ class AutoStepper:
         self._pipe = None
         self._pipe_loaded = None  # the batch object the pipeline holds for its next step
         self.captures = 0
+        # a capture's warm-up runs with collectives suspended, so the
+        # collective code paths (bucket all-reduces issued from the weight-
+        # gradient stream, the normaliser and log reductions) would execute for
+        # the first time INSIDE a capture.  The first step of a multi-process job
+        # -- which every rank takes at the same iteration -- is therefore an
+        # eager step with the capture's code paths, collectives on.
+        self._collective_warm = not collectives_on()
 
     def _saved_state(self):
         tr = self.trainer
@@ -708,6 +761,10 @@ class AutoStepper:
     def step(self, data, next_data=None):
         if self.mode == 'eager':
             return self.trainer.step(data, next_data=next_data)
+        if not self._collective_warm:
+            self._collective_warm = True
+            with Y.capture_warmup():
+                return self.trainer.step(data)
         if self.mode == 'graph':
             key = (tuple(data['img'].shape), len(data['img_metas']))
             g = self._graphs.get(key)
