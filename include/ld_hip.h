@@ -608,6 +608,50 @@ int ld_conv_bf16_tune_forward_c8(const ld_conv_t* c, const void* x_c8,
                                  float* y, ld_stream_t stream);
 int ld_conv_bf16_dgrad_c8(const ld_conv_t* c, const void* dy_c8, const void* wt_bwd,
                           float* dx, ld_stream_t stream);
+/* ---- launch lists ------------------------------------------------------------
+ * Between ld_record_begin and ld_record_end every launch the calling thread makes
+ * through this library is executed AND appended (kernel, grid, by-value copy of
+ * its arguments) to a list; ld_record_replay re-issues the list on any stream with
+ * one C loop -- no shape-table lookup, no descriptor building, no host language in
+ * the per-launch path.  Everything a recorded launch points at (activations,
+ * weight images, workspaces) must stay allocated while the list is used; tuning
+ * entry points must not be called while recording.  ld_record_end returns a handle
+ * > 0 (or a negative error); ld_record_count = launches in the list.  Used for the
+ * frozen teacher's forward (mmdet/models/detectors/kd_one_stage.py:70-72: the same
+ * ~150 launches on the same buffers every step). */
+int ld_record_begin(void);
+int64_t ld_record_end(void);
+int ld_record_abort(void);
+int ld_record_count(int64_t handle);
+int ld_record_replay(int64_t handle, ld_stream_t stream);
+int ld_record_free(int64_t handle);
+
+/* ---- one frozen bottleneck as ONE launch (bf16 mode, C8-only activations) -----
+ * y = relu(bn3(conv1x1(relu(bn2(conv3x3(relu(bn1(conv1x1(x)))))))) + x) for an
+ * identity block (no downsample, stride 1) of a frozen ResNet trunk
+ * (mmdet/models/backbones/resnet.py:260-299; the R101 teacher's layer3).  x_c8 /
+ * y_c8: (N, Cin/8, H*W, 8) bf16 images (y_c8 != x_c8); w1 / w2 / w3: the bf16
+ * forward images of the three convs (ld_conv_bf16_weight_transform: (mid, Cin, 1,
+ * 1), (mid, mid, 3, 3), (Cin, mid, 1, 1)); scale / shift: the folded eval-BN
+ * coefficients (ld_bn_prepare), 16-byte aligned.  The mid activations stay in
+ * LDS; results are bit-identical to the three ld_conv_bf16_forward_c8 launches
+ * with C8-only outputs.  ld_bottleneck_c8_supported: which widths the kernel is
+ * built for (Cin 1024 / mid 256); LD_EUNSUPPORTED otherwise. */
+typedef struct {
+  int32_t N, H, W, Cin, mid, reserved;
+  const void* w1;
+  const void* w2;
+  const void* w3;
+  const float* scale1;
+  const float* shift1;
+  const float* scale2;
+  const float* shift2;
+  const float* scale3;
+  const float* shift3;
+} ld_bottleneck_t;
+int ld_bottleneck_c8_supported(int Cin, int mid, int H, int W);
+int ld_bottleneck_c8_forward(const ld_bottleneck_t* b, const void* x_c8, void* y_c8,
+                             ld_stream_t stream);
 int ld_conv_bf16_dgrad_acc(const ld_conv_t* c, const float* dy, const void* wt_bwd,
                            const float* addend, float* dx, ld_stream_t stream);
 int ld_conv_bf16_dgrad_c8_acc(const ld_conv_t* c, const void* dy_c8, const void* wt_bwd,

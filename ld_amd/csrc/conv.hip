@@ -1674,7 +1674,7 @@ int launch_stream_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream,
       const int nb = ((k.Cout + bm - 1) / bm) * ((k.J + bn - 1) / bn);
 #define LD_DBG_CASE(V_)                                                                  \
   if (dbg == V_ && c.ks == 4) {                                                          \
-    hipLaunchKernelGGL((conv_stream_kernel<1, 1, 1, 0, 16, 4, 4, V_>), dim3(nb), dim3(256), \
+    LD_LAUNCH((conv_stream_kernel<1, 1, 1, 0, 16, 4, 4, V_>), dim3(nb), dim3(256), \
                        0, stream, k);                                                    \
     return (int)hipGetLastError();                                                       \
   }
@@ -1690,7 +1690,7 @@ int launch_stream_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream,
       cap_lds_bytes(cap, c.ks == 4 ? 2 * c.tm * c.tn * 16 * 64 * 4 : 4);
 #define LD_STREAM_CASE(TM_, TN_, WVM_, D_, KS_)                                    \
   if (c.tm == TM_ && c.tn == TN_ && c.wvm == WVM_ && c.d == D_ && c.ks == KS_) {   \
-    hipLaunchKernelGGL((conv_stream_kernel<TM_, TN_, WVM_, MODE, D_, (KS_ == 4 ? 4 : 2), KS_>), \
+    LD_LAUNCH((conv_stream_kernel<TM_, TN_, WVM_, MODE, D_, (KS_ == 4 ? 4 : 2), KS_>), \
                        dim3(nb), dim3(256), lds, stream, k);                       \
     return (int)hipGetLastError();                                                 \
   }
@@ -1701,7 +1701,7 @@ int launch_stream_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream,
   if constexpr (MODE == 0) {
 #define LD_VEC_CASE(TM_, TN_, WVM_, D_, KS_)                                       \
   if (c.ks == 2 && c.tm == TM_ && c.tn == TN_ && c.wvm == WVM_ && c.d == D_) {     \
-    hipLaunchKernelGGL((conv1x1_vec_kernel<TM_, TN_, WVM_, D_>), dim3(nb), dim3(256), lds, \
+    LD_LAUNCH((conv1x1_vec_kernel<TM_, TN_, WVM_, D_>), dim3(nb), dim3(256), lds, \
                        stream, k);                                                 \
     return (int)hipGetLastError();                                                 \
   }
@@ -1929,7 +1929,7 @@ int launch_igemm(const ConvK& k_in, hipStream_t stream) {
       kgroups = v;
   }
 #define LD_CONV_LAUNCH(BM_, BN_, BK_, KG_)                                        \
-  hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, BK_, MODE, KG_, 2, 2>),         \
+  LD_LAUNCH((conv_igemm_kernel<BM_, BN_, BK_, MODE, KG_, 2, 2>),         \
                      dim3(nb), dim3(kThreads * KG_), 0, stream, k)
 #define LD_CONV_CASE(BM_, BN_, BK_)                                               \
   if (c.bm == BM_ && c.bn == BN_ && c.bk == BK_) {                                \
@@ -1948,10 +1948,10 @@ int launch_igemm(const ConvK& k_in, hipStream_t stream) {
   }
   if (c.bm == 32 && c.bn == 64) {  // 2-wavefront workgroups
     if (c.bk == 32)
-      hipLaunchKernelGGL((conv_igemm_kernel<32, 64, 32, MODE, 1, 1, 2>), dim3(nb),
+      LD_LAUNCH((conv_igemm_kernel<32, 64, 32, MODE, 1, 1, 2>), dim3(nb),
                          dim3(128), 0, stream, k);
     else
-      hipLaunchKernelGGL((conv_igemm_kernel<32, 64, 16, MODE, 1, 1, 2>), dim3(nb),
+      LD_LAUNCH((conv_igemm_kernel<32, 64, 16, MODE, 1, 1, 2>), dim3(nb),
                          dim3(128), 0, stream, k);
     return (int)hipGetLastError();
   }
@@ -2067,7 +2067,7 @@ extern "C" int ld_conv_weight_transform(const float* w, int Cout, int Cin, int K
   size_t total = 0;
   if (wt_fwd) total = (size_t)KH * KW * cip * Cout;
   if (wt_bwd) total = max(total, (size_t)KH * KW * cop * Cin);
-  hipLaunchKernelGGL(conv_weight_transform_kernel,
+  LD_LAUNCH(conv_weight_transform_kernel,
                      dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, w, Cout, Cin, KH * KW, cip, cop, wt_fwd,
                      wt_bwd);
@@ -2078,7 +2078,7 @@ extern "C" int ld_conv_weight_transform_batch(const ld_wt_job_t* jobs,
                                               const int32_t* block_job, int nblocks,
                                               ld_stream_t stream) {
   if (!jobs || !block_job || nblocks < 1) return LD_EINVAL;
-  hipLaunchKernelGGL(conv_weight_transform_batch_kernel, dim3(nblocks), dim3(256), 0,
+  LD_LAUNCH(conv_weight_transform_batch_kernel, dim3(nblocks), dim3(256), 0,
                      (hipStream_t)stream, jobs, block_job);
   return (int)hipGetLastError();
 }
@@ -2227,10 +2227,10 @@ extern "C" int ld_conv_forward_smallc(const ld_conv_t* c, const float* x,
     // workgroup, 8 k-pairs in flight
     if (c->Cout == 64) {
       const int nb = (k.J + 4 * 64 - 1) / (4 * 64);
-      hipLaunchKernelGGL((conv_stem_kernel<2, 2, 8>), dim3(nb), dim3(256), 0, st, k);
+      LD_LAUNCH((conv_stem_kernel<2, 2, 8>), dim3(nb), dim3(256), 0, st, k);
     } else {
       const int nb = (k.J + 4 * 128 - 1) / (4 * 128);
-      hipLaunchKernelGGL((conv_stem_kernel<1, 4, 8>), dim3(nb), dim3(256), 0, st, k);
+      LD_LAUNCH((conv_stem_kernel<1, 4, 8>), dim3(nb), dim3(256), 0, st, k);
     }
     return (int)hipGetLastError();
   }
@@ -2315,9 +2315,9 @@ int dgrad_walk(const ld_conv_t* c, const float* dy, const void* wt_bwd, float* d
     const size_t bytes = (size_t)c->N * c->Cin * c->Pin * sizeof(float);
     hipError_t err = hipSuccess;
     if (!addend)
-      err = hipMemsetAsync(dx, 0, bytes, stream);
+      err = ldrec::memset_async(dx, 0, bytes, stream);
     else if (addend != dx)
-      err = hipMemcpyAsync(dx, addend, bytes, hipMemcpyDeviceToDevice, stream);
+      err = ldrec::memcpy_d2d_async(dx, addend, bytes, stream);
     if (err) return (int)err;
   }
   for (int ph = 0; ph < 2; ++ph)
@@ -2677,15 +2677,15 @@ int wgrad_run(const ld_conv_t* c, const float* x, const float* dy, float* dw,
   } else if (wmode) {
     const int blocks = ((c->Cout + 63) / 64) * ((c->Cin + 63) / 64) * ntaps * k.splits;
     if (wmode == 32)
-      hipLaunchKernelGGL(conv_wgrad_wave_kernel<32>, dim3(blocks), dim3(64), 0,
+      LD_LAUNCH(conv_wgrad_wave_kernel<32>, dim3(blocks), dim3(64), 0,
                          stream, k);
     else
-      hipLaunchKernelGGL(conv_wgrad_wave_kernel<16>, dim3(blocks), dim3(64), 0,
+      LD_LAUNCH(conv_wgrad_wave_kernel<16>, dim3(blocks), dim3(64), 0,
                          stream, k);
   } else {
     const int blocks =
         ((c->Cout + 127) / 128) * ((c->Cin + 127) / 128) * ntaps * k.splits;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(blocks), dim3(kThreads), 0, stream, k);
+    LD_LAUNCH(conv_wgrad_kernel, dim3(blocks), dim3(kThreads), 0, stream, k);
   }
   if (defer) {
     if (hipError_t e = hipGetLastError()) return (int)e;
@@ -2760,7 +2760,7 @@ extern "C" int ld_conv_wgrad_partial(const ld_conv_t* c, int family, const void*
 extern "C" int ld_wgrad_reduce_batch(const ld_wgrad_job_t* jobs, const int32_t* block_job,
                                      int nblocks, ld_stream_t stream) {
   if (!jobs || !block_job || nblocks < 1) return LD_EINVAL;
-  hipLaunchKernelGGL(conv_wgrad_reduce_batch_kernel, dim3(nblocks), dim3(256), 0,
+  LD_LAUNCH(conv_wgrad_reduce_batch_kernel, dim3(nblocks), dim3(256), 0,
                      (hipStream_t)stream, jobs, block_job);
   return (int)hipGetLastError();
 }
@@ -2770,11 +2770,11 @@ int ld_wgrad_reduce_launch(const float* slabs, int splits, int ntaps, int Cout, 
   const size_t per = (size_t)ntaps * Cout * Cin;
   if (Cin % 4 == 0 && (uintptr_t)slabs % 16 == 0 &&
       (ntaps > 1 || (uintptr_t)dw % 16 == 0))  // 1x1: dW rows are stored 16 bytes at a time
-    hipLaunchKernelGGL(conv_wgrad_reduce4_kernel,
+    LD_LAUNCH(conv_wgrad_reduce4_kernel,
                        dim3((unsigned)((per / 4 + 255) / 256)), dim3(256), 0, stream,
                        slabs, splits, ntaps, Cout, Cin, dw, accumulate);
   else
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)),
+    LD_LAUNCH(conv_wgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)),
                        dim3(256), 0, stream, slabs, splits, ntaps, Cout, Cin, dw,
                        accumulate);
   return (int)hipGetLastError();

@@ -1935,7 +1935,7 @@ int launch_c8_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream) {
   const int nb = ((k.Cout + BM - 1) / BM) * ((k.J + BN - 1) / BN);
 #define LD_CASE(BM_, BN_, NST_, BK_, SCH_)                                         \
   if (BM == BM_ && BN == BN_ && c.ks == NST_ && c.d == BK_ && c.sch == SCH_) {     \
-    hipLaunchKernelGGL((conv_tile_c8_kernel<BM_, BN_, MODE, NST_, BK_, SCH_>),     \
+    LD_LAUNCH((conv_tile_c8_kernel<BM_, BN_, MODE, NST_, BK_, SCH_>),     \
                        dim3(nb), dim3(256), 0, stream, k);                         \
     return (int)hipGetLastError();                                                 \
   }
@@ -1982,7 +1982,7 @@ int launch_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream) {
     const int nb = ((k.Cout + BM - 1) / BM) * ((k.J + BN - 1) / BN);
 #define LD_CASE(BM_, BN_, NST_)                                                    \
   if (BM == BM_ && BN == BN_ && c.ks == NST_) {                                    \
-    hipLaunchKernelGGL((conv_tile_bf16_kernel<BM_, BN_, MODE, NST_>), dim3(nb),    \
+    LD_LAUNCH((conv_tile_bf16_kernel<BM_, BN_, MODE, NST_>), dim3(nb),    \
                        dim3(256), 0, stream, k);                                   \
     return (int)hipGetLastError();                                                 \
   }
@@ -1995,7 +1995,7 @@ int launch_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream) {
   const int nb = ((k.Cout + bm - 1) / bm) * ((k.J + bn - 1) / bn);
 #define LD_CASE(TM_, TN_, WVM_, D_, KS_)                                           \
   if (c.tm == TM_ && c.tn == TN_ && c.wvm == WVM_ && c.d == D_ && c.ks == KS_) {   \
-    hipLaunchKernelGGL(                                                            \
+    LD_LAUNCH(                                                            \
         (conv_stream_bf16_kernel<TM_, TN_, WVM_, MODE, D_,                         \
                                  (KS_ == 4 ? (TM_ * TN_ < 2 ? 4 : TM_ * TN_ < 4 ? 3 : 2) : 2), KS_>),       \
         dim3(nb), dim3(256), 0, stream, k);                                        \
@@ -2321,16 +2321,16 @@ int ld_bf16_wgrad_c8_launch(const WgradK& k, hipStream_t stream) {
   if (ld_bf16_wgrad_c8_tiled(k.Cout, k.Cin)) {
     const int blocks =
         ((k.Cout + 127) / 128) * ((k.Cin + 127) / 128) * ntaps * k.splits;
-    hipLaunchKernelGGL(conv_wgrad_c8_tile_kernel<4>, dim3(blocks), dim3(256), 0, stream,
+    LD_LAUNCH(conv_wgrad_c8_tile_kernel<4>, dim3(blocks), dim3(256), 0, stream,
                        k);
     return (int)hipGetLastError();
   }
   const int blocks = ((k.Cout + 63) / 64) * ((k.Cin + 63) / 64) * ntaps * k.splits;
   const char* env = getenv("LD_CONV_WGRAD_C8_RING");
   if (env && env[0] == '2')
-    hipLaunchKernelGGL(conv_wgrad_c8_kernel<2>, dim3(blocks), dim3(64), 0, stream, k);
+    LD_LAUNCH(conv_wgrad_c8_kernel<2>, dim3(blocks), dim3(64), 0, stream, k);
   else
-    hipLaunchKernelGGL(conv_wgrad_c8_kernel<3>, dim3(blocks), dim3(64), 0, stream, k);
+    LD_LAUNCH(conv_wgrad_c8_kernel<3>, dim3(blocks), dim3(64), 0, stream, k);
   return (int)hipGetLastError();
 }
 
@@ -2339,7 +2339,7 @@ int ld_bf16_wgrad_launch(const WgradK& k, hipStream_t stream) {
   if (ld_bf16_wgrad_tiled(k.Cout, k.Cin, k.Pout)) {
     const int blocks =
         ((k.Cout + 127) / 128) * ((k.Cin + 127) / 128) * ntaps * k.splits;
-    hipLaunchKernelGGL(conv_wgrad_tile_bf16_kernel, dim3(blocks), dim3(256), 0, stream,
+    LD_LAUNCH(conv_wgrad_tile_bf16_kernel, dim3(blocks), dim3(256), 0, stream,
                        k);
     return (int)hipGetLastError();
   }
@@ -2356,13 +2356,13 @@ int ld_bf16_wgrad_launch(const WgradK& k, hipStream_t stream) {
   // bound by the latency of its one-step-ahead loads, not by instruction count
   const bool vy_only = vy && !vx && env && env[0] == 'y';  // test hook
   if (vx)
-    hipLaunchKernelGGL((conv_wgrad_wave_bf16_kernel<true, true>), dim3(blocks), dim3(64),
+    LD_LAUNCH((conv_wgrad_wave_bf16_kernel<true, true>), dim3(blocks), dim3(64),
                        0, stream, k);
   else if (vy_only)
-    hipLaunchKernelGGL((conv_wgrad_wave_bf16_kernel<true, false>), dim3(blocks), dim3(64),
+    LD_LAUNCH((conv_wgrad_wave_bf16_kernel<true, false>), dim3(blocks), dim3(64),
                        0, stream, k);
   else
-    hipLaunchKernelGGL((conv_wgrad_wave_bf16_kernel<false, false>), dim3(blocks),
+    LD_LAUNCH((conv_wgrad_wave_bf16_kernel<false, false>), dim3(blocks),
                        dim3(64), 0, stream, k);
   return (int)hipGetLastError();
 }
@@ -2370,7 +2370,7 @@ int ld_bf16_wgrad_launch(const WgradK& k, hipStream_t stream) {
 extern "C" int ld_conv_to_c8(const float* x, int N, int C, int P, void* out,
                              ld_stream_t stream) {
   if (!x || !out || N < 1 || C < 8 || C % 8 != 0 || P < 1) return LD_EINVAL;
-  hipLaunchKernelGGL(to_c8_kernel, dim3((P + 255) / 256, C / 8, N), dim3(256), 0,
+  LD_LAUNCH(to_c8_kernel, dim3((P + 255) / 256, C / 8, N), dim3(256), 0,
                      (hipStream_t)stream, x, C / 8, P, (uintx4*)out);
   return (int)hipGetLastError();
 }
@@ -2390,7 +2390,7 @@ extern "C" int ld_conv_bf16_weight_transform(const float* w, int Cout, int Cin, 
   size_t total = 0;
   if (wt_fwd) total = ld_conv_bf16_weight_image_elems(Cout, Cin, KH, KW, 0);
   if (wt_bwd) total = max(total, ld_conv_bf16_weight_image_elems(Cout, Cin, KH, KW, 1));
-  hipLaunchKernelGGL(conv_weight_transform_bf16_kernel,
+  LD_LAUNCH(conv_weight_transform_bf16_kernel,
                      dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, w, Cout, Cin, KH * KW, (__bf16*)wt_fwd,
                      (__bf16*)wt_bwd);
@@ -2401,7 +2401,7 @@ extern "C" int ld_conv_bf16_weight_transform_batch(const ld_wt_job_t* jobs,
                                                    const int32_t* block_job, int nblocks,
                                                    ld_stream_t stream) {
   if (!jobs || !block_job || nblocks < 1) return LD_EINVAL;
-  hipLaunchKernelGGL(conv_weight_transform_bf16_batch_kernel, dim3(nblocks), dim3(256),
+  LD_LAUNCH(conv_weight_transform_bf16_batch_kernel, dim3(nblocks), dim3(256),
                      0, (hipStream_t)stream, jobs, block_job);
   return (int)hipGetLastError();
 }

@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "../../include/ld_hip.h"
+#include "ld_launch.h"
 
 struct Geo {  // pyramid geometry as the gather sees it
   int stride, pad, num_levels;

@@ -780,7 +780,7 @@ unsigned* ticket_slice(const void* workspace, hipStream_t stream) {
 
 template <int DBG>
 void launch_tile_dbg(const WgradK& k, const WgradTileOut& o, int blocks, hipStream_t stream) {
-  hipLaunchKernelGGL((conv_wgrad_tile_kernel<1, 32, true, DBG>), dim3(blocks), dim3(256), 0,
+  LD_LAUNCH((conv_wgrad_tile_kernel<1, 32, true, DBG>), dim3(blocks), dim3(256), 0,
                      stream, k, o);
 }
 
@@ -810,10 +810,10 @@ void launch_tile(const WgradK& k, const WgradTileOut& o, int blocks, hipStream_t
     }
   }
   if (k.g.num_levels > 1)
-    hipLaunchKernelGGL((conv_wgrad_tile_kernel<KG, BK, true>), dim3(blocks), dim3(256 * KG),
+    LD_LAUNCH((conv_wgrad_tile_kernel<KG, BK, true>), dim3(blocks), dim3(256 * KG),
                        0, stream, k, o);
   else
-    hipLaunchKernelGGL((conv_wgrad_tile_kernel<KG, BK, false>), dim3(blocks), dim3(256 * KG),
+    LD_LAUNCH((conv_wgrad_tile_kernel<KG, BK, false>), dim3(blocks), dim3(256 * KG),
                        0, stream, k, o);
 }
 
@@ -850,13 +850,13 @@ int ld_f32_wgrad_tap3_launch(const WgradK& k_in, int splits, float* dw, int accu
   const int blocks = ntiles * splits;
   if (k.g.num_levels > 1 && getenv("LD_ALLOW_WRONG_RESULTS") && getenv("LD_WGRAD_DBG") &&
       atoi(getenv("LD_WGRAD_DBG")) == 1)
-    hipLaunchKernelGGL((conv_wgrad_tap3_kernel<true, 1>), dim3(blocks), dim3(768), 0, stream,
+    LD_LAUNCH((conv_wgrad_tap3_kernel<true, 1>), dim3(blocks), dim3(768), 0, stream,
                        k, o);
   else if (k.g.num_levels > 1)
-    hipLaunchKernelGGL((conv_wgrad_tap3_kernel<true>), dim3(blocks), dim3(768), 0, stream, k,
+    LD_LAUNCH((conv_wgrad_tap3_kernel<true>), dim3(blocks), dim3(768), 0, stream, k,
                        o);
   else
-    hipLaunchKernelGGL((conv_wgrad_tap3_kernel<false>), dim3(blocks), dim3(768), 0, stream, k,
+    LD_LAUNCH((conv_wgrad_tap3_kernel<false>), dim3(blocks), dim3(768), 0, stream, k,
                        o);
   if (hipError_t e = hipGetLastError()) return (int)e;
   if (slabs_only) {

@@ -25,6 +25,8 @@
 // Cin*KH*KW*4 B written per output position.
 #include <hip/hip_runtime.h>
 
+#include "ld_launch.h"
+
 #include "../../include/ld_hip.h"
 
 namespace {
@@ -79,7 +81,7 @@ extern "C" int ld_deform_im2col(const float* x, const float* offset, int N, int 
   const int Wout = (Win + 2 * pad - dilation * (KW - 1) - 1) / stride + 1;
   if (Hout < 1 || Wout < 1) return LD_EINVAL;
   const int Pout = Hout * Wout;
-  hipLaunchKernelGGL(deform_im2col_kernel, dim3((Pout + 255) / 256, KH * KW, N),
+  LD_LAUNCH(deform_im2col_kernel, dim3((Pout + 255) / 256, KH * KW, N),
                      dim3(256), 0, (hipStream_t)stream, x, offset, Cin, Hin, Win, Hout,
                      Wout, KH, KW, stride, pad, dilation, col);
   return (int)hipGetLastError();

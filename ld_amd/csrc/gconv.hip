@@ -20,6 +20,8 @@
 // Epilogue as the dense convs': y = relu(scale[c] * acc + shift[c]).
 #include <hip/hip_runtime.h>
 
+#include "ld_launch.h"
+
 #include "../../include/ld_hip.h"
 
 namespace {
@@ -96,7 +98,7 @@ int launch_gconv(int CG, dim3 grid, hipStream_t st, const float* x, const float*
                  int Win, int Hout, int Wout, const float* scale, const float* shift,
                  int relu) {
 #define LD_GC(C)                                                                      \
-  hipLaunchKernelGGL((gconv_forward_kernel<C, K>), grid, dim3(256), 0, st, x, wimg, y, \
+  LD_LAUNCH((gconv_forward_kernel<C, K>), grid, dim3(256), 0, st, x, wimg, y, \
                      Cin, Cout, cin_g, stride, pad, Hin, Win, Hout, Wout, scale, shift, \
                      relu)
   switch (CG) {
@@ -122,7 +124,7 @@ extern "C" int ld_gconv_weight_transform(const float* w, int Cout, int Cin, int 
   if (!w || !image || groups < 1 || Cout % groups || Cin % groups || K < 1)
     return LD_EINVAL;
   const int total = Cout * (Cin / groups) * K * K;
-  hipLaunchKernelGGL(gconv_weight_image_kernel, dim3((total + 255) / 256), dim3(256), 0,
+  LD_LAUNCH(gconv_weight_image_kernel, dim3((total + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, w, image, groups, Cout / groups, Cin / groups,
                      K * K);
   return (int)hipGetLastError();

@@ -28,6 +28,8 @@
 //                stops at max_per_img: O(candidates examined x kept), not
 //                O(candidates^2)
 #include <hip/hip_runtime.h>
+
+#include "ld_launch.h"
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -640,9 +642,9 @@ static int get_bboxes_impl(const ld_geom_t* g, const ld_maps_t* cls,
   int* count = (int*)(ws + o.count);
   unsigned* maxc = (unsigned*)(ws + o.maxc);
   hipError_t err;
-  if ((err = hipMemsetAsync(count, 0, (size_t)p.N * sizeof(int), stream)))
+  if ((err = ldrec::memset_async(count, 0, (size_t)p.N * sizeof(int), stream)))
     return (int)err;
-  if ((err = hipMemsetAsync(maxc, 0, (size_t)p.N * sizeof(unsigned), stream)))
+  if ((err = ldrec::memset_async(maxc, 0, (size_t)p.N * sizeof(unsigned), stream)))
     return (int)err;
   unsigned long long* cand_top = (unsigned long long*)(ws + o.cand_top);
   int* flags = (int*)(ws + o.flags);
@@ -657,16 +659,16 @@ static int get_bboxes_impl(const ld_geom_t* g, const ld_maps_t* cls,
   const bool force_global = voting || (env && env[0] == 'g');
   const bool fast_topk = !force_global && nms_pre <= kSelN;
   if (nsorted > 0) {
-    hipLaunchKernelGGL(infer_keys_kernel, dim3((maxpad + 255) / 256, p.L, p.N),
+    LD_LAUNCH(infer_keys_kernel, dim3((maxpad + 255) / 256, p.L, p.N),
                        dim3(256), 0, stream, p, *cls, ctr_maps, keys);
     if (fast_topk)
-      hipLaunchKernelGGL(infer_topk_select_kernel, dim3(nsorted, p.N),
+      LD_LAUNCH(infer_topk_select_kernel, dim3(nsorted, p.N),
                          dim3(kSortThreads), 0, stream, p, keys);
     else
-      hipLaunchKernelGGL(infer_topk_sort_kernel, dim3(nsorted, p.N),
+      LD_LAUNCH(infer_topk_sort_kernel, dim3(nsorted, p.N),
                          dim3(kSortThreads), 0, stream, p, keys);
   }
-  hipLaunchKernelGGL(infer_decode_kernel, dim3((p.Ktot + 255) / 256, p.N), dim3(256), 0,
+  LD_LAUNCH(infer_decode_kernel, dim3((p.Ktot + 255) / 256, p.N), dim3(256), 0,
                      stream, p, *cls, *reg, ctr_maps, keys, img_hw, scale_factors, score_thr,
                      boxes, scores, cand, count, maxc, pre_factors);
   if (pre_only) {
@@ -683,14 +685,14 @@ static int get_bboxes_impl(const ld_geom_t* g, const ld_maps_t* cls,
   bool need_global = force_global;
   if (!force_global) {
     // fast path: NMS over the kSelN best candidates of every image
-    hipLaunchKernelGGL(infer_cand_select_kernel, dim3(p.N), dim3(kSortThreads), 0,
+    LD_LAUNCH(infer_cand_select_kernel, dim3(p.N), dim3(kSortThreads), 0,
                        stream, p, cand, count, cand_top);
     int limit = kSelN;  // LD_INFER_LIMIT: test hook to provoke the fallback
     if (const char* lim = getenv("LD_INFER_LIMIT")) {
       const int v = atoi(lim);
       if (v >= 1 && v <= kSelN) limit = v;
     }
-    hipLaunchKernelGGL(infer_nms_kernel<false>, dim3(p.N), dim3(kNmsThreads), 0, stream,
+    LD_LAUNCH(infer_nms_kernel<false>, dim3(p.N), dim3(kNmsThreads), 0, stream,
                        p, cand_top, (size_t)kSelN, limit, count, maxc, boxes, iou_thr,
                        max_per_img, dets, (long long*)labels, counts, flags,
                        (int*)nullptr);
@@ -709,18 +711,18 @@ static int get_bboxes_impl(const ld_geom_t* g, const ld_maps_t* cls,
     }
   }
   if (need_global) {
-    hipLaunchKernelGGL(infer_cand_sort_kernel, dim3(p.N), dim3(kSortThreads), 0, stream,
+    LD_LAUNCH(infer_cand_sort_kernel, dim3(p.N), dim3(kSortThreads), 0, stream,
                        p, cand, count);
     if (voting) {
       int* rank = (int*)(ws + o.rank);
-      hipLaunchKernelGGL(infer_nms_kernel<true>, dim3(p.N), dim3(kNmsThreads), 0, stream,
+      LD_LAUNCH(infer_nms_kernel<true>, dim3(p.N), dim3(kNmsThreads), 0, stream,
                          p, cand, (size_t)p.cand_cap, p.cand_cap, count, maxc, boxes,
                          iou_thr, max_per_img, dets, (long long*)labels, counts,
                          (int*)nullptr, rank);
-      hipLaunchKernelGGL(infer_vote_kernel, dim3(max_per_img, p.N), dim3(256), 0, stream,
+      LD_LAUNCH(infer_vote_kernel, dim3(max_per_img, p.N), dim3(256), 0, stream,
                          p, cand, count, boxes, max_per_img, counts, rank, dets);
     } else {
-      hipLaunchKernelGGL(infer_nms_kernel<false>, dim3(p.N), dim3(kNmsThreads), 0,
+      LD_LAUNCH(infer_nms_kernel<false>, dim3(p.N), dim3(kNmsThreads), 0,
                          stream, p, cand, (size_t)p.cand_cap, p.cand_cap, count, maxc,
                          boxes, iou_thr, max_per_img, dets, (long long*)labels, counts,
                          (int*)nullptr, (int*)nullptr);

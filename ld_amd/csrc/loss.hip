@@ -23,6 +23,8 @@
 // atomics).
 #include <hip/hip_runtime.h>
 
+#include "ld_launch.h"
+
 #include "../../include/ld_hip.h"
 #include "ld_math.h"
 
@@ -1212,7 +1214,7 @@ void launch_reg_lean_t(bool fast, bool w8, dim3 grid, size_t lds, hipStream_t st
                        const float* upstream, const float* posrec,
                        const ld_maps_t& grad_reg, float* partial) {
 #define LD_LEAN_GO(F, W)                                                                  \
-  hipLaunchKernelGGL((loss_reg_lean_kernel<VEC, NTL, NTS, F, W>), grid, dim3(kBlk), lds,  \
+  LD_LAUNCH((loss_reg_lean_kernel<VEC, NTL, NTS, F, W>), grid, dim3(kBlk), lds,  \
                      stream, geom, hp, bm, bmv, side_fast, reg, t_reg, labels,            \
                      bbox_targets, vlr, weight_targets, norm, upstream, posrec, grad_reg, \
                      partial)
@@ -1311,11 +1313,11 @@ extern "C" int ld_loss_prepass_ex(const ld_geom_t* geom, const ld_loss_hp_t* hp,
   const BlockMap bm = make_block_map(*geom, kWave);
   float* partial = (float*)workspace;
   dim3 grid(bm.blocks_per_img, geom->num_imgs);
-  hipLaunchKernelGGL(loss_prepass_kernel, grid, dim3(kWave), 0, stream, *geom,
+  LD_LAUNCH(loss_prepass_kernel, grid, dim3(kWave), 0, stream, *geom,
                      *hp, bm, *cls, *reg, labels, bbox_targets, vlr, weight_targets,
                      score, partial);
   const int nparts = geom->num_imgs * bm.blocks_per_img;
-  hipLaunchKernelGGL(loss_norm_kernel, dim3(1), dim3(256), 0, stream, nparts,
+  LD_LAUNCH(loss_norm_kernel, dim3(1), dim3(256), 0, stream, nparts,
                      partial + (size_t)S_WSUM * nparts, counts,
                      geom->num_imgs + 2 * geom->num_levels, norm);
   return (int)hipGetLastError();
@@ -1357,7 +1359,7 @@ extern "C" int ld_loss_main_parts(
   float* posrec = partial + w.main_floats;
   const unsigned bx = bm.blocks_per_img, by = geom->num_imgs;
   if (parts & LD_LOSS_PART_POS)
-    hipLaunchKernelGGL(loss_pos_kernel, dim3(bx, by), dim3(kBlk), 0, stream, *geom, *hp,
+    LD_LAUNCH(loss_pos_kernel, dim3(bx, by), dim3(kBlk), 0, stream, *geom, *hp,
                        bm, split ? *kd_s : *cls, split ? *kd_t : *t_cls, *reg, labels,
                        bbox_targets, weight_targets, score, norm, upstream, posrec,
                        partial);
@@ -1383,23 +1385,23 @@ extern "C" int ld_loss_main_parts(
     // re-read by the next kernel and should stay cached
     const size_t bytes = (size_t)geom->num_imgs * geom->num_anchors * 68 * 4 * 3;
     if (bytes > ((size_t)192 << 20))
-      hipLaunchKernelGGL(loss_reg_dense_kernel<true>, dim3(bx, by, 4), dim3(kBlk), 0,
+      LD_LAUNCH(loss_reg_dense_kernel<true>, dim3(bx, by, 4), dim3(kBlk), 0,
                          stream, *geom, *hp, bm, *reg, *t_reg, labels, bbox_targets, vlr,
                          weight_targets, norm, upstream, posrec, *grad_reg, partial);
     else
-      hipLaunchKernelGGL(loss_reg_dense_kernel<false>, dim3(bx, by, 4), dim3(kBlk), 0,
+      LD_LAUNCH(loss_reg_dense_kernel<false>, dim3(bx, by, 4), dim3(kBlk), 0,
                          stream, *geom, *hp, bm, *reg, *t_reg, labels, bbox_targets, vlr,
                          weight_targets, norm, upstream, posrec, *grad_reg, partial);
   }
   if (parts & LD_LOSS_PART_CLS) {
     const unsigned zc = (CC + kClsChunk - 1) / kClsChunk;
     if (split)
-      hipLaunchKernelGGL(loss_cls_dense_kernel<true>, dim3(bx, by, zc), dim3(kBlk), 0,
+      LD_LAUNCH(loss_cls_dense_kernel<true>, dim3(bx, by, zc), dim3(kBlk), 0,
                          stream, *geom, *hp, bm, *cls, *kd_s, *kd_t, labels,
                          label_weights, score, counts, norm, upstream, posrec,
                          *grad_cls, *grad_kd, partial);
     else
-      hipLaunchKernelGGL(loss_cls_dense_kernel<false>, dim3(bx, by, zc), dim3(kBlk), 0,
+      LD_LAUNCH(loss_cls_dense_kernel<false>, dim3(bx, by, zc), dim3(kBlk), 0,
                          stream, *geom, *hp, bm, *cls, *cls, *t_cls, labels,
                          label_weights, score, counts, norm, upstream, posrec,
                          *grad_cls, *grad_cls, partial);
@@ -1407,7 +1409,7 @@ extern "C" int ld_loss_main_parts(
   if (parts & LD_LOSS_PART_IM) {
     const int chunk = im_chunk(hp->feat_channels);
     const unsigned zi = (hp->feat_channels + chunk - 1) / chunk;
-    hipLaunchKernelGGL(loss_im_dense_kernel, dim3(bx, by, zi), dim3(kBlk), 0, stream,
+    LD_LAUNCH(loss_im_dense_kernel, dim3(bx, by, zi), dim3(kBlk), 0, stream,
                        *geom, *hp, bm, *x, *t_x, im, counts, upstream, *grad_x, chunk,
                        partial);
   }
@@ -1428,7 +1430,7 @@ extern "C" int ld_loss_centerness(const ld_geom_t* geom, const ld_loss_hp_t* hp,
     return LD_ENOSPACE;
   const LossWs w = loss_ws(*geom);
   float* partial = (float*)workspace + w.pre_floats;
-  hipLaunchKernelGGL(loss_ctr_dense_kernel, dim3(w.bm256.blocks_per_img, geom->num_imgs),
+  LD_LAUNCH(loss_ctr_dense_kernel, dim3(w.bm256.blocks_per_img, geom->num_imgs),
                      dim3(kBlk), 0, (hipStream_t)stream_, *geom, *hp, w.bm256, *ctr,
                      labels, score, norm, upstream, *grad_ctr, partial);
   return (int)hipGetLastError();
@@ -1462,7 +1464,7 @@ extern "C" int ld_loss_finalize(const ld_geom_t* geom, const ld_loss_hp_t* hp,
   if (!counts || !norm || !workspace || !losses) return LD_EINVAL;
   const LossWs w = loss_ws(*geom);
   const int chunk = im_chunk(hp->feat_channels);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(geom->num_levels), dim3(kWave), 0,
+  LD_LAUNCH(loss_finalize_kernel, dim3(geom->num_levels), dim3(kWave), 0,
                      (hipStream_t)stream_, *geom, *hp, w.bm256,
                      ((hp->cls_channels > 0 ? hp->cls_channels : hp->num_classes) +
                       kClsChunk - 1) / kClsChunk,
@@ -1493,10 +1495,10 @@ extern "C" int ld_gi_region(const ld_geom_t* geom, const ld_loss_hp_t* hp,
   const BlockMap bm = make_block_map(*geom, kBlk);
   float* giscore = (float*)workspace;
   float* gibox = giscore + (size_t)geom->num_imgs * geom->num_anchors;
-  hipLaunchKernelGGL(gi_score_kernel, dim3(bm.blocks_per_img, geom->num_imgs),
+  LD_LAUNCH(gi_score_kernel, dim3(bm.blocks_per_img, geom->num_imgs),
                      dim3(kBlk), 0, stream, *geom, *hp, bm, *cls, *t_cls, *reg, *t_reg,
                      giscore, gibox);
-  hipLaunchKernelGGL(gi_select_kernel, dim3(geom->num_levels), dim3(1024), 0, stream,
+  LD_LAUNCH(gi_select_kernel, dim3(geom->num_levels), dim3(1024), 0, stream,
                      *geom, topn, iou_thr, giscore, gibox, im, counts);
   return (int)hipGetLastError();
 }
@@ -1535,7 +1537,7 @@ extern "C" int ld_kl_integral_dense(const float* s_reg, const float* t_reg,
   const int64_t threads = (rows + R - 1) / R;
   const dim3 block(256), grid((unsigned)((threads + 255) / 256), 4);
 #define LD_LAUNCH_KL(RR, GG, NN)                                                  \
-  hipLaunchKernelGGL((kl_integral_dense_kernel<RR, GG, NN>), grid, block, 0,      \
+  LD_LAUNCH((kl_integral_dense_kernel<RR, GG, NN>), grid, block, 0,      \
                      stream, s_reg, t_reg, weight, rows, T, scale, integral,      \
                      loss_rows, grad)
 #define LD_LAUNCH_KL_R(RR)                                                        \

@@ -14,6 +14,8 @@
 //   SGD(momentum, weight_decay)                       apis/train.py:88
 #include <hip/hip_runtime.h>
 
+#include "ld_launch.h"
+
 #include "../../include/ld_hip.h"
 
 namespace {
@@ -1081,7 +1083,7 @@ extern "C" int ld_bn_prepare(const float* gamma, const float* beta,
                              ld_stream_t stream) {
   if (!gamma || !beta || !mean || !var || !scale || !shift || C < 1)
     return LD_EINVAL;
-  hipLaunchKernelGGL(bn_prepare_kernel, dim3((C + 255) / 256), dim3(256), 0,
+  LD_LAUNCH(bn_prepare_kernel, dim3((C + 255) / 256), dim3(256), 0,
                      LD_STREAM, gamma, beta, mean, var, eps, C, scale, shift, rstd);
   return (int)hipGetLastError();
 }
@@ -1101,7 +1103,7 @@ __global__ __launch_bounds__(256) void bn_prepare_batch_kernel(
 extern "C" int ld_bn_prepare_batch(const ld_bn_job_t* jobs, const int32_t* block_job,
                                    int nblocks, ld_stream_t stream) {
   if (!jobs || !block_job || nblocks < 1) return LD_EINVAL;
-  hipLaunchKernelGGL(bn_prepare_batch_kernel, dim3(nblocks), dim3(256), 0, LD_STREAM,
+  LD_LAUNCH(bn_prepare_batch_kernel, dim3(nblocks), dim3(256), 0, LD_STREAM,
                      jobs, block_job);
   return (int)hipGetLastError();
 }
@@ -1115,7 +1117,7 @@ extern "C" int ld_bn_act_forward_c8(const float* x, const float* residual,
   if (P % 4 != 0 || C % 8 != 0 || (uintptr_t)x % 16 != 0 || (uintptr_t)y % 16 != 0 ||
       (residual && (uintptr_t)residual % 16 != 0))
     return LD_EUNSUPPORTED;
-  hipLaunchKernelGGL(bn_act_fwd_c8_kernel, dim3((P / 4 + 255) / 256, N * (C / 8)),
+  LD_LAUNCH(bn_act_fwd_c8_kernel, dim3((P / 4 + 255) / 256, N * (C / 8)),
                      dim3(256), 0, LD_STREAM, x, residual, scale, shift, C, P, relu, y,
                      (gn_uintx4*)y_c8);
   return (int)hipGetLastError();
@@ -1130,11 +1132,11 @@ extern "C" int ld_bn_act_forward(const float* x, const float* residual,
                    ((uintptr_t)y % 16 == 0) &&
                    (!residual || (uintptr_t)residual % 16 == 0);
   if (vec)
-    hipLaunchKernelGGL((bn_act_fwd_kernel<true>), dim3((P / 4 + 255) / 256, N * C),
+    LD_LAUNCH((bn_act_fwd_kernel<true>), dim3((P / 4 + 255) / 256, N * C),
                        dim3(256), 0, LD_STREAM, x, residual, scale, shift, C, P,
                        relu, y);
   else
-    hipLaunchKernelGGL((bn_act_fwd_kernel<false>), dim3((P + 255) / 256, N * C),
+    LD_LAUNCH((bn_act_fwd_kernel<false>), dim3((P + 255) / 256, N * C),
                        dim3(256), 0, LD_STREAM, x, residual, scale, shift, C, P,
                        relu, y);
   return (int)hipGetLastError();
@@ -1163,15 +1165,15 @@ extern "C" int ld_bn_act_backward(const float* dy, const float* y, const float* 
                    ((uintptr_t)dy | (uintptr_t)(y ? y : dy) | (uintptr_t)(x ? x : dy) |
                     (uintptr_t)(dx ? dx : dy) | (uintptr_t)(dres ? dres : dy)) % 16 == 0;
   if (vec)
-    hipLaunchKernelGGL((bn_act_bwd_kernel<true>), dim3(C, ns), dim3(256), 0, LD_STREAM,
+    LD_LAUNCH((bn_act_bwd_kernel<true>), dim3(C, ns), dim3(256), 0, LD_STREAM,
                        dy, y, x, scale, mean, rstd, N, C, P, relu, dx, dres,
                        params ? (double*)workspace : nullptr);
   else
-    hipLaunchKernelGGL((bn_act_bwd_kernel<false>), dim3(C, ns), dim3(256), 0,
+    LD_LAUNCH((bn_act_bwd_kernel<false>), dim3(C, ns), dim3(256), 0,
                        LD_STREAM, dy, y, x, scale, mean, rstd, N, C, P, relu, dx, dres,
                        params ? (double*)workspace : nullptr);
   if (params && accumulate != LD_GRAD_DEFER)
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0,
+    LD_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0,
                        LD_STREAM, (const double*)workspace, C, ns, dgamma, dbeta,
                        accumulate);
   return (int)hipGetLastError();
@@ -1195,11 +1197,11 @@ extern "C" int ld_bn_act_backward_c8(const float* dy, const float* y, const floa
       ((uintptr_t)dy | (uintptr_t)(y ? y : dy) | (uintptr_t)(x ? x : dy) |
        (uintptr_t)(dx ? dx : dy) | (uintptr_t)(dres ? dres : dy) | (uintptr_t)dx_c8) % 16)
     return LD_EUNSUPPORTED;
-  hipLaunchKernelGGL(bn_act_bwd_c8_kernel, dim3(xb, N * (C / 8)), dim3(64), 0, LD_STREAM,
+  LD_LAUNCH(bn_act_bwd_c8_kernel, dim3(xb, N * (C / 8)), dim3(64), 0, LD_STREAM,
                      dy, y, x, scale, mean, rstd, C, P, relu, dx, dres,
                      (gn_uintx4*)dx_c8, params ? (double*)workspace : nullptr, nslots);
   if (params && accumulate != LD_GRAD_DEFER)
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0,
+    LD_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0,
                        LD_STREAM, (const double*)workspace, C, nslots, dgamma, dbeta,
                        accumulate);
   return (int)hipGetLastError();
@@ -1243,7 +1245,7 @@ extern "C" int ld_bn_bwd_finalize_batch(const ld_bn_fin_job_t* jobs,
                                         const int32_t* block_job, int nblocks,
                                         ld_stream_t stream) {
   if (!jobs || !block_job || nblocks < 1) return LD_EINVAL;
-  hipLaunchKernelGGL(bn_bwd_finalize_batch_kernel, dim3(nblocks), dim3(256), 0, LD_STREAM,
+  LD_LAUNCH(bn_bwd_finalize_batch_kernel, dim3(nblocks), dim3(256), 0, LD_STREAM,
                      jobs, block_job);
   return (int)hipGetLastError();
 }
@@ -1251,7 +1253,7 @@ extern "C" int ld_bn_bwd_finalize_batch(const ld_bn_fin_job_t* jobs,
 extern "C" int ld_bias_grad(const float* dy, int N, int C, int P, float* db,
                             int accumulate, ld_stream_t stream) {
   if (!dy || !db || N < 1 || C < 1 || P < 1) return LD_EINVAL;
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, LD_STREAM, dy, N, C, P,
+  LD_LAUNCH(bias_grad_kernel, dim3(C), dim3(256), 0, LD_STREAM, dy, N, C, P,
                      db, accumulate);
   return (int)hipGetLastError();
 }
@@ -1277,23 +1279,23 @@ static int gn_forward_impl(const ld_levels_t* lv, const float* x, const float* g
   const int ngl = N * G * k.num_levels;
   int per_ng = 0;
   for (int l = 0; l < k.num_levels; ++l) per_ng += gn_slices(k.off[l + 1] - k.off[l]);
-  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(N * G * per_ng), dim3(256), 0,
+  LD_LAUNCH(gn_stats_partial_kernel, dim3(N * G * per_ng), dim3(256), 0,
                      LD_STREAM, x, k, C, G, (double*)workspace);
-  hipLaunchKernelGGL(gn_stats_final_kernel, dim3((ngl + 255) / 256), dim3(256), 0,
+  LD_LAUNCH(gn_stats_final_kernel, dim3((ngl + 255) / 256), dim3(256), 0,
                      LD_STREAM, (const double*)workspace, k, N, C, G, eps, mean,
                      rstd);
   if (y_c8) {
     if (k.P % 4 != 0 || C % 8 != 0 || ((uintptr_t)x | (uintptr_t)y) % 16 != 0)
       return LD_EUNSUPPORTED;
-    hipLaunchKernelGGL(gn_apply_c8_kernel, dim3((k.P / 4 + 255) / 256, N * (C / 8)),
+    LD_LAUNCH(gn_apply_c8_kernel, dim3((k.P / 4 + 255) / 256, N * (C / 8)),
                        dim3(256), 0, LD_STREAM, x, k, C, G, mean, rstd, gamma, beta,
                        relu, y, (gn_uintx4*)y_c8);
   } else if (k.P % 4 == 0 && ((uintptr_t)x | (uintptr_t)y) % 16 == 0)
-    hipLaunchKernelGGL(gn_apply4_kernel, dim3((k.P / 4 + 255) / 256, N * C),
+    LD_LAUNCH(gn_apply4_kernel, dim3((k.P / 4 + 255) / 256, N * C),
                        dim3(256), 0, LD_STREAM, x, k, C, G, mean, rstd, gamma, beta,
                        relu, y);
   else
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((k.P + 255) / 256, N * C), dim3(256), 0,
+    LD_LAUNCH(gn_apply_kernel, dim3((k.P + 255) / 256, N * C), dim3(256), 0,
                        LD_STREAM, x, k, C, G, mean, rstd, gamma, beta, relu, y);
   return (int)hipGetLastError();
 }
@@ -1349,35 +1351,35 @@ static int gn_backward_impl(const ld_levels_t* lv, const float* dy, const float*
   const bool rowwise = k.P % 4 == 0 &&
                        ((uintptr_t)dy | (uintptr_t)x | (uintptr_t)(relu ? y : x)) % 16 == 0;
   if (rowwise) {
-    hipLaunchKernelGGL(gn_bwd_reduce_row_kernel, dim3(N * C), dim3(256), 0, LD_STREAM, dy,
+    LD_LAUNCH(gn_bwd_reduce_row_kernel, dim3(N * C), dim3(256), 0, LD_STREAM, dy,
                        y, x, k, C, G, mean, rstd, relu, sums);
   } else {
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(rl * kGnBwdSplit), dim3(256), 0,
+    LD_LAUNCH(gn_bwd_reduce_kernel, dim3(rl * kGnBwdSplit), dim3(256), 0,
                        LD_STREAM, dy, y, x, k, C, G, mean, rstd, relu, sums);
-    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((rl + 255) / 256), dim3(256), 0,
+    LD_LAUNCH(gn_bwd_fold_kernel, dim3((rl + 255) / 256), dim3(256), 0,
                        LD_STREAM, sums, rl);
   }
-  hipLaunchKernelGGL(gn_bwd_group_kernel, dim3((ngl + 255) / 256), dim3(256), 0,
+  LD_LAUNCH(gn_bwd_group_kernel, dim3((ngl + 255) / 256), dim3(256), 0,
                      LD_STREAM, sums, k, N, C, G, gamma, gm);
   const bool vec = k.P % 4 == 0 &&
                    ((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx |
                     (uintptr_t)(relu ? y : x)) % 16 == 0;
   if (dx_c8) {
     if (!vec || C % 8 != 0) return LD_EUNSUPPORTED;
-    hipLaunchKernelGGL(gn_bwd_apply_c8_kernel,
+    LD_LAUNCH(gn_bwd_apply_c8_kernel,
                        dim3((k.P / 4 + 255) / 256, N * (C / 8)), dim3(256), 0,
                        LD_STREAM, dy, y, x, k, C, G, mean, rstd, gamma, gm, relu, dx,
                        (gn_uintx4*)dx_c8);
   } else if (vec)
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<4>, dim3((k.P / 4 + 255) / 256, N * C),
+    LD_LAUNCH(gn_bwd_apply_kernel<4>, dim3((k.P / 4 + 255) / 256, N * C),
                        dim3(256), 0, LD_STREAM, dy, y, x, k, C, G, mean, rstd, gamma,
                        gm, relu, dx);
   else
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, dim3((k.P + 255) / 256, N * C),
+    LD_LAUNCH(gn_bwd_apply_kernel<1>, dim3((k.P + 255) / 256, N * C),
                        dim3(256), 0, LD_STREAM, dy, y, x, k, C, G, mean, rstd, gamma,
                        gm, relu, dx);
   if (dgamma && dbeta)
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0,
+    LD_LAUNCH(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0,
                        LD_STREAM, sums, N, C, k.num_levels, dgamma, dbeta,
                        accumulate);
   return (int)hipGetLastError();
@@ -1414,11 +1416,11 @@ extern "C" int ld_maxpool3x3s2(const float* x, int rows, int H, int W, float* y,
   const size_t total = (size_t)rows * Ho * Wo;
   if (W % 4 == 0 && W >= 8 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0) {
     const size_t threads = total / 2;  // Wo = W / 2 is even
-    hipLaunchKernelGGL(maxpool3x3s2_vec_kernel, dim3((unsigned)((threads + 255) / 256)),
+    LD_LAUNCH(maxpool3x3s2_vec_kernel, dim3((unsigned)((threads + 255) / 256)),
                        dim3(256), 0, LD_STREAM, x, rows, H, W, Ho, Wo, y);
     return (int)hipGetLastError();
   }
-  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)((total + 255) / 256)),
+  LD_LAUNCH(maxpool3x3s2_kernel, dim3((unsigned)((total + 255) / 256)),
                      dim3(256), 0, LD_STREAM, x, rows, H, W, Ho, Wo, y);
   return (int)hipGetLastError();
 }
@@ -1428,7 +1430,7 @@ extern "C" int ld_upsample_add_forward(const float* fine, const float* coarse,
                                        float* out, ld_stream_t stream) {
   if (!fine || !coarse || !out || rows < 1 || Hf < 1 || Wf < 1 || Hc < 1 || Wc < 1)
     return LD_EINVAL;
-  hipLaunchKernelGGL(upsample_add_fwd_kernel, dim3((Hf * Wf + 255) / 256, rows),
+  LD_LAUNCH(upsample_add_fwd_kernel, dim3((Hf * Wf + 255) / 256, rows),
                      dim3(256), 0, LD_STREAM, fine, coarse, Hf, Wf, Hc, Wc, out);
   return (int)hipGetLastError();
 }
@@ -1438,7 +1440,7 @@ extern "C" int ld_upsample_add_backward_acc(const float* dout, int rows, int Hf,
                                             float* dcoarse, ld_stream_t stream) {
   if (!dout || !dcoarse || rows < 1 || Hf < 1 || Wf < 1 || Hc < 1 || Wc < 1)
     return LD_EINVAL;
-  hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3((Hc * Wc + 255) / 256, rows),
+  LD_LAUNCH(upsample_add_bwd_kernel, dim3((Hc * Wc + 255) / 256, rows),
                      dim3(256), 0, LD_STREAM, dout, Hf, Wf, Hc, Wc, addend, dcoarse);
   return (int)hipGetLastError();
 }
@@ -1461,7 +1463,7 @@ int pack_levels_run(const ld_levels_t* lv, float* const* levels, int rows, float
     lp.p[l] = levels[l];
   }
   const Levels k = make_levels(lv);
-  hipLaunchKernelGGL(pack_levels_kernel<PACK>, dim3((k.P + 255) / 256, rows), dim3(256), 0,
+  LD_LAUNCH(pack_levels_kernel<PACK>, dim3((k.P + 255) / 256, rows), dim3(256), 0,
                      LD_STREAM, k, lp, x3);
   return (int)hipGetLastError();
 }
@@ -1483,7 +1485,7 @@ extern "C" int ld_scale_levels_forward(const ld_levels_t* lv, const float* x,
   if (int e = check_levels(lv)) return e;
   if (!x || !scales || !y || rows < 1) return LD_EINVAL;
   const Levels k = make_levels(lv);
-  hipLaunchKernelGGL(scale_levels_kernel, dim3((k.P + 255) / 256, rows), dim3(256),
+  LD_LAUNCH(scale_levels_kernel, dim3((k.P + 255) / 256, rows), dim3(256),
                      0, LD_STREAM, x, k, scales, y);
   return (int)hipGetLastError();
 }
@@ -1504,13 +1506,13 @@ extern "C" int ld_scale_levels_backward(const ld_levels_t* lv, const float* dy,
                   workspace_bytes < ld_scale_levels_backward_workspace_bytes(lv)))
     return LD_ENOSPACE;
   const Levels k = make_levels(lv);
-  hipLaunchKernelGGL(scale_levels_kernel, dim3((k.P + 255) / 256, rows), dim3(256),
+  LD_LAUNCH(scale_levels_kernel, dim3((k.P + 255) / 256, rows), dim3(256),
                      0, LD_STREAM, dy, k, scales, dx);
   if (dscales) {
-    hipLaunchKernelGGL(scale_levels_bwd_partial_kernel,
+    LD_LAUNCH(scale_levels_bwd_partial_kernel,
                        dim3(k.num_levels * kScaleSplit), dim3(256), 0, LD_STREAM, dy,
                        x, k, rows, (double*)workspace);
-    hipLaunchKernelGGL(scale_levels_bwd_final_kernel, dim3(1), dim3(64), 0,
+    LD_LAUNCH(scale_levels_bwd_final_kernel, dim3(1), dim3(64), 0,
                        LD_STREAM, (const double*)workspace, k.num_levels, dscales,
                        accumulate);
   }
@@ -1524,7 +1526,7 @@ extern "C" int ld_sgd_step_dev(float* params, const float* grads, float* momentu
   if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)momentum_buf) % 16)
     return LD_EINVAL;
   const size_t threads = (n + 3) / 4;
-  hipLaunchKernelGGL(sgd_dev_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256),
+  LD_LAUNCH(sgd_dev_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256),
                      0, LD_STREAM, params, grads, momentum_buf, n, hyper);
   return (int)hipGetLastError();
 }
@@ -1537,7 +1539,7 @@ extern "C" int ld_sgd_step(float* params, const float* grads, float* momentum_bu
   if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)momentum_buf) % 16)
     return LD_EINVAL;
   const size_t threads = (n + 3) / 4;
-  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256),
+  LD_LAUNCH(sgd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256),
                      0, LD_STREAM, params, grads, momentum_buf, n, lr, momentum,
                      weight_decay, grad_scale);
   return (int)hipGetLastError();

@@ -24,6 +24,8 @@
 // numpy restatement in oracle/pipeline_oracle.py).
 #include <hip/hip_runtime.h>
 
+#include "ld_launch.h"
+
 #include "../../include/ld_hip.h"
 
 namespace {
@@ -94,7 +96,7 @@ extern "C" int ld_preprocess_batch(const ld_image_t* imgs, int N, int Hpad, int 
                                    float* out, ld_stream_t stream) {
   if (!imgs || !mean || !std_inv || !out || N < 1 || Hpad < 1 || Wpad < 1)
     return LD_EINVAL;
-  hipLaunchKernelGGL(preprocess_kernel, dim3((Wpad + 63) / 64, (Hpad + 3) / 4, N),
+  LD_LAUNCH(preprocess_kernel, dim3((Wpad + 63) / 64, (Hpad + 3) / 4, N),
                      dim3(256), 0, (hipStream_t)stream, imgs, Hpad, Wpad, mean[0],
                      mean[1], mean[2], std_inv[0], std_inv[1], std_inv[2], to_rgb, out);
   return (int)hipGetLastError();

@@ -6,6 +6,8 @@
 //       2 reads : 1 write -- the ceiling the fused kernel can approach.
 // Measurement support, not on the train step.  gfx950 only.
 #include <hip/hip_runtime.h>
+
+#include "ld_launch.h"
 #include <stdint.h>
 
 #include "../../include/ld_hip.h"
@@ -70,11 +72,11 @@ extern "C" int ld_probe_copy(const float* src, float* dst, int64_t n, int width,
   const dim3 grid((unsigned)((threads + 255) / 256));
   hipStream_t st = (hipStream_t)stream;
   if (width == 4) {
-    if (nt) hipLaunchKernelGGL((copy_kernel<4, true>), grid, dim3(256), 0, st, src, dst, n);
-    else hipLaunchKernelGGL((copy_kernel<4, false>), grid, dim3(256), 0, st, src, dst, n);
+    if (nt) LD_LAUNCH((copy_kernel<4, true>), grid, dim3(256), 0, st, src, dst, n);
+    else LD_LAUNCH((copy_kernel<4, false>), grid, dim3(256), 0, st, src, dst, n);
   } else {
-    if (nt) hipLaunchKernelGGL((copy_kernel<1, true>), grid, dim3(256), 0, st, src, dst, n);
-    else hipLaunchKernelGGL((copy_kernel<1, false>), grid, dim3(256), 0, st, src, dst, n);
+    if (nt) LD_LAUNCH((copy_kernel<1, true>), grid, dim3(256), 0, st, src, dst, n);
+    else LD_LAUNCH((copy_kernel<1, false>), grid, dim3(256), 0, st, src, dst, n);
   }
   return (int)hipGetLastError();
 }
@@ -86,11 +88,11 @@ extern "C" int ld_probe_planes(const float* s, const float* t, float* g, int64_t
   const dim3 grid = side_fast ? dim3(nb * 4, 1) : dim3(nb, 4);
   hipStream_t st = (hipStream_t)stream;
   if (side_fast) {
-    if (nt) hipLaunchKernelGGL((planes_kernel<true, true>), grid, dim3(256), 0, st, s, t, g, rows);
-    else hipLaunchKernelGGL((planes_kernel<false, true>), grid, dim3(256), 0, st, s, t, g, rows);
+    if (nt) LD_LAUNCH((planes_kernel<true, true>), grid, dim3(256), 0, st, s, t, g, rows);
+    else LD_LAUNCH((planes_kernel<false, true>), grid, dim3(256), 0, st, s, t, g, rows);
   } else {
-    if (nt) hipLaunchKernelGGL((planes_kernel<true, false>), grid, dim3(256), 0, st, s, t, g, rows);
-    else hipLaunchKernelGGL((planes_kernel<false, false>), grid, dim3(256), 0, st, s, t, g, rows);
+    if (nt) LD_LAUNCH((planes_kernel<true, false>), grid, dim3(256), 0, st, s, t, g, rows);
+    else LD_LAUNCH((planes_kernel<false, false>), grid, dim3(256), 0, st, s, t, g, rows);
   }
   return (int)hipGetLastError();
 }

@@ -15,6 +15,8 @@
 // order by a second kernel: deterministic, no float atomics.
 #include <hip/hip_runtime.h>
 
+#include "ld_launch.h"
+
 #include "../../include/ld_hip.h"
 
 namespace {
@@ -247,7 +249,7 @@ extern "C" int ld_quality_forward(const float* reg, const float* cls_feat, int N
   if (!reg || !cls_feat || !w1 || !b1 || !w2 || !b2 || !cls_score || !quality ||
       N < 1 || C < 1 || P < 1)
     return LD_EINVAL;
-  hipLaunchKernelGGL(quality_fwd_kernel, dim3((P + kBlk - 1) / kBlk, N), dim3(kBlk), 0,
+  LD_LAUNCH(quality_fwd_kernel, dim3((P + kBlk - 1) / kBlk, N), dim3(kBlk), 0,
                      (hipStream_t)stream, reg, cls_feat, C, P, w1, b1, w2, b2,
                      cls_score, quality);
   return (int)hipGetLastError();
@@ -275,10 +277,10 @@ extern "C" int ld_quality_backward(const float* reg, const float* cls_feat,
     return LD_ENOSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   const int bx = (P + kBlk - 1) / kBlk;
-  hipLaunchKernelGGL(quality_bwd_kernel, dim3(bx, N), dim3(kBlk), 0, stream, reg,
+  LD_LAUNCH(quality_bwd_kernel, dim3(bx, N), dim3(kBlk), 0, stream, reg,
                      cls_feat, quality, g_cls_score, C, P, w1, b1, w2, g_cls_feat, g_reg,
                      (float*)workspace);
-  hipLaunchKernelGGL(quality_param_reduce_kernel, dim3((NPAR + 255) / 256), dim3(256), 0,
+  LD_LAUNCH(quality_param_reduce_kernel, dim3((NPAR + 255) / 256), dim3(256), 0,
                      stream, (const float*)workspace, bx * N, g_w1, g_b1, g_w2, g_b2,
                      accumulate);
   return (int)hipGetLastError();

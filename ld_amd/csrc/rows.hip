@@ -7,6 +7,8 @@
 // wavefront touches 64 consecutive rows = one contiguous span.
 #include <hip/hip_runtime.h>
 
+#include "ld_launch.h"
+
 #include "../../include/ld_hip.h"
 #include "ld_math.h"
 
@@ -217,7 +219,7 @@ extern "C" int ld_kd_kl_rows(const float* pred, const float* soft,
   if (!pred || !soft || !loss_rows || rows < 0 || K < 1 || T < 1.0f)
     return LD_EINVAL;
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(kd_kl_rows_kernel, grid_for(rows, 128), dim3(128), 0,
+  LD_LAUNCH(kd_kl_rows_kernel, grid_for(rows, 128), dim3(128), 0,
                      LD_STREAM, pred, soft, weight, rows, K, T, gscale, loss_rows,
                      grad);
   return (int)hipGetLastError();
@@ -230,7 +232,7 @@ extern "C" int ld_qfl_rows(const float* pred, const int64_t* label,
   if (!pred || !label || !score || !loss_rows || rows < 0 || C < 1)
     return LD_EINVAL;
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(qfl_rows_kernel, grid_for(rows, 128), dim3(128), 0, LD_STREAM,
+  LD_LAUNCH(qfl_rows_kernel, grid_for(rows, 128), dim3(128), 0, LD_STREAM,
                      pred, label, score, weight, rows, C, gscale, loss_rows, grad);
   return (int)hipGetLastError();
 }
@@ -241,7 +243,7 @@ extern "C" int ld_dfl_rows(const float* pred, const float* target,
   if (!pred || !target || !loss_rows || rows < 0) return LD_EINVAL;
   if (K != K17) return LD_EUNSUPPORTED;
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(dfl_rows_kernel, grid_for(rows, 128), dim3(128), 0, LD_STREAM,
+  LD_LAUNCH(dfl_rows_kernel, grid_for(rows, 128), dim3(128), 0, LD_STREAM,
                      pred, target, weight, rows, gscale, loss_rows, grad);
   return (int)hipGetLastError();
 }
@@ -252,7 +254,7 @@ extern "C" int ld_giou_rows(const float* pred, const float* target,
                             ld_stream_t stream) {
   if (!pred || !target || !loss_rows || rows < 0) return LD_EINVAL;
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(giou_rows_kernel, grid_for(rows, 128), dim3(128), 0, LD_STREAM,
+  LD_LAUNCH(giou_rows_kernel, grid_for(rows, 128), dim3(128), 0, LD_STREAM,
                      pred, target, weight, rows, eps, gscale, loss_rows, grad);
   return (int)hipGetLastError();
 }
@@ -261,7 +263,7 @@ extern "C" int ld_integral_rows(const float* x, int64_t rows, float* out,
                                 ld_stream_t stream) {
   if (!x || !out || rows < 0) return LD_EINVAL;
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(integral_rows_kernel, grid_for(rows * 4, 128), dim3(128), 0,
+  LD_LAUNCH(integral_rows_kernel, grid_for(rows * 4, 128), dim3(128), 0,
                      LD_STREAM, x, rows, out);
   return (int)hipGetLastError();
 }
@@ -271,7 +273,7 @@ extern "C" int ld_integral_rows_bwd(const float* x, const float* grad_out,
                                     ld_stream_t stream) {
   if (!x || !grad_out || !grad_x || rows < 0) return LD_EINVAL;
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(integral_rows_bwd_kernel, grid_for(rows * 4, 128), dim3(128),
+  LD_LAUNCH(integral_rows_bwd_kernel, grid_for(rows * 4, 128), dim3(128),
                      0, LD_STREAM, x, grad_out, rows, grad_x);
   return (int)hipGetLastError();
 }
@@ -284,7 +286,7 @@ extern "C" int ld_bbox_overlaps(const float* b1, const float* b2, int64_t m,
   if (aligned && m != n) return LD_EINVAL;
   const int64_t total = aligned ? m : m * n;
   if (total == 0) return 0;
-  hipLaunchKernelGGL(bbox_overlaps_kernel, grid_for(total, 256), dim3(256), 0,
+  LD_LAUNCH(bbox_overlaps_kernel, grid_for(total, 256), dim3(256), 0,
                      LD_STREAM, b1, b2, m, n, mode, aligned, eps, out);
   return (int)hipGetLastError();
 }
@@ -295,9 +297,9 @@ extern "C" int ld_sum(const float* x, int64_t n, float* out, void* workspace,
   if (!workspace || workspace_bytes < kSumBlocks * sizeof(float))
     return LD_ENOSPACE;
   float* part = (float*)workspace;
-  hipLaunchKernelGGL(sum_stage1, dim3(kSumBlocks), dim3(256), 0, LD_STREAM, x, n,
+  LD_LAUNCH(sum_stage1, dim3(kSumBlocks), dim3(256), 0, LD_STREAM, x, n,
                      part);
-  hipLaunchKernelGGL(sum_stage1, dim3(1), dim3(256), 0, LD_STREAM, part,
+  LD_LAUNCH(sum_stage1, dim3(1), dim3(256), 0, LD_STREAM, part,
                      (int64_t)kSumBlocks, out);
   return (int)hipGetLastError();
 }

@@ -24,6 +24,8 @@
 // the reference CPU path on tie-free inputs; fp32 op order follows the
 // reference (no FMA contraction in this file).
 #include <hip/hip_runtime.h>
+
+#include "ld_launch.h"
 #include <float.h>
 #include <limits.h>
 
@@ -636,28 +638,28 @@ extern "C" int ld_atss_targets_ex(const ld_geom_t* geom, const ld_loss_hp_t* hp,
   float* thr = (float*)(ws + keys_b);
   float* colmax = (float*)(ws + keys_b + per_gt);
   hipError_t err;
-  if ((err = hipMemsetAsync(keys, 0, (size_t)N * A * 8, stream))) return (int)err;
-  if ((err = hipMemsetAsync(counts, 0, sizeof(int32_t) * (N + 2 * L + 1), stream)))
+  if ((err = ldrec::memset_async(keys, 0, (size_t)N * A * 8, stream))) return (int)err;
+  if ((err = ldrec::memset_async(counts, 0, sizeof(int32_t) * (N + 2 * L + 1), stream)))
     return (int)err;
   if (max_gt > 0) {
     dim3 grid(max_gt, N);
     if (hp->topk <= 9)
-      hipLaunchKernelGGL(atss_select_kernel<9>, grid, dim3(kBlock), 0, stream,
+      LD_LAUNCH(atss_select_kernel<9>, grid, dim3(kBlock), 0, stream,
                          *geom, hp->topk, anchors, gt_bboxes, num_gt, max_gt,
                          valid_hw, 1, keys, thr, colmax);
     else
-      hipLaunchKernelGGL(atss_select_kernel<16>, grid, dim3(kBlock), 0, stream,
+      LD_LAUNCH(atss_select_kernel<16>, grid, dim3(kBlock), 0, stream,
                          *geom, hp->topk, anchors, gt_bboxes, num_gt, max_gt,
                          valid_hw, 1, keys, thr, colmax);
   }
   dim3 gridb((A + kBlock - 1) / kBlock, N);
-  hipLaunchKernelGGL(atss_dense_kernel, gridb, dim3(kBlock), 0, stream, *geom,
+  LD_LAUNCH(atss_dense_kernel, gridb, dim3(kBlock), 0, stream, *geom,
                      hp->num_classes, (hp->flags & LD_IM_CENTER_INSIDE) ? 1 : 0, anchors,
                      gt_bboxes, gt_labels, num_gt,
                      max_gt > 0 ? max_gt : 1, valid_hw, keys, thr, colmax,
                      labels, label_weights, bbox_targets, vlr, im, counts, gt_inds,
                      max_overlaps);
-  hipLaunchKernelGGL(atss_counts_finalize, dim3(1), dim3(64), 0, stream, N, L,
+  LD_LAUNCH(atss_counts_finalize, dim3(1), dim3(64), 0, stream, N, L,
                      counts);
   return (int)hipGetLastError();
 }
@@ -711,22 +713,22 @@ extern "C" int ld_retina_targets(const ld_geom_t* geom, int num_base, const floa
   float* thr = (float*)(ws + keys_b);
   float* colmax = (float*)(ws + keys_b + per_gt);
   hipError_t err;
-  if ((err = hipMemsetAsync(keys, 0, (size_t)N * AB * 8, stream))) return (int)err;
-  if ((err = hipMemsetAsync(counts, 0, sizeof(int32_t) * (N * num_base + 2 * L + 1),
+  if ((err = ldrec::memset_async(keys, 0, (size_t)N * AB * 8, stream))) return (int)err;
+  if ((err = ldrec::memset_async(counts, 0, sizeof(int32_t) * (N * num_base + 2 * L + 1),
                             stream)))
     return (int)err;
   // per gt: the VLR threshold (mean + std IoU of the topk closest anchors of every
   // level) and its best IoU over all valid anchors
   if (max_gt > 0)
-    hipLaunchKernelGGL(atss_select_kernel<9>, dim3(max_gt, N), dim3(kBlock), 0, stream, f,
+    LD_LAUNCH(atss_select_kernel<9>, dim3(max_gt, N), dim3(kBlock), 0, stream, f,
                        topk, anchors, gt_bboxes, num_gt, max_gt, valid_hw, num_base, keys,
                        thr, colmax);
   MaxIouCfg cfg{pos_iou_thr, neg_iou_thr, min_pos_iou, num_base};
-  hipLaunchKernelGGL(maxiou_dense_kernel, dim3((AB + kBlock - 1) / kBlock, N),
+  LD_LAUNCH(maxiou_dense_kernel, dim3((AB + kBlock - 1) / kBlock, N),
                      dim3(kBlock), 0, stream, f, num_classes, cfg, anchors, gt_bboxes,
                      gt_labels, num_gt, max_gt > 0 ? max_gt : 1, valid_hw, thr, colmax,
                      labels, label_weights, bbox_targets, vlr, im, counts, gt_inds);
-  hipLaunchKernelGGL(maxiou_counts_finalize, dim3(1), dim3(64), 0, stream, N, num_base, L,
+  LD_LAUNCH(maxiou_counts_finalize, dim3(1), dim3(64), 0, stream, N, num_base, L,
                      counts);
   return (int)hipGetLastError();
 }
@@ -753,13 +755,13 @@ extern "C" int ld_fcos_targets(const ld_geom_t* geom, int num_classes,
   cfg.radius = center_sample_radius;
   cfg.center_sampling = center_sampling;
   hipError_t err;
-  if ((err = hipMemsetAsync(counts, 0, sizeof(int32_t) * (N + 2 * L + 1), stream)))
+  if ((err = ldrec::memset_async(counts, 0, sizeof(int32_t) * (N + 2 * L + 1), stream)))
     return (int)err;
-  hipLaunchKernelGGL(fcos_dense_kernel, dim3((A + kBlock - 1) / kBlock, N), dim3(kBlock),
+  LD_LAUNCH(fcos_dense_kernel, dim3((A + kBlock - 1) / kBlock, N), dim3(kBlock),
                      0, stream, *geom, num_classes, cfg, gt_bboxes, gt_labels, num_gt,
                      max_gt > 0 ? max_gt : 1, labels, label_weights, bbox_targets, vlr,
                      im, counts);
-  hipLaunchKernelGGL(fcos_counts_finalize, dim3(1), dim3(64), 0, stream, N, L, counts);
+  LD_LAUNCH(fcos_counts_finalize, dim3(1), dim3(64), 0, stream, N, L, counts);
   return (int)hipGetLastError();
 }
 
@@ -767,7 +769,7 @@ extern "C" int ld_grid_anchors(const ld_geom_t* geom, float* anchors,
                                ld_stream_t stream) {
   if (int e = check_geom(geom)) return e;
   if (!anchors) return LD_EINVAL;
-  hipLaunchKernelGGL(grid_anchors_kernel,
+  LD_LAUNCH(grid_anchors_kernel,
                      dim3((geom->num_anchors + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, *geom, anchors);
   return (int)hipGetLastError();

@@ -245,10 +245,115 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
                                                  '1') == '1'
 
     def _teacher_forward(self, img):
+        if self._replay_enabled(img):
+            return self._teacher_replay(img)
         with torch.no_grad():
             teacher_x = self.teacher_model.extract_feat(img)
             out_teacher = self.teacher_model.bbox_head(teacher_x)
         return teacher_x, out_teacher
+
+    # ---- the frozen teacher as launch lists (round 5) -------------------------
+    # kd_one_stage.py:70-72 runs the teacher under no_grad in eval mode: the same
+    # ~150 launches on the same shapes every step, a quarter of the step's
+    # launches and ~3.5 ms of Python / ctypes per step.  After one ordinary
+    # forward per (image shape, precision) -- which fills the weight-image / BN /
+    # workspace caches -- the next TEACHER_SLOTS forwards are RECORDED
+    # (ld_record_begin .. ld_record_end, include/ld_hip.h "launch lists"), each
+    # into its own set of buffers; from then on a teacher forward is one copy of
+    # the batch into a slot's input buffer + ONE C call that re-issues that slot's
+    # launches.  Slots rotate so that a result is not overwritten while the step
+    # it was computed for (up to two steps of look-ahead, prefetch_teacher) still
+    # reads it.  The kernels, operands and results are those of the ordinary
+    # forward, bit for bit (tests/test_gpu_teacher_replay.py).
+    TEACHER_SLOTS = 3
+
+    def _teacher_fingerprint(self):
+        ts = getattr(self, '_teacher_tensors', None)
+        if ts is None:
+            ts = list(self.teacher_model.parameters()) + \
+                list(self.teacher_model.buffers())
+            object.__setattr__(self, '_teacher_tensors', ts)
+        v = 0
+        for t in ts:
+            v += t._version
+        return (v, ts[0].data_ptr(), ts[-1].data_ptr(), len(ts))
+
+    def _replay_enabled(self, img):
+        from . import layers as Y
+        return (self.eval_teacher and img.is_cuda and img.is_contiguous() and
+                os.environ.get('LD_TEACHER_REPLAY', '1') == '1' and
+                not self.teacher_model.training and
+                Y.KernelProfile.active is None and not Y._AUTOTUNE[0])
+
+    def reset_teacher_replay(self):
+        """Drop the recorded teacher launch lists (they are re-recorded on
+        demand): after anything the fingerprint cannot see."""
+        from . import lib as L
+        plans = getattr(self, '_tplans', None) or {}
+        if plans and L.lib_available():
+            lib = L.get_lib()
+            for pl in plans.values():
+                for sl in pl['slots']:
+                    lib.ld_record_free(sl['handle'])
+        object.__setattr__(self, '_tplans', {})
+
+    def _teacher_replay(self, img):
+        from . import layers as Y
+        from . import lib as L
+        plans = getattr(self, '_tplans', None)
+        if plans is None:
+            plans = {}
+            object.__setattr__(self, '_tplans', plans)
+        fp = self._teacher_fingerprint()
+        key = (tuple(img.shape), str(img.device), Y.get_precision(), Y._C8[0],
+               Y._FUSED_BLOCK[0])
+        pl = plans.get(key)
+        if pl is not None and pl['fp'] != fp:  # the teacher's weights changed
+            self.reset_teacher_replay()
+            plans, pl = self._tplans, None
+        if pl is None:
+            pl = plans[key] = dict(fp=fp, warm=False, slots=[], next=0)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not pl['warm'] or (capturing and
+                              len(pl['slots']) < self.TEACHER_SLOTS):
+            # the ordinary forward: fills the caches a recording must not contain
+            # (weight transforms, BN folding, workspaces); also what a hipGraph
+            # capture takes until the slots exist (recording allocates)
+            with torch.no_grad():
+                teacher_x = self.teacher_model.extract_feat(img)
+                out_teacher = self.teacher_model.bbox_head(teacher_x)
+            pl['warm'] = True
+            return teacher_x, out_teacher
+        lib = L.get_lib()
+        if len(pl['slots']) < self.TEACHER_SLOTS:
+            sl = dict(img=torch.empty_like(img), keep=[])
+            sl['img'].copy_(img)
+            L._KEEP[0] = sl['keep']
+            L.check(lib.ld_record_begin(), 'ld_record_begin')
+            try:
+                with torch.no_grad():
+                    teacher_x = self.teacher_model.extract_feat(sl['img'])
+                    out_teacher = self.teacher_model.bbox_head(teacher_x)
+            except BaseException:
+                lib.ld_record_abort()
+                raise
+            finally:
+                L._KEEP[0] = None
+            sl['handle'] = lib.ld_record_end()
+            if sl['handle'] <= 0:
+                raise L.LdError(f'ld_record_end failed ({sl["handle"]})')
+            sl['out'] = (teacher_x, out_teacher)
+            sl['launches'] = lib.ld_record_count(sl['handle'])
+            pl['slots'].append(sl)
+            return teacher_x, out_teacher
+        sl = pl['slots'][pl['next']]
+        pl['next'] = (pl['next'] + 1) % len(pl['slots'])
+        if img.data_ptr() != sl['img'].data_ptr():
+            sl['img'].copy_(img)
+        L.check(lib.ld_record_replay(sl['handle'], L.stream_ptr(img.device)),
+                'ld_record_replay')
+        self.teacher_replays = getattr(self, 'teacher_replays', 0) + 1
+        return sl['out']
 
     @staticmethod
     def _same_batch(entry, img):

@@ -103,7 +103,25 @@ def out_size(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
 
+_DESC_CACHE = {}
+
+
 def conv_desc(N, Cin, Cout, KH, KW, stride, pad, levels):
+    """(ld_conv_t, output levels) of a conv geometry; memoised (the struct is
+    read-only for every caller: ~300 calls per step built it field by field)."""
+    if type(levels) is not tuple or type(levels[0]) is not tuple:
+        levels = tuple(tuple(int(v) for v in lv) for lv in levels)
+    key = (N, Cin, Cout, KH, KW, stride, pad, levels)
+    hit = _DESC_CACHE.get(key)
+    if hit is None:
+        if len(_DESC_CACHE) > 4096:
+            _DESC_CACHE.clear()
+        hit = _DESC_CACHE[key] = _conv_desc(N, Cin, Cout, KH, KW, stride, pad,
+                                            tuple(levels))
+    return hit
+
+
+def _conv_desc(N, Cin, Cout, KH, KW, stride, pad, levels):
     d = L.ConvT()
     d.N, d.Cin, d.Cout, d.KH, d.KW = N, Cin, Cout, KH, KW
     d.stride, d.pad, d.num_levels = stride, pad, len(levels)
@@ -121,6 +139,15 @@ def conv_desc(N, Cin, Cout, KH, KW, stride, pad, levels):
 
 
 def levels_desc(levels):
+    if type(levels) is not tuple or type(levels[0]) is not tuple:
+        levels = tuple(tuple(int(v) for v in lv) for lv in levels)
+    hit = _DESC_CACHE.get(levels)
+    if hit is None:
+        hit = _DESC_CACHE[levels] = _levels_desc(levels)
+    return hit
+
+
+def _levels_desc(levels):
     d = L.LevelsT()
     d.num_levels = len(levels)
     for l, (h, w) in enumerate(levels):
@@ -541,6 +568,7 @@ def _epilogue(bias=None, scale=None, shift=None, residual=None, relu=False,
     ep.y_c8 = y_c8.data_ptr() if y_c8 is not None else None
     ep.residual_c8 = None
     if isinstance(residual, C8Act):
+        L.keep(residual.buf)
         ep.residual_c8, residual = residual.buf.data_ptr(), None
     ep.y_raw = None
     ep.bias = bias.data_ptr() if bias is not None else None
@@ -548,6 +576,7 @@ def _epilogue(bias=None, scale=None, shift=None, residual=None, relu=False,
     ep.shift = shift.data_ptr() if shift is not None else None
     ep.residual = residual.data_ptr() if residual is not None else None
     ep.relu = 1 if relu else 0
+    L.keep(y_c8, bias, scale, shift, residual)
     return ep
 
 
@@ -594,6 +623,7 @@ def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
             raise L.LdError('conv: y_raw needs a plain fp32 output of the '
                             'same shape')
         ep.y_raw = y_raw.data_ptr()
+        L.keep(y_raw)
     c8 = in8 or (bf16 and _use_c8(cin, kh, stride, N * d.Pout, x3))
     fn = lib.ld_conv_forward_smallc if smallc else (
         lib.ld_conv_bf16_forward_c8 if c8 else
@@ -1423,6 +1453,51 @@ def conv_bn_act_infer(x3, w, gamma, beta, mean, var, eps, stride, pad, levels,
 
 
 # ---------------------------------------------------------------------------
+# one frozen bottleneck as ONE launch (bf16 mode, C8-only trunk: the R101 teacher)
+# ---------------------------------------------------------------------------
+_FUSED_BLOCK = [os.environ.get('LD_FUSED_BOTTLENECK', '1') == '1']
+
+
+def fused_bottleneck_available(x3, cin, mid, levels):
+    """Whether ``bottleneck_c8_forward`` serves this block input."""
+    if not (_FUSED_BLOCK[0] and isinstance(x3, C8Act) and _C8_ONLY[0] and
+            len(levels) == 1):
+        return False
+    h, w = levels[0]
+    return bool(L.get_lib().ld_bottleneck_c8_supported(cin, mid, h, w))
+
+
+def bottleneck_c8_forward(x8, levels, convs, bns):
+    """relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + x) of an identity
+    bottleneck (resnet.py:260-299) as ONE launch on C8 images
+    (ld_bottleneck_c8_forward, csrc/conv_fused.hip): the mid activations stay in
+    LDS.  ``convs`` / ``bns``: the block's three conv weights and (gamma, beta,
+    mean, var, eps) tuples.  Bit-identical to the three fused conv+BN launches."""
+    lib = L.get_lib()
+    N, cin, P = x8.shape
+    (h, w), = levels
+    mid = convs[0].shape[0]
+    b = L.BottleneckT()
+    b.N, b.H, b.W, b.Cin, b.mid = N, h, w, cin, mid
+    keep = []
+    for i, (wt, bn) in enumerate(zip(convs, bns)):
+        img, _ = weight_images(wt, False, bf16=True)
+        scale, shift, _ = bn_prepare(*bn)
+        if scale.data_ptr() % 16 or shift.data_ptr() % 16:
+            scale, shift = scale.clone(), shift.clone()
+        keep += [img, scale, shift]
+        L.keep(img, scale, shift)
+        setattr(b, f'w{i + 1}', img.data_ptr())
+        setattr(b, f'scale{i + 1}', scale.data_ptr())
+        setattr(b, f'shift{i + 1}', shift.data_ptr())
+    y = torch.empty(N * cin * P, dtype=torch.bfloat16, device=x8.device)
+    L.check(lib.ld_bottleneck_c8_forward(C.byref(b), L.ptr(x8.buf), L.ptr(y),
+                                         L.stream_ptr(x8.device)),
+            'ld_bottleneck_c8_forward')
+    return C8Act(y, (N, cin, P)), levels
+
+
+# ---------------------------------------------------------------------------
 # GroupNorm + ReLU on level-concatenated tensors
 # ---------------------------------------------------------------------------
 def _c8_side_output(t):
@@ -1799,6 +1874,7 @@ def sgd_step(params_flat, grads_flat, momentum_flat, lr, momentum,
 # level packing: the shared head towers run on ONE level-concatenated tensor
 # ---------------------------------------------------------------------------
 def _level_ptrs(ts):
+    L.keep(*ts)
     return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
 
 

@@ -98,6 +98,15 @@ class BnFinJobT(C.Structure):  # ld_bn_fin_job_t
 LD_GRAD_DEFER = 2
 
 
+class BottleneckT(C.Structure):  # ld_bottleneck_t
+    _fields_ = [('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('Cin', C.c_int32), ('mid', C.c_int32), ('reserved', C.c_int32),
+                ('w1', C.c_void_p), ('w2', C.c_void_p), ('w3', C.c_void_p),
+                ('scale1', C.c_void_p), ('shift1', C.c_void_p),
+                ('scale2', C.c_void_p), ('shift2', C.c_void_p),
+                ('scale3', C.c_void_p), ('shift3', C.c_void_p)]
+
+
 class BnJobT(C.Structure):  # ld_bn_job_t
     _fields_ = [('gamma', C.c_void_p), ('beta', C.c_void_p),
                 ('mean', C.c_void_p), ('var', C.c_void_p),
@@ -291,6 +300,15 @@ SIGNATURES = {
     'ld_conv_bf16_tune_forward_c8': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
     'ld_conv_bf16_dgrad_c8': (C.c_int, [_CV, _vp, _vp, _vp, _vp]),
     'ld_conv_bf16_dgrad_c8_acc': (C.c_int, [_CV, _vp, _vp, _vp, _vp, _vp]),
+    'ld_record_begin': (C.c_int, []),
+    'ld_record_end': (C.c_int64, []),
+    'ld_record_abort': (C.c_int, []),
+    'ld_record_count': (C.c_int, [C.c_int64]),
+    'ld_record_replay': (C.c_int, [C.c_int64, _vp]),
+    'ld_record_free': (C.c_int, [C.c_int64]),
+    'ld_bottleneck_c8_supported': (C.c_int, [_i32, _i32, _i32, _i32]),
+    'ld_bottleneck_c8_forward': (C.c_int, [C.POINTER(BottleneckT), _vp, _vp,
+                                           _vp]),
     'ld_conv_bf16_tune_dgrad_c8': (C.c_int, [_CV, _vp, _vp, _vp, _vp]),
     'ld_conv_tune_load': (C.c_int, [C.c_char_p]),
     'ld_conv_tune_save': (C.c_int, [C.c_char_p]),
@@ -382,12 +400,53 @@ def require_device(t, dtype=None, name='tensor'):
     return t
 
 
+# While a launch list is being recorded (ld_record_begin .. ld_record_end, see
+# detectors.TeacherPlan) every tensor whose address goes to the library is kept
+# alive with the list: a replay re-issues the launches with these very pointers.
+_KEEP = [None]
+
+
 def ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    if t is None:
+        return C.c_void_p(0)
+    k = _KEEP[0]
+    if k is not None:
+        k.append(t)
+    return C.c_void_p(t.data_ptr())
+
+
+def keep(*ts):
+    """For call sites that put ``t.data_ptr()`` into a struct themselves."""
+    k = _KEEP[0]
+    if k is not None:
+        k.extend(t for t in ts if t is not None)
+
+
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
 def stream_ptr(device=None):
+    """The current HIP stream of ``device`` as a void*.  (torch.cuda.
+    current_stream() builds a Python Stream object per call: 4-5 us, ~420 calls
+    per step in the round-5 host profile; the raw accessor is a plain C call.)"""
+    if isinstance(device, torch.device) and device.type != 'cuda':
+        return C.c_void_p(0)
+    if _RAW_STREAM is not None:
+        if device is None:
+            idx = torch.cuda.current_device()
+        elif isinstance(device, int):
+            idx = device
+        else:
+            idx = device.index
+            if idx is None:
+                idx = torch.cuda.current_device()
+        return C.c_void_p(_RAW_STREAM(idx))
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def stream_id(device=None):
+    """An integer identifying the current stream (cache keys)."""
+    return stream_ptr(device).value or 0
 
 
 def make_geom(featmap_sizes, strides, num_imgs, anchor_scale=8):

@@ -24,7 +24,7 @@ def workspace(device, nbytes, tag='ws'):
     """A cached scratch buffer (never shrinks), private to (device, current
     stream, tag): the teacher runs on its own stream concurrently with the
     student, so scratch must not be shared across streams."""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag)
+    key = (device, L.stream_id(device), tag)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
         if t is not None:

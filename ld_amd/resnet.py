@@ -138,7 +138,30 @@ class Bottleneck(nn.Module):
     def norm3(self):
         return getattr(self, self.norm3_name)
 
+    def _fusable(self):
+        """An identity block of plain convs with eval-mode norms: what
+        layers.bottleneck_c8_forward runs as one launch when the trunk is frozen
+        and C8-only (the R101 teacher's layer3, bf16 mode)."""
+        ok = getattr(self, '_ld_fusable', None)
+        if ok is None:
+            ok = self.downsample is None and not self.with_dcn and \
+                all(type(c) is Conv2d and c.bias is None and c.stride[0] == 1
+                    for c in (self.conv1, self.conv2, self.conv3)) and \
+                self.conv2.padding[0] == 1 and type(self) is Bottleneck
+            self._ld_fusable = ok
+        return ok and not any(n.training for n in
+                              (self.norm1, self.norm2, self.norm3))
+
     def forward3(self, x3, levels):
+        if isinstance(x3, Y.C8Act) and not torch.is_grad_enabled() and \
+                self._fusable() and Y.fused_bottleneck_available(
+                    x3, self.conv1.weight.shape[1], self.conv1.weight.shape[0],
+                    levels):
+            return Y.bottleneck_c8_forward(
+                x3, levels,
+                [c.weight for c in (self.conv1, self.conv2, self.conv3)],
+                [(n.weight, n.bias, n.running_mean, n.running_var, n.eps)
+                 for n in (self.norm1, self.norm2, self.norm3)])
         out, lv = _conv_bn(x3, levels, self.conv1, self.norm1)
         out, lv = _conv_bn(out, lv, self.conv2, self.norm2)
         identity = x3
