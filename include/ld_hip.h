@@ -754,6 +754,13 @@ int ld_bn_bwd_finalize_batch(const ld_bn_fin_job_t* jobs, const int32_t* block_j
 /* db[c] = sum_{n,p} dy (conv bias gradient, fpn.py / gfl_cls / gfl_reg). */
 int ld_bias_grad(const float* dy, int N, int C, int P, float* db, int accumulate,
                  ld_stream_t stream);
+/* The same sum as [C][nsplit] fp64 partial pairs (sum, 0), nsplit =
+ * ld_bias_grad_nsplit(N, C, P), for ld_bn_bwd_finalize_batch (a job with dgamma ==
+ * NULL, dbeta = db): the bias gradients of a bucket are finalised with its norm
+ * gradients in one launch. */
+int ld_bias_grad_nsplit(int N, int C, int P);
+int ld_bias_grad_partial(const float* dy, int N, int C, int P, void* partial,
+                         size_t partial_bytes, ld_stream_t stream);
 /* GroupNorm(G) (+ReLU) applied per FPN level of a level-concatenated tensor
  * (gfl_head.py:102-126: each level is normalised on its own).  mean/rstd:
  * (N, G, num_levels) outputs kept for the backward. */

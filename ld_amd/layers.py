@@ -1036,12 +1036,20 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b,
                 # GEMM epilogue (fan protocol above)
                 if addend.numel() != dx.numel() or not addend.is_contiguous():
                     raise L.LdError('conv dgrad: addend shape mismatch')
+                if stride == 2 and kh == 1 and getattr(addend, '_ld_fresh',
+                                                       False):
+                    # 1x1 stride 2 reaches a quarter of the positions; the rest
+                    # of dx IS the addend -- accumulate in place into the
+                    # (exclusively owned) buffer another conv's data gradient
+                    # deposited instead of copying it first
+                    dx = addend.view(dx.shape)
                 L.check(dgrad_acc(C.byref(d), L.ptr(dyin), L.ptr(wt_bwd),
                                   L.ptr(addend), L.ptr(dx), st),
                         'ld_conv_dgrad_acc')
             else:
                 L.check(dgrad(C.byref(d), L.ptr(dyin), L.ptr(wt_bwd),
                               L.ptr(dx), st), 'ld_conv_dgrad')
+        dx._ld_fresh = True  # nobody else holds this tensor yet
     pw, pb = params
     if need_w:
         sink = _sink(pw)
@@ -1122,6 +1130,25 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b,
             _emit(pw)
     if has_bias and need_b:
         sink = _sink(pb)
+        if sink is not None and _DEFER_ON[0]:
+            # per-channel partial sums now, finalised with the bucket's norm
+            # gradients (ld_bn_bwd_finalize_batch, a job without dgamma)
+            if any(j.dbeta == sink.data_ptr() for j, _ in _DEFER_B):
+                flush_deferred()
+            ns = lib.ld_bias_grad_nsplit(N, cout, dy.shape[2])
+            part = _defer_buffer(pb, '_ld_bias_partial', cout * ns * 16,
+                                 dy.device)
+            L.check(lib.ld_bias_grad_partial(L.ptr(dy), N, cout, dy.shape[2],
+                                             L.ptr(part), part.numel(), st),
+                    'ld_bias_grad_partial')
+            job = L.BnFinJobT()
+            job.partial, job.dgamma, job.dbeta = (part.data_ptr(), None,
+                                                  sink.data_ptr())
+            job.C, job.nsplit, job.accumulate = cout, ns, 1
+            _DEFER_B.append((job, dy.device))
+            DEFER_STATS['bn_jobs'] += 1
+            _emit(pb)
+            return dx, dw, None
         db = sink if sink is not None else \
             torch.empty(cout, dtype=torch.float32, device=dy.device)
         L.check(lib.ld_bias_grad(L.ptr(dy), N, cout, dy.shape[2],

@@ -318,6 +318,8 @@ SIGNATURES = {
                                         C.POINTER(WgradJobT), _vp]),
     'ld_wgrad_reduce_batch': (C.c_int, [_vp, _vp, _i32, _vp]),
     'ld_bn_act_backward_nsplit': (C.c_int, [_i32, _i32, _i32, _i32]),
+    'ld_bias_grad_nsplit': (C.c_int, [_i32, _i32, _i32]),
+    'ld_bias_grad_partial': (C.c_int, [_vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     'ld_bn_bwd_finalize_batch': (C.c_int, [_vp, _vp, _i32, _vp]),
     'ld_conv_tune_wgrad_workspace_bytes': (_sz, [_CV]),
     'ld_conv_wgrad': (C.c_int, [_CV, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),

@@ -436,6 +436,17 @@ class SGDTrainer:
                     num_samples=len(data['img_metas']))
 
 
+def _capture_mode():
+    """hipStreamCaptureMode for the step captures.  Under a process group RCCL's
+    watchdog THREAD polls the events of earlier collectives; in the default
+    'global' mode such a query from another thread while this thread captures is an
+    error that takes the process down ("operation not permitted when stream is
+    capturing", seen in round 5 as a race in tests/test_gpu_graph_pg.py).
+    'thread_local' restricts the checks to the capturing thread."""
+    return 'thread_local' if dist.is_available() and dist.is_initialized() \
+        else 'global'
+
+
 class GraphedStep:
     """The steady-state train step captured ONCE into a hipGraph and replayed:
     ~750 launches per step (conv / norm / loss / optimizer kernels, the
@@ -518,7 +529,8 @@ class GraphedStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):
+        with torch.cuda.graph(self.graph, stream=side,
+                              capture_error_mode=_capture_mode()):
             out = trainer.step(self.data)
         self._loss = out['loss']
         lv = out['log_vars']
@@ -628,7 +640,8 @@ class PipelinedGraphedStep:
         self.graphs, self.outs = [], []
         for k in (0, 1):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=cap):
+            with torch.cuda.graph(g, stream=cap,
+                                  capture_error_mode=_capture_mode()):
                 out = self._one(k)
             lv = out['log_vars']
             self.graphs.append(g)
