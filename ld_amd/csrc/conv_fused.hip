@@ -18,7 +18,7 @@
 // CU).  The mid activations never leave the CU:
 //   G1  h1 on the tile + 1-pixel halo (6 x 18 = 108 positions, padded to 128
 //       GEMM columns): [256 x 1024] x [1024 x 128].  x arrives as the C8 image,
-//       64 channels at a time through a double-buffered LDS image [k8][128][8]
+//       128 channels at a time through a double-buffered LDS image [k8][128][8]
 //       (the MFMA B layout: fragments are conflict-free ds_read_b128).  h1 ->
 //       bf16 -> LDS [32][128][8]; halo positions outside the image are ZERO
 //       (conv2's padding pads h1, not x).
@@ -72,7 +72,7 @@ constexpr int kHW = kTW + 2;                // halo row length (18)
 constexpr int kNH = (kTH + 2) * kHW;        // halo positions (108)
 constexpr int kNQ = 128;                    // ... padded to GEMM columns
 constexpr int kNP = kTH * kTW;              // output positions (64)
-constexpr int kKC = 64;                     // channels of x per LDS chunk
+constexpr int kKC = 128;                    // channels of x per LDS chunk (8 k16 steps)
 
 __device__ __forceinline__ uintx4 ldg16(rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(uintx4,
@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256, 1) void fused_bottleneck_c8_kernel(FusedK a) {
   uintx4* Xs = lds + M8 * kNQ;          // [2][kKC / 8][kNQ]
   uintx4* H2 = Xs;                      // [M8][kNP], after G1 (same 32 KB)
   static_assert(M8 * kNP <= 2 * (kKC / 8) * kNQ, "h2 must fit the x staging buffers");
+  static_assert(kKC % 64 == 0 && (kKC / 16) % 4 == 0, "ring slots repeat per chunk");
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -135,12 +136,12 @@ __global__ __launch_bounds__(256, 1) void fused_bottleneck_c8_kernel(FusedK a) {
     const unsigned vx = xok ? (unsigned)((n * C8 + xk) * P + xp) * 16u : kOOB;
     auto load_x = [&](int c, uintx4* xr, bool live) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < kKC / 16; ++i)
         xr[i] = ldg16(rx, live ? vx : kOOB, (unsigned)((c * (kKC / 8) + 2 * i) * P) * 16u);
     };
     auto store_x = [&](int buf, const uintx4* xr) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) Xs[(buf * (kKC / 8) + xk + 2 * i) * kNQ + xq] = xr[i];
+      for (int i = 0; i < kKC / 16; ++i) Xs[(buf * (kKC / 8) + xk + 2 * i) * kNQ + xq] = xr[i];
     };
     // weights: this wave's 64 rows, lane = (row l31, k half lk) of an M tile
     unsigned va[2];
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256, 1) void fused_bottleneck_c8_kernel(FusedK a) {
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int i = 0; i < 2; ++i) ar[s][i] = ldg16(rw1, va[i], (unsigned)(2 * s * MID) * 16u);
-    uintx4 xr[4];
+    uintx4 xr[kKC / 16];
     load_x(0, xr, true);
     store_x(0, xr);
     __syncthreads();
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256, 1) void fused_bottleneck_c8_kernel(FusedK a) {
     // Issue order is pinned with scheduling fences (hipcc otherwise sinks every
     // load below the MFMAs and waits for it at once -- ISA reading, as in
     // conv.hip's ring): per chunk  [x loads of chunk c + 1]  then per k16 step
-    // [fragment reads of step s + 1] [refill of the ring slot just taken] [8 MFMAs];
+    // [fragment reads of step s + 1] [8 MFMAs] [refill of the ring slot just used];
     // the x loads have a whole chunk (~1000 clk) to land before their LDS write, a
     // ring slot four steps.
     for (int c = 0; c < NCH; ++c) {
@@ -170,26 +171,28 @@ __global__ __launch_bounds__(256, 1) void fused_bottleneck_c8_kernel(FusedK a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) bf[0][j] = xb[lk * kNQ + j * 32 + l31];
       __builtin_amdgcn_sched_barrier(0);
+      constexpr int SPC = kKC / 16;  // k16 steps per chunk
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        if (s < 3) {
+      for (int s = 0; s < SPC; ++s) {
+        if (s + 1 < SPC) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             bf[(s + 1) & 1][j] = xb[(2 * (s + 1) + lk) * kNQ + j * 32 + l31];
         }
-        const int kn = (c + 1) * 4 + s;  // the step this ring slot serves next
+        const int kn = c * SPC + s + 4;  // the step this ring slot serves next
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          acc1[0][j] = mfma(ar[s][0], bf[s & 1][j], acc1[0][j]);
-          acc1[1][j] = mfma(ar[s][1], bf[s & 1][j], acc1[1][j]);
+          acc1[0][j] = mfma(ar[s & 3][0], bf[s & 1][j], acc1[0][j]);
+          acc1[1][j] = mfma(ar[s & 3][1], bf[s & 1][j], acc1[1][j]);
         }
         __builtin_amdgcn_sched_barrier(0);
         // refilled IN PLACE behind its MFMAs: the slot is the oldest load in flight
         // when it is needed again (exact vmcnt, no wait for younger slots)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          ar[s][i] = ldg16(rw1, kn < NSTEP ? va[i] : kOOB, (unsigned)(2 * kn * MID) * 16u);
+          ar[s & 3][i] =
+              ldg16(rw1, kn < NSTEP ? va[i] : kOOB, (unsigned)(2 * kn * MID) * 16u);
         __builtin_amdgcn_sched_barrier(0);
       }
       store_x((c + 1) & 1, xr);
@@ -199,13 +202,24 @@ __global__ __launch_bounds__(256, 1) void fused_bottleneck_c8_kernel(FusedK a) {
     bool qok[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) (void)halo_pos(j * 32 + l31, qok[j]);
+    // every load of the epilogue is issued before the first use (one exposed
+    // round trip instead of eight: a single wavefront per SIMD hides nothing)
+    floatx4_t sc1[2][4], sh1[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int row0 = wave * 64 + i * 32 + 8 * g + 4 * lk;
-        const floatx4_t sc = *reinterpret_cast<const floatx4_t*>(a.s1 + row0);
-        const floatx4_t sh = *reinterpret_cast<const floatx4_t*>(a.b1 + row0);
+        sc1[i][g] = *reinterpret_cast<const floatx4_t*>(a.s1 + row0);
+        sh1[i][g] = *reinterpret_cast<const floatx4_t*>(a.b1 + row0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row0 = wave * 64 + i * 32 + 8 * g + 4 * lk;
+        const floatx4_t sc = sc1[i][g], sh = sh1[i][g];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           floatx4_t v;
@@ -241,9 +255,14 @@ __global__ __launch_bounds__(256, 1) void fused_bottleneck_c8_kernel(FusedK a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) va[i] = (unsigned)(lk * MID + wave * 64 + i * 32 + l31) * 16u;
     constexpr int NSTEP = 9 * MID / 16;  // 144: the image is contiguous in k8 across taps
-    uintx4 ar[4][2];
+    // G2 / G3 steps are 4 MFMAs (128 clk) long: an 8-slot ring keeps a weight
+    // fragment ~1000 clk in flight, the L2 latency under load (a 4-slot ring, 512
+    // clk, stalled every step: the first version ran at 54 us per block)
+    constexpr int RD = 8;
+    static_assert(NSTEP % RD == 0 && (MID / 16) % RD == 0, "ring groups per tap");
+    uintx4 ar[RD][2];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < RD; ++s)
 #pragma unroll
       for (int i = 0; i < 2; ++i) ar[s][i] = ldg16(rw2, va[i], (unsigned)(2 * s * MID) * 16u);
     auto h1_frag = [&](int st, int j) -> uintx4 {  // B fragment of flat step st
@@ -254,14 +273,14 @@ __global__ __launch_bounds__(256, 1) void fused_bottleneck_c8_kernel(FusedK a) {
     uintx4 bf[2][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) bf[0][j] = h1_frag(0, j);
-    for (int g4 = 0; g4 < NSTEP / 4; ++g4) {
+    for (int g8 = 0; g8 < NSTEP / RD; ++g8) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int st = g4 * 4 + s;
+      for (int s = 0; s < RD; ++s) {
+        const int st = g8 * RD + s;
         const int sn = st + 1 < NSTEP ? st + 1 : st;  // the last prefetch is a repeat
 #pragma unroll
         for (int j = 0; j < 2; ++j) bf[(s + 1) & 1][j] = h1_frag(sn, j);
-        const int kn = st + 4;
+        const int kn = st + RD;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -275,13 +294,22 @@ __global__ __launch_bounds__(256, 1) void fused_bottleneck_c8_kernel(FusedK a) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    floatx4_t sc2[2][4], sh2[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int row0 = wave * 64 + i * 32 + 8 * g + 4 * lk;
-        const floatx4_t sc = *reinterpret_cast<const floatx4_t*>(a.s2 + row0);
-        const floatx4_t sh = *reinterpret_cast<const floatx4_t*>(a.b2 + row0);
+        sc2[i][g] = *reinterpret_cast<const floatx4_t*>(a.s2 + row0);
+        sh2[i][g] = *reinterpret_cast<const floatx4_t*>(a.b2 + row0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row0 = wave * 64 + i * 32 + 8 * g + 4 * lk;
+        const floatx4_t sc = sc2[i][g], sh = sh2[i][g];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           floatx4_t v;
@@ -298,14 +326,18 @@ __global__ __launch_bounds__(256, 1) void fused_bottleneck_c8_kernel(FusedK a) {
   // ======================= G3: y = relu(bn3(W3 h2) + x) =======================
   {
     // this lane's two output positions
-    bool pok[2];
-    size_t pbase[2];  // byte offset of (n, c8 = 0, p) in a C8 image, + the lane's half
+    // byte offset of (n, c8 = 0, p) in a C8 image + the lane's half; a position
+    // outside the image gets the out-of-range offset (loads 0, stores dropped: no
+    // branch, no exec mask in the pipelined region)
+    unsigned pbase[2];
+    const rsrc_t ry = make_rsrc(a.y, a.x_bytes);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int np = j * 32 + l31;
       const int ir = r0 + (np >> 4), ic = c0 + (np & 15);
-      pok[j] = ir < H && ic < W;
-      pbase[j] = ((size_t)n * C8 * P + (size_t)(ir * W + ic)) * 16 + lk * 8;
+      pbase[j] = ir < H && ic < W
+                     ? (unsigned)(((size_t)n * C8 * P + (size_t)(ir * W + ic)) * 16 + lk * 8)
+                     : kOOB;
     }
     constexpr int NSTEP = 4 * (MID / 16);  // 4 passes of 64 rows x 16 k16 steps
     auto va3 = [&](int f, int i) -> unsigned {  // weight row of flat step f
@@ -315,66 +347,81 @@ __global__ __launch_bounds__(256, 1) void fused_bottleneck_c8_kernel(FusedK a) {
     auto so3 = [&](int f) -> unsigned {
       return (unsigned)(2 * (f % (MID / 16)) * CIN) * 16u;
     };
-    uintx4 ar[4][2];
+    constexpr int RD = 8;
+    static_assert((MID / 16) % RD == 0, "ring groups per pass");
+    uintx4 ar[RD][2];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < RD; ++s)
 #pragma unroll
       for (int i = 0; i < 2; ++i) ar[s][i] = ldg16(rw3, va3(s, i), so3(s));
     floatx16 acc3[2][2];
     uintx4 bf[2][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) bf[0][j] = H2[lk * kNP + j * 32 + l31];
-    for (int g4 = 0; g4 < NSTEP / 4; ++g4) {
-      const int mc = g4 / (MID / 64);
-      const int kk0 = (g4 % (MID / 64)) * 4;
-      if (kk0 == 0) {
+    constexpr int GPP = MID / 16 / RD;  // ring groups per pass (2)
+    for (int mc = 0; mc < 4; ++mc) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc3[i][j][r] = 0.0f;
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int kn1 = (kk0 + s + 1) % (MID / 16);  // next step's k (wraps into the next pass)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          bf[(s + 1) & 1][j] = H2[(2 * kn1 + lk) * kNP + j * 32 + l31];
-        const int fn = g4 * 4 + s + 4;
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc3[0][j] = mfma(ar[s][0], bf[s & 1][j], acc3[0][j]);
-          acc3[1][j] = mfma(ar[s][1], bf[s & 1][j], acc3[1][j]);
+          for (int r = 0; r < 16; ++r) acc3[i][j][r] = 0.0f;
+      // the pass's epilogue operands (bn3 coefficients, the identity as 8-byte C8
+      // halves) are requested under its LAST ring group: older than that group's
+      // refills in the load queue, they have landed when the epilogue starts
+      floatx4_t sc3[2][4], sh3[2][4];
+      uintx2 rr[2][4][2];
+#pragma unroll
+      for (int gp = 0; gp < GPP; ++gp) {
+        const int kk0 = gp * RD;
+        if (gp == GPP - 1) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int row0 = wave * 256 + mc * 64 + i * 32 + 8 * g + 4 * lk;
+              const unsigned crow = (unsigned)(row0 >> 3) * (unsigned)P * 16u;
+              sc3[i][g] = *reinterpret_cast<const floatx4_t*>(a.s3 + row0);
+              sh3[i][g] = *reinterpret_cast<const floatx4_t*>(a.b3 + row0);
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                rr[i][g][j] = __builtin_bit_cast(
+                    uintx2, __builtin_amdgcn_raw_buffer_load_b64(rx, pbase[j], crow, 0));
+            }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-          ar[s][i] = ldg16(rw3, fn < NSTEP ? va3(fn, i) : kOOB, fn < NSTEP ? so3(fn) : 0u);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < RD; ++s) {
+          const int kn1 = (kk0 + s + 1) % (MID / 16);  // next step's k (wraps into the next pass)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            bf[(s + 1) & 1][j] = H2[(2 * kn1 + lk) * kNP + j * 32 + l31];
+          const int fn = (mc * GPP + gp) * RD + s + RD;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc3[0][j] = mfma(ar[s][0], bf[s & 1][j], acc3[0][j]);
+            acc3[1][j] = mfma(ar[s][1], bf[s & 1][j], acc3[1][j]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            ar[s][i] = ldg16(rw3, fn < NSTEP ? va3(fn, i) : kOOB, fn < NSTEP ? so3(fn) : 0u);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      if (kk0 + 4 < MID / 16) continue;
       // pass complete: bn3 + identity + ReLU -> the C8 image of y
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int row0 = wave * 256 + mc * 64 + i * 32 + 8 * g + 4 * lk;
-          const size_t crow = (size_t)(row0 >> 3) * P * 16;
-          const floatx4_t sc = *reinterpret_cast<const floatx4_t*>(a.s3 + row0);
-          const floatx4_t sh = *reinterpret_cast<const floatx4_t*>(a.b3 + row0);
-          uintx2 rraw[2];
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            rraw[j] = pok[j] ? *reinterpret_cast<const uintx2*>(
-                                   reinterpret_cast<const char*>(a.x) + pbase[j] + crow)
-                             : uintx2{0u, 0u};
+          const unsigned crow = (unsigned)(row0 >> 3) * (unsigned)P * 16u;
+          const floatx4_t sc = sc3[i][g], sh = sh3[i][g];
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            if (!pok[j]) continue;
             const floatx4_t rq =
-                __builtin_convertvector(__builtin_bit_cast(bf16x4, rraw[j]), floatx4_t);
+                __builtin_convertvector(__builtin_bit_cast(bf16x4, rr[i][g][j]), floatx4_t);
             floatx4_t v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -382,15 +429,16 @@ __global__ __launch_bounds__(256, 1) void fused_bottleneck_c8_kernel(FusedK a) {
               u += rq[e];
               v[e] = fmaxf(u, 0.0f);
             }
-            *reinterpret_cast<uintx2*>(reinterpret_cast<char*>(a.y) + pbase[j] + crow) =
-                __builtin_bit_cast(uintx2, __builtin_convertvector(v, bf16x4));
+            __builtin_amdgcn_raw_buffer_store_b64(
+                __builtin_bit_cast(uintx2, __builtin_convertvector(v, bf16x4)), ry, pbase[j],
+                crow, 0);
           }
         }
     }
   }
 }
 
-constexpr size_t kFusedLds = ((size_t)(256 / 8) * kNQ + 2 * (kKC / 8) * kNQ) * 16;  // 96 KB
+constexpr size_t kFusedLds = ((size_t)(256 / 8) * kNQ + 2 * (kKC / 8) * kNQ) * 16;  // 128 KB
 
 }  // namespace
 
