@@ -72,11 +72,6 @@ def parse():
     ap.add_argument('--profile-steps', type=int, default=2)
     ap.add_argument('--no-graph', action='store_true',
                     help='skip the hipGraph-replay leg')
-    ap.add_argument('--graph-multi', action='store_true',
-                    help='run the hipGraph-replay leg with N > 1 ranks too (RCCL '
-                    'all-reduces issued on the capturing stream: exercised only '
-                    'through a forced-collective 1-rank group so far, off by '
-                    'default so that an untested path cannot hang a scaling run)')
     ap.add_argument('--no-bf16', action='store_true',
                     help='skip the bf16 (BASELINE config 3) leg')
     ap.add_argument('--no-prefetch', action='store_true',
@@ -719,7 +714,9 @@ def main():
     # ~750 launches of a step cost ~13 ms of Python + ctypes on the host, which
     # binds once the kernels are faster than that).  Reported beside the eager
     # numbers; `value` stays the eager fp32 step.
-    if not args.no_graph and (world == 1 or args.graph_multi):
+    # (not with N > 1 ranks: a captured step would contain RCCL collectives, which
+    # train.GraphedStep refuses -- they race with ProcessGroupNCCL's watchdog)
+    if not args.no_graph and world == 1 and not os.environ.get('LD_FORCE_COLLECTIVES') == '1':
         from ld_amd import layers as Y
         from ld_amd.train import GraphedStep
         graph_res = {}

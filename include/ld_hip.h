@@ -815,6 +815,12 @@ int ld_pack_levels(const ld_levels_t* lv, const float* const* levels, int rows,
                    float* x3, ld_stream_t stream);
 int ld_unpack_levels(const ld_levels_t* lv, const float* x3, int rows,
                      float* const* levels, ld_stream_t stream);
+/* The same with the bf16 C8 image ((N, C/8, len, 8), see ld_conv_to_c8) of the
+ * destination as a side output: x3_c8 for pack, levels_c8[l] for unpack; C % 8 == 0. */
+int ld_pack_levels_c8(const ld_levels_t* lv, const float* const* levels, int N, int C,
+                      float* x3, void* x3_c8, ld_stream_t stream);
+int ld_unpack_levels_c8(const ld_levels_t* lv, const float* x3, int N, int C,
+                        float* const* levels, void* const* levels_c8, ld_stream_t stream);
 /* mmcv Scale per level (gfl_head.py:182): y = x * scales[level]. */
 int ld_scale_levels_forward(const ld_levels_t* lv, const float* x,
                             const float* scales, int rows, float* y,

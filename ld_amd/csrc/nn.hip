@@ -973,6 +973,46 @@ __global__ __launch_bounds__(256) void pack_levels_kernel(Levels lv, LevelPtrs l
   else *a = *b;
 }
 
+// The same with the bf16 C8 image of the destination as a side output (bf16 mode:
+// the packed head input feeds the first tower convs, the unpacked level gradients
+// feed the neck convs' data / weight gradients -- no conversion launch): thread =
+// (n, 8 channels, one position); c8_levels[l] / x3_c8 = (N, C/8, len, 8) images.
+typedef float pk_floatx8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pk_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned pk_uintx4 __attribute__((ext_vector_type(4)));
+struct LevelC8Ptrs {
+  pk_uintx4* p[LD_MAX_LEVELS];
+};
+template <bool PACK>
+__global__ __launch_bounds__(256) void pack_levels_c8_kernel(Levels lv, LevelPtrs lp, int C,
+                                                             float* __restrict__ x3,
+                                                             LevelC8Ptrs c8l,
+                                                             pk_uintx4* __restrict__ x3_c8) {
+  const int C8 = C >> 3;
+  const int blk = blockIdx.y;  // n * C8 + c8
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= lv.P) return;
+  const int l = level_of_pos(lv, p);
+  const int len = lv.off[l + 1] - lv.off[l], q = p - lv.off[l];
+  pk_floatx8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const size_t row = (size_t)blk * 8 + e;  // n * C + c
+    float* a = lp.p[l] + row * len + q;
+    float* b = x3 + row * lv.P + p;
+    if (PACK) {
+      v[e] = *a;
+      *b = v[e];
+    } else {
+      v[e] = *b;
+      *a = v[e];
+    }
+  }
+  const pk_uintx4 w = __builtin_bit_cast(pk_uintx4, __builtin_convertvector(v, pk_bf16x8));
+  if (PACK) x3_c8[(size_t)blk * lv.P + p] = w;
+  else c8l.p[l][(size_t)blk * len + q] = w;
+}
+
 // ------------------------------------------------------------- Scale layer --
 // y[n,c,p] = x[n,c,p] * scale[level(p)]
 __global__ __launch_bounds__(256) void scale_levels_kernel(
@@ -1520,6 +1560,40 @@ int pack_levels_run(const ld_levels_t* lv, float* const* levels, int rows, float
   return (int)hipGetLastError();
 }
 }  // namespace
+
+namespace {
+template <bool PACK>
+int pack_levels_c8_run(const ld_levels_t* lv, float* const* levels, int N, int C, float* x3,
+                       void* const* levels_c8, void* x3_c8, ld_stream_t stream) {
+  if (int e = check_levels(lv)) return e;
+  if (!levels || !x3 || N < 1 || C < 8 || C % 8 != 0) return LD_EINVAL;
+  if (PACK ? !x3_c8 : !levels_c8) return LD_EINVAL;
+  LevelPtrs lp{};
+  LevelC8Ptrs lc{};
+  for (int l = 0; l < lv->num_levels; ++l) {
+    if (!levels[l] || (!PACK && !levels_c8[l])) return LD_EINVAL;
+    lp.p[l] = levels[l];
+    if (!PACK) lc.p[l] = (pk_uintx4*)levels_c8[l];
+  }
+  const Levels k = make_levels(lv);
+  LD_LAUNCH(pack_levels_c8_kernel<PACK>, dim3((k.P + 255) / 256, N * (C / 8)), dim3(256), 0,
+            LD_STREAM, k, lp, C, x3, lc, (pk_uintx4*)x3_c8);
+  return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int ld_pack_levels_c8(const ld_levels_t* lv, const float* const* levels, int N,
+                                 int C, float* x3, void* x3_c8, ld_stream_t stream) {
+  return pack_levels_c8_run<true>(lv, const_cast<float* const*>(levels), N, C, x3, nullptr,
+                                  x3_c8, stream);
+}
+
+extern "C" int ld_unpack_levels_c8(const ld_levels_t* lv, const float* x3, int N, int C,
+                                   float* const* levels, void* const* levels_c8,
+                                   ld_stream_t stream) {
+  return pack_levels_c8_run<false>(lv, levels, N, C, const_cast<float*>(x3), levels_c8,
+                                   nullptr, stream);
+}
 
 extern "C" int ld_pack_levels(const ld_levels_t* lv, const float* const* levels, int rows,
                               float* x3, ld_stream_t stream) {

@@ -328,7 +328,10 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
         if len(pl['slots']) < self.TEACHER_SLOTS:
             sl = dict(img=torch.empty_like(img), keep=[])
             sl['img'].copy_(img)
+            from . import lossblock as LB
             L._KEEP[0] = sl['keep']
+            # scratch buffers private to this list (lossblock.workspace)
+            LB._WS_SCOPE[0] = ('teacher-list', id(self), key, len(pl['slots']))
             L.check(lib.ld_record_begin(), 'ld_record_begin')
             try:
                 with torch.no_grad():
@@ -339,6 +342,7 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
                 raise
             finally:
                 L._KEEP[0] = None
+                LB._WS_SCOPE[0] = None
             sl['handle'] = lib.ld_record_end()
             if sl['handle'] <= 0:
                 raise L.LdError(f'ld_record_end failed ({sl["handle"]})')

@@ -251,6 +251,14 @@ if _C8_ALL:
 
 def _c8_cached(x3):
     hit = getattr(x3, '_ld_c8', None)
+    if hit is None:
+        # a reshape-view of the tensor the producer attached the image to (a stage
+        # output handed to the neck as (N, C, H, W) and flattened again by the
+        # lateral conv): same memory, same image
+        b = getattr(x3, '_base', None)
+        if b is not None and b.numel() == x3.numel() and \
+                b.data_ptr() == x3.data_ptr() and x3.is_contiguous():
+            hit = getattr(b, '_ld_c8', None)
     if hit is not None and hit[0] == (x3._version, x3.data_ptr()):
         return hit[1]
     return None
@@ -262,10 +270,10 @@ C8_STATS = dict(converted=0, reused=0)
 def to_c8(x3):
     """bf16 (N, C/8, P, 8) image of an fp32 (N, C, P) tensor (cached)."""
     key = (x3._version, x3.data_ptr())
-    hit = getattr(x3, '_ld_c8', None)
-    if hit is not None and hit[0] == key:
+    img = _c8_cached(x3)
+    if img is not None:
         C8_STATS['reused'] += 1
-        return hit[1]
+        return img
     C8_STATS['converted'] += 1
     N, Cc, P = x3.shape
     out = torch.empty(N * Cc * P, dtype=torch.bfloat16, device=x3.device)
@@ -773,13 +781,18 @@ def _defer_table(jobs, blocks_of, device):
     key = (str(device), bytes(b''.join(bytes(j) for j in jobs)))
     hit = _DEFER_TABLES.get(key)
     if hit is None:
-        if len(_DEFER_TABLES) > 256:
-            _DEFER_TABLES.clear()
+        if torch.cuda.is_current_stream_capturing():
+            # a table is an H2D copy from a host temporary: recorded into a graph
+            # it would be re-read from freed memory at every replay.  The warm-up
+            # steps before a capture take the capture's code paths, so this only
+            # happens when they did not (loud, not a wrong gradient)
+            raise L.LdError(
+                'deferred-gradient job table of %d jobs was not built during the '
+                'warm-up that preceded this hipGraph capture' % len(jobs))
         structs = [type(j).from_buffer_copy(bytes(j)) for j in jobs]
         hit = _job_table(structs, blocks_of, device)
         DEFER_STATS['tables_built'] += 1
-        if not torch.cuda.is_current_stream_capturing():
-            _DEFER_TABLES[key] = hit
+        _DEFER_TABLES[key] = hit
     return hit
 
 
@@ -897,6 +910,7 @@ def wgrad_join(device=None):
 # collected by the end of the backward pass raises (a consumer's branch did not
 # take part in this backward: the gradient would be silently incomplete).
 _FAN_ON = [os.environ.get('LD_FAN_FUSE', '1') == '1']
+_FAN_INPLACE = [os.environ.get('LD_FAN_INPLACE', '1') == '1']
 _FAN_OPEN = []
 FAN_STATS = dict(fused=0, fallback_adds=0)
 
@@ -1036,8 +1050,8 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b,
                 # GEMM epilogue (fan protocol above)
                 if addend.numel() != dx.numel() or not addend.is_contiguous():
                     raise L.LdError('conv dgrad: addend shape mismatch')
-                if stride == 2 and kh == 1 and getattr(addend, '_ld_fresh',
-                                                       False):
+                if stride == 2 and kh == 1 and _FAN_INPLACE[0] and \
+                        getattr(addend, '_ld_fresh', False):
                     # 1x1 stride 2 reaches a quarter of the positions; the rest
                     # of dx IS the addend -- accumulate in place into the
                     # (exclusively owned) buffer another conv's data gradient
@@ -1912,6 +1926,15 @@ def _pack_launch(feats, levels):
     x3 = torch.empty((N, c, P), dtype=torch.float32, device=f0.device)
     fs = [_dev_f32(f, 'level map') for f in feats]
     lv = levels_desc(levels)
+    if _C8[0] and _PRECISION[0] == 'bf16' and c % 32 == 0:
+        # bf16 mode: the C8 image of the packed tensor from the same launch (the
+        # first tower convs read it)
+        x8 = torch.empty(N * c * P, dtype=torch.bfloat16, device=f0.device)
+        L.check(L.get_lib().ld_pack_levels_c8(
+            C.byref(lv), _level_ptrs(fs), N, c, L.ptr(x3), L.ptr(x8),
+            L.stream_ptr(f0.device)), 'ld_pack_levels_c8')
+        _attach_c8(x3, x8)
+        return x3
     L.check(L.get_lib().ld_pack_levels(C.byref(lv), _level_ptrs(fs), N * c,
                                        L.ptr(x3), L.stream_ptr(f0.device)),
             'ld_pack_levels')
@@ -1936,9 +1959,20 @@ class PackLevelsFn(torch.autograd.Function):
         outs = [torch.empty((N, c, h, w), dtype=torch.float32,
                             device=dx3.device) for h, w in ctx.levels]
         lv = levels_desc(ctx.levels)
-        L.check(L.get_lib().ld_unpack_levels(
-            C.byref(lv), L.ptr(dx3), N * c, _level_ptrs(outs),
-            L.stream_ptr(dx3.device)), 'ld_unpack_levels')
+        if _C8[0] and _PRECISION[0] == 'bf16' and c % 32 == 0:
+            # the level gradients feed the neck convs' C8 data / weight gradients
+            o8 = [torch.empty(N * c * h * w, dtype=torch.bfloat16,
+                              device=dx3.device) for h, w in ctx.levels]
+            L.check(L.get_lib().ld_unpack_levels_c8(
+                C.byref(lv), L.ptr(dx3), N, c, _level_ptrs(outs),
+                _level_ptrs(o8), L.stream_ptr(dx3.device)),
+                'ld_unpack_levels_c8')
+            for o, b in zip(outs, o8):
+                _attach_c8(o, b)
+        else:
+            L.check(L.get_lib().ld_unpack_levels(
+                C.byref(lv), L.ptr(dx3), N * c, _level_ptrs(outs),
+                L.stream_ptr(dx3.device)), 'ld_unpack_levels')
         return (None, ) + tuple(fan_give(f, o)
                                 for f, o in zip(ctx.fans, outs))
 

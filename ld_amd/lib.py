@@ -360,6 +360,11 @@ SIGNATURES = {
                                                _vp, _vp, _vp]),
     'ld_pack_levels': (C.c_int, [_LV, C.POINTER(C.c_void_p), _i32, _vp, _vp]),
     'ld_unpack_levels': (C.c_int, [_LV, _vp, _i32, C.POINTER(C.c_void_p), _vp]),
+    'ld_pack_levels_c8': (C.c_int, [_LV, C.POINTER(C.c_void_p), _i32, _i32, _vp,
+                                    _vp, _vp]),
+    'ld_unpack_levels_c8': (C.c_int, [_LV, _vp, _i32, _i32,
+                                      C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_void_p), _vp]),
     'ld_scale_levels_forward': (C.c_int, [_LV, _vp, _vp, _i32, _vp, _vp]),
     'ld_scale_levels_backward_workspace_bytes': (_sz, [_LV]),
     'ld_scale_levels_backward': (C.c_int, [_LV, _vp, _vp, _vp, _i32, _vp, _vp,

@@ -18,13 +18,21 @@ _WS = {}
 # slabs into memory the allocator has handed to someone else.  Sizes
 # only grow, so the list stays short.
 _WS_RETIRED = []
+_WS_SCOPE = [None]
 
 
 def workspace(device, nbytes, tag='ws'):
     """A cached scratch buffer (never shrinks), private to (device, current
     stream, tag): the teacher runs on its own stream concurrently with the
     student, so scratch must not be shared across streams."""
-    key = (device, L.stream_id(device), tag)
+    # a launch list being recorded (detectors._teacher_replay) is replayed later on
+    # whatever stream the teacher runs on: its scratch must belong to the LIST, not
+    # to the stream it happened to be recorded on (round 5: lists recorded on the
+    # capture stream and replayed on the teacher stream shared the student's
+    # GroupNorm scratch -- an intermittent 1e-5 mismatch of every parameter)
+    scope = _WS_SCOPE[0]
+    key = (device, scope, tag) if scope is not None else \
+        (device, L.stream_id(device), tag)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
         if t is not None:

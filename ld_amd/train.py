@@ -436,6 +436,24 @@ class SGDTrainer:
                     num_samples=len(data['img_metas']))
 
 
+def _refuse_collectives_in_capture(what):
+    """RCCL collectives inside a hipGraph capture: measured in round 5 under a
+    one-rank RCCL group with the collectives forced (the only form a one-GPU box
+    admits): the captured step replays bit-identical to the eager one when it
+    works, but 2 of 3 runs died in ProcessGroupNCCL's WATCHDOG thread, which polls
+    the events of collective work objects from another thread -- "operation not
+    permitted when stream is capturing" in the default capture mode, "operation not
+    permitted on an event last recorded in a capturing stream" in thread-local
+    mode.  Not something this library can order, so it is refused unless
+    LD_GRAPH_COLLECTIVES=1 (experiments)."""
+    if collectives_on() and os.environ.get('LD_GRAPH_COLLECTIVES') != '1':
+        raise RuntimeError(
+            f'{what}: capturing a train step that issues RCCL collectives is '
+            'refused (it races with ProcessGroupNCCL\'s watchdog thread on this '
+            'stack); multi-process jobs step eagerly -- AutoStepper does that by '
+            'default -- or set LD_GRAPH_COLLECTIVES=1 to try')
+
+
 def _capture_mode():
     """hipStreamCaptureMode for the step captures.  Under a process group RCCL's
     watchdog THREAD polls the events of earlier collectives; in the default
@@ -477,20 +495,18 @@ class GraphedStep:
     Every launch entry point of libldhip.so only enqueues (no timing, no
     synchronisation: include/ld_hip.h), which is what makes the step capturable;
     shape tuning must have happened before (ld_conv_tune_* refuse a capturing
-    stream).  Under a process group the bucketed RCCL all-reduces are issued on
-    the capturing streams like any other launch and become graph nodes:
-    tests/test_gpu_graph_pg.py captures the step under an RCCL group (one rank,
-    collectives forced -- the only form a one-GPU box admits) with 8 hardware
-    queues and replays it bit-identical to the eager steps; a multi-GPU node was
-    never available to this build, so bench.py keeps the graph leg off for N > 1
-    unless asked (--graph-multi).  ``warmup_collectives = False`` runs the
-    warm-up steps without collectives (see ``suspend_collectives``): for captures
-    that only this rank performs.
+    stream).  Under a process group the captured step would contain the bucketed
+    RCCL all-reduces; that is REFUSED (see ``_refuse_collectives_in_capture``: it
+    races with ProcessGroupNCCL's watchdog thread) -- multi-process jobs step
+    eagerly, which round 5 made GPU-bound in bf16 as well.  ``warmup_collectives =
+    False`` runs the warm-up steps without collectives (see
+    ``suspend_collectives``): for captures that only this rank performs.
     """
 
     def __init__(self, trainer, data, warmup=2, max_gt=128,
                  warmup_collectives=True):
         from . import lossblock as LB
+        _refuse_collectives_in_capture('GraphedStep')
         _warn_graph_queues('GraphedStep')
         self.trainer = trainer
         dev = data['img'].device
@@ -594,6 +610,7 @@ class PipelinedGraphedStep:
 
     def __init__(self, trainer, first, second, warmup=1, max_gt=128):
         from . import lossblock as LB
+        _refuse_collectives_in_capture('PipelinedGraphedStep')
         _warn_graph_queues('PipelinedGraphedStep')
         self.trainer = trainer
         model = trainer.model
@@ -718,15 +735,20 @@ class AutoStepper:
     def __init__(self, trainer, mode=None, warmup=1, max_gt=128, max_graphs=6):
         if mode is None:
             on_gpu = next(trainer.model.parameters()).is_cuda
-            # bf16: the graph path, also in a multi-process job (BASELINE config
-            # 3's form) -- a process group needs 8 hardware queues for the step's
-            # streams to overlap next to RCCL's, and with DEBUG_HIP_FORCE_GRAPH_
-            # QUEUES=2 beside it a replay keeps its speed (round 4 had to fall
-            # back to the eager step here; tests/test_gpu_graph_pg.py replays a
-            # step captured WITH its bucket all-reduces under an RCCL group bit
-            # for bit).  A runtime configured otherwise enqueues eagerly.
+            # bf16, single process: the graph path.  A multi-process job (BASELINE
+            # config 3's form) enqueues EAGERLY, for two measured reasons (round
+            # 5): (i) with the frozen teacher replayed from launch lists the eager
+            # bf16 step is no longer host-bound (host enqueue 13.7 -> 10.8 ms for a
+            # 13.6 ms step; eager 146.5 img/s vs 140.6 / 147.3 as one / two
+            # hipGraphs, profiles/r05_bench_s4.json), so a graph has nothing left
+            # to win there; (ii) capturing RCCL collectives races with
+            # ProcessGroupNCCL's watchdog thread on this stack (GraphedStep refuses
+            # it, see _refuse_collectives_in_capture).  The round-4 obstacle --
+            # replays collapsing with the 8 hardware queues a process group needs --
+            # is gone either way (DEBUG_HIP_FORCE_GRAPH_QUEUES=2).
             mode = 'graph' if (on_gpu and Y.get_precision() == 'bf16' and
-                               graph_queues_ok()) else 'eager'
+                               graph_queues_ok() and not collectives_on()) \
+                else 'eager'
         if mode not in ('eager', 'graph', 'pipelined'):
             raise ValueError(f'AutoStepper: unknown mode {mode!r}')
         self.trainer, self.mode = trainer, mode

@@ -1,11 +1,11 @@
 """Worker of tests/test_gpu_graph_pg.py (own process: the runtime's queue
 configuration is read at the first HIP call).  An RCCL process group of ONE rank
-with every collective forced (LD_FORCE_COLLECTIVES=1), 8 hardware queues and the
-graph executor held to 2 streams -- what importing ld_amd sets up in a
-multi-process job.  Runs a batch sequence (different GT counts, two padded
-shapes) through eager ``SGDTrainer.step`` and through ``AutoStepper`` in its
-DEFAULT mode for the precision (bf16: one captured hipGraph per shape, bucket
-all-reduces inside the capture) and prints one JSON line."""
+with every collective forced (LD_FORCE_COLLECTIVES=1): what importing ld_amd sets
+up in a multi-process job, which stepper AutoStepper picks there, that its steps
+equal plain SGDTrainer.step bit for bit over a batch sequence with two padded shapes
+and changing GT counts, that capturing collectives is refused, and -- without
+collectives in the capture -- that a hipGraph replay keeps its speed with the 8
+hardware queues a process group needs.  Prints one JSON line."""
 import json
 import os
 import sys
@@ -55,24 +55,24 @@ def main():
         tr = T.SGDTrainer(det, lr=0.01, bucket_bytes=4 << 20)
         stepper = make_stepper(tr)
         losses = []
-        for d in seq:
-            out = stepper(d)
+        for i, d in enumerate(seq):
+            out = stepper(d, seq[i + 1] if i + 1 < len(seq) else None)
             losses.append(float(out['log_vars']['loss']))
         torch.cuda.synchronize()
         return tr, losses
 
-    tr0, l0 = run(lambda tr: tr.step)
+    tr0, l0 = run(lambda tr: (lambda d, nxt: tr.step(d)))
     eager_calls = calls['all_reduce']
     calls['all_reduce'] = 0
     auto = {}
 
     def make(tr):
         auto['s'] = T.AutoStepper(tr)
-        return auto['s'].step
+        return lambda d, nxt: auto['s'].step(d, next_data=nxt)
 
     tr1, l1 = run(make)
     res = dict(
-        precision=precision, mode=auto['s'].mode, captures=auto['s'].captures,
+        precision=precision, mode=auto['s'].mode,
         collectives_on=bool(T.collectives_on()), graph_queues_ok=bool(T.graph_queues_ok()),
         hwq=os.environ.get('GPU_MAX_HW_QUEUES'),
         graph_queues=os.environ.get('DEBUG_HIP_FORCE_GRAPH_QUEUES'),
@@ -80,26 +80,32 @@ def main():
         auto_all_reduce_calls=calls['all_reduce'],
         params_equal=bool(torch.equal(tr0.arena.flat_param, tr1.arena.flat_param)),
         momentum_equal=bool(torch.equal(tr0.flat_momentum, tr1.flat_momentum)),
-        losses_equal=l0 == l1, losses=l1)
-    # replay vs eager time of this small step, same process (informational)
-    s = auto['s']
+        losses_equal=l0 == l1, teacher_prefetch_hits=getattr(tr1.model, 'prefetch_hits', 0))
+    try:
+        T.GraphedStep(tr1, seq[0])
+        res['capture_refused'] = False
+    except RuntimeError as e:
+        res['capture_refused'] = 'refused' in str(e)
+    # a capture WITHOUT collectives (suspended): replay speed under 8 hardware queues
     d = seq[0]
-    for _ in range(3):
-        s.step(d)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(10):
-        s.step(d)
-    torch.cuda.synchronize()
-    res['auto_ms_per_step'] = (time.perf_counter() - t0) * 100
-    for _ in range(3):
-        tr1.step(d)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(10):
-        tr1.step(d)
-    torch.cuda.synchronize()
-    res['eager_ms_per_step'] = (time.perf_counter() - t0) * 100
+    with T.suspend_collectives():
+        g = T.GraphedStep(tr1, d, warmup=2, warmup_collectives=False)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            g.replay()
+        torch.cuda.synchronize()
+        res['graph_ms_per_step'] = (time.perf_counter() - t0) * 100
+        for _ in range(3):
+            tr1.step(d)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            tr1.step(d)
+        torch.cuda.synchronize()
+        res['eager_ms_per_step'] = (time.perf_counter() - t0) * 100
     print(json.dumps(res), flush=True)
     dist.destroy_process_group()
 

@@ -1,14 +1,13 @@
-"""BASELINE config 3's stepper under a process group (-m gpu; VERDICT r4 next
-#3): with an RCCL group present the runtime needs 8 hardware queues, and round 4
-found hipGraph replays collapsing there (bf16 15 -> 28 ms), so the bf16 step of a
-multi-process job fell back to the host-bound eager path.  Round 5: the graph
-executor's internal streams are held to 2 (DEBUG_HIP_FORCE_GRAPH_QUEUES, set at
-import beside GPU_MAX_HW_QUEUES); AutoStepper's bf16 default is the graph path
-again.  This test runs it in a worker process under a one-rank RCCL group with
-every collective forced: the captured steps (bucket all-reduces inside the
-capture, issued from the weight-gradient stream) must reproduce the eager steps
-BIT FOR BIT over a batch sequence with two padded shapes and changing GT counts,
-and the collectives must really have been issued during the captures."""
+"""BASELINE config 3's stepper under a process group (-m gpu).
+Round 4 left the bf16 step of a multi-process job on a host-bound eager path because
+hipGraph replays collapsed with the 8 hardware queues a process group needs (15 ->
+28 ms).  Round 5: (i) the collapse is the graph executor's internal streams each
+getting a hardware queue -- DEBUG_HIP_FORCE_GRAPH_QUEUES=2, set at import beside
+GPU_MAX_HW_QUEUES=8, removes it (checked here: a replay is not slower than the eager
+step under that configuration); (ii) capturing RCCL collectives races with
+ProcessGroupNCCL's watchdog thread, so it is refused loudly; (iii) the eager step is
+no longer host-bound, so that is what AutoStepper picks under a process group --
+checked here against plain steps bit for bit, collectives counted."""
 import json
 import os
 import socket
@@ -30,10 +29,10 @@ def _free_port():
 
 
 @pytest.mark.parametrize('precision', ['bf16', 'fp32'])
-def test_auto_stepper_under_process_group_bit_exact(precision):
+def test_auto_stepper_under_process_group(precision):
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
     for k in ('GPU_MAX_HW_QUEUES', 'DEBUG_HIP_FORCE_GRAPH_QUEUES', 'RANK',
-              'WORLD_SIZE', 'LOCAL_RANK'):
+              'WORLD_SIZE', 'LOCAL_RANK', 'LD_GRAPH_COLLECTIVES'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(REPO, 'tests', '_graph_pg_worker.py'),
                         precision], env=env, capture_output=True, text=True, timeout=600)
@@ -42,14 +41,15 @@ def test_auto_stepper_under_process_group_bit_exact(precision):
     print(res)
     assert res['collectives_on'] and res['hwq'] == '8' and res['graph_queues'] == '2'
     assert res['graph_queues_ok']
-    assert res['mode'] == ('graph' if precision == 'bf16' else 'eager')
+    assert res['mode'] == 'eager'
     assert res['params_equal'] and res['momentum_equal'] and res['losses_equal'], res
     nb = res['buckets']
     assert nb >= 2
-    # eager: 6 steps x (buckets + normaliser + logs)
+    # 6 steps x (buckets + normaliser + logs), the same with AutoStepper
     assert res['eager_all_reduce_calls'] == 6 * (nb + 2), res
-    if precision == 'bf16':
-        assert res['captures'] == 2  # one graph per padded shape
-        # 1 communicator warm-up + the first (eager, collective-warm) step + one
-        # CAPTURED step per shape: the collectives are inside the graphs
-        assert res['auto_all_reduce_calls'] == 1 + 3 * (nb + 2), res
+    assert res['auto_all_reduce_calls'] == 6 * (nb + 2), res
+    assert res['teacher_prefetch_hits'] >= 4  # the teacher runs one step ahead
+    assert res['capture_refused'] is True
+    # round 4 measured replays ~1.8x slower than eager with 8 queues; with the graph
+    # executor held to 2 streams a replay of this (host-bound, small) step is faster
+    assert res['graph_ms_per_step'] <= 1.15 * res['eager_ms_per_step'], res
