@@ -466,6 +466,17 @@ typedef struct {
 } ld_wt_job_t;
 int ld_conv_weight_transform_batch(const ld_wt_job_t* jobs, const int32_t* block_job,
                                    int nblocks, ld_stream_t stream);
+/* The same images from 32 x 32 x ntaps channel tiles staged through LDS (round 5:
+ * coalesced reads AND writes; the per-element kernels read the parameter with a
+ * stride of Cin * ntaps floats -- 250 us per step for the R50 student).  A job owns
+ * ld_conv_weight_transform_tiles(Cout, Cin, ntaps, bf16) consecutive blocks (0:
+ * more than 9 taps, not served); bf16 != 0 writes the bf16 images of
+ * ld_conv_bf16_weight_transform (wt_fwd / wt_bwd of the job then point at those).
+ * Bit-identical to the per-element kernels. */
+int ld_conv_weight_transform_tiles(int Cout, int Cin, int ntaps, int bf16);
+int ld_conv_weight_transform_batch_tiled(const ld_wt_job_t* jobs,
+                                         const int32_t* block_job, int nblocks, int bf16,
+                                         ld_stream_t stream);
 /* Enqueue only: no timing, no synchronisation, capturable into a hipGraph.
  * The tile shape of a launch comes from the tuning table (below) and, for a
  * geometry the table does not hold, from a model that is a pure function of the

@@ -387,8 +387,13 @@ def refresh_params(device):
     key = str(device)
     tabs = _TABLES.get(key)
     if tabs is None:
-        def _wt_jobs(reg, attr):
-            live, jobs, blocks = [], [], []
+        tiled_on = os.environ.get('LD_WT_TILED', '1') == '1'
+
+        def _wt_jobs(reg, attr, bf16):
+            """jobs of one image family + blocks per job; tiled = every job is
+            served by the LDS-tiled transform (ld_conv_weight_transform_batch_
+            tiled: 1x1 / 3x3 convs), else the per-element batch kernel."""
+            live, jobs, blocks, tiles = [], [], [], []
             for ref in list(reg.values()):
                 w = ref()
                 cache = getattr(w, attr, None) if w is not None else None
@@ -410,10 +415,14 @@ def refresh_params(device):
                              cache['bwd'] is not None))
                 jobs.append(j)
                 blocks.append((n + 255) // 256)
-            return live, jobs, blocks
+                tiles.append(lib.ld_conv_weight_transform_tiles(
+                    cout, cin, kh * kw, 1 if bf16 else 0))
+            tiled = tiled_on and bool(tiles) and all(t > 0 for t in tiles)
+            return live, jobs, (tiles if tiled else blocks), tiled
 
-        live_w, wjobs, wblocks = _wt_jobs(_WT_REG, '_ld_images')
-        live_wb, wbjobs, wbblocks = _wt_jobs(_WT_REG_BF16, '_ld_images_bf16')
+        live_w, wjobs, wblocks, wtiled = _wt_jobs(_WT_REG, '_ld_images', False)
+        live_wb, wbjobs, wbblocks, wbtiled = _wt_jobs(
+            _WT_REG_BF16, '_ld_images_bf16', True)
         live_b, bjobs, bblocks = [], [], []
         for ref in list(_BN_REG.values()):
             g = ref()
@@ -435,7 +444,8 @@ def refresh_params(device):
             w=_job_table(wjobs, wblocks, device) if wjobs else None,
             wb=_job_table(wbjobs, wbblocks, device) if wbjobs else None,
             b=_job_table(bjobs, bblocks, device) if bjobs else None,
-            live_w=live_w, live_wb=live_wb, live_b=live_b)
+            live_w=live_w, live_wb=live_wb, live_b=live_b,
+            tiled=dict(w=wtiled, wb=wbtiled))
         _TABLES[key] = tabs
     st = L.stream_ptr(device)
     for tkey, lkey, fn, what in (
@@ -446,7 +456,12 @@ def refresh_params(device):
         if tabs[tkey] is None:
             continue
         jobs, bmap, nb = tabs[tkey]
-        L.check(fn(L.ptr(jobs), L.ptr(bmap), nb, st), what)
+        if tabs['tiled'][tkey]:
+            L.check(lib.ld_conv_weight_transform_batch_tiled(
+                L.ptr(jobs), L.ptr(bmap), nb, 1 if tkey == 'wb' else 0, st),
+                'ld_conv_weight_transform_batch_tiled')
+        else:
+            L.check(fn(L.ptr(jobs), L.ptr(bmap), nb, st), what)
         for w, cache, has_fwd, has_bwd in tabs[lkey]:
             stamp = (w._version, gen, w.data_ptr(), False)
             if cache['ident'] == stamp[2:]:

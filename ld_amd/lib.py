@@ -275,6 +275,9 @@ SIGNATURES = {
                                    _f32, _i32, _i32, _vp, _vp, _vp, _vp, _sz,
                                    _vp]),
     'ld_conv_weight_transform_batch': (C.c_int, [_vp, _vp, _i32, _vp]),
+    'ld_conv_weight_transform_tiles': (C.c_int, [_i32, _i32, _i32, _i32]),
+    'ld_conv_weight_transform_batch_tiled': (C.c_int, [_vp, _vp, _i32, _i32,
+                                                       _vp]),
     'ld_bn_prepare_batch': (C.c_int, [_vp, _vp, _i32, _vp]),
     'ld_conv_forward': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),
     'ld_conv_forward_smallc': (C.c_int, [_CV, _vp, _vp, _EP, _vp, _vp]),

@@ -718,9 +718,9 @@ class AutoStepper:
 
     ``step`` has the meaning of ``SGDTrainer.step``: ONE optimizer update on
     ``data``; the results are bit-identical in every mode.
-      * ``'eager'`` (fp32 default, every CPU run): ``trainer.step`` with the
-        frozen teacher of ``next_data`` one step ahead on its own stream;
-      * ``'graph'`` (bf16 default on a GPU in a single-process job): one ``GraphedStep`` per padded
+      * ``'eager'`` (the default since round 5, every precision): ``trainer.step``
+        with the frozen teacher of ``next_data`` one step ahead on its own stream;
+      * ``'graph'`` (on request; single-process jobs): one ``GraphedStep`` per padded
         image shape (the reference's GroupSampler yields two aspect-ratio
         groups, mmdet/datasets/samplers/group_sampler.py), captured the first
         time a shape is seen.  The capture's warm-up steps are real steps on
@@ -735,20 +735,20 @@ class AutoStepper:
     def __init__(self, trainer, mode=None, warmup=1, max_gt=128, max_graphs=6):
         if mode is None:
             on_gpu = next(trainer.model.parameters()).is_cuda
-            # bf16, single process: the graph path.  A multi-process job (BASELINE
-            # config 3's form) enqueues EAGERLY, for two measured reasons (round
-            # 5): (i) with the frozen teacher replayed from launch lists the eager
-            # bf16 step is no longer host-bound (host enqueue 13.7 -> 10.8 ms for a
-            # 13.6 ms step; eager 146.5 img/s vs 140.6 / 147.3 as one / two
-            # hipGraphs, profiles/r05_bench_s4.json), so a graph has nothing left
-            # to win there; (ii) capturing RCCL collectives races with
-            # ProcessGroupNCCL's watchdog thread on this stack (GraphedStep refuses
-            # it, see _refuse_collectives_in_capture).  The round-4 obstacle --
-            # replays collapsing with the 8 hardware queues a process group needs --
-            # is gone either way (DEBUG_HIP_FORCE_GRAPH_QUEUES=2).
-            mode = 'graph' if (on_gpu and Y.get_precision() == 'bf16' and
-                               graph_queues_ok() and not collectives_on()) \
-                else 'eager'
+            # Every precision, every job: the EAGER step with the teacher one step
+            # ahead (round 5).  Round 3 made the graph path the bf16 default because
+            # the eager bf16 step was host-bound; with the frozen teacher replayed
+            # from launch lists it is GPU-bound (host enqueue 13.7 -> 10.6 ms for a
+            # 13.4 ms step) and FASTER than the replays: 149.6 img/s against 142.1 /
+            # 149.1 as one / two hipGraphs (profiles/r05_bench_s7.json) -- a graph
+            # launch costs ~19 us of host time per node on this runtime
+            # (profiles/r05_graph_launch_knobs.jsonl), more than an eager launch
+            # now does.  A multi-process job (BASELINE config 3's form) could not
+            # capture anyway: RCCL collectives inside a capture race with
+            # ProcessGroupNCCL's watchdog (_refuse_collectives_in_capture).  'graph'
+            # and 'pipelined' stay available on request.
+            mode = 'eager'
+            del on_gpu
         if mode not in ('eager', 'graph', 'pipelined'):
             raise ValueError(f'AutoStepper: unknown mode {mode!r}')
         self.trainer, self.mode = trainer, mode

@@ -539,3 +539,53 @@ def test_fused_conv_bn_matches_unfused_pair(mode, case):
         sc = float(a.abs().max()) + 1e-12
         err = float((a - b).abs().max())
         assert err <= 2e-5 * sc, (nm, err, sc)
+
+
+@pytest.mark.parametrize('bf16', [False, True])
+def test_weight_transform_tiled_equals_per_element(bf16):
+    """The LDS-tiled batch transform (round 5) writes the same images bit for bit as
+    the per-element kernels, pad rows included, on ragged channel counts."""
+    import ctypes as C
+    from ld_amd import layers as Y
+    from ld_amd import lib as L
+    dev = _dev()
+    lib = L.get_lib()
+    st = L.stream_ptr(dev)
+    g = torch.Generator().manual_seed(12)
+    jobs, blocks, pairs, keep = [], [], [], []
+    for cout, cin, k in ((256, 256, 3), (1024, 256, 1), (64, 256, 1), (80, 256, 3),
+                         (68, 256, 3), (48, 16, 3), (40, 24, 1), (512, 2048, 1)):
+        w = torch.randn(cout, cin, k, k, generator=g).to(dev)
+        if bf16:
+            nf = lib.ld_conv_bf16_weight_image_elems(cout, cin, k, k, 0)
+            nb_ = lib.ld_conv_bf16_weight_image_elems(cout, cin, k, k, 1)
+            dt = torch.bfloat16
+        else:
+            nf = lib.ld_conv_weight_image_floats(cout, cin, k, k, 0)
+            nb_ = lib.ld_conv_weight_image_floats(cout, cin, k, k, 1)
+            dt = torch.float32
+        ref_f = torch.empty(nf, dtype=dt, device=dev)
+        ref_b = torch.empty(nb_, dtype=dt, device=dev)
+        fn = lib.ld_conv_bf16_weight_transform if bf16 else lib.ld_conv_weight_transform
+        L.check(fn(L.ptr(w), cout, cin, k, k, L.ptr(ref_f), L.ptr(ref_b), st), 'ref')
+        out_f = torch.full((nf, ), 7.0, dtype=dt, device=dev)
+        out_b = torch.full((nb_, ), 7.0, dtype=dt, device=dev)
+        j = L.WtJobT()
+        j.w, j.wt_fwd, j.wt_bwd = w.data_ptr(), out_f.data_ptr(), out_b.data_ptr()
+        j.Cout, j.Cin, j.ntaps = cout, cin, k * k
+        t = lib.ld_conv_weight_transform_tiles(cout, cin, k * k, 1 if bf16 else 0)
+        assert t > 0
+        jobs.append(j)
+        blocks.append(t)
+        pairs.append((ref_f, out_f, ref_b, out_b, (cout, cin, k)))
+        keep.append(w)
+    assert lib.ld_conv_weight_transform_tiles(64, 3, 49, 0) == 0  # the 7x7 stem
+    tab, bmap, nb = Y._job_table(jobs, blocks, dev)
+    L.check(lib.ld_conv_weight_transform_batch_tiled(L.ptr(tab), L.ptr(bmap), nb,
+                                                     1 if bf16 else 0, st), 'tiled')
+    torch.cuda.synchronize()
+    for ref_f, out_f, ref_b, out_b, shape in pairs:
+        a, b = (ref_f.view(torch.int16), out_f.view(torch.int16)) if bf16 else (ref_f, out_f)
+        assert torch.equal(a, b), ('fwd', shape)
+        a, b = (ref_b.view(torch.int16), out_b.view(torch.int16)) if bf16 else (ref_b, out_b)
+        assert torch.equal(a, b), ('bwd', shape)
