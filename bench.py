@@ -128,6 +128,7 @@ def kernel_roofline(trainer, dbatch, steps, bf16=False):
             trainer.step(dbatch)
     agg = prof.summary()
     alg_bytes = prof.algorithmic_bytes()
+    alg_rd, alg_wr = prof.algorithmic_read_write()
     model.use_teacher_stream = prev
     by_kind = {k: dict(ms_per_step=v[0] / steps * 1e3,
                        tflops=v[1] / v[0] / 1e12 if v[0] else 0.0,
@@ -148,26 +149,36 @@ def kernel_roofline(trainer, dbatch, steps, bf16=False):
     tot_f = sum(v[1] for v in main.values())
     tot_n = sum(v[2] for v in main.values())
     ach = tot_f / tot_t / 1e12 if tot_t > 0 else 0.0
+    alg_per_launch = alg_bytes / max(tot_n, 1)
+    # ONE ratio, computed from the two fields of this very line
+    ratio = PMC_CONV_TRAFFIC_BYTES_PER_LAUNCH / alg_per_launch if alg_per_launch else 0.0
     out = dict(
         kernel=kernel, bound='mfma', achieved=ach, peak=peak,
         unit='TFLOP/s', frac=ach / peak,
         traffic=None if bf16 else PMC_CONV_TRAFFIC_BYTES_PER_LAUNCH,
-        algorithmic_bytes_per_launch=alg_bytes / max(tot_n, 1),
-        traffic_note=(
-            'bf16: not collected' if bf16 else
+        algorithmic_bytes_per_launch=alg_per_launch,
+        traffic_over_algorithmic=None if bf16 else ratio,
+        algorithmic_read_bytes_per_launch=alg_rd / max(tot_n, 1),
+        algorithmic_write_bytes_per_launch=alg_wr / max(tot_n, 1),
+        fetch_over_algorithmic_reads=None if bf16 or not alg_rd else
+        PMC_CONV_FETCH_BYTES_PER_STEP / (alg_rd / steps),
+        write_over_algorithmic_writes=None if bf16 or not alg_wr else
+        PMC_CONV_WRITE_BYTES_PER_STEP / (alg_wr / steps),
+        traffic_note='bf16: not collected' if bf16 else (
             'fabric-side bytes per GEMM launch (requests leaving the XCD L2s, '
-            'Infinity-Cache hits included), averaged over the 324 forward / '
+            'Infinity-Cache hits included), averaged over the %d forward / '
             'dgrad / wgrad launches of this very step: rocprofv3 --pmc '
             'FETCH_SIZE (x 2: calibrated on a known-size copy at 4 B and 16 B '
             'per lane, profiles/r04_pmc_calib_copy_*) and WRITE_SIZE in '
             'separate passes of tools/profile_step.py --serial, '
-            'profiles/r04_pmc_traffic_conv_step_fp32_by_kernel.txt = 1.79 x '
-            'algorithmic_bytes_per_launch (both operands + the output once): '
+            '%s = %.2f x '
+            'algorithmic_bytes_per_launch (both operands + the output once, '
+            'the figure next to it in this line): '
             'every XCD fetches its own copy of the operands it works on; the '
             'kernels are MFMA-bound, but the bytes through the L1 miss path are '
             'what the time above the MFMA floor is made of '
             '(profiles/r04_wgrad_attribution.txt); not re-measured inside '
-            'bench.py'),
+            'bench.py') % (PMC_CONV_LAUNCHES_PER_STEP, PMC_CONV_TRAFFIC_FILE, ratio),
         launches_per_step=tot_n / steps,
         avg_launch_us=tot_t / max(tot_n, 1) * 1e6,
         conv_ms_per_step=tot_t / steps * 1e3,
@@ -253,7 +264,12 @@ PMC_LDKL_TRAFFIC_BYTES = (2 * 1212475.4 + 1115649.4) * 1024.0
 # requests at 64 bytes.  It counts requests LEAVING an XCD's L2, Infinity-Cache
 # hits included.  (The slab reduce launches add 1.65 GB, the weight transforms
 # 1.72 GB per step; not part of `traffic`.)
-PMC_CONV_TRAFFIC_BYTES_PER_LAUNCH = 32.96e9 / 324.0
+PMC_CONV_TRAFFIC_FILE = 'profiles/r04_pmc_traffic_conv_step_fp32_by_kernel.txt'
+PMC_CONV_LAUNCHES_PER_STEP = 324
+PMC_CONV_FETCH_BYTES_PER_STEP = 2 * 11.66e9
+PMC_CONV_WRITE_BYTES_PER_STEP = 9.62e9
+PMC_CONV_TRAFFIC_BYTES_PER_LAUNCH = (PMC_CONV_FETCH_BYTES_PER_STEP + PMC_CONV_WRITE_BYTES_PER_STEP) \
+    / PMC_CONV_LAUNCHES_PER_STEP
 
 
 def hbm_ceilings(dev):

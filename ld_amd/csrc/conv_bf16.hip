@@ -2292,7 +2292,14 @@ bool ld_bf16_wgrad_c8_tiled(int Cout, int Cin) {
 int ld_bf16_wgrad_c8_tile_splits(int Cout, int Cin, int ntaps, int J) {
   const int tiles = ((Cout + 127) / 128) * ((Cin + 127) / 128) * ntaps;
   const int slots = 512;     // two workgroups per CU (190 VGPRs)
-  const double fixed = 6.0;  // prologue + slab store, in steps
+  // prologue + slab store + this split's share of the reduce pass (64 KB written,
+  // 64 KB read back per workgroup), in steps of 32 positions; LD_WGRAD_C8_FIXED
+  // overrides (round 5 sweep: tools/sessions/r05_s9.sh)
+  static const double fixed = [] {
+    const char* e = getenv("LD_WGRAD_C8_FIXED");
+    const double v = e ? atof(e) : 0.0;
+    return v > 0.0 ? v : 6.0;
+  }();
   const size_t wbytes = (size_t)ntaps * Cout * Cin * sizeof(float);
   int best = 1;
   double best_cost = 0;

@@ -24,6 +24,7 @@ class KernelProfile:
     def __init__(self):
         self.records = []  # (tag, flops, start_event, end_event, shape key)
         self.bytes = []
+        self.rw = []       # (algorithmic bytes read, written) per launch
 
     def __enter__(self):
         KernelProfile.active = self
@@ -45,6 +46,10 @@ class KernelProfile:
         operands once + the output once, fp32 (a fused residual is not
         counted)."""
         return float(sum(self.bytes))
+
+    def algorithmic_read_write(self):
+        """The same sum split by direction: (bytes read, bytes written)."""
+        return (float(sum(r for r, _ in self.rw)), float(sum(w for _, w in self.rw)))
 
     def by_shape(self):
         """{(tag, shape key): (seconds, flops, launches)} -- the per-layer
@@ -77,9 +82,13 @@ class _timed:
                    f'P{d.Pout} L{d.num_levels}')
             self.prof.records.append((self.tag, _conv_flops(d), self.a, self.b,
                                       key))
-            self.prof.bytes.append(4.0 * (d.N * d.Cin * d.Pin +
-                                          d.N * d.Cout * d.Pout +
-                                          d.Cout * d.Cin * d.KH * d.KW))
+            xb = 4.0 * d.N * d.Cin * d.Pin
+            yb = 4.0 * d.N * d.Cout * d.Pout
+            wb = 4.0 * d.Cout * d.Cin * d.KH * d.KW
+            self.prof.bytes.append(xb + yb + wb)
+            # the same sum split by direction: what the launch reads / writes
+            out = wb if 'wgrad' in self.tag else xb if 'dgrad' in self.tag else yb
+            self.prof.rw.append((xb + yb + wb - out, out))
 
 
 def _conv_flops(d):
