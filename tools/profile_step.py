@@ -27,6 +27,10 @@ def main():
                          'kernels overlap, so a rocprofv3 --kernel-trace --stats '
                          'of this run sums to the serialised conv time that '
                          'bench.py\'s roofline.conv_ms_per_step reports')
+    ap.add_argument('--hi-prio', action='store_true',
+                    help='experiment: the whole step on a HIGH-priority stream '
+                         '(the teacher / weight-gradient side streams stay at '
+                         'normal priority and fill what the student chain leaves)')
     ap.add_argument('--buckets', default='',
                     help='write the gradient-bucket timeline (when each '
                          'bucket of the arena is complete, relative to '
@@ -45,6 +49,10 @@ def main():
         torch.cuda.set_device(dev)
         dist.init_process_group('nccl', device_id=dev)
     Y.set_precision(args.mode)
+    if args.hi_prio:
+        hi = torch.cuda.Stream(dev, priority=-1)
+        hi.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(hi)
     if args.serial:
         Y._WGRAD_STREAM[0] = False
     det = model_zoo.build_seeded_ld_detector(50, 101, dev)
