@@ -129,6 +129,7 @@ def kernel_roofline(trainer, dbatch, steps, bf16=False):
     agg = prof.summary()
     alg_bytes = prof.algorithmic_bytes()
     alg_rd, alg_wr = prof.algorithmic_read_write()
+    fus_rd, fus_wr = prof.fused_read_write()
     model.use_teacher_stream = prev
     by_kind = {k: dict(ms_per_step=v[0] / steps * 1e3,
                        tflops=v[1] / v[0] / 1e12 if v[0] else 0.0,
@@ -150,35 +151,50 @@ def kernel_roofline(trainer, dbatch, steps, bf16=False):
     tot_n = sum(v[2] for v in main.values())
     ach = tot_f / tot_t / 1e12 if tot_t > 0 else 0.0
     alg_per_launch = alg_bytes / max(tot_n, 1)
-    # ONE ratio, computed from the two fields of this very line
-    ratio = PMC_CONV_TRAFFIC_BYTES_PER_LAUNCH / alg_per_launch if alg_per_launch else 0.0
+    # `traffic` is per conv call of THIS line (the PMC total per step divided by
+    # this line's own launches_per_step), so that traffic / algorithmic_bytes_per_
+    # launch is the per-step ratio: ONE ratio, in the fields and in the note
+    pmc_per_launch = PMC_CONV_TRAFFIC_BYTES_PER_STEP / max(tot_n / steps, 1)
+    ratio = pmc_per_launch / alg_per_launch if alg_per_launch else 0.0
+    rd_ratio = PMC_CONV_FETCH_BYTES_PER_STEP / (alg_rd / steps) if alg_rd else 0.0
+    wr_ratio = PMC_CONV_WRITE_BYTES_PER_STEP / (alg_wr / steps) if alg_wr else 0.0
     out = dict(
         kernel=kernel, bound='mfma', achieved=ach, peak=peak,
         unit='TFLOP/s', frac=ach / peak,
-        traffic=None if bf16 else PMC_CONV_TRAFFIC_BYTES_PER_LAUNCH,
+        traffic=None if bf16 else pmc_per_launch,
         algorithmic_bytes_per_launch=alg_per_launch,
         traffic_over_algorithmic=None if bf16 else ratio,
         algorithmic_read_bytes_per_launch=alg_rd / max(tot_n, 1),
         algorithmic_write_bytes_per_launch=alg_wr / max(tot_n, 1),
-        fetch_over_algorithmic_reads=None if bf16 or not alg_rd else
-        PMC_CONV_FETCH_BYTES_PER_STEP / (alg_rd / steps),
-        write_over_algorithmic_writes=None if bf16 or not alg_wr else
-        PMC_CONV_WRITE_BYTES_PER_STEP / (alg_wr / steps),
+        fetch_over_algorithmic_reads=None if bf16 else rd_ratio,
+        write_over_algorithmic_writes=None if bf16 else wr_ratio,
+        # what the fused epilogues read (residual, gradient addend) and write
+        # (the raw second output of conv+BN launches) on top, by design; the
+        # ratios with those bytes in the denominator
+        fused_epilogue_read_bytes_per_step=fus_rd / steps,
+        fused_epilogue_write_bytes_per_step=fus_wr / steps,
+        fetch_over_reads_incl_fused=None if bf16 or not alg_rd else
+        PMC_CONV_FETCH_BYTES_PER_STEP / ((alg_rd + fus_rd) / steps),
+        write_over_writes_incl_fused=None if bf16 or not alg_wr else
+        PMC_CONV_WRITE_BYTES_PER_STEP / ((alg_wr + fus_wr) / steps),
         traffic_note='bf16: not collected' if bf16 else (
-            'fabric-side bytes per GEMM launch (requests leaving the XCD L2s, '
-            'Infinity-Cache hits included), averaged over the %d forward / '
-            'dgrad / wgrad launches of this very step: rocprofv3 --pmc '
-            'FETCH_SIZE (x 2: calibrated on a known-size copy at 4 B and 16 B '
-            'per lane, profiles/r04_pmc_calib_copy_*) and WRITE_SIZE in '
-            'separate passes of tools/profile_step.py --serial, '
-            '%s = %.2f x '
-            'algorithmic_bytes_per_launch (both operands + the output once, '
-            'the figure next to it in this line): '
-            'every XCD fetches its own copy of the operands it works on; the '
-            'kernels are MFMA-bound, but the bytes through the L1 miss path are '
-            'what the time above the MFMA floor is made of '
-            '(profiles/r04_wgrad_attribution.txt); not re-measured inside '
-            'bench.py') % (PMC_CONV_LAUNCHES_PER_STEP, PMC_CONV_TRAFFIC_FILE, ratio),
+            'fabric-side bytes of the GEMM kernels per step (requests leaving the '
+            'XCD L2s, Infinity-Cache hits included) divided by this line\'s '
+            'launches_per_step: rocprofv3 --pmc FETCH_SIZE (x 2: calibrated on a '
+            'known-size copy at 4 B and 16 B per lane, '
+            'profiles/r04_pmc_calib_copy_*) and WRITE_SIZE in separate passes of '
+            'tools/profile_step.py --serial (%d dispatches per step), %s = %.2f x '
+            'algorithmic_bytes_per_launch (both operands + the output once, the '
+            'field next to it); by direction: reads %.2f x, writes %.2f x.  The '
+            'algorithmic figure leaves out what the fused epilogues read and '
+            'write on purpose (the residual / gradient addend, the second output '
+            'of conv+BN launches) and counts the weights once where each of the '
+            '8 XCD L2s fetches its own copy; the kernels are MFMA-bound, but the '
+            'bytes through the L1 miss path are what the time above the MFMA '
+            'floor is made of (profiles/r04_wgrad_attribution.txt); not '
+            're-measured inside bench.py') % (
+                PMC_CONV_DISPATCHES_PER_STEP, PMC_CONV_TRAFFIC_FILE, ratio,
+                rd_ratio, wr_ratio),
         launches_per_step=tot_n / steps,
         avg_launch_us=tot_t / max(tot_n, 1) * 1e6,
         conv_ms_per_step=tot_t / steps * 1e3,
@@ -254,22 +270,20 @@ def _median_launch_us(launch, warm, iters):
 # 1 212 475.4 KB (x 2, gfx950 correction) + WRITE_SIZE 1 115 649.4 KB per launch
 # at 2^24 rows
 PMC_LDKL_TRAFFIC_BYTES = (2 * 1212475.4 + 1115649.4) * 1024.0
-# profiles/r04_pmc_traffic_conv_step_fp32_by_kernel.txt (round 4, the serialised
+# profiles/r05_pmc_traffic_conv_step_fp32_by_kernel.txt (round 5, the serialised
 # fp32 step, 6 steps): the GEMM kernels (forward / dgrad streaming shapes + the
-# weight-gradient kernels; 324 launches per step incl. the stride-2 dgrad parity
-# classes) move FETCH_SIZE 2 x 11.66 GB + WRITE_SIZE 9.62 GB = 32.96 GB per step
-# = 101.7 MB per launch.  FETCH_SIZE x 2 is CALIBRATED for this access width:
-# a 1 GiB copy reports exactly half its read bytes at 4 B per lane and at 16 B
-# per lane (profiles/r04_pmc_calib_copy_*): the counter tallies 128-byte fabric
-# requests at 64 bytes.  It counts requests LEAVING an XCD's L2, Infinity-Cache
-# hits included.  (The slab reduce launches add 1.65 GB, the weight transforms
-# 1.72 GB per step; not part of `traffic`.)
-PMC_CONV_TRAFFIC_FILE = 'profiles/r04_pmc_traffic_conv_step_fp32_by_kernel.txt'
-PMC_CONV_LAUNCHES_PER_STEP = 324
-PMC_CONV_FETCH_BYTES_PER_STEP = 2 * 11.66e9
+# weight-gradient kernels; 324 dispatches per step incl. the stride-2 dgrad parity
+# classes, 316 conv calls) move FETCH_SIZE 2 x 12.12 GB + WRITE_SIZE 9.62 GB =
+# 33.87 GB per step.  FETCH_SIZE x 2 is CALIBRATED for this access width: a 1 GiB
+# copy reports exactly half its read bytes at 4 B per lane and at 16 B per lane
+# (profiles/r04_pmc_calib_copy_*): the counter tallies 128-byte fabric requests at
+# 64 bytes.  It counts requests LEAVING an XCD's L2, Infinity-Cache hits included.
+# (The per-bucket slab reduce adds 1.7 GB per step; not part of `traffic`.)
+PMC_CONV_TRAFFIC_FILE = 'profiles/r05_pmc_traffic_conv_step_fp32_by_kernel.txt'
+PMC_CONV_DISPATCHES_PER_STEP = 324
+PMC_CONV_FETCH_BYTES_PER_STEP = 2 * 12.12e9
 PMC_CONV_WRITE_BYTES_PER_STEP = 9.62e9
-PMC_CONV_TRAFFIC_BYTES_PER_LAUNCH = (PMC_CONV_FETCH_BYTES_PER_STEP + PMC_CONV_WRITE_BYTES_PER_STEP) \
-    / PMC_CONV_LAUNCHES_PER_STEP
+PMC_CONV_TRAFFIC_BYTES_PER_STEP = PMC_CONV_FETCH_BYTES_PER_STEP + PMC_CONV_WRITE_BYTES_PER_STEP
 
 
 def hbm_ceilings(dev):

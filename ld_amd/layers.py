@@ -25,6 +25,7 @@ class KernelProfile:
         self.records = []  # (tag, flops, start_event, end_event, shape key)
         self.bytes = []
         self.rw = []       # (algorithmic bytes read, written) per launch
+        self.fused = []    # (bytes read, written) by fused epilogues on top
 
     def __enter__(self):
         KernelProfile.active = self
@@ -51,6 +52,13 @@ class KernelProfile:
         """The same sum split by direction: (bytes read, bytes written)."""
         return (float(sum(r for r, _ in self.rw)), float(sum(w for _, w in self.rw)))
 
+    def fused_read_write(self):
+        """What the fused epilogues move on top of the algorithmic bytes, by
+        design: the residual / gradient addend they read, the raw second output
+        of a conv+BN launch they write (fp32 sizes)."""
+        return (float(sum(r for r, _ in self.fused)),
+                float(sum(w for _, w in self.fused)))
+
     def by_shape(self):
         """{(tag, shape key): (seconds, flops, launches)} -- the per-layer
         table tools/profile_step.py prints."""
@@ -64,8 +72,12 @@ class KernelProfile:
 
 class _timed:
 
-    def __init__(self, tag, d):
-        self.tag, self.d = tag, d
+    def __init__(self, tag, d, explicit=None, fused=(0, 0)):
+        # explicit = (flops, bytes read, bytes written, shape key) for a launch
+        # that is not ONE conv geometry (the fused bottleneck); fused = how many
+        # output-sized fp32 tensors the epilogue reads / writes IN ADDITION to
+        # the conv's own operands (residual, gradient addend / raw second output)
+        self.tag, self.d, self.explicit, self.fused = tag, d, explicit, fused
         self.prof = KernelProfile.active
 
     def __enter__(self):
@@ -77,6 +89,12 @@ class _timed:
     def __exit__(self, *exc):
         if self.prof is not None:
             self.b.record()
+            if self.explicit is not None:
+                flops, rd, wr, key = self.explicit
+                self.prof.records.append((self.tag, flops, self.a, self.b, key))
+                self.prof.bytes.append(rd + wr)
+                self.prof.rw.append((rd, wr))
+                return
             d = self.d
             key = (f'{d.Cin}>{d.Cout} k{d.KH} s{d.stride} N{d.N} '
                    f'P{d.Pout} L{d.num_levels}')
@@ -89,6 +107,7 @@ class _timed:
             # the same sum split by direction: what the launch reads / writes
             out = wb if 'wgrad' in self.tag else xb if 'dgrad' in self.tag else yb
             self.prof.rw.append((xb + yb + wb - out, out))
+            self.prof.fused.append((self.fused[0] * out, self.fused[1] * out))
 
 
 def _conv_flops(d):
@@ -660,7 +679,8 @@ def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
     fn = lib.ld_conv_forward_smallc if smallc else (
         lib.ld_conv_bf16_forward_c8 if c8 else
         lib.ld_conv_bf16_forward if bf16 else lib.ld_conv_forward)
-    with _timed('conv_fwd_bf16' if bf16 else 'conv_fwd', d):
+    with _timed('conv_fwd_bf16' if bf16 else 'conv_fwd', d,
+                fused=(int(residual is not None), int(y_raw is not None))):
         # the conversion launch is part of the conv's measured time
         xin = x3.buf if in8 else to_c8(x3) if c8 else x3
         if not smallc:
@@ -1063,7 +1083,8 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b,
             lib.ld_conv_bf16_dgrad if bf16 else lib.ld_conv_dgrad
         dgrad_acc = lib.ld_conv_bf16_dgrad_c8_acc if c8 else \
             lib.ld_conv_bf16_dgrad_acc if bf16 else lib.ld_conv_dgrad_acc
-        with _timed('conv_dgrad_bf16' if bf16 else 'conv_dgrad', d):
+        with _timed('conv_dgrad_bf16' if bf16 else 'conv_dgrad', d,
+                    fused=(int(addend is not None), 0)):
             dyin = to_c8(dy) if c8 else dy
             _tune_once('c8_dgrad' if c8 else
                        'bf16_dgrad' if bf16 else 'dgrad', d, (),
@@ -1556,9 +1577,15 @@ def bottleneck_c8_forward(x8, levels, convs, bns):
         setattr(b, f'scale{i + 1}', scale.data_ptr())
         setattr(b, f'shift{i + 1}', shift.data_ptr())
     y = torch.empty(N * cin * P, dtype=torch.bfloat16, device=x8.device)
-    L.check(lib.ld_bottleneck_c8_forward(C.byref(b), L.ptr(x8.buf), L.ptr(y),
-                                         L.stream_ptr(x8.device)),
-            'ld_bottleneck_c8_forward')
+    # bench.py's roofline leg: the three GEMMs' FLOPs; bytes = the block's input
+    # and output once (fp32 sizes, as for the single convs) + the three weights
+    wsz = 2 * cin * mid + 9 * mid * mid
+    with _timed('conv_fwd_bf16', None,
+                (2.0 * N * P * wsz, 4.0 * (N * cin * P + wsz), 4.0 * N * cin * P,
+                 f'bottleneck {cin}>{mid}>{cin} N{N} P{P} L1')):
+        L.check(lib.ld_bottleneck_c8_forward(C.byref(b), L.ptr(x8.buf), L.ptr(y),
+                                             L.stream_ptr(x8.device)),
+                'ld_bottleneck_c8_forward')
     return C8Act(y, (N, cin, P)), levels
 
 
