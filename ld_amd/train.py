@@ -155,6 +155,7 @@ class GradArena:
         self._ready = [0] * len(self.buckets)
         self._works = []
         self._seen = set()
+        self._complete, self._next = set(), 0  # all-reduces go out in bucket order
         self._hooks = [
             p.register_post_accumulate_grad_hook(self._on_grad)
             for p in self.params
@@ -177,6 +178,7 @@ class GradArena:
         self._ready = [0] * len(self.buckets)
         self._works = []
         self._seen = set()
+        self._complete, self._next = set(), 0
 
     def _on_grad(self, p):
         """A parameter's gradient is complete (called by autograd's
@@ -192,11 +194,22 @@ class GradArena:
             ev.record()
             self.trace.append((b, ev))
         if self._ready[b] == self.buckets[b]['n']:
-            bk = self.buckets[b]
-            grad = self.flat_grad[bk['start']:bk['end']]
+            self._complete.add(b)
             reduce = collectives_on() and not _diag_skip('buckets')
             if not (reduce or Y.deferred_pending()):
                 return
+            # All-reduces go out in BUCKET ORDER on every rank, whatever order the
+            # buckets complete in: a bucket that completes before an earlier one
+            # (a rank on which some parameters get no gradient this step) is held
+            # until the earlier ones have been issued -- by a later completion or
+            # by finish().  Ranks that disagree about WHICH buckets completed
+            # still issue the same sequence of collectives
+            # (tests/test_ddp_real_arena.py).  In the LD step the buckets
+            # complete in order, so nothing is ever held.
+            todo = []
+            while reduce and self._next in self._complete:
+                todo.append(self._next)
+                self._next += 1
             # The bucket is complete: sum the deferred partials of its weight /
             # norm gradients (layers.flush_deferred: one launch per family for
             # everything pending) and, in a multi-process job, issue its
@@ -209,32 +222,35 @@ class GradArena:
             # pays.  So both are issued from the SIDE stream once that has caught
             # up with the main stream: RCCL's stream waits for the stream the
             # collective is issued from, the main stream for nobody.
-            side = Y.wgrad_pending_stream(grad.device) if grad.is_cuda else None
+            dev = self.flat_grad.device
+            side = Y.wgrad_pending_stream(dev) if self.flat_grad.is_cuda else None
             if side is not None and os.environ.get('LD_BUCKET_FROM_SIDE', '1') == '1':
-                side.wait_stream(torch.cuda.current_stream(grad.device))
+                side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
                     Y.flush_deferred()
-                    if reduce:
-                        self._works.append(dist.all_reduce(grad, async_op=True))
+                    self._all_reduce(todo)
             else:
                 Y.wgrad_join()
                 Y.flush_deferred()
-                if reduce:
-                    self._works.append(dist.all_reduce(grad, async_op=True))
+                self._all_reduce(todo)
+
+    def _all_reduce(self, buckets):
+        for b in buckets:
+            bk = self.buckets[b]
+            self._works.append(dist.all_reduce(
+                self.flat_grad[bk['start']:bk['end']], async_op=True))
 
     def finish(self):
         """Wait for the in-flight bucket reductions (sums, not yet averaged).
-        Buckets whose parameters received no gradient this step are reduced
-        here so every rank issues the same collectives."""
+        Buckets whose parameters received no gradient this step, and buckets
+        held back behind them, are reduced here: every rank issues the same
+        collectives in the same (bucket) order."""
         Y.wgrad_join()
         Y.flush_deferred()  # parameters whose bucket never completed this step
         if collectives_on() and not _diag_skip('buckets'):
-            for b, bk in enumerate(self.buckets):
-                if self._ready[b] != bk['n']:
-                    self._works.append(
-                        dist.all_reduce(
-                            self.flat_grad[bk['start']:bk['end']],
-                            async_op=True))
+            # what was held back or never completed, still in bucket order
+            self._all_reduce(range(self._next, len(self.buckets)))
+            self._next = len(self.buckets)
             for w in self._works:
                 w.wait()
         self._works = []
