@@ -636,6 +636,12 @@ int ld_record_abort(void);
 int ld_record_count(int64_t handle);
 int ld_record_replay(int64_t handle, ld_stream_t stream);
 int ld_record_free(int64_t handle);
+/* Stream `to` continues after everything enqueued on `from` so far (event record
+ * + stream wait on a reusable per-device event): torch's
+ * `side.wait_stream(main)` as one call.  Nothing in the reference: the fork of a
+ * weight gradient onto the background stream of the backward pass.  Not on a
+ * capturing stream. */
+int ld_stream_fork(ld_stream_t from, ld_stream_t to);
 
 /* ---- one frozen bottleneck as ONE launch (bf16 mode, C8-only activations) -----
  * y = relu(bn3(conv1x1(relu(bn2(conv3x3(relu(bn1(conv1x1(x)))))))) + x) for an

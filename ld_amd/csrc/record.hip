@@ -74,3 +74,25 @@ extern "C" int ld_record_free(int64_t handle) {
   g_lists.erase(it);
   return 0;
 }
+
+// ---- stream ordering without the host language in the path ---------------------
+// `to` continues after everything enqueued on `from` so far: one event record +
+// one stream wait on a reusable per-device event (a wait binds to the record
+// that precedes it; re-recording the event later does not affect it).  What
+// torch's side.wait_stream(main) does, as ONE call from the host language: the
+// weight gradients of the backward pass fork onto their side stream ~65 times
+// per step.  Not for use on a capturing stream.
+extern "C" int ld_stream_fork(ld_stream_t from, ld_stream_t to) {
+  static std::mutex mu;
+  static hipEvent_t events[64] = {};
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev)) return (int)e;
+  if (dev < 0 || dev >= 64) return LD_EINVAL;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!events[dev])
+    if (hipError_t e = hipEventCreateWithFlags(&events[dev], hipEventDisableTiming))
+      return (int)e;
+  if (hipError_t e = hipEventRecord(events[dev], (hipStream_t)from)) return (int)e;
+  if (hipError_t e = hipStreamWaitEvent((hipStream_t)to, events[dev], 0)) return (int)e;
+  return 0;
+}

@@ -785,6 +785,7 @@ _WGRAD_STREAM = [os.environ.get('LD_WGRAD_STREAM', '1') == '1']
 _WGRAD_SIDE = {}
 _WGRAD_PENDING = [False]
 _WGRAD_FORCE = [False]
+_WGRAD_BF16_EAGER = [os.environ.get('LD_WGRAD_STREAM_BF16', '1') == '1']
 
 
 # ---- parameter gradients finalised per BUCKET, not per layer (round 5) ---------
@@ -1120,15 +1121,21 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b,
         wgrad = lib.ld_conv_bf16_wgrad_c8 if c8w else \
             lib.ld_conv_bf16_wgrad if bf16 else lib.ld_conv_wgrad
         side = None
-        # Eager bf16 steps are HOST-bound (~14 ms of enqueue per 15.5 ms step):
-        # the three extra stream calls per weight gradient cost more host time
-        # than the overlap returns (measured: 15.56 -> 17.31 ms), so there the
-        # side stream is used only while the step is being captured into a
-        # hipGraph (no host cost on replay).  fp32: 36.88 -> 35.98 ms eager.
-        # (profiles/r03_wgrad_side_stream.txt)
+        # Round 3: eager bf16 steps were HOST-bound (~14 ms of enqueue per 15.5 ms
+        # step) and the three extra stream calls per weight gradient cost more
+        # host time than the overlap returned (15.56 -> 17.31 ms), so bf16 used
+        # the side stream only inside hipGraph captures.  Round 5: the step is
+        # GPU-bound (launch lists, fan protocol, deferred finalisation) and its
+        # main queue is the critical path (65 % busy against 22 % on the side
+        # queue, profiles/r05_queue_busy_bf16.txt): with the weight gradients
+        # behind the teacher on the side stream 13.46 -> 12.42 ms per step
+        # (profiles/r05_bf16_wgrad_side_stream.txt).  LD_WGRAD_STREAM_BF16=0
+        # restores the old placement.  fp32: 36.88 -> 35.98 ms eager
+        # (profiles/r03_wgrad_side_stream.txt).
         if sink is not None and _WGRAD_STREAM[0] and dy.is_cuda and \
                 KernelProfile.active is None and (
                     _PRECISION[0] != 'bf16' or _WGRAD_FORCE[0] or
+                    _WGRAD_BF16_EAGER[0] or
                     torch.cuda.is_current_stream_capturing()):
             side = _wgrad_side(dy.device)
         if not bf16 and not c8w:
@@ -1146,7 +1153,10 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b,
         # sum runs once per bucket (flush_deferred)
         defer = sink is not None and _DEFER_ON[0]
         if defer and any(j.dw == sink.data_ptr() for j, _ in _DEFER_W):
-            flush_deferred()  # a weight used twice: its slabs are still pending
+            # a weight used twice: its slabs are still pending, possibly on the
+            # side stream
+            wgrad_join()
+            flush_deferred()
         family = 2 if c8w else 1 if bf16 else 0
 
         def _launch(ws_, stream_ptr):
@@ -1172,6 +1182,18 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b,
                        to_c8(dy)) if c8w else (x3, dy)
             if side is None:
                 _launch(ws, st)
+            elif defer and not torch.cuda.is_current_stream_capturing():
+                # no workspace, no host-side stream switch: fork the side stream
+                # off the main one with ONE C call and hand the launch its raw
+                # pointer (~65 weight gradients per step; the torch calls below
+                # are ~25 us of host time each, this path ~6)
+                sp = C.c_void_p(side.cuda_stream)
+                L.check(lib.ld_stream_fork(st, sp), 'ld_stream_fork')
+                _launch(ws, sp)
+                for t in (xw, dyw):
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(side)
+                _WGRAD_PENDING[0] = True
             else:
                 side.wait_stream(torch.cuda.current_stream(dy.device))
                 with torch.cuda.stream(side):

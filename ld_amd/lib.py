@@ -309,6 +309,7 @@ SIGNATURES = {
     'ld_record_count': (C.c_int, [C.c_int64]),
     'ld_record_replay': (C.c_int, [C.c_int64, _vp]),
     'ld_record_free': (C.c_int, [C.c_int64]),
+    'ld_stream_fork': (C.c_int, [_vp, _vp]),
     'ld_bottleneck_c8_supported': (C.c_int, [_i32, _i32, _i32, _i32]),
     'ld_bottleneck_c8_forward': (C.c_int, [C.POINTER(BottleneckT), _vp, _vp,
                                            _vp]),
