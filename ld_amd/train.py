@@ -724,11 +724,9 @@ class PipelinedGraphedStep:
                     num_samples=ns)
 
 class AutoStepper:
-    """How a train step is enqueued, chosen per precision mode (VERDICT round 2,
-    #8: the hipGraph path is the DEFAULT in bf16 mode, where the eager step is
-    host-bound -- DESIGN.md section 5):
+    """How a train step is enqueued (DESIGN.md sections 4 and 5):
 
-        stepper = AutoStepper(trainer)            # mode=None: by precision
+        stepper = AutoStepper(trainer)            # mode=None: 'eager'
         for data, nxt in pairs(loader):           # nxt = the following batch
             out = stepper.step(data, next_data=nxt)
 
@@ -750,21 +748,20 @@ class AutoStepper:
 
     def __init__(self, trainer, mode=None, warmup=1, max_gt=128, max_graphs=6):
         if mode is None:
-            on_gpu = next(trainer.model.parameters()).is_cuda
             # Every precision, every job: the EAGER step with the teacher one step
             # ahead (round 5).  Round 3 made the graph path the bf16 default because
-            # the eager bf16 step was host-bound; with the frozen teacher replayed
-            # from launch lists it is GPU-bound (host enqueue 13.7 -> 10.6 ms for a
-            # 13.4 ms step) and FASTER than the replays: 149.6 img/s against 142.1 /
-            # 149.1 as one / two hipGraphs (profiles/r05_bench_s7.json) -- a graph
-            # launch costs ~19 us of host time per node on this runtime
+            # the eager bf16 step was host-bound then; with the frozen teacher
+            # replayed from launch lists, the gradient sums inside the consumers'
+            # kernels and the weight gradients on the background stream it is
+            # FASTER than the replays: 162.0 img/s against 141.2 / 148.4 as one /
+            # two hipGraphs (profiles/r05_bench_final_bf16_wgrad_side.json) -- a
+            # graph launch costs ~19 us of host time per node on this runtime
             # (profiles/r05_graph_launch_knobs.jsonl), more than an eager launch
             # now does.  A multi-process job (BASELINE config 3's form) could not
             # capture anyway: RCCL collectives inside a capture race with
             # ProcessGroupNCCL's watchdog (_refuse_collectives_in_capture).  'graph'
             # and 'pipelined' stay available on request.
             mode = 'eager'
-            del on_gpu
         if mode not in ('eager', 'graph', 'pipelined'):
             raise ValueError(f'AutoStepper: unknown mode {mode!r}')
         self.trainer, self.mode = trainer, mode

@@ -29,6 +29,8 @@ def main():
     ap.add_argument('--num-gt', type=int, default=7)
     ap.add_argument('--seed', type=int, default=1234)
     args = ap.parse_args()
+    if args.reps < 1 or args.reps % 2 == 0:
+        raise SystemExit('--reps must be odd: the reported step is the median')
     import torch
     torch.set_num_threads(args.threads)
     import gen_golden as G  # installs the shim, imports the reference
@@ -76,8 +78,6 @@ def main():
         step(tm)
         runs.append(tm)
     runs.sort(key=lambda r: r['total'])
-    if len(runs) % 2 == 0:
-        raise SystemExit('--reps must be odd: the reported step is the median')
     med = runs[len(runs) // 2]
     print(json.dumps(dict(images=2, threads=args.threads, reps=args.reps,
                           stages_s={k: round(v, 4) for k, v in med.items()},
