@@ -122,3 +122,41 @@ def test_fp32_tiled_weight_gradient_loops_and_registers(wgrad_asm):
             assert int(vgpr) <= 128, (name, vgpr)
         if 'tap3' in name:
             assert int(vgpr) <= 168, (name, vgpr)  # three waves per SIMD
+
+
+@pytest.fixture(scope='module')
+def fused_asm():
+    import isa_lint
+    src = os.path.join(REPO, 'ld_amd', 'csrc', 'conv_fused.hip')
+    if not os.path.exists(isa_lint.os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')):
+        pytest.skip('hipcc not available')
+    return isa_lint.device_asm(src)
+
+
+def test_fused_bottleneck_rings_prefetch_and_no_spill(fused_asm):
+    """Round 5, conv_fused.hip: the first version of the fused teacher bottleneck
+    lost its prefetch distance twice while it was written -- hipcc sank every
+    weight load below the MFMAs (one vmcnt(0) per step) until the ring was pinned
+    with scheduling barriers, and a 4-slot ring in G2 / G3 covered only 512 clk.
+    The shipped kernel waits with COUNTED vmcnt values (ring depth 8 in G2 / G3:
+    waits of 13-15 outstanding loads dominate), drains with vmcnt(0) only at the
+    pass ends, keeps its accumulators in AGPRs and does not spill."""
+    import isa_lint
+    import re
+    rows = [(n, h) for n, h, _ in isa_lint.lint(fused_asm)
+            if 'fused_bottleneck_c8_kernel' in n and h]
+    assert len(rows) == 1, [n for n, _ in rows]
+    name, hist = rows[0]
+    deep = sum(c for v, c in hist.items() if v >= 12)
+    assert deep >= 40, (name, hist)
+    assert hist.get(0, 0) <= 6, (name, hist)
+    meta = re.findall(r'\.name:\s+(\S*fused_bottleneck_c8_kernel\S*)\n(?:.*\n)*?'
+                      r'\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?'
+                      r'\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)',
+                      fused_asm)
+    assert len(meta) == 1
+    _, scratch, vgpr, spill = meta[0]
+    assert int(spill) == 0 and int(scratch) == 0, meta
+    assert int(vgpr) <= 512, meta  # unified VGPR + AGPR file of one wave per SIMD
+    agpr = re.findall(r'\.agpr_count:\s+(\d+)', fused_asm)
+    assert agpr and max(int(a) for a in agpr) >= 128, agpr
