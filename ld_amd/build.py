@@ -56,25 +56,35 @@ def _digest(path, flags):
 
 def build(force=False, verbose=True):
     os.makedirs(OUT_DIR, exist_ok=True)
-    objs, rebuilt = [], False
+    objs, jobs = [], []
     for src in _sources():
         path = os.path.join(CSRC, src)
-        flags = COMMON + PER_FILE.get(src, [])
+        # LD_BUILD_DEFS: extra -D flags for instrumented debug builds
+        flags = COMMON + PER_FILE.get(src, []) + os.environ.get('LD_BUILD_DEFS', '').split()
         obj = os.path.join(OUT_DIR, src + '.o')
         stamp = obj + '.sha1'
         dig = _digest(path, flags)
         fresh = (not force and os.path.exists(obj) and os.path.exists(stamp)
                  and open(stamp).read() == dig)
         if not fresh:
-            cmd = [HIPCC] + flags + ['-c', path, '-o', obj]
-            if verbose:
-                print('[ld_amd.build]', ' '.join(cmd), flush=True)
-            subprocess.check_call(cmd)
-            with open(stamp, 'w') as f:
-                f.write(dig)
-            rebuilt = True
+            jobs.append(([HIPCC] + flags + ['-c', path, '-o', obj], stamp, dig))
         objs.append(obj)
-    if rebuilt or not os.path.exists(LIB):
+
+    def compile_one(job):
+        cmd, stamp, dig = job
+        if verbose:
+            print('[ld_amd.build]', ' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        with open(stamp, 'w') as f:
+            f.write(dig)
+
+    if jobs:  # translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        workers = max(1, min(len(jobs), int(os.environ.get('LD_BUILD_JOBS', '0'))
+                             or (os.cpu_count() or 2) // 2))
+        with ThreadPoolExecutor(workers) as ex:
+            list(ex.map(compile_one, jobs))
+    if jobs or not os.path.exists(LIB):
         cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB
                ] + objs
         if verbose:

@@ -1908,9 +1908,15 @@ struct StreamCfg {
   X(64, 64, 2, 64, 0) X(64, 64, 4, 64, 0) X(64, 128, 4, 64, 0)                     \
   X(128, 128, 4, 32, 1) X(64, 128, 4, 32, 1) X(128, 64, 4, 32, 1)                  \
   X(64, 64, 4, 32, 1) X(64, 64, 4, 64, 1) X(64, 128, 4, 64, 1)
+// ks = 8: the 8-wave LDS-DMA kernel of conv_t256.hip (BM x BN workgroup tiles,
+// 64-deep steps, two LDS stages)
+#define LD_C8_T256_SHAPES(X) X(256, 256) X(256, 192) X(128, 256)
 constexpr StreamCfg kC8Cfgs[] = {
 #define LD_ROW(BM_, BN_, NST_, BK_, SCH_) {BM_ / 32, BN_ / 32, 0, BK_, NST_, SCH_},
     LD_C8_TILE_SHAPES(LD_ROW)
+#undef LD_ROW
+#define LD_ROW(BM_, BN_) {BM_ / 32, BN_ / 32, 0, 64, 8, 0},
+    LD_C8_T256_SHAPES(LD_ROW)
 #undef LD_ROW
 };
 constexpr int kNumC8Cfgs = sizeof(kC8Cfgs) / sizeof(kC8Cfgs[0]);
@@ -1932,6 +1938,7 @@ template <int MODE>
 int launch_c8_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream) {
   const int BM = c.tm * 32, BN = c.tn * 32;
   if (c.d < 32 || k.Cin % c.d != 0) return LD_EUNSUPPORTED;
+  if (c.ks == 8) return ld_bf16_t256_launch(MODE, k, BM, BN, stream);
   const int nb = ((k.Cout + BM - 1) / BM) * ((k.J + BN - 1) / BN);
 #define LD_CASE(BM_, BN_, NST_, BK_, SCH_)                                         \
   if (BM == BM_ && BN == BN_ && c.ks == NST_ && c.d == BK_ && c.sch == SCH_) {     \
@@ -1946,6 +1953,7 @@ int launch_c8_cfg(const ConvK& k, const StreamCfg& c, hipStream_t stream) {
 
 inline bool c8_cfg_fits(const ConvK& k, const StreamCfg& c) {
   if (c.d < 32 || k.Cin % c.d != 0) return false;
+  if (c.ks == 8) return ld_bf16_t256_fits(k, c.tm * 32, c.tn * 32);
   const int BM = c.tm * 32;
   const int cout32 = (k.Cout + 31) / 32 * 32;
   return BM <= cout32 + 32;

@@ -64,6 +64,9 @@ int ld_bf16_wgrad_c8_launch(const WgradK& k, hipStream_t stream);
 bool ld_bf16_wgrad_c8_tiled(int Cout, int Cin);  // 128 x 128 workgroup tiles?
 int ld_bf16_wgrad_c8_tile_splits(int Cout, int Cin, int ntaps, int J);
 int ld_bf16_stream_tune(int mode, const ConvK& k, hipStream_t stream);
+// conv_t256.hip: C8 operands, 8-wave workgroup tiles (BM x BN) fed by LDS-DMA
+bool ld_bf16_t256_fits(const ConvK& k, int BM, int BN);
+int ld_bf16_t256_launch(int mode, const ConvK& k, int BM, int BN, hipStream_t stream);
 int ld_bf16_wgrad_launch(const WgradK& k, hipStream_t stream);
 bool ld_bf16_wgrad_tiled(int Cout, int Cin, int Pout);     // which bf16 wgrad kernel
 int ld_bf16_wgrad_splits(int Cout, int Cin, int ntaps, int J);  // its j-split count

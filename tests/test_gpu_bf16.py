@@ -214,7 +214,9 @@ C8_SHAPES = ['4x4x2', '4x4x4', '2x4x4', '4x2x4', '2x2x4', '2x4x2', '4x2x2',
              '2x4x4x64',
              # LDS image written after the barrier (... x BK x SCH)
              '4x4x4x32x1', '2x4x4x32x1', '4x2x4x32x1', '2x2x4x32x1',
-             '2x2x4x64x1', '2x4x4x64x1']
+             '2x2x4x64x1', '2x4x4x64x1',
+             # the 8-wave LDS-DMA kernel of conv_t256.hip (NST field = 8)
+             '8x8x8x64', '8x6x8x64', '4x8x8x64']
 
 
 def test_to_c8_layout():
@@ -390,7 +392,8 @@ def test_conv_c8_only_output_and_c8_residual(bf16_mode, monkeypatch):
                           ('LD_CONV_BF16_SHAPE', '2x1x1x4x4', x),
                           ('LD_CONV_BF16_SHAPE', '4x2x0x32x2', x),
                           ('LD_CONV_C8_SHAPE', '2x2x2', x),
-                          ('LD_CONV_C8_SHAPE', '4x4x2', x8)):
+                          ('LD_CONV_C8_SHAPE', '4x4x2', x8),
+                          ('LD_CONV_C8_SHAPE', '4x8x8x64', x8)):
         monkeypatch.setenv(env, val)
         if env != 'LD_CONV_C8_SHAPE':
             monkeypatch.setattr(Y, '_use_c8', lambda *a, **k: False)
