@@ -1910,7 +1910,7 @@ struct StreamCfg {
   X(64, 64, 4, 32, 1) X(64, 64, 4, 64, 1) X(64, 128, 4, 64, 1)
 // ks = 8: the 8-wave LDS-DMA kernel of conv_t256.hip (BM x BN workgroup tiles,
 // 64-deep steps, two LDS stages)
-#define LD_C8_T256_SHAPES(X) X(256, 256) X(256, 192) X(128, 256)
+#define LD_C8_T256_SHAPES(X) X(256, 256) X(256, 192) X(128, 256) X(256, 128)
 constexpr StreamCfg kC8Cfgs[] = {
 #define LD_ROW(BM_, BN_, NST_, BK_, SCH_) {BM_ / 32, BN_ / 32, 0, BK_, NST_, SCH_},
     LD_C8_TILE_SHAPES(LD_ROW)

@@ -42,12 +42,22 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // 16 bytes per lane, global -> LDS at (wave-uniform dst) + lane * 16
 __device__ __forceinline__ void dma16(rsrc_t r, uintx4* dst, unsigned voff,
                                       unsigned soff) {
+#if defined(LD_T256_ABL) && (LD_T256_ABL & 4)  // ablation: the same loads into registers
+  if (voff != 0x7fffff00u) {
+    uintx4 v = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    asm volatile("" ::"v"(v));
+    return;
+  }
+#endif
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)dst, 16, voff, soff, 0, 0);
 }
 
 // Debug build only (LD_BUILD_DEFS=-DLD_T256_STAMP): lane 0 of every wave writes
 // the shader clock at five points of the kernel into a buffer set through
 // ld_debug_t256_stamps (tools/t256_stamps.py prints the phase breakdown).
+#ifndef LD_T256_SPREAD
+#define LD_T256_SPREAD 1  // 0: the whole DMA of a step in one burst (A/B builds)
+#endif
 #ifdef LD_T256_STAMP
 __device__ unsigned long long* g_t256_stamps;
 #define LD_STAMP(i)                                                               \
@@ -172,35 +182,39 @@ __global__ __launch_bounds__(512) void conv_t256_c8_kernel(ConvK a) {
   const int csteps = Cin >> 6;  // host guarantees Cin % 64 == 0
   const int nsteps = ntaps * csteps;
   int c_step = 0, c_kh = 0, c_kw = 0, c_ci0 = 0;
-  // issue the DMA of the next k-step into `stage`
-  auto stage_load = [&](int stage) {
-    if (c_step >= nsteps) return;  // wave-uniform: nothing to fetch past the last step
-    const bool live = true;
+  // The DMA of one k-step = NT wave instructions (A rows first, then B rows),
+  // issued in three groups: a burst of all of them right behind the barrier (8
+  // waves x 7) queues on the CU's address unit and stalls the issuing waves in
+  // front of their MFMAs (clock stamps: the main loop of the head tower is 23 %
+  // shorter with the DMA removed) -- so only group 0 goes there, groups 1 and 2
+  // follow under the next step's first two sub-steps.
+  constexpr int NT = MA::NI + MB::NI;
+  constexpr int G1 = LD_T256_SPREAD ? (NT + 2) / 3 : NT;
+  constexpr int G2 = LD_T256_SPREAD ? G1 + (NT - G1 + 1) / 2 : NT;
+  bool x_live = false, x_aoob = false;
+  unsigned x_sa0 = 0, x_sob = 0, x_vb[MB::NPOS];
+  // addresses of the next k-step (kept until its last group is issued)
+  auto dma_begin = [&]() {
+    x_live = c_step < nsteps;  // wave-uniform: nothing to fetch past the last step
+#if defined(LD_T256_ABL) && (LD_T256_ABL & 1)  // ablation: no DMA after the first two steps
+    x_live = x_live && c_step < 2;
+#endif
+#if defined(LD_T256_ABL) && (LD_T256_ABL & 2)  // ablation: out-of-range DMA after two steps
+    const bool x_oob = c_step >= 2;
+#else
+    const bool x_oob = false;
+#endif
+    x_aoob = x_oob;
     const int wtap = MODE == 1 ? (a.kh0 + 2 * c_kh) * KW + a.kw0 + 2 * c_kw
                                : c_kh * ntw + c_kw;
-    uintx4* As = lds + stage * STAGE;
-    uintx4* Bs = As + KB * BM;
-    const unsigned sa0 = (unsigned)((wtap * Kp8 + (c_ci0 >> 3)) * Cout) * 16u;
-#pragma unroll
-    for (int i = 0; i < MA::NI; ++i) {
-      const int kg = MA::kg(wave, i), ch = MA::chunk(wave, i);
-      dma16(rw, As + kg * BM + ch * 64, live ? va[MA::pos(i)] : kOOB,
-            sa0 + (unsigned)(kg * Cout) * 16u);
-    }
-    unsigned vb[MB::NPOS];
+    x_sa0 = (unsigned)((wtap * Kp8 + (c_ci0 >> 3)) * Cout) * 16u;
+    x_sob = (unsigned)(c_ci0 >> 3) * (unsigned)Pin * 16u;
 #pragma unroll
     for (int q = 0; q < MB::NPOS; ++q) {
       const int hi = bh0[q] + c_kh, wi = bw0[q] + c_kw;
-      const bool ok = live & ((unsigned)hi < (unsigned)bHin[q]) &
+      const bool ok = x_live & !x_oob & ((unsigned)hi < (unsigned)bHin[q]) &
                       ((unsigned)wi < (unsigned)bWin[q]);
-      vb[q] = ok ? (unsigned)(boff[q] + hi * bWin[q] + wi) * 16u : kOOB;
-    }
-    const unsigned prow = (unsigned)Pin * 16u;
-#pragma unroll
-    for (int i = 0; i < MB::NI; ++i) {
-      const int kg = MB::kg(wave, i), ch = MB::chunk(wave, i);
-      dma16(rx, Bs + kg * BN + ch * 64, vb[MB::pos(i)],
-            (unsigned)((c_ci0 >> 3) + kg) * prow);
+      x_vb[q] = ok ? (unsigned)(boff[q] + hi * bWin[q] + wi) * 16u : kOOB;
     }
     ++c_step;
     c_ci0 += 64;
@@ -210,6 +224,27 @@ __global__ __launch_bounds__(512) void conv_t256_c8_kernel(ConvK a) {
     const bool wk = c_kw >= ntw;
     c_kw = wk ? 0 : c_kw;
     c_kh += wk ? 1 : 0;
+  };
+  // (branch-free: past the last step the offsets are out of range and the DMA
+  // writes zeros into a stage nobody reads any more -- a branch here would cut the
+  // step into basic blocks and break the MFMA / LDS interleave below)
+  auto dma_ops = [&](int stage, int lo, int hi) {
+    uintx4* As = lds + stage * STAGE;
+    uintx4* Bs = As + KB * BM;
+    const unsigned prow = (unsigned)Pin * 16u;
+#pragma unroll
+    for (int o = 0; o < NT; ++o) {
+      if (o < lo || o >= hi) continue;
+      if (o < MA::NI) {
+        const int kg = MA::kg(wave, o), ch = MA::chunk(wave, o);
+        dma16(rw, As + kg * BM + ch * 64, x_live && !x_aoob ? va[MA::pos(o)] : kOOB,
+              x_sa0 + (unsigned)(kg * Cout) * 16u);
+      } else {
+        const int i = o - MA::NI;
+        const int kg = MB::kg(wave, i), ch = MB::chunk(wave, i);
+        dma16(rx, Bs + kg * BN + ch * 64, x_vb[MB::pos(i)], x_sob + (unsigned)kg * prow);
+      }
+    }
   };
   // fragments of one 16-deep sub-step: TM weight-row tiles, TN position tiles
   auto frags = [&](int stage, int s, uintx4* af, uintx4* bf) {
@@ -252,9 +287,11 @@ __global__ __launch_bounds__(512) void conv_t256_c8_kernel(ConvK a) {
 #endif
   auto step = [&](int S) {
     frags(S, 1, afB, bfB);
+    dma_ops(S ^ 1, G1, G2);  // step u + 1, second group
     mfmas(afA, bfA);
     interleave();
     frags(S, 2, afA, bfA);
+    dma_ops(S ^ 1, G2, NT);  // step u + 1, third group
     mfmas(afB, bfB);
     interleave();
     frags(S, 3, afB, bfB);
@@ -277,16 +314,19 @@ __global__ __launch_bounds__(512) void conv_t256_c8_kernel(ConvK a) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
     frags(S ^ 1, 0, afA, bfA);
-    stage_load(S);
+    dma_begin();
+    dma_ops(S, 0, G1);  // step u + 2, first group
     mfmas(afB, bfB);
   };
 
   LD_STAMP(1);
-  stage_load(0);
-  stage_load(1);
+  dma_begin();
+  dma_ops(0, 0, NT);
+  dma_begin();
+  dma_ops(1, 0, G1);
   // the first step's share has landed once at most the second's is outstanding
   if (nsteps > 1)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MA::NI + MB::NI) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G1) : "memory");
   else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_barrier" ::: "memory");
@@ -505,7 +545,8 @@ extern "C" int ld_debug_t256_stamps(void* p) {
 #endif
 
 // (BM, BN, WM, WN): workgroup tile and the wave grid inside it
-#define LD_T256_SHAPES(X) X(256, 256, 2, 4) X(256, 192, 4, 2) X(128, 256, 2, 4)
+#define LD_T256_SHAPES(X) \
+  X(256, 256, 2, 4) X(256, 192, 4, 2) X(128, 256, 2, 4) X(256, 128, 4, 2)
 
 bool ld_bf16_t256_fits(const ConvK& k, int BM, int BN) {
   if (!k.x_c8 || k.Cin % 64 != 0) return false;

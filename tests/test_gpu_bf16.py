@@ -216,7 +216,7 @@ C8_SHAPES = ['4x4x2', '4x4x4', '2x4x4', '4x2x4', '2x2x4', '2x4x2', '4x2x2',
              '4x4x4x32x1', '2x4x4x32x1', '4x2x4x32x1', '2x2x4x32x1',
              '2x2x4x64x1', '2x4x4x64x1',
              # the 8-wave LDS-DMA kernel of conv_t256.hip (NST field = 8)
-             '8x8x8x64', '8x6x8x64', '4x8x8x64']
+             '8x8x8x64', '8x6x8x64', '4x8x8x64', '8x4x8x64']
 
 
 def test_to_c8_layout():
