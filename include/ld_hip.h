@@ -636,6 +636,31 @@ int ld_record_abort(void);
 int ld_record_count(int64_t handle);
 int ld_record_replay(int64_t handle, ld_stream_t stream);
 int ld_record_free(int64_t handle);
+/* ---- step lists: a captured hipGraph re-issued as plain stream launches ---------
+ * ld_step_list_build walks the nodes of a captured hipGraph_t ONCE (kernel / memcpy
+ * / memset parameters, dependency edges, capture order), assigns them to at most
+ * max_lanes streams so that the capture's concurrency survives, and returns a
+ * handle > 0 (negative: LD_EUNSUPPORTED for host / child-graph / allocation nodes,
+ * LD_EINVAL otherwise).  ld_step_list_replay re-issues the step with one C loop of
+ * hipLaunchKernel / hipMemcpyAsync / hipMemsetAsync calls (+ an event pair per
+ * cross-lane edge): lane 0 is `stream`, the other lanes are streams the list owns;
+ * they start behind everything enqueued on `stream` and `stream` ends up behind
+ * them.  The graph and every buffer the captured step touched must outlive the
+ * list.  ld_step_list_info: counts[8] = {kernel, memcpy, memset, ordering-only
+ * nodes, lanes, cross-lane waits, nodes, 0}.  Nothing in the reference (mmcv's
+ * runner issues every kernel from Python, mmdet/apis/train.py:74-127): what takes
+ * the host language out of the student's ~350 launches per step. */
+int64_t ld_step_list_build(void* hip_graph, int max_lanes);
+/* Device-to-device copy as ONE kernel launch (16 bytes per lane): what a step that
+ * will be captured uses instead of hipMemcpyAsync, whose captured 1-D memcpy node
+ * this runtime cannot describe back to ld_step_list_build. */
+int ld_copy_d2d(void* dst, const void* src, size_t bytes, ld_stream_t stream);
+int ld_step_list_info(int64_t handle, int* counts);
+int ld_step_list_replay(int64_t handle, ld_stream_t stream);
+int ld_step_list_free(int64_t handle);
+/* debugging aid: the node the last failing replay stopped at: out8 = {node index,
+ * hipGraphNodeType, hipError_t, lane, four type-specific details} */
+int ld_step_list_last_failure(int* out8);
 /* Stream `to` continues after everything enqueued on `from` so far (event record
  * + stream wait on a reusable per-device event): torch's
  * `side.wait_stream(main)` as one call.  Nothing in the reference: the fork of a

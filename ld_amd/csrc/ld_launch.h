@@ -39,13 +39,19 @@ inline hipError_t memset_async(void* p, int v, size_t bytes, hipStream_t stream)
   return hipMemsetAsync(p, v, bytes, stream);
 }
 
+// Device-to-device copy as a KERNEL launch (record.hip): a hipMemcpyAsync captured
+// into a hipGraph becomes a 1-D memcpy node whose parameters this runtime does not
+// hand back (hipGraphMemcpyNodeGetParams returns an unfilled 3-D descriptor), so a
+// step list (graphlist.hip) could not re-issue it.
+hipError_t copy_d2d_launch(void* dst, const void* src, size_t bytes, hipStream_t stream);
+
 inline hipError_t memcpy_d2d_async(void* dst, const void* src, size_t bytes,
                                    hipStream_t stream) {
   if (Recorder* r = active())
     r->ops.emplace_back([=](hipStream_t s) -> hipError_t {
-      return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+      return copy_d2d_launch(dst, src, bytes, s);
     });
-  return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
+  return copy_d2d_launch(dst, src, bytes, stream);
 }
 }  // namespace ldrec
 

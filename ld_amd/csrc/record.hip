@@ -1,6 +1,7 @@
 // Launch lists: the recording side of ld_launch.h and its C ABI.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <mutex>
 #include <unordered_map>
 
@@ -13,6 +14,54 @@ Recorder*& active() {
   return r;
 }
 }  // namespace ldrec
+
+namespace {
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+// 16 bytes per lane, grid-stride; the byte tail by the last lanes
+__global__ __launch_bounds__(256) void copy_d2d_kernel(uintx4* __restrict__ dst,
+                                                       const uintx4* __restrict__ src,
+                                                       size_t n16, size_t bytes) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride)
+    dst[i] = src[i];
+  const size_t tail = bytes - n16 * 16;
+  if (blockIdx.x == 0 && threadIdx.x < tail)
+    ((char*)dst)[n16 * 16 + threadIdx.x] = ((const char*)src)[n16 * 16 + threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void copy_d2d_bytes_kernel(char* __restrict__ dst,
+                                                             const char* __restrict__ src,
+                                                             size_t bytes) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < bytes; i += stride)
+    dst[i] = src[i];
+}
+}  // namespace
+
+namespace ldrec {
+hipError_t copy_d2d_launch(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  if (!bytes) return hipSuccess;
+  if ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
+    const size_t n16 = bytes / 16;
+    const size_t blocks = std::min<size_t>((n16 + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(copy_d2d_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       (uintx4*)dst, (const uintx4*)src, n16, bytes);
+  } else {
+    const size_t blocks = std::min<size_t>((bytes + 255) / 256, 2048);
+    hipLaunchKernelGGL(copy_d2d_bytes_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       (char*)dst, (const char*)src, bytes);
+  }
+  return hipGetLastError();
+}
+}  // namespace ldrec
+
+// Device-to-device copy of `bytes` bytes as one kernel launch (capturable into a
+// hipGraph as a kernel node; see ld_launch.h).
+extern "C" int ld_copy_d2d(void* dst, const void* src, size_t bytes, ld_stream_t stream) {
+  if ((!dst || !src) && bytes) return LD_EINVAL;
+  return (int)ldrec::memcpy_d2d_async(dst, src, bytes, (hipStream_t)stream);
+}
 
 namespace {
 std::mutex g_mu;

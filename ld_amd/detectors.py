@@ -273,10 +273,13 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
             ts = list(self.teacher_model.parameters()) + \
                 list(self.teacher_model.buffers())
             object.__setattr__(self, '_teacher_tensors', ts)
-        v = 0
-        for t in ts:
+        # every tensor's storage AND version: a `p.data = ...` reassignment or a
+        # re-materialised middle parameter changes a data_ptr but no _version
+        v, h = 0, 0
+        for i, t in enumerate(ts):
             v += t._version
-        return (v, ts[0].data_ptr(), ts[-1].data_ptr(), len(ts))
+            h = (h * 1000003 + t.data_ptr() + i) & 0xFFFFFFFFFFFFFFFF
+        return (v, h, len(ts))
 
     def _replay_enabled(self, img):
         from . import layers as Y
@@ -353,7 +356,7 @@ class KnowledgeDistillationSingleStageDetector(SingleStageDetector):
         sl = pl['slots'][pl['next']]
         pl['next'] = (pl['next'] + 1) % len(pl['slots'])
         if img.data_ptr() != sl['img'].data_ptr():
-            sl['img'].copy_(img)
+            Y.copy_into(sl['img'], img)  # a kernel node if this step is captured
         L.check(lib.ld_record_replay(sl['handle'], L.stream_ptr(img.device)),
                 'ld_record_replay')
         self.teacher_replays = getattr(self, 'teacher_replays', 0) + 1

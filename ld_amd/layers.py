@@ -819,7 +819,15 @@ def _defer_buffer(owner, attr, nbytes, device):
                 setattr(owner, attr, t)
             except AttributeError:
                 pass
+        else:
+            # only the raw pointer goes into the deferred job: hold the tensor
+            # until the capture's flush has read it, or a later allocation of the
+            # same capture could be handed its block
+            _DEFER_CAPTURE_KEEP.append(t)
     return t
+
+
+_DEFER_CAPTURE_KEEP = []  # buffers created during a hipGraph capture (process lifetime)
 
 
 def _defer_table(jobs, blocks_of, device):
@@ -885,6 +893,18 @@ def deferred_pending():
 def drop_deferred():
     del _DEFER_W[:]
     del _DEFER_B[:]
+    drop_fan()
+
+
+def drop_fan():
+    """Forget fan-out deposits of a backward pass that did not finish (an
+    exception skips the engine's final callbacks, so _fan_verify never ran: the
+    list would then grow by every later step's activations and the check would stay
+    off).  Called at the start of every step (GradArena.zero_grad)."""
+    for c in _FAN_OPEN:
+        c._ld_stash = None
+        c._ld_fan = 0
+    del _FAN_OPEN[:]
 
 
 class capture_warmup:
@@ -1215,6 +1235,9 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b,
             # per-channel partial sums now, finalised with the bucket's norm
             # gradients (ld_bn_bwd_finalize_batch, a job without dgamma)
             if any(j.dbeta == sink.data_ptr() for j, _ in _DEFER_B):
+                # flush_deferred also reduces the pending WEIGHT slabs, which the
+                # side stream may still be writing
+                wgrad_join(dy.device)
                 flush_deferred()
             ns = lib.ld_bias_grad_nsplit(N, cout, dy.shape[2])
             part = _defer_buffer(pb, '_ld_bias_partial', cout * ns * 16,
@@ -1399,7 +1422,10 @@ def _bn_act_backward(dy, x3, y, scale, mean, rstd, relu, params, need_x,
     need = lib.ld_bn_act_backward_workspace_bytes(N, c, P)
     defer = direct and _DEFER_ON[0]
     if defer and any(j.dgamma == sg.data_ptr() for j, _ in _DEFER_B):
-        flush_deferred()  # a norm used twice: its partials are still pending
+        # a norm used twice: its partials are still pending.  The flush also
+        # reduces the pending weight slabs: wait for the side stream first
+        wgrad_join(x3.device)
+        flush_deferred()
     ws = _defer_buffer(pg, '_ld_bn_partial', need, x3.device) if defer else \
         workspace(x3.device, need, 'bn')
     acc = L.LD_GRAD_DEFER if defer else 1 if direct else 0
@@ -1731,6 +1757,21 @@ def gn_act(x3, gamma, beta, groups, eps, levels, relu=True):
 # ---------------------------------------------------------------------------
 # small layers
 # ---------------------------------------------------------------------------
+def copy_into(dst, src):
+    """dst.copy_(src) for two contiguous device tensors of one dtype and size, as ONE
+    kernel launch of this library (ld_copy_d2d): inside a step that is captured, a
+    torch copy is a hipMemcpyAsync, i.e. a 1-D memcpy graph node that a step list
+    cannot re-issue (include/ld_hip.h "step lists")."""
+    if not (dst.is_cuda and src.is_cuda and dst.is_contiguous() and src.is_contiguous()
+            and dst.dtype == src.dtype and dst.numel() == src.numel()):
+        dst.copy_(src)
+        return dst
+    L.check(L.get_lib().ld_copy_d2d(L.ptr(dst), L.ptr(src),
+                                    dst.numel() * dst.element_size(),
+                                    L.stream_ptr(dst.device)), 'ld_copy_d2d')
+    return dst
+
+
 def maxpool3x3s2(x4):
     """MaxPool2d(3, 2, 1), forward only (frozen stem)."""
     lib = L.get_lib()

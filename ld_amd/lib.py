@@ -181,7 +181,7 @@ def save_tune_table(path):
     return get_lib().ld_conv_tune_save(str(path).encode())
 
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 _G, _H, _M = C.POINTER(GeomT), C.POINTER(LossHpT), C.POINTER(MapsT)
 _CV, _EP, _LV = C.POINTER(ConvT), C.POINTER(ConvEpilogueT), C.POINTER(LevelsT)
@@ -310,6 +310,12 @@ SIGNATURES = {
     'ld_record_replay': (C.c_int, [C.c_int64, _vp]),
     'ld_record_free': (C.c_int, [C.c_int64]),
     'ld_stream_fork': (C.c_int, [_vp, _vp]),
+    'ld_step_list_build': (C.c_int64, [_vp, _i32]),
+    'ld_copy_d2d': (C.c_int, [_vp, _vp, _sz, _vp]),
+    'ld_step_list_info': (C.c_int, [C.c_int64, C.POINTER(C.c_int)]),
+    'ld_step_list_replay': (C.c_int, [C.c_int64, _vp]),
+    'ld_step_list_free': (C.c_int, [C.c_int64]),
+    'ld_step_list_last_failure': (C.c_int, [C.POINTER(C.c_int)]),
     'ld_bottleneck_c8_supported': (C.c_int, [_i32, _i32, _i32, _i32]),
     'ld_bottleneck_c8_forward': (C.c_int, [C.POINTER(BottleneckT), _vp, _vp,
                                            _vp]),

@@ -22,6 +22,7 @@ The reducer itself is device-agnostic torch.distributed code (tested on gloo
 with 2 CPU processes); the optimizer launch is the HIP kernel.
 """
 import os
+import ctypes as C
 
 import torch
 import torch.distributed as dist
@@ -481,6 +482,55 @@ def _capture_mode():
         else 'global'
 
 
+class _StepList:
+    """A captured step re-issued as plain stream launches (csrc/graphlist.hip,
+    include/ld_hip.h "step lists"): the hipGraph is only the record.  hipGraphLaunch
+    costs ~22 us of host time per node on this runtime and serialises the capture's
+    branches; one C loop of hipLaunchKernel calls costs ~3-4 us per launch and keeps
+    the weight gradients / the teacher on their own streams."""
+
+    def __init__(self, graph, max_lanes=None):
+        from . import lib as L
+        if max_lanes is None:
+            max_lanes = int(os.environ.get('LD_STEP_LIST_LANES', '4'))
+        self.graph = graph  # owns the nodes' argument copies and the memory pool
+        self.handle = L.get_lib().ld_step_list_build(
+            C.c_void_p(graph.raw_cuda_graph()), int(max_lanes))
+        if self.handle <= 0:
+            raise L.LdError(f'ld_step_list_build failed ({self.handle}): the captured '
+                            'step holds a node kind a launch list cannot re-issue')
+        counts = (C.c_int * 8)()
+        L.check(L.get_lib().ld_step_list_info(self.handle, counts), 'ld_step_list_info')
+        self.info = dict(zip(('kernels', 'memcpys', 'memsets', 'ordering_nodes',
+                              'lanes', 'cross_lane_waits', 'nodes'), list(counts)))
+
+    def replay(self, device):
+        from . import lib as L
+        rc = L.get_lib().ld_step_list_replay(self.handle, L.stream_ptr(device))
+        if rc != 0:
+            f = (C.c_int * 8)()
+            L.get_lib().ld_step_list_last_failure(f)
+            raise L.LdError(f'ld_step_list_replay failed (hipError_t {rc}) at node '
+                            f'{f[0]} of {self.info["nodes"]}: type {f[1]}, lane {f[3]}, '
+                            f'details {list(f)[4:]}')
+
+    def __del__(self):
+        try:
+            from . import lib as L
+            if L.lib_available() and getattr(self, 'handle', 0) > 0:
+                L.get_lib().ld_step_list_free(self.handle)
+        except Exception:
+            pass
+
+
+def _new_graph(launcher):
+    if launcher == 'list':
+        return torch.cuda.CUDAGraph(keep_graph=True)
+    if launcher != 'graph':
+        raise ValueError(f"launcher must be 'graph' or 'list', got {launcher!r}")
+    return torch.cuda.CUDAGraph()
+
+
 class GraphedStep:
     """The steady-state train step captured ONCE into a hipGraph and replayed:
     ~750 launches per step (conv / norm / loss / optimizer kernels, the
@@ -520,11 +570,15 @@ class GraphedStep:
     """
 
     def __init__(self, trainer, data, warmup=2, max_gt=128,
-                 warmup_collectives=True):
+                 warmup_collectives=True, launcher='graph'):
+        """``launcher='list'``: the captured graph is re-issued by a C launch loop
+        (``_StepList``) instead of hipGraphLaunch -- same launches, same buffers."""
         from . import lossblock as LB
         _refuse_collectives_in_capture('GraphedStep')
-        _warn_graph_queues('GraphedStep')
+        if launcher == 'graph':
+            _warn_graph_queues('GraphedStep')
         self.trainer = trainer
+        self.dev = data['img'].device
         dev = data['img'].device
         n = len(data['img_metas'])
         max_gt = max(int(max_gt), max(int(b.shape[0])
@@ -560,10 +614,11 @@ class GraphedStep:
                             trainer.step(self.data)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = _new_graph(launcher)
         with torch.cuda.graph(self.graph, stream=side,
                               capture_error_mode=_capture_mode()):
             out = trainer.step(self.data)
+        self.list = _StepList(self.graph) if launcher == 'list' else None
         self._loss = out['loss']
         lv = out['log_vars']
         self._log_keys, self._log_tensor = list(lv._keys), lv._tensor
@@ -598,7 +653,10 @@ class GraphedStep:
     def replay(self):
         from .heads import LazyScalars
         self.trainer._push_hyper()
-        self.graph.replay()
+        if self.list is not None:
+            self.list.replay(self.dev)
+        else:
+            self.graph.replay()
         self.trainer.iter += 1
         return dict(loss=self._loss,
                     log_vars=LazyScalars(self._log_keys, self._log_tensor),
@@ -624,10 +682,12 @@ class PipelinedGraphedStep:
     are bit-identical to eager steps on the same batch sequence
     (tests/test_gpu_graph.py)."""
 
-    def __init__(self, trainer, first, second, warmup=1, max_gt=128):
+    def __init__(self, trainer, first, second, warmup=1, max_gt=128,
+                 launcher='graph'):
         from . import lossblock as LB
         _refuse_collectives_in_capture('PipelinedGraphedStep')
-        _warn_graph_queues('PipelinedGraphedStep')
+        if launcher == 'graph':
+            _warn_graph_queues('PipelinedGraphedStep')
         self.trainer = trainer
         model = trainer.model
         if not hasattr(model, 'teacher_model') or not model.eval_teacher:
@@ -670,14 +730,15 @@ class PipelinedGraphedStep:
                                        for lvl in tout))
         torch.cuda.current_stream(dev).wait_stream(cap)
         torch.cuda.synchronize(dev)
-        self.graphs, self.outs = [], []
+        self.graphs, self.outs, self.lists = [], [], []
         for k in (0, 1):
-            g = torch.cuda.CUDAGraph()
+            g = _new_graph(launcher)
             with torch.cuda.graph(g, stream=cap,
                                   capture_error_mode=_capture_mode()):
                 out = self._one(k)
             lv = out['log_vars']
             self.graphs.append(g)
+            self.lists.append(_StepList(g) if launcher == 'list' else None)
             self.outs.append((out['loss'], list(lv._keys), lv._tensor,
                               out['num_samples']))
         self.cur = 0
@@ -691,10 +752,10 @@ class PipelinedGraphedStep:
         with torch.cuda.stream(side):
             tx, tout = model._teacher_forward(nxt['data']['img'])
             for dst, src in zip(nxt['teacher'][0], tx):
-                dst.copy_(src)
+                Y.copy_into(dst, src)
             for dl, sl in zip(nxt['teacher'][1], tout):
                 for dst, src in zip(dl, sl):
-                    dst.copy_(src)
+                    Y.copy_into(dst, src)
         model._forced_teacher = cur['teacher']
         try:
             out = self.trainer.step(cur['data'])
@@ -716,7 +777,10 @@ class PipelinedGraphedStep:
         nxt['static'].load(next_data['img_metas'], next_data['gt_bboxes'],
                            next_data['gt_labels'])
         self.trainer._push_hyper()
-        self.graphs[self.cur].replay()
+        if self.lists[self.cur] is not None:
+            self.lists[self.cur].replay(self.dev)
+        else:
+            self.graphs[self.cur].replay()
         loss, keys, tensor, ns = self.outs[self.cur]
         self.cur = 1 - self.cur
         self.trainer.iter += 1

@@ -24,8 +24,11 @@ def _trainer(dev):
     return SGDTrainer(det, lr=0.01)
 
 
+@pytest.mark.parametrize('launcher', ['graph', 'list'])
 @pytest.mark.parametrize('mode', ['fp32', 'bf16'])
-def test_graphed_step_equals_eager(mode):
+def test_graphed_step_equals_eager(mode, launcher):
+    """launcher='list': the captured graph re-issued by the C launch loop of
+    csrc/graphlist.hip (ld_step_list_*) instead of hipGraphLaunch."""
     from ld_amd import layers as Y
     from ld_amd.train import GraphedStep
     dev = torch.device('cuda:0')
@@ -38,7 +41,9 @@ def test_graphed_step_equals_eager(mode):
         torch.cuda.synchronize()
         tr = _trainer(dev)
         static = _batch(21, dev)
-        g = GraphedStep(tr, static, warmup=2)  # two eager steps on d1
+        g = GraphedStep(tr, static, warmup=2, launcher=launcher)  # two eager steps on d1
+        if launcher == 'list':
+            assert g.list.info['kernels'] > 100 and g.list.info['lanes'] >= 1
         out_g = g.replay()                     # third step on d1
         torch.cuda.synchronize()
         g.copy_inputs(d2)
@@ -104,8 +109,9 @@ def test_graphed_step_takes_real_batches():
         g.copy_inputs(_batch_g(26, [17, 1], dev))  # more boxes than max_gt
 
 
+@pytest.mark.parametrize('launcher', ['graph', 'list'])
 @pytest.mark.parametrize('mode', ['fp32', 'bf16'])
-def test_pipelined_graphed_step_equals_eager(mode):
+def test_pipelined_graphed_step_equals_eager(mode, launcher):
     """train.PipelinedGraphedStep (two hipGraphs over two slots: student step
     of batch i + teacher forward of batch i + 1 in one replay, weight gradients
     on their side stream) against plain eager steps on the same batch
@@ -124,7 +130,8 @@ def test_pipelined_graphed_step_equals_eager(mode):
             out_e = eager.step(d)
         torch.cuda.synchronize()
         tr = _trainer(dev)
-        ps = PipelinedGraphedStep(tr, b[0], b[1], warmup=1, max_gt=16)
+        ps = PipelinedGraphedStep(tr, b[0], b[1], warmup=1, max_gt=16,
+                                  launcher=launcher)
         outs = [ps.step(b[1]), ps.step(b[2]), ps.step(b[3]), ps.step(b[4])]
         torch.cuda.synchronize()
         assert torch.equal(tr.arena.flat_param, eager.arena.flat_param)
