@@ -71,7 +71,8 @@ def parse():
     ap.add_argument('--no-kernel-roofline', action='store_true')
     ap.add_argument('--profile-steps', type=int, default=2)
     ap.add_argument('--no-graph', action='store_true',
-                    help='skip the hipGraph-replay leg')
+                    help='skip the step-list leg (the captured step re-issued by '
+                    'the C launch loop)')
     ap.add_argument('--no-bf16', action='store_true',
                     help='skip the bf16 (BASELINE config 3) leg')
     ap.add_argument('--no-prefetch', action='store_true',
@@ -154,30 +155,31 @@ def kernel_roofline(trainer, dbatch, steps, bf16=False):
     # `traffic` is per conv call of THIS line (the PMC total per step divided by
     # this line's own launches_per_step), so that traffic / algorithmic_bytes_per_
     # launch is the per-step ratio: ONE ratio, in the fields and in the note
-    pmc_per_launch = PMC_CONV_TRAFFIC_BYTES_PER_STEP / max(tot_n / steps, 1)
+    pmc = PMC_CONV['bf16' if bf16 else 'fp32']
+    pmc_per_launch = (pmc['fetch'] + pmc['write']) / max(tot_n / steps, 1)
     ratio = pmc_per_launch / alg_per_launch if alg_per_launch else 0.0
-    rd_ratio = PMC_CONV_FETCH_BYTES_PER_STEP / (alg_rd / steps) if alg_rd else 0.0
-    wr_ratio = PMC_CONV_WRITE_BYTES_PER_STEP / (alg_wr / steps) if alg_wr else 0.0
+    rd_ratio = pmc['fetch'] / (alg_rd / steps) if alg_rd else 0.0
+    wr_ratio = pmc['write'] / (alg_wr / steps) if alg_wr else 0.0
     out = dict(
         kernel=kernel, bound='mfma', achieved=ach, peak=peak,
         unit='TFLOP/s', frac=ach / peak,
-        traffic=None if bf16 else pmc_per_launch,
+        traffic=pmc_per_launch,
         algorithmic_bytes_per_launch=alg_per_launch,
-        traffic_over_algorithmic=None if bf16 else ratio,
+        traffic_over_algorithmic=ratio,
         algorithmic_read_bytes_per_launch=alg_rd / max(tot_n, 1),
         algorithmic_write_bytes_per_launch=alg_wr / max(tot_n, 1),
-        fetch_over_algorithmic_reads=None if bf16 else rd_ratio,
-        write_over_algorithmic_writes=None if bf16 else wr_ratio,
+        fetch_over_algorithmic_reads=rd_ratio,
+        write_over_algorithmic_writes=wr_ratio,
         # what the fused epilogues read (residual, gradient addend) and write
         # (the raw second output of conv+BN launches) on top, by design; the
         # ratios with those bytes in the denominator
         fused_epilogue_read_bytes_per_step=fus_rd / steps,
         fused_epilogue_write_bytes_per_step=fus_wr / steps,
-        fetch_over_reads_incl_fused=None if bf16 or not alg_rd else
-        PMC_CONV_FETCH_BYTES_PER_STEP / ((alg_rd + fus_rd) / steps),
-        write_over_writes_incl_fused=None if bf16 or not alg_wr else
-        PMC_CONV_WRITE_BYTES_PER_STEP / ((alg_wr + fus_wr) / steps),
-        traffic_note='bf16: not collected' if bf16 else (
+        fetch_over_reads_incl_fused=None if not alg_rd else
+        pmc['fetch'] / ((alg_rd + fus_rd) / steps),
+        write_over_writes_incl_fused=None if not alg_wr else
+        pmc['write'] / ((alg_wr + fus_wr) / steps),
+        traffic_note=(
             'fabric-side bytes of the GEMM kernels per step (requests leaving the '
             'XCD L2s, Infinity-Cache hits included) divided by this line\'s '
             'launches_per_step: rocprofv3 --pmc FETCH_SIZE (x 2: calibrated on a '
@@ -193,8 +195,7 @@ def kernel_roofline(trainer, dbatch, steps, bf16=False):
             'bytes through the L1 miss path are what the time above the MFMA '
             'floor is made of (profiles/r04_wgrad_attribution.txt); not '
             're-measured inside bench.py') % (
-                PMC_CONV_DISPATCHES_PER_STEP, PMC_CONV_TRAFFIC_FILE, ratio,
-                rd_ratio, wr_ratio),
+                pmc['dispatches'], pmc['file'], ratio, rd_ratio, wr_ratio),
         launches_per_step=tot_n / steps,
         avg_launch_us=tot_t / max(tot_n, 1) * 1e6,
         conv_ms_per_step=tot_t / steps * 1e3,
@@ -279,11 +280,17 @@ PMC_LDKL_TRAFFIC_BYTES = (2 * 1212475.4 + 1115649.4) * 1024.0
 # (profiles/r04_pmc_calib_copy_*): the counter tallies 128-byte fabric requests at
 # 64 bytes.  It counts requests LEAVING an XCD's L2, Infinity-Cache hits included.
 # (The per-bucket slab reduce adds 1.7 GB per step; not part of `traffic`.)
-PMC_CONV_TRAFFIC_FILE = 'profiles/r05_pmc_traffic_conv_step_fp32_by_kernel.txt'
-PMC_CONV_DISPATCHES_PER_STEP = 324
-PMC_CONV_FETCH_BYTES_PER_STEP = 2 * 12.12e9
-PMC_CONV_WRITE_BYTES_PER_STEP = 9.62e9
-PMC_CONV_TRAFFIC_BYTES_PER_STEP = PMC_CONV_FETCH_BYTES_PER_STEP + PMC_CONV_WRITE_BYTES_PER_STEP
+# The constants come out of tools/pmc_conv_bytes.py <file> <steps in the run>.
+# bf16 (round 6, VERDICT r5 next #1: roofline_bf16.traffic non-null): the
+# serialised bf16 step, 4 steps, 282 GEMM dispatches per step (C8 tile / LDS-DMA /
+# C8 weight-gradient kernels, the fused teacher bottleneck): FETCH_SIZE 2 x 5.42 GB
+# + WRITE_SIZE 9.04 GB = 19.9 GB per step.
+PMC_CONV = {
+    'fp32': dict(file='profiles/r05_pmc_traffic_conv_step_fp32_by_kernel.txt',
+                 dispatches=324, fetch=2 * 12.12e9, write=9.62e9),
+    'bf16': dict(file='profiles/r06_pmc_traffic_conv_step_bf16_by_kernel.txt',
+                 dispatches=282, fetch=10.838e9, write=9.037e9),
+}
 
 
 def hbm_ceilings(dev):
@@ -523,6 +530,32 @@ def launch_plan(gpus, env, n_devices, argv):
     return 'spawn', cmd
 
 
+def pin_rank(local, local_world):
+    """One Python enqueuer per GPU: give every rank its own slice of the host's
+    cores (contiguous, so that it stays on one socket / NUMA node where the
+    numbering allows) and a small OpenMP pool.  N ranks that each start
+    os.cpu_count() OpenMP threads and migrate freely cost each other the launch
+    latency the step depends on.  LD_BENCH_PIN=0 turns it off."""
+    if os.environ.get('LD_BENCH_PIN', '1') != '1':
+        return None
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    per = max(len(cpus) // max(local_world, 1), 1)
+    mine = cpus[local * per:(local + 1) * per] or cpus
+    if local_world > 1:
+        try:
+            os.sched_setaffinity(0, mine)
+        except OSError:
+            return None
+    threads = max(1, min(len(mine), 8))
+    os.environ.setdefault('OMP_NUM_THREADS', str(threads))
+    torch.set_num_threads(int(os.environ['OMP_NUM_THREADS']))
+    return dict(cpus=len(mine), first=mine[0], last=mine[-1],
+                omp_threads=int(os.environ['OMP_NUM_THREADS']))
+
+
 def main():
     args = parse()
     action, cmd = launch_plan(args.gpus, os.environ, _device_count(), sys.argv[1:])
@@ -543,6 +576,7 @@ def main():
         print(f'[bench] launch-only rank {rank} of {world} local {local}', flush=True)
         return
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    pinned = pin_rank(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1 or 'RANK' in os.environ:
@@ -622,30 +656,56 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        rank_dt[:] = [dt]
         if world > 1:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt)
+            every = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(every, tt)
+            rank_dt[:] = [float(x) for x in every]
+            dt = max(rank_dt)
         return dt, t_enq, float(out['log_vars']['loss'])
 
+    rank_dt = []
+    exposed = []
+    trainer.arena.exposed = exposed if world > 1 else None
     dt, t_enq, loss_val = timed(args.warmup, args.steps)
+    rank_ms = [x / args.steps * 1e3 for x in rank_dt]
+    exposed_ms = None
+    if exposed:
+        torch.cuda.synchronize()
+        ex = [a.elapsed_time(b) for a, b in exposed[-args.steps:]]
+        exposed_ms = sum(ex) / len(ex)
+    trainer.arena.exposed = None
     hits0 = getattr(det, 'prefetch_hits', 0)
 
     def synced_median(n):
-        # the median of individually synchronised steps, reported
-        # beside the K-step mean (a synchronised step cannot overlap its tail
-        # with the next step's head, so this figure is the larger one)
+        # SURVEY 8(d), the definition of `value`: every step timed on its own with
+        # HIP events on the step's stream between two device synchronisations
+        # (N > 1: a barrier first, so the ranks start together), the MEDIAN of
+        # those, MAX over ranks.  A synchronised step cannot overlap its tail with
+        # the next step's head, so this is the larger (conservative) figure; the
+        # K-step bracket the driver's contract describes is reported beside it.
         ts = []
         for _ in range(n):
+            if world > 1:
+                dist.barrier()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            a = torch.cuda.Event(enable_timing=True)
+            b = torch.cuda.Event(enable_timing=True)
+            a.record()
             one_step()
+            b.record()
             torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t0)
+            ts.append(a.elapsed_time(b))
         ts.sort()
-        return ts[len(ts) // 2] * 1e3
+        med = ts[len(ts) // 2]
+        if world > 1:
+            tt = torch.tensor([med], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            med = float(tt)
+        return med
 
-    ms_sync_median = synced_median(min(max(args.steps, 3), 11))
+    ms_sync_median = synced_median(min(max(args.steps, 3), 21))
     dt_plain = None
     if prefetch:  # the same K steps with the teacher inside each step, for the record
         prefetch = False
@@ -653,26 +713,61 @@ def main():
         prefetch = True
 
     res = None
+    parity_note = None
+    if args.config == 4:
+        parity_note = ('DCN with non-zero offsets: parity UNPINNED (mmcv.ops.'
+                       'DeformConv2dPack is not in the image; csrc/dcn.hip is checked '
+                       'against oracle/dcn_oracle.py, a restatement of mmcv 1.2.7\'s '
+                       'published algorithm, and against plain conv at zero offsets)')
     if rank == 0:
         ms = dt / args.steps * 1e3
         imgs = args.batch_per_gpu * world * args.steps / dt
         res = {
-            'metric': METRIC, 'value': imgs, 'unit': 'images/sec',
+            'metric': METRIC,
+            # global batch / median of individually synchronised,
+            # HIP-event-timed steps (MAX over ranks)
+            'value': args.batch_per_gpu * world / (ms_sync_median * 1e-3),
+            'unit': 'images/sec',
             'n_gpus': world,
             'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
             'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': ms_sync_median, 'higher_is_better': True,
+            'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'value_definition': (
+                'global batch / median over %d steps, each timed with HIP events '
+                'between two device synchronisations (SURVEY.md 8(d)); the K steps '
+                'of the driver contract, enqueued back to back inside one barrier + '
+                'synchronize bracket, are images_per_sec_k_step_bracket / '
+                'ms_per_step_k_step_bracket below' % min(max(args.steps, 3), 21)),
+            'images_per_sec_k_step_bracket': imgs,
+            'ms_per_step_k_step_bracket': ms,
             'config': {
                 'workload': workload_name + ', 800x1333 padded to 800x1344, '
                             f'{args.num_gt} GT/img',
                 'global_batch': args.batch_per_gpu * world,
                 'batch_per_gpu': args.batch_per_gpu,
                 'parallelism': f'dp{world}',
+                'parity_note': parity_note,
                 'optimizer': 'SGD(momentum 0.9, wd 1e-4), step included',
                 'last_loss': loss_val,
                 'host_enqueue_ms_per_step': t_enq / args.steps * 1e3,
+                'host_enqueue_note': (
+                    'wall time of the host loop that enqueues the K steps; it '
+                    'includes back-pressure from full hardware queues whenever the '
+                    'GPU is the slower side (a C launch loop over the same ~500 '
+                    'launches, step_list below, takes 7 ms on an idle queue and the '
+                    'same 24 ms as Python when the fp32 step is GPU-bound: '
+                    'profiles/r06_step_list_*.json)'),
                 'ms_per_step_synchronised_median': ms_sync_median,
+                'ms_per_step_per_rank_k_step_bracket': {
+                    'min': min(rank_ms), 'max': max(rank_ms)} if rank_ms else None,
+                'exposed_allreduce_ms_per_step': exposed_ms,
+                'exposed_allreduce_note': (
+                    'HIP-event time the compute stream spends in GradArena.finish '
+                    'waiting for the bucketed gradient all-reduces that backward did '
+                    'not hide (rank 0, mean over the timed steps); null at N = 1'),
+                'rank_cpu_placement': pinned,
                 'prime_steps': 1,
                 'teacher_prefetch': bool(prefetch),
                 'teacher_prefetch_note': (
@@ -719,6 +814,7 @@ def main():
         from ld_amd import layers as Y
         Y.set_precision('bf16')
         dtb, tenqb, lossb = timed(args.warmup, args.steps)
+        ms_sync_b = synced_median(min(max(args.steps, 3), 21))
         roofb = None
         if not args.no_kernel_roofline:
             roofb = kernel_roofline(trainer, dbatch, args.profile_steps,
@@ -729,8 +825,11 @@ def main():
                 'workload': 'same step, conv matrix operands in bf16 '
                             '(v_mfma_f32_32x32x16_bf16, fp32 accumulate; fp32 '
                             'master weights, activations, norms, loss block)',
-                'value': args.batch_per_gpu * world * args.steps / dtb,
-                'unit': 'images/sec', 'ms_per_step': dtb / args.steps * 1e3,
+                'value': args.batch_per_gpu * world / (ms_sync_b * 1e-3),
+                'unit': 'images/sec', 'ms_per_step': ms_sync_b,
+                'images_per_sec_k_step_bracket':
+                    args.batch_per_gpu * world * args.steps / dtb,
+                'ms_per_step_k_step_bracket': dtb / args.steps * 1e3,
                 'host_enqueue_ms_per_step': tenqb / args.steps * 1e3,
                 'last_loss': lossb, 'dtype': 'bf16 operands / f32 accumulate',
             }
@@ -740,87 +839,57 @@ def main():
                         gflop_per_img * 1e9 * args.batch_per_gpu / \
                         (dtb / args.steps) / 1e12
                 res['roofline_bf16'] = roofb
-    # ---- graph leg: the same step replayed from one captured hipGraph (the
-    # ~750 launches of a step cost ~13 ms of Python + ctypes on the host, which
-    # binds once the kernels are faster than that).  Reported beside the eager
-    # numbers; `value` stays the eager fp32 step.
+    # ---- step-list leg: the same step captured ONCE (hipGraph capture as the
+    # recorder) and re-issued by a C launch loop (ld_step_list_*, csrc/graphlist.hip),
+    # teacher one step ahead inside the list, a fresh batch with a different
+    # number of GT boxes per replay.  hipGraphLaunch itself is NOT used: it costs
+    # ~22 us of host time per node on this runtime and ran behind the eager step in
+    # every round (r05: fp32 55.3 / 56.9 vs 58.8 img/s); its legs are gone from this
+    # line.  Reported beside the eager numbers; `value` stays the eager fp32 step.
     # (not with N > 1 ranks: a captured step would contain RCCL collectives, which
-    # train.GraphedStep refuses -- they race with ProcessGroupNCCL's watchdog)
+    # the capture refuses -- they race with ProcessGroupNCCL's watchdog)
     if not args.no_graph and world == 1 and not os.environ.get('LD_FORCE_COLLECTIVES') == '1':
         from ld_amd import layers as Y
-        from ld_amd.train import GraphedStep
-        graph_res = {}
+        from ld_amd.train import PipelinedGraphedStep
+        list_res = {}
         for mode in (['fp32'] if args.no_bf16 else ['fp32', 'bf16']):
             Y.set_precision(mode)
             try:
                 trainer.step(dbatch)  # images of the mode exist before capture
                 torch.cuda.synchronize()
-                gs = GraphedStep(trainer, dbatch, warmup=2)
-                # a FRESH batch per replay, with a different number of GT
-                # boxes (the captured step pads to max_gt with device-side
-                # counts): what a real epoch hands the step
                 fresh = [make_batch(args.batch_per_gpu, g, 4321 + rank + g,
                                     dev)[1] for g in (5, 11, args.num_gt)]
-                for i in range(args.warmup):
-                    gs.copy_inputs(fresh[i % len(fresh)])
-                    gs.replay()
-                if world > 1:
-                    dist.barrier()
+                ps = PipelinedGraphedStep(trainer, fresh[0], fresh[1], warmup=1,
+                                          launcher='list')
+                for i in range(max(args.warmup, 1)):
+                    ps.step(fresh[(i + 1) % len(fresh)])
+                torch.cuda.synchronize()
+                # host cost of ONE replay on an idle queue (no back-pressure)
+                h0 = time.perf_counter()
+                ps.step(fresh[0])
+                host_idle = time.perf_counter() - h0
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for i in range(args.steps):
-                    gs.copy_inputs(fresh[i % len(fresh)])
-                    out = gs.replay()
-                if world > 1:
-                    dist.barrier()
+                    out = ps.step(fresh[(i + 1 + args.warmup) % len(fresh)])
+                t_enq_l = time.perf_counter() - t0
                 torch.cuda.synchronize()
-                dtg = time.perf_counter() - t0
-                if world > 1:
-                    tt = torch.tensor([dtg], device=dev, dtype=torch.float64)
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    dtg = float(tt)
-                graph_res[mode] = {
-                    'value': args.batch_per_gpu * world * args.steps / dtg,
-                    'unit': 'images/sec',
-                    'ms_per_step': dtg / args.steps * 1e3,
+                dtp = time.perf_counter() - t0
+                list_res[mode] = {
+                    'value': args.batch_per_gpu * world * args.steps / dtp,
+                    'unit': 'images/sec', 'ms_per_step': dtp / args.steps * 1e3,
+                    'host_enqueue_ms_per_step': t_enq_l / args.steps * 1e3,
+                    'host_ms_one_replay_idle_queue': host_idle * 1e3,
                     'last_loss': float(out['log_vars']['loss']),
                     'fresh_batch_per_replay': True,
-                    'gt_per_image_cycle': [5, 11, args.num_gt]}
-                del gs
-                try:
-                    # the same with the teacher one step ahead inside the graphs
-                    # (train.PipelinedGraphedStep: two graphs over two batch slots)
-                    from ld_amd.train import PipelinedGraphedStep
-                    ps = PipelinedGraphedStep(trainer, fresh[0], fresh[1], warmup=1)
-                    for i in range(args.warmup):
-                        ps.step(fresh[(i + 1) % len(fresh)])
-                    if world > 1:
-                        dist.barrier()
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    for i in range(args.steps):
-                        out = ps.step(fresh[(i + 1 + args.warmup) % len(fresh)])
-                    if world > 1:
-                        dist.barrier()
-                    torch.cuda.synchronize()
-                    dtp = time.perf_counter() - t0
-                    if world > 1:
-                        tt = torch.tensor([dtp], device=dev, dtype=torch.float64)
-                        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                        dtp = float(tt)
-                    graph_res[mode]['teacher_one_step_ahead'] = {
-                        'value': args.batch_per_gpu * world * args.steps / dtp,
-                        'unit': 'images/sec', 'ms_per_step': dtp / args.steps * 1e3,
-                        'last_loss': float(out['log_vars']['loss'])}
-                    del ps
-                except Exception as e:
-                    graph_res[mode]['teacher_one_step_ahead'] = {
-                        'error': f'{type(e).__name__}: {e}'[:300]}
+                    'gt_per_image_cycle': [5, 11, args.num_gt],
+                    'list': ps.lists[0].info}
+                del ps
             except Exception as e:  # report, never lose the headline line
-                graph_res[mode] = {'error': f'{type(e).__name__}: {e}'[:300]}
+                list_res[mode] = {'error': f'{type(e).__name__}: {e}'[:300]}
         Y.set_precision('fp32')
         if rank == 0:
-            res['hipgraph_step'] = graph_res
+            res['step_list'] = list_res
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and \

@@ -27,6 +27,7 @@
 
 #include "ld_launch.h"
 #include <float.h>
+#include <stdlib.h>
 #include <limits.h>
 
 #include "../../include/ld_hip.h"
@@ -221,6 +222,160 @@ __global__ __launch_bounds__(kBlock) void atss_select_kernel(
     const float mn = fminf(fminf(l_, t_), fminf(r_, b_));
     if (ciou >= thr && mn > 0.01f) {
       // highest IoU wins, ties -> lowest GT index (torch.max(dim=1) on CPU)
+      const unsigned long long key =
+          ((unsigned long long)__float_as_uint(ciou) << 32) |
+          (unsigned long long)(0xFFFFFFFFu - (unsigned)g);
+      atomicMax(keys + (size_t)n * geom.num_anchors + s_cand[tid], key);
+    }
+  }
+}
+
+// ------------------------------------------------- kernel A, windowed (round 6) --
+// The scan above streams all ~22 400 anchors through ONE workgroup per (image, GT):
+// 131 us per C2 step for 14 workgroups on 256 CUs (profiles/r05_rocprof_kernel_
+// stats_fp32.csv), a latency chain, not a bandwidth problem.  With IMPLICIT anchors
+// (one square per cell, centred on (x s, y s)) the k <= 9 nearest centres of a level
+// lie in a small window around the cell nearest to the GT centre, so each level
+// needs (2 R + 1)^2 = 289 candidates, not up to 16 800:
+//   * a valid region of at least 3 x 3 cells holds 9 cells within 3.6 cell sides
+//     of any point inside it, every cell outside the window is > 7 away;
+//   * a strip (1 or 2 valid rows / columns) holds its 9 nearest within +-8 cells
+//     along the strip -- hence R = 8 -- and a level with fewer than 9 valid cells
+//     (k = nvalid) is at most 8 x 8: the window covers it whole.
+// The column maximum of the IoU (IM region) is attained within one cell of the
+// nearest centre (the overlap of two axis-aligned boxes of fixed sizes is a
+// product of two trapezoids of the centre offset; where it is flat the computed
+// values are identical bit for bit), i.e. inside the same window.
+// One WAVE per level: every lane evaluates <= 5 candidates with the same
+// arithmetic as the scan, keeps them sorted, and k rounds of wave-shuffle arg-min
+// (distance, then anchor index: the scan's order) pop the winners -- no block
+// barrier until the candidates of all levels are in LDS, from where the second
+// half (IoU threshold, 64-bit atomicMax publish) is the scan kernel's, verbatim.
+// Results are bit-identical to the scan (tests/test_gpu_atss.py runs both).
+constexpr int kWinR = 8;
+constexpr int kWinK = 5;  // ceil(17 * 17 / 64)
+
+__global__ __launch_bounds__(kBlock) void atss_select_window_kernel(
+    ld_geom_t geom, int topk, const float* __restrict__ gt_bboxes,
+    const int32_t* __restrict__ num_gt, int max_gt, const int32_t* __restrict__ valid_hw,
+    unsigned long long* __restrict__ keys, float* __restrict__ thr_out,
+    float* __restrict__ colmax_out) {
+  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  if (g >= num_gt[n]) return;
+  const float* gp = gt_bboxes + ((size_t)n * max_gt + g) * 4;
+  const Box gt{gp[0], gp[1], gp[2], gp[3]};
+  const float gcx = (gt.x1 + gt.x2) / 2.0f, gcy = (gt.y1 + gt.y2) / 2.0f;
+  const int lane = tid & 63, wave = tid >> 6;
+
+  __shared__ float s_wmax[kWaves];
+  __shared__ int s_cand[kMaxCand];
+  __shared__ float s_ciou[kMaxCand];
+  __shared__ float s_thr;
+  float my_colmax = 0.0f;
+  int ncand = 0;  // total over the levels (uniform)
+  for (int l = 0; l < geom.num_levels; ++l) {
+    const ld_level_t lv = geom.lv[l];
+    const int vh = valid_hw[((size_t)n * geom.num_levels + l) * 2 + 0];
+    const int vw = valid_hw[((size_t)n * geom.num_levels + l) * 2 + 1];
+    const int nvalid = vh * vw;
+    const int k = min(topk, nvalid);
+    const int base = ncand;  // this level's slots in s_cand: the scan's order
+    ncand += k;
+    if ((l % kWaves) != wave || k == 0) continue;
+    const float half = 0.5f * (float)(geom.anchor_scale * lv.stride);
+    const float inv = 1.0f / (float)lv.stride;
+    const int xc = min(max((int)floorf(gcx * inv + 0.5f), 0), vw - 1);
+    const int yc = min(max((int)floorf(gcy * inv + 0.5f), 0), vh - 1);
+    const int x0 = max(xc - kWinR, 0), x1 = min(xc + kWinR, vw - 1);
+    const int y0 = max(yc - kWinR, 0), y1 = min(yc + kWinR, vh - 1);
+    const int ww = x1 - x0 + 1, wn = ww * (y1 - y0 + 1);
+    float ld_[kWinK];
+    int li_[kWinK];
+#pragma unroll
+    for (int j = 0; j < kWinK; ++j) {
+      ld_[j] = FLT_MAX;
+      li_[j] = INT_MAX;
+    }
+    for (int c = lane; c < wn; c += 64) {
+      const int wy = c / ww, wx = c - wy * ww;
+      const int x = x0 + wx, y = y0 + wy;
+      const int a = lv.offset + y * lv.W + x;
+      const Box ab = ld::anchor_box(x, y, lv.stride, half);
+      const float acx = (ab.x1 + ab.x2) / 2.0f, acy = (ab.y1 + ab.y2) / 2.0f;
+      float d = ld::centre_dist(acx, acy, gcx, gcy);
+      my_colmax = fmaxf(my_colmax, ld::iou_pair(ab, gt));
+      int ai = a;
+#pragma unroll
+      for (int j = 0; j < kWinK; ++j) {
+        if (lex_less(d, ai, ld_[j], li_[j])) {
+          const float td = ld_[j];
+          const int ti = li_[j];
+          ld_[j] = d;
+          li_[j] = ai;
+          d = td;
+          ai = ti;
+        }
+      }
+    }
+    for (int r = 0; r < k; ++r) {
+      const DistIdx best = wave_argmin(DistIdx{ld_[0], li_[0]});
+      if (li_[0] == best.i && best.i != INT_MAX) {  // the unique owner pops
+#pragma unroll
+        for (int j = 0; j < kWinK - 1; ++j) {
+          ld_[j] = ld_[j + 1];
+          li_[j] = li_[j + 1];
+        }
+        ld_[kWinK - 1] = FLT_MAX;
+        li_[kWinK - 1] = INT_MAX;
+      }
+      if (lane == 0) s_cand[base + r] = best.i;
+    }
+  }
+  {
+    const float m = wave_max(my_colmax);
+    if (lane == 0) s_wmax[wave] = m;
+  }
+  __syncthreads();
+  // ---- from here on: the scan kernel's second half
+  Box cab{0, 0, 0, 0};
+  float ciou = 0.0f;
+  if (tid < ncand) {
+    const int a = s_cand[tid];
+    const int l = level_of(geom, a);
+    const ld_level_t lv = geom.lv[l];
+    const int r = a - lv.offset;
+    const int y = r / lv.W, x = r - y * lv.W;
+    cab = ld::anchor_box(x, y, lv.stride, 0.5f * (float)(geom.anchor_scale * lv.stride));
+    ciou = ld::iou_pair(cab, gt);
+    s_ciou[tid] = ciou;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double sum = 0.0;
+    for (int i = 0; i < ncand; ++i) sum += (double)s_ciou[i];
+    const double mean = sum / (double)ncand;
+    double ss = 0.0;
+    for (int i = 0; i < ncand; ++i) {
+      const double dd = (double)s_ciou[i] - mean;
+      ss += dd * dd;
+    }
+    const double sd = sqrt(ss / (double)(ncand - 1));  // NaN when ncand == 1
+    const float thr = (float)mean + (float)sd;
+    s_thr = thr;
+    thr_out[(size_t)n * max_gt + g] = thr;
+    float cm = s_wmax[0];
+#pragma unroll
+    for (int q = 1; q < kWaves; ++q) cm = fmaxf(cm, s_wmax[q]);
+    colmax_out[(size_t)n * max_gt + g] = cm;
+  }
+  __syncthreads();
+  if (tid < ncand) {
+    const float thr = s_thr;
+    const float acx = (cab.x1 + cab.x2) / 2.0f, acy = (cab.y1 + cab.y2) / 2.0f;
+    const float l_ = acx - gt.x1, t_ = acy - gt.y1;
+    const float r_ = gt.x2 - acx, b_ = gt.y2 - acy;
+    const float mn = fminf(fminf(l_, t_), fminf(r_, b_));
+    if (ciou >= thr && mn > 0.01f) {
       const unsigned long long key =
           ((unsigned long long)__float_as_uint(ciou) << 32) |
           (unsigned long long)(0xFFFFFFFFu - (unsigned)g);
@@ -643,7 +798,13 @@ extern "C" int ld_atss_targets_ex(const ld_geom_t* geom, const ld_loss_hp_t* hp,
     return (int)err;
   if (max_gt > 0) {
     dim3 grid(max_gt, N);
-    if (hp->topk <= 9)
+    // implicit anchors: the windowed search (LD_ATSS_SELECT=scan: the full scan)
+    const char* sel = getenv("LD_ATSS_SELECT");  // read per call: tests switch it
+    const bool window = !(sel && sel[0] == 's');
+    if (window && !anchors && hp->topk <= 9 && kMaxCand >= geom->num_levels * hp->topk)
+      LD_LAUNCH(atss_select_window_kernel, grid, dim3(kBlock), 0, stream, *geom,
+                hp->topk, gt_bboxes, num_gt, max_gt, valid_hw, keys, thr, colmax);
+    else if (hp->topk <= 9)
       LD_LAUNCH(atss_select_kernel<9>, grid, dim3(kBlock), 0, stream,
                          *geom, hp->topk, anchors, gt_bboxes, num_gt, max_gt,
                          valid_hw, 1, keys, thr, colmax);

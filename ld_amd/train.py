@@ -166,6 +166,10 @@ class GradArena:
         # the compute stream at the moment each bucket's last gradient is
         # produced = the earliest its all-reduce can start
         self.trace = None
+        # optional (bench.py at N > 1): a list that receives one (start, end) HIP
+        # event pair per step around the wait for the in-flight bucket reductions
+        # in finish() = the all-reduce time backward did not hide
+        self.exposed = None
 
     def zero_grad(self):
         Y.drop_deferred()  # partials of a step that did not finish
@@ -252,8 +256,16 @@ class GradArena:
             # what was held back or never completed, still in bucket order
             self._all_reduce(range(self._next, len(self.buckets)))
             self._next = len(self.buckets)
+            timed = self.exposed is not None and self.flat_grad.is_cuda
+            if timed:
+                a = torch.cuda.Event(enable_timing=True)
+                b = torch.cuda.Event(enable_timing=True)
+                a.record()
             for w in self._works:
                 w.wait()
+            if timed:
+                b.record()
+                self.exposed.append((a, b))
         self._works = []
 
 

@@ -172,8 +172,9 @@ def test_bf16_train_step_vs_fp32_golden(golden, bf16_mode):
     Measured on an MI355X (profiles/r02_pytest_gpu_s1_bf16_rccl.txt): every
     entry of the (8 keys x 5 levels) loss table within 0.41 % of the fp32
     reference, per-parameter gradient norms median 0.65 % / p90 0.87 % / max
-    1.2 % off.  Asserted at ~5x that: loss table rtol 2 % (+ atol 1e-3 for the
-    near-empty coarse levels), gradient norms p90 < 3 %, max < 6 %."""
+    1.2 % off.  Asserted at ~2.5x that (round 6, VERDICT r5: the 5x margin hid
+    regressions): loss table rtol 1 % (+ atol 1e-3 for the near-empty coarse
+    levels), gradient norms p90 < 2 %, max < 3 %."""
     from test_gpu_e2e import LOSS_KEYS, _setup
     name = 'c2_r50'
     g, det, batch, dbatch = _setup(golden, name, 50, 2.0)
@@ -187,7 +188,7 @@ def test_bf16_train_step_vs_fp32_golden(golden, bf16_mode):
     rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)
     print('bf16 loss table\n', got, '\nfp32 reference\n', ref,
           '\nrelative error per (key, level)\n', rel)
-    np.testing.assert_allclose(got, ref, rtol=2e-2, atol=1e-3)
+    np.testing.assert_allclose(got, ref, rtol=1e-2, atol=1e-3)
     # targets do not depend on the precision mode (bit-exactness of labels /
     # positive sets is test_gpu_lossblock.py's job): loss_kd_neg stays exactly 0
     assert not got[LOSS_KEYS.index('loss_kd_neg')].any()
@@ -202,8 +203,8 @@ def test_bf16_train_step_vs_fp32_golden(golden, bf16_mode):
     print('grad-norm relative error: median %.3e  p90 %.3e  max %.3e (%s)' %
           (np.median(rels), np.quantile(rels, 0.9), rels.max(),
            names[int(rels.argmax())]))
-    assert np.quantile(rels, 0.9) < 3e-2
-    assert rels.max() < 6e-2
+    assert np.quantile(rels, 0.9) < 2e-2
+    assert rels.max() < 3e-2
     assert np.isfinite(float(loss))
 
 
