@@ -1103,6 +1103,154 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(ConvK a) {
   }
 }
 
+// ------------------------------------- the 7x7 stem, operands through LDS ----
+// Round 6.  conv_stem_kernel above gathers every B element with its own 4-byte
+// load: per k-pair a wave issues TM + TN = 4 gather instructions for 4 MFMAs, 8
+// waves per CU keep the CU's address unit busy ~2x longer than the matrix pipes
+// (60-62 TFLOP/s in every round's layer table).  Here a workgroup owns TH x 64
+// output positions of ONE image (one output row segment per wave), stages the
+// input patch ((TH - 1) S + KH rows x 63 S + KW columns x Cin) and the whole
+// [Kpad][Cout] weight image in LDS with coalesced loads, and the k-loop reads
+// both operands with ds_read_b32 (A: 32 consecutive channels per half-wave; B:
+// stride-S positions, 2-way bank conflicts at S = 2, hidden under the 64-cycle
+// MFMAs).  The reduction runs over the same k pairs in the same order with the
+// same operand values as conv_stem_kernel: results are bit-identical
+// (tests/test_gpu_layers.py).  One level only (the stem has one).
+// (First version, measured: 233 us per launch against the gather kernel's 164 --
+// its staging loop walked the patch with one dependent load per iteration.  The
+// geometry is a template now: every staging load of a thread is in flight at once,
+// the k-loop is fully unrolled with compile-time LDS offsets.)
+template <int TH, int CIN, int KH, int KW, int S>
+__global__ __launch_bounds__(TH * 64) void conv_stem_lds_kernel(ConvK a, int tiles_w,
+                                                               int tiles_h) {
+  constexpr int TM = 2, TN = 2;  // 64 channels x 64 positions per wave
+  constexpr int NT = TH * 64;    // one wave per output row of the tile
+  constexpr int COUT = 64;
+  constexpr int K = CIN * KH * KW;
+  constexpr int KPAD = (K + kKPad - 1) / kKPad * kKPad;
+  constexpr int PR = (TH - 1) * S + KH;  // patch rows
+  constexpr int PC = 63 * S + KW;        // patch columns
+  constexpr int PCP = PC + 1;            // row pitch in LDS
+  constexpr int TOT = CIN * PR * PC;
+  constexpr int NIT = (TOT + NT - 1) / NT;
+  constexpr int NW4 = KPAD * COUT / 4 / NT;  // float4 weight loads per thread
+  static_assert(KPAD * COUT % (4 * NT) == 0, "weight image in whole 16-byte rounds");
+  __shared__ __attribute__((aligned(16))) float wsm[KPAD * COUT];  // [Kpad][Cout]
+  __shared__ float psm[CIN * PR * PCP];                            // [Cin][PR][PCP]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31 = lane & 31, lk = lane >> 5;
+  const int pad = __builtin_amdgcn_readfirstlane(a.g.pad);
+  const int Hin = __builtin_amdgcn_readfirstlane(a.g.lv[0].Hin);
+  const int Win = __builtin_amdgcn_readfirstlane(a.g.lv[0].Win);
+  const int Hout = __builtin_amdgcn_readfirstlane(a.g.lv[0].Hout);
+  const int Wout = __builtin_amdgcn_readfirstlane(a.g.lv[0].Wout);
+  const int Pin = __builtin_amdgcn_readfirstlane(a.Pin);
+  int b = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tw = b % tiles_w;
+  b /= tiles_w;
+  const int th = b % tiles_h;
+  const int n = b / tiles_h;
+  const int ho0 = th * TH, wo0 = tw * 64;
+  // ---- stage: every load of this thread issued before the first LDS write
+  {
+    const rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    const rsrc_t rw = make_rsrc(a.wt, a.wt_bytes);
+    typedef unsigned uintx4_ __attribute__((ext_vector_type(4)));
+    uintx4_ wv[NW4];
+#pragma unroll
+    for (int i = 0; i < NW4; ++i)
+      wv[i] = __builtin_bit_cast(
+          uintx4_, __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)(t + i * NT) * 16u, 0, 0));
+    const int h00 = ho0 * S - pad, w00 = wo0 * S - pad;
+    const int xbase = n * CIN * Pin + a.g.lv[0].off_in;
+    float pv[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int e = t + i * NT;
+      const int c = e % PC, r = (e / PC) % PR, ci = e / (PC * PR);
+      const int hi = h00 + r, wi = w00 + c;
+      const bool ok = (e < TOT) & ((unsigned)hi < (unsigned)Hin) & ((unsigned)wi < (unsigned)Win);
+      pv[i] = buf_load(rx, ok ? (unsigned)(xbase + ci * Pin + hi * Win + wi) * 4u : kOOB, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NW4; ++i) ((uintx4_*)wsm)[t + i * NT] = wv[i];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int e = t + i * NT;
+      const int c = e % PC, r = (e / PC) % PR, ci = e / (PC * PR);
+      if (e < TOT) psm[(ci * PR + r) * PCP + c] = pv[i];
+    }
+  }
+  __syncthreads();
+  const int ho = ho0 + wave;  // this wave's output row
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  const float* wl = wsm + lk * COUT + l31;
+  const float* pl = psm + (wave * S) * PCP + l31 * S;
+#pragma unroll
+  for (int pr = 0; pr < KPAD / 2; ++pr) {
+    // k = 2 pr + lk -> (ci, kh, kw): compile-time for either half-wave
+    constexpr auto off_of = [](int k) {
+      const int ci = k / (KH * KW), kh = (k / KW) % KH, kw = k % KW;
+      return (ci * PR + kh) * PCP + kw;
+    };
+    const int k0 = 2 * pr, k1 = 2 * pr + 1;
+    float ra[TM], rb[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ra[i] = wl[(2 * pr) * COUT + i * 32];
+    const int o0 = k0 < K ? off_of(k0) : 0, o1 = k1 < K ? off_of(k1) : 0;
+    const bool kin = lk ? (k1 < K) : (k0 < K);
+    const float* pk = pl + (lk ? o1 : o0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float v = pk[j * 32 * S];
+      rb[j] = kin ? v : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i], rb[j], acc[i][j], 0, 0, 0);
+  }
+  if (ho >= Hout) return;
+  // ---- epilogue (conv_stem_kernel's arithmetic)
+  const bool relu = a.relu != 0;
+  const bool has_aff = a.scale != nullptr, has_bias = a.bias != nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int rbase = i * 32 + 4 * lk;
+    float sc[16], sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rbase + (r & 3) + 8 * (r >> 2);
+      sc[r] = has_aff ? a.scale[row] : 1.0f;
+      sh[r] = has_aff ? a.shift[row] : 0.0f;
+      if (has_bias) sh[r] += a.bias[row];
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int wo = wo0 + j * 32 + l31;
+      if (wo >= Wout) continue;
+      const int p = a.g.lv[0].off_out + ho * Wout + wo;
+      const size_t colbase = (size_t)n * COUT * a.Pout + p;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        float v = acc[i][j][r] * sc[r] + sh[r];
+        if (a.residual) v += a.residual[colbase + (size_t)row * a.Pout];
+        if (relu) v = fmaxf(v, 0.0f);
+        a.y[colbase + (size_t)row * a.Pout] = v;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ wgrad --
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(WgradK a) {
   constexpr int BM = 128, BNc = 128;  // co x ci tile
@@ -2223,6 +2371,23 @@ extern "C" int ld_conv_forward_smallc(const ld_conv_t* c, const float* x,
   if (stem_on && (c->Cout == 64 || c->Cout == 32) && k.Kpad % 32 == 0 &&
       (size_t)c->N * c->Cout * c->Pout * 4 < (size_t)kOOB) {
     hipStream_t st = (hipStream_t)stream;
+    // round 6: both operands through LDS for THE stem geometry (3 -> 64, 7 x 7,
+    // stride 2); LD_CONV_STEM=stream: the gather kernel
+    const char* sel = getenv("LD_CONV_STEM");
+    if (c->Cout == 64 && c->Cin == 3 && c->KH == 7 && c->KW == 7 && c->stride == 2 &&
+        c->num_levels == 1 && !(sel && sel[0] == 's')) {
+      const int tw = (c->lv[0].Wout + 63) / 64;
+      if (sel && sel[0] == '8') {  // A/B: eight-row tiles (78 vs 81 TFLOP/s measured)
+        const int th = (c->lv[0].Hout + 7) / 8;
+        LD_LAUNCH((conv_stem_lds_kernel<8, 3, 7, 7, 2>), dim3(tw * th * c->N), dim3(512), 0,
+                  st, k, tw, th);
+      } else {
+        const int th = (c->lv[0].Hout + 3) / 4;
+        LD_LAUNCH((conv_stem_lds_kernel<4, 3, 7, 7, 2>), dim3(tw * th * c->N), dim3(256), 0,
+                  st, k, tw, th);
+      }
+      return (int)hipGetLastError();
+    }
     // 2 x 2 wave tiles of 32: 64 channels x 64 positions per wave, 4 waves per
     // workgroup, 8 k-pairs in flight
     if (c->Cout == 64) {

@@ -345,6 +345,34 @@ def test_maxpool_vector_and_scalar_paths(shape):
     assert torch.equal(got, F.max_pool2d(x, 3, 2, 1))
 
 
+@pytest.mark.parametrize('hw', [(38, 50), (64, 256), (131, 203), (800, 1344)])
+def test_stem_lds_kernel_bit_identical_to_gather_kernel(hw, monkeypatch):
+    """conv_stem_lds_kernel (round 6: patch + weight image through LDS) against
+    conv_stem_kernel (LD_CONV_STEM=stream, per-element gathers): same k pairs in
+    the same order on the same operand values -> identical bits, incl. ragged
+    right / bottom tiles and the zero padding."""
+    from ld_amd import layers as Y
+    dev = _dev()
+    g = torch.Generator().manual_seed(hw[0] + hw[1])
+    x = torch.randn(2, 3, hw[0], hw[1], generator=g).to(dev)
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).to(dev)
+    gamma, beta = (torch.rand(64, generator=g) + .5).to(dev), torch.randn(64, generator=g).to(dev)
+    mean, var = (torch.randn(64, generator=g) * .1).to(dev), (torch.rand(64, generator=g) + .5).to(dev)
+    outs = []
+    for sel in ('stream', 'lds'):
+        monkeypatch.setenv('LD_CONV_STEM', sel)
+        y, lv = Y.conv_bn_act_infer(x.reshape(2, 3, -1), w, gamma, beta, mean, var,
+                                    1e-5, 2, 3, (hw, ))
+        torch.cuda.synchronize()
+        outs.append(y.clone())
+    assert torch.equal(outs[0], outs[1])
+    if hw[0] <= 131:
+        ref = F.relu(F.batch_norm(F.conv2d(x.cpu(), w.cpu(), stride=2, padding=3),
+                                  mean.cpu(), var.cpu(), gamma.cpu(), beta.cpu(),
+                                  False, 0.0, 1e-5))
+        _close(outs[1].reshape(ref.shape), ref, what='stem (LDS kernel)')
+
+
 def test_conv_fused_epilogue_and_stem():
     from ld_amd import layers as Y
     dev = _dev()
