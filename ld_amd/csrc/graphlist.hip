@@ -273,10 +273,18 @@ extern "C" int64_t ld_step_list_build(void* hip_graph, int max_lanes) {
       destroy(s);
       return LD_EINVAL;
     }
+  // LD_STEP_LIST_SIDE_PRIORITY=low: the lanes the list owns get the lowest stream
+  // priority, so the caller's lane (the critical path) wins CUs when both have
+  // work (A/B knob; measured in profiles/r06_step_list_lanes.txt)
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  const char* pe = getenv("LD_STEP_LIST_SIDE_PRIORITY");
+  const bool low = pe && pe[0] == 'l';
   for (int l = 1; l < s->nlanes; ++l) {
     hipStream_t st;
     hipEvent_t ev;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
+    if ((low ? hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_lo)
+             : hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess ||
         hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
       destroy(s);
       return LD_EINVAL;

@@ -172,5 +172,7 @@ def test_bench_traffic_fields_state_one_ratio(monkeypatch):
     assert ('= %.2f x' % ratio) in r['traffic_note']
     assert 1.0 < r['write_over_writes_incl_fused'] < r['write_over_algorithmic_writes']
     assert 1.0 < r['fetch_over_reads_incl_fused'] < r['fetch_over_algorithmic_reads']
+    # round 6: the bf16 leg carries its own PMC figures
     rb = bench.kernel_roofline(_Trainer(), None, 1, bf16=True)
-    assert rb['traffic'] is None and rb['traffic_over_algorithmic'] is None
+    assert rb['traffic'] is None or rb['traffic'] > 0
+    assert bench.PMC_CONV['bf16']['file'].startswith('profiles/r06_')
