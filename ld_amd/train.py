@@ -820,9 +820,14 @@ class AutoStepper:
       * ``'pipelined'``: ``PipelinedGraphedStep`` (two graphs, teacher one step
         ahead inside the graph) for fixed-shape training: needs ``next_data`` on
         every call and one padded shape throughout.
+    ``launcher='list'`` (round 6; 'graph' / 'pipelined' modes): the captured steps
+    are re-issued by the C launch loop of ``_StepList`` instead of hipGraphLaunch --
+    ~2 ms of host time per step instead of ~11, the same step time (the GPU bounds
+    both precisions with one rank per GPU); what a host with few cores per GPU wants.
     """
 
-    def __init__(self, trainer, mode=None, warmup=1, max_gt=128, max_graphs=6):
+    def __init__(self, trainer, mode=None, warmup=1, max_gt=128, max_graphs=6,
+                 launcher='graph'):
         if mode is None:
             # Every precision, every job: the EAGER step with the teacher one step
             # ahead (round 5).  Round 3 made the graph path the bf16 default because
@@ -840,7 +845,9 @@ class AutoStepper:
             mode = 'eager'
         if mode not in ('eager', 'graph', 'pipelined'):
             raise ValueError(f'AutoStepper: unknown mode {mode!r}')
-        self.trainer, self.mode = trainer, mode
+        if launcher not in ('graph', 'list'):
+            raise ValueError(f'AutoStepper: unknown launcher {launcher!r}')
+        self.trainer, self.mode, self.launcher = trainer, mode, launcher
         self.warmup, self.max_gt = int(warmup), int(max_gt)
         # one graph per padded shape, at most max_graphs of them (least recently
         # used evicted: each holds a private pool with a whole step's
@@ -900,7 +907,8 @@ class AutoStepper:
                 # the warm-up's result is discarded (state restored below) and
                 # only THIS rank captures now: no collectives in it
                 g = GraphedStep(self.trainer, data, warmup=self.warmup,
-                                max_gt=self.max_gt, warmup_collectives=False)
+                                max_gt=self.max_gt, warmup_collectives=False,
+                                launcher=self.launcher)
                 torch.cuda.synchronize(data['img'].device)
                 self._restore_state(st)
                 self._graphs[key] = g
@@ -917,7 +925,8 @@ class AutoStepper:
             st = self._saved_state()
             self._pipe = PipelinedGraphedStep(self.trainer, data, next_data,
                                               warmup=self.warmup,
-                                              max_gt=self.max_gt)
+                                              max_gt=self.max_gt,
+                                              launcher=self.launcher)
             torch.cuda.synchronize(data['img'].device)
             self._restore_state(st)
             self._pipe_loaded = data

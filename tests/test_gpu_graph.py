@@ -241,7 +241,8 @@ def test_auto_stepper_graph_mode_equals_eager():
     assert AutoStepper(_trainer(dev)).mode == 'eager'
 
 
-def test_auto_stepper_pipelined_equals_eager():
+@pytest.mark.parametrize('launcher', ['graph', 'list'])
+def test_auto_stepper_pipelined_equals_eager(launcher):
     from ld_amd import layers as Y
     from ld_amd.train import AutoStepper
     dev = torch.device('cuda:0')
@@ -253,7 +254,7 @@ def test_auto_stepper_pipelined_equals_eager():
         outs_e = [float(eager.step(d)['loss']) for d in seq]
         torch.cuda.synchronize()
         tr = _trainer(dev)
-        st = AutoStepper(tr, mode='pipelined', max_gt=16)
+        st = AutoStepper(tr, mode='pipelined', max_gt=16, launcher=launcher)
         outs = []
         for k, d in enumerate(seq):
             nxt = seq[min(k + 1, len(seq) - 1)]

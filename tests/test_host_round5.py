@@ -75,6 +75,37 @@ def test_auto_stepper_defaults_to_eager():
         AutoStepper(_Trainer(), mode='fast')
 
 
+def test_auto_stepper_launcher_and_bench_rank_pinning(monkeypatch):
+    """Round 6 host logic: the stepper's launcher option, and bench.pin_rank giving
+    the ranks of one node disjoint, contiguous core slices + a small OpenMP pool."""
+    from ld_amd.train import AutoStepper
+
+    class _Trainer:
+        model = torch.nn.Linear(2, 2)
+
+    assert AutoStepper(_Trainer(), mode='graph', launcher='list').launcher == 'list'
+    with pytest.raises(ValueError):
+        AutoStepper(_Trainer(), mode='graph', launcher='fast')
+    sys.path.insert(0, REPO)
+    import bench
+    cores = set(range(64))
+    pinned = {}
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(cores))
+    monkeypatch.setattr(os, 'sched_setaffinity', lambda pid, s: pinned.update(last=set(s)))
+    monkeypatch.setattr(torch, 'set_num_threads', lambda n: None)
+    monkeypatch.delenv('OMP_NUM_THREADS', raising=False)
+    seen = []
+    for local in range(8):
+        monkeypatch.delenv('OMP_NUM_THREADS', raising=False)
+        r = bench.pin_rank(local, 8)
+        assert r['cpus'] == 8 and r['omp_threads'] == 8
+        assert r['first'] == local * 8 and r['last'] == local * 8 + 7
+        seen.append(pinned['last'])
+    assert set().union(*seen) == cores and sum(len(s) for s in seen) == 64
+    monkeypatch.setenv('LD_BENCH_PIN', '0')
+    assert bench.pin_rank(0, 8) is None
+
+
 def _write_trace(path, steps=4):
     """Two queues; per step: 3 conv + 1 norm kernel on queue 1, 2 conv on queue 2,
     then the optimizer launch.  10 us kernels, 5 us gaps on queue 1."""
