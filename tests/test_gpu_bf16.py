@@ -280,6 +280,35 @@ def test_c8_kernel_bit_identical_to_fp32_input_tile_kernel(shape, monkeypatch,
     assert ran >= 4
 
 
+@pytest.mark.parametrize('cout', [68, 80, 160])
+def test_t256_kernel_ragged_cout_bit_identical(cout, monkeypatch, bf16_mode):
+    """The head's output convs (256 -> 80 classes / 68 = 4 x 17 bins, gfl_head.py:
+    130-133) run the 8-wave LDS-DMA kernel with a PARTLY EMPTY 128-row weight tile:
+    rows past Cout are out-of-range DMA lanes (zeros) and masked in both epilogues.
+    Against the 4-wave tile kernel, forward with bias, every level of a pyramid."""
+    from ld_amd import layers as Y
+    dev = _dev()
+    monkeypatch.setattr(Y, '_C8_ALL', True)
+    Y.set_c8(True)
+    levels = ((20, 28), (10, 14), (6, 8), (3, 4), (2, 2))
+    P = sum(h * w for h, w in levels)
+    g = torch.Generator().manual_seed(cout)
+    x = torch.randn(2, 256, P, generator=g).to(dev)
+    w = (torch.randn(cout, 256, 3, 3, generator=g) / 48.0).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    Y.to_c8(x)  # the operand image rides on the fp32 tensor, as in the step
+    outs = []
+    for shape in ('4x4x2', '4x8x8x64', '8x6x8x64'):
+        monkeypatch.setenv('LD_CONV_C8_SHAPE', shape)
+        y, _ = Y.conv_forward_raw(x, w, 1, 1, levels, bias=b)
+        torch.cuda.synchronize()
+        outs.append(y.clone())
+    assert torch.equal(outs[0], outs[1]), 'BM = 128 tile'
+    assert torch.equal(outs[0], outs[2]), 'BM = 256 tile (refused below 224 rows: the default kernel)'
+    ref = _ref_conv_levels(_bf16r(x.cpu()), _bf16r(w.cpu()), b.cpu(), 1, 1, levels)
+    _close(outs[1], ref.reshape(outs[1].shape), what='ragged Cout vs rounded-operand reference')
+
+
 def test_gn_c8_side_output(bf16_mode):
     """GroupNorm(+ReLU) forward and backward write the C8 image of their fp32
     output in the same launch: the fp32 tensors equal the plain kernels' bit for
