@@ -667,7 +667,8 @@ def main():
 
     rank_dt = []
     exposed = []
-    trainer.arena.exposed = exposed if world > 1 else None
+    from ld_amd.train import collectives_on
+    trainer.arena.exposed = exposed if collectives_on() else None
     dt, t_enq, loss_val = timed(args.warmup, args.steps)
     rank_ms = [x / args.steps * 1e3 for x in rank_dt]
     exposed_ms = None
@@ -766,7 +767,7 @@ def main():
                 'exposed_allreduce_note': (
                     'HIP-event time the compute stream spends in GradArena.finish '
                     'waiting for the bucketed gradient all-reduces that backward did '
-                    'not hide (rank 0, mean over the timed steps); null at N = 1'),
+                    'not hide (rank 0, mean over the timed steps); null without a process group'),
                 'rank_cpu_placement': pinned,
                 'prime_steps': 1,
                 'teacher_prefetch': bool(prefetch),
