@@ -13,6 +13,7 @@
 //   mmcv Scale                                        gfl_head.py:131-133,182
 //   SGD(momentum, weight_decay)                       apis/train.py:88
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "ld_launch.h"
 
@@ -123,30 +124,50 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(
       const int p0 = (int)max(beg - (long long)n * P, 0LL);
       const int p1 = (int)min(end - (long long)n * P, (long long)P);
       const size_t base = ((size_t)n * C + c) * P;
-      for (int p = p0 + 4 * threadIdx.x; p < p1; p += 1024) {
-        const size_t idx = base + p;
-        const float4 g = *reinterpret_cast<const float4*>(dy + idx);
-        float dz[4] = {g.x, g.y, g.z, g.w};
-        if (relu) {
-          const float4 yy = *reinterpret_cast<const float4*>(y + idx);
-          if (!(yy.x > 0.f)) dz[0] = 0.f;
-          if (!(yy.y > 0.f)) dz[1] = 0.f;
-          if (!(yy.z > 0.f)) dz[2] = 0.f;
-          if (!(yy.w > 0.f)) dz[3] = 0.f;
-        }
-        if (dx)
-          *reinterpret_cast<float4*>(dx + idx) =
-              make_float4(dz[0] * s, dz[1] * s, dz[2] * s, dz[3] * s);
-        if (dres)
-          *reinterpret_cast<float4*>(dres + idx) =
-              make_float4(dz[0], dz[1], dz[2], dz[3]);
-        if (partial) {
-          const float4 xx = *reinterpret_cast<const float4*>(x + idx);
-          const float xv[4] = {xx.x, xx.y, xx.z, xx.w};
+      // Round 6: the loads of FOUR iterations are issued before the first use (up
+      // to 12 x 16 bytes in flight per thread).  The loop used to wait for each
+      // iteration's three loads in turn: 2.1 TB/s, 47 us per launch, 1.55 ms per C2
+      // step on the critical stream.  Same per-thread accumulation order.
+      const float* yq = relu ? y : dy;
+      const float* xq = partial ? x : dy;
+      for (int pb = p0 + 4 * threadIdx.x; pb < p1; pb += 4 * 1024) {
+        float4 g4[4], y4[4], x4[4];
+        bool ok[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            s1 += (double)dz[k];
-            s2 += (double)(dz[k] * ((xv[k] - mu) * rs));
+        for (int u = 0; u < 4; ++u) {
+          const int p = pb + u * 1024;
+          ok[u] = p < p1;
+          const size_t idx = base + (ok[u] ? p : pb);
+          // unconditional loads (an absent operand aliases dy): a branch around a
+          // load costs a vmcnt(0) at its join and the loop is serial again
+          g4[u] = *reinterpret_cast<const float4*>(dy + idx);
+          y4[u] = *reinterpret_cast<const float4*>(yq + idx);
+          x4[u] = *reinterpret_cast<const float4*>(xq + idx);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (!ok[u]) continue;
+          const size_t idx = base + pb + u * 1024;
+          float dz[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
+          if (relu) {
+            if (!(y4[u].x > 0.f)) dz[0] = 0.f;
+            if (!(y4[u].y > 0.f)) dz[1] = 0.f;
+            if (!(y4[u].z > 0.f)) dz[2] = 0.f;
+            if (!(y4[u].w > 0.f)) dz[3] = 0.f;
+          }
+          if (dx)
+            *reinterpret_cast<float4*>(dx + idx) =
+                make_float4(dz[0] * s, dz[1] * s, dz[2] * s, dz[3] * s);
+          if (dres)
+            *reinterpret_cast<float4*>(dres + idx) =
+                make_float4(dz[0], dz[1], dz[2], dz[3]);
+          if (partial) {
+            const float xv[4] = {x4[u].x, x4[u].y, x4[u].z, x4[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              s1 += (double)dz[k];
+              s2 += (double)(dz[k] * ((xv[k] - mu) * rs));
+            }
           }
         }
       }
@@ -497,6 +518,23 @@ __global__ __launch_bounds__(64) void bn_act_bwd_c8_kernel(
   const bool live = p < P;
   float out[8][4];
   double s1[8], s2[8];
+  // Round 6: every load of the thread -- dy, y, x of its eight channels, 24 x 16
+  // bytes -- is issued before the first use.  The per-channel loop used to wait for
+  // its own three loads each time round (eight dependent memory latencies per wave:
+  // 2.9 TB/s, 1.26 ms per C2 step on the critical stream).  A lane past the end of
+  // the row reads the row's first cells and discards them.  Same expressions.
+  float4 g8[8], y8[8], x8[8];
+  const int pl = live ? p : 0;
+  const float* yq = relu ? y : dy;
+  const float* xq = partial ? x : dy;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const size_t idx = ((size_t)n * C + c8 * 8 + e) * P + pl;
+    // unconditional (an absent operand aliases dy): no branch, no vmcnt(0) joins
+    g8[e] = *reinterpret_cast<const float4*>(dy + idx);
+    y8[e] = *reinterpret_cast<const float4*>(yq + idx);
+    x8[e] = *reinterpret_cast<const float4*>(xq + idx);
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int c = c8 * 8 + e;
@@ -507,14 +545,12 @@ __global__ __launch_bounds__(64) void bn_act_bwd_c8_kernel(
     for (int k = 0; k < 4; ++k) out[e][k] = 0.0f;
     if (!live) continue;
     const size_t idx = ((size_t)n * C + c) * P + p;
-    const float4 g = *reinterpret_cast<const float4*>(dy + idx);
-    float dz[4] = {g.x, g.y, g.z, g.w};
+    float dz[4] = {g8[e].x, g8[e].y, g8[e].z, g8[e].w};
     if (relu) {
-      const float4 yy = *reinterpret_cast<const float4*>(y + idx);
-      if (!(yy.x > 0.f)) dz[0] = 0.f;
-      if (!(yy.y > 0.f)) dz[1] = 0.f;
-      if (!(yy.z > 0.f)) dz[2] = 0.f;
-      if (!(yy.w > 0.f)) dz[3] = 0.f;
+      if (!(y8[e].x > 0.f)) dz[0] = 0.f;
+      if (!(y8[e].y > 0.f)) dz[1] = 0.f;
+      if (!(y8[e].z > 0.f)) dz[2] = 0.f;
+      if (!(y8[e].w > 0.f)) dz[3] = 0.f;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) out[e][k] = dz[k] * s;
@@ -525,8 +561,7 @@ __global__ __launch_bounds__(64) void bn_act_bwd_c8_kernel(
       *reinterpret_cast<float4*>(dres + idx) = make_float4(dz[0], dz[1], dz[2], dz[3]);
     if (partial) {
       const float mu = mean[c], rs = rstd[c];
-      const float4 xx = *reinterpret_cast<const float4*>(x + idx);
-      const float xv[4] = {xx.x, xx.y, xx.z, xx.w};
+      const float xv[4] = {x8[e].x, x8[e].y, x8[e].z, x8[e].w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         s1[e] += (double)dz[k];
@@ -590,6 +625,114 @@ __global__ __launch_bounds__(256) void gn_apply_c8_kernel(
   store_c8x4(y_c8 + (size_t)blk * lv.P + p, out);
 }
 
+// Round 6: the per-(image, group, level) statistics a thread needs -- mean, rstd
+// and the two group means of the gradient -- are the same for a whole workgroup
+// row, so they are read ONCE per workgroup through scalar loads (uniform address)
+// into a small table and selected by level with v_cndmask, with a fast path when a
+// thread's four positions share a level (all but <= 4 threads of a row).  Rounds
+// 2-5 fetched them per element with per-lane loads: 16 tiny gathers per 48 bytes
+// of payload (15 / 120 vector loads per thread where 3 / 24 carry data).  Same
+// expressions, same operand values: bit-identical outputs (LD_NN_OLD=1 keeps the
+// old kernels for tests/test_gpu_layers.py::test_round6_norm_backward_kernels_bit_
+// identical).  Measured in the step, same box, old vs new (with the BN backward
+// change below): bf16 11.99 -> 11.85 ms, fp32 34.23 -> 34.20 ms -- in fp32 these
+// HBM-bound launches run UNDER the other stream's MFMA-bound convolutions (their
+// in-step durations, 199 us average against 65 us alone, are contention, not cost),
+// which is why the fp32 step only moves with the conv kernels.
+struct GnRowTab {
+  float mu[LD_MAX_LEVELS], rs[LD_MAX_LEVELS], f1[LD_MAX_LEVELS], f2[LD_MAX_LEVELS];
+};
+
+__device__ __forceinline__ void gn_load_tab(GnRowTab& t, const float* __restrict__ mean,
+                                            const float* __restrict__ rstd,
+                                            const float* __restrict__ gm, size_t ob,
+                                            int L) {
+#pragma unroll
+  for (int l = 0; l < LD_MAX_LEVELS; ++l) {
+    const size_t o = ob + (l < L ? l : 0);  // wave-uniform address: scalar loads
+    t.mu[l] = mean[o];
+    t.rs[l] = rstd[o];
+    t.f1[l] = gm[o * 2 + 0];
+    t.f2[l] = gm[o * 2 + 1];
+  }
+}
+
+__device__ __forceinline__ void gn_pick(const GnRowTab& t, int l, float& mu, float& rs,
+                                        float& f1, float& f2) {
+  mu = t.mu[0];
+  rs = t.rs[0];
+  f1 = t.f1[0];
+  f2 = t.f2[0];
+#pragma unroll
+  for (int i = 1; i < LD_MAX_LEVELS; ++i)
+    if (l == i) {
+      mu = t.mu[i];
+      rs = t.rs[i];
+      f1 = t.f1[i];
+      f2 = t.f2[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_c8_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y,
+    const float* __restrict__ x, Levels lv, int C, int G,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ gm, int relu,
+    float* __restrict__ dx, gn_uintx4* __restrict__ dx_c8) {
+  const int C8 = C >> 3;
+  const int blk = blockIdx.y;
+  const int c8 = blk % C8, n = blk / C8;
+  const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (p >= lv.P) return;
+  const int L = lv.num_levels;
+  const int cpg = C / G;
+  const bool one_group = (cpg & 7) == 0;  // the 8 channels of a block share a group
+  const int l0 = level_of_pos(lv, p), l3 = level_of_pos(lv, p + 3);
+  GnRowTab tab;
+  float mu0 = 0.f, rs0 = 0.f, f10 = 0.f, f20 = 0.f;
+  if (one_group) {
+    gn_load_tab(tab, mean, rstd, gm, ((size_t)n * G + (c8 * 8) / cpg) * L, L);
+    gn_pick(tab, l0, mu0, rs0, f10, f20);
+  }
+  // every load of the thread first (24 x 16 bytes in flight)
+  const float* yq = relu ? y : dy;
+  float4 t0[8], t2[8], t1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const size_t idx = ((size_t)n * C + c8 * 8 + e) * lv.P + p;
+    t0[e] = *reinterpret_cast<const float4*>(dy + idx);
+    t2[e] = *reinterpret_cast<const float4*>(x + idx);
+    t1[e] = *reinterpret_cast<const float4*>(yq + idx);  // unconditional: no branch
+  }
+  float out[8][4];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c8 * 8 + e;
+    const size_t idx = ((size_t)n * C + c) * lv.P + p;
+    const float ga = gamma[c];
+    if (!one_group) {
+      gn_load_tab(tab, mean, rstd, gm, ((size_t)n * G + c / cpg) * L, L);
+      gn_pick(tab, l0, mu0, rs0, f10, f20);
+    }
+    const float a_dy[4] = {t0[e].x, t0[e].y, t0[e].z, t0[e].w};
+    const float a_x[4] = {t2[e].x, t2[e].y, t2[e].z, t2[e].w};
+    const float a_y[4] = {t1[e].x, t1[e].y, t1[e].z, t1[e].w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float mu = mu0, rs = rs0, fm1 = f10, fm2 = f20;
+      if (l0 != l3) gn_pick(tab, level_of_pos(lv, p + k), mu, rs, fm1, fm2);
+      float dz = a_dy[k];
+      if (relu && !(a_y[k] > 0.f)) dz = 0.f;
+      const float xh = (a_x[k] - mu) * rs;
+      out[e][k] = rs * (ga * dz - fm1 - xh * fm2);
+    }
+    *reinterpret_cast<float4*>(dx + idx) =
+        make_float4(out[e][0], out[e][1], out[e][2], out[e][3]);
+  }
+  store_c8x4(dx_c8 + (size_t)blk * lv.P + p, out);
+}
+
+namespace old_r5 {
 __global__ __launch_bounds__(256) void gn_bwd_apply_c8_kernel(
     const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ x, Levels lv, int C, int G,
@@ -633,6 +776,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_c8_kernel(
   }
   store_c8x4(dx_c8 + (size_t)blk * lv.P + p, out);
 }
+
+}  // namespace old_r5
 
 // backward pass A: per (n, c, level): s1 = sum dz, s2 = sum dz * xhat, each
 // level cut into kGnBwdSplit slices (the 16800-cell level would otherwise sit
@@ -784,6 +929,56 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
   const int p = (blockIdx.x * 256 + threadIdx.x) * V;
   if (p >= lv.P) return;
   const int L = lv.num_levels, g = c / (C / G);
+  const size_t idx = (size_t)row * lv.P + p;
+  const float ga = gamma[c];
+  GnRowTab tab;  // the row's statistics: scalar loads, once per workgroup (see above)
+  gn_load_tab(tab, mean, rstd, gm, ((size_t)n * G + g) * L, L);
+  float a_dy[V], a_y[V], a_x[V], out[V];
+  if (V == 4) {
+    const float4 t0 = *reinterpret_cast<const float4*>(dy + idx);
+    const float4 t2 = *reinterpret_cast<const float4*>(x + idx);
+    a_dy[0] = t0.x; a_dy[1] = t0.y; a_dy[2] = t0.z; a_dy[3] = t0.w;
+    a_x[0] = t2.x; a_x[1] = t2.y; a_x[2] = t2.z; a_x[3] = t2.w;
+    if (relu) {
+      const float4 t1 = *reinterpret_cast<const float4*>(y + idx);
+      a_y[0] = t1.x; a_y[1] = t1.y; a_y[2] = t1.z; a_y[3] = t1.w;
+    }
+  } else {
+    a_dy[0] = dy[idx];
+    a_x[0] = x[idx];
+    if (relu) a_y[0] = y[idx];
+  }
+  const int l0 = level_of_pos(lv, p), l3 = level_of_pos(lv, p + V - 1);
+  float mu0, rs0, f10, f20;
+  gn_pick(tab, l0, mu0, rs0, f10, f20);
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    float mu = mu0, rs = rs0, fm1 = f10, fm2 = f20;
+    if (l0 != l3) gn_pick(tab, level_of_pos(lv, p + k), mu, rs, fm1, fm2);
+    float dz = a_dy[k];
+    if (relu && !(a_y[k] > 0.f)) dz = 0.f;
+    const float xh = (a_x[k] - mu) * rs;
+    out[k] = rs * (ga * dz - fm1 - xh * fm2);
+  }
+  if (V == 4)
+    *reinterpret_cast<float4*>(dx + idx) = make_float4(out[0], out[1], out[2], out[3]);
+  else
+    dx[idx] = out[0];
+}
+
+namespace old_r5 {
+template <int V>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y,
+    const float* __restrict__ x, Levels lv, int C, int G,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ gm, int relu,
+    float* __restrict__ dx) {
+  const int row = blockIdx.y;
+  const int c = row % C, n = row / C;
+  const int p = (blockIdx.x * 256 + threadIdx.x) * V;
+  if (p >= lv.P) return;
+  const int L = lv.num_levels, g = c / (C / G);
   const size_t ob = ((size_t)n * G + g) * L;
   const size_t idx = (size_t)row * lv.P + p;
   const float ga = gamma[c];
@@ -817,6 +1012,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
   else
     dx[idx] = out[0];
 }
+
+}  // namespace old_r5
 
 // dgamma[c] = sum_{n,l} s2, dbeta[c] = sum_{n,l} s1
 __global__ void gn_bwd_param_kernel(const double* __restrict__ sums, int N, int C,
@@ -1456,7 +1653,19 @@ static int gn_backward_impl(const ld_levels_t* lv, const float* dy, const float*
   const bool vec = k.P % 4 == 0 &&
                    ((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx |
                     (uintptr_t)(relu ? y : x)) % 16 == 0;
-  if (dx_c8) {
+  const char* old_env = getenv("LD_NN_OLD");  // A/B: the round-5 kernels
+  const bool use_old = old_env && old_env[0] == '1';
+  if (dx_c8 && use_old) {
+    if (!vec || C % 8 != 0) return LD_EUNSUPPORTED;
+    LD_LAUNCH(old_r5::gn_bwd_apply_c8_kernel,
+                       dim3((k.P / 4 + 255) / 256, N * (C / 8)), dim3(256), 0,
+                       LD_STREAM, dy, y, x, k, C, G, mean, rstd, gamma, gm, relu, dx,
+                       (gn_uintx4*)dx_c8);
+  } else if (use_old && vec) {
+    LD_LAUNCH(old_r5::gn_bwd_apply_kernel<4>, dim3((k.P / 4 + 255) / 256, N * C),
+                       dim3(256), 0, LD_STREAM, dy, y, x, k, C, G, mean, rstd, gamma,
+                       gm, relu, dx);
+  } else if (dx_c8) {
     if (!vec || C % 8 != 0) return LD_EUNSUPPORTED;
     LD_LAUNCH(gn_bwd_apply_c8_kernel,
                        dim3((k.P / 4 + 255) / 256, N * (C / 8)), dim3(256), 0,

@@ -467,6 +467,47 @@ def test_gn_act_levels():
     _close(bd.grad, br.grad, what='gn dbeta')
 
 
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('cfg', [(64, 32, True), (256, 32, True), (48, 12, False),
+                                 (64, 16, True)])
+def test_round6_norm_backward_kernels_bit_identical(cfg, mode, monkeypatch):
+    """GroupNorm backward (round 6: the row's statistics in a scalar table, every
+    load issued up front) against the round-5 kernels (LD_NN_OLD=1): dx, its C8
+    image in bf16 mode, dgamma, dbeta -- identical bits, on a pyramid whose small
+    levels put level boundaries inside a thread's four positions, with 2, 4 and 8
+    channels per group."""
+    from ld_amd import layers as Y
+    dev = _dev()
+    C, G, relu = cfg
+    levels = ((12, 20), (6, 10), (3, 5), (2, 3), (1, 2)) if C < 256 else \
+        ((100, 168), (50, 84), (25, 42), (13, 21), (7, 11))
+    P = sum(h * w for h, w in levels)
+    g = torch.Generator().manual_seed(C + G)
+    x = (torch.randn(2, C, P, generator=g) * 2 + 0.5).to(dev)
+    gamma = (torch.rand(C, generator=g) + .5).to(dev)
+    beta = torch.randn(C, generator=g).to(dev)
+    go = torch.randn(2, C, P, generator=g).to(dev)
+    Y.set_precision(mode)
+    try:
+        outs = []
+        for old in ('1', '0'):
+            monkeypatch.setenv('LD_NN_OLD', old)
+            xd, gd, bd = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+            y = Y.gn_act(xd, gd, bd, G, 1e-5, levels, relu)
+            y.backward(go)
+            torch.cuda.synchronize()
+            img = Y._c8_cached(xd.grad)
+            outs.append((xd.grad.clone(), gd.grad.clone(), bd.grad.clone(),
+                         None if img is None else img.clone()))
+        for a, b, what in zip(outs[0], outs[1], ('dx', 'dgamma', 'dbeta', 'dx C8')):
+            if a is None:
+                assert b is None
+                continue
+            assert torch.equal(a, b), (cfg, mode, what)
+    finally:
+        Y.set_precision('fp32')
+
+
 @pytest.mark.parametrize('fine,coarse', [((50, 84), (25, 42)),
                                          ((25, 25), (13, 13)),
                                          ((13, 21), (7, 11))])
