@@ -271,7 +271,7 @@ def _median_launch_us(launch, warm, iters):
 # 1 212 475.4 KB (x 2, gfx950 correction) + WRITE_SIZE 1 115 649.4 KB per launch
 # at 2^24 rows
 PMC_LDKL_TRAFFIC_BYTES = (2 * 1212475.4 + 1115649.4) * 1024.0
-# profiles/r05_pmc_traffic_conv_step_fp32_by_kernel.txt (round 5, the serialised
+# profiles/r0N_pmc_traffic_conv_step_*_by_kernel.txt (the serialised
 # fp32 step, 6 steps): the GEMM kernels (forward / dgrad streaming shapes + the
 # weight-gradient kernels; 324 dispatches per step incl. the stride-2 dgrad parity
 # classes, 316 conv calls) move FETCH_SIZE 2 x 12.12 GB + WRITE_SIZE 9.62 GB =
@@ -280,16 +280,17 @@ PMC_LDKL_TRAFFIC_BYTES = (2 * 1212475.4 + 1115649.4) * 1024.0
 # (profiles/r04_pmc_calib_copy_*): the counter tallies 128-byte fabric requests at
 # 64 bytes.  It counts requests LEAVING an XCD's L2, Infinity-Cache hits included.
 # (The per-bucket slab reduce adds 1.7 GB per step; not part of `traffic`.)
-# The constants come out of tools/pmc_conv_bytes.py <file> <steps in the run>.
-# bf16 (round 6, VERDICT r5 next #1: roofline_bf16.traffic non-null): the
-# serialised bf16 step, 4 steps, 282 GEMM dispatches per step (C8 tile / LDS-DMA /
-# C8 weight-gradient kernels, the fused teacher bottleneck): FETCH_SIZE 2 x 5.42 GB
-# + WRITE_SIZE 9.04 GB = 19.9 GB per step.
+# The constants come out of tools/pmc_conv_bytes.py <file> <steps in the run>, on the
+# round-6 final build (tools/sessions/r6_pmc.sh; the serialised step, FETCH_SIZE and
+# WRITE_SIZE in separate rocprofv3 --pmc passes):
+#   fp32: 6 steps, 324 GEMM dispatches per step: FETCH 2 x 12.13 + WRITE 9.63 GB
+#   bf16: 7 steps, 282 GEMM dispatches per step (C8 tile / LDS-DMA / C8 weight-
+#         gradient kernels, the fused teacher bottleneck): FETCH 2 x 5.51 + WRITE 9.08 GB
 PMC_CONV = {
-    'fp32': dict(file='profiles/r05_pmc_traffic_conv_step_fp32_by_kernel.txt',
-                 dispatches=324, fetch=2 * 12.12e9, write=9.62e9),
+    'fp32': dict(file='profiles/r06_pmc_traffic_conv_step_fp32_by_kernel.txt',
+                 dispatches=324, fetch=24.261e9, write=9.625e9),
     'bf16': dict(file='profiles/r06_pmc_traffic_conv_step_bf16_by_kernel.txt',
-                 dispatches=282, fetch=10.838e9, write=9.037e9),
+                 dispatches=282, fetch=11.024e9, write=9.081e9),
 }
 
 

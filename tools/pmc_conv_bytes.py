@@ -10,7 +10,7 @@ import re
 import sys
 
 GEMM = ('conv_stream_kernel', 'conv_wgrad_tile_kernel', 'conv_wgrad_tap3_kernel',
-        'conv_stem_kernel', 'conv_igemm_kernel', 'conv_tile_c8_kernel',
+        'conv_stem_kernel', 'conv_stem_lds_kernel', 'conv_igemm_kernel', 'conv_tile_c8_kernel',
         'conv_t256_c8_kernel', 'conv_wgrad_c8_tile_kernel', 'conv_wgrad_c8_kernel',
         'fused_bottleneck_c8_kernel', 'conv_stream_bf16_kernel', 'conv_tile_bf16_kernel',
         'conv_wgrad_wave_bf16_kernel', 'conv_wgrad_tile_bf16_kernel', 'conv_wgrad_kernel')
