@@ -106,6 +106,24 @@ def test_auto_stepper_launcher_and_bench_rank_pinning(monkeypatch):
     assert bench.pin_rank(0, 8) is None
 
 
+def test_bench_pmc_constants_match_the_committed_profiles():
+    """bench.PMC_CONV (roofline.traffic / roofline_bf16.traffic) == what
+    tools/pmc_conv_bytes.py derives from the committed by-kernel PMC summaries."""
+    import re
+    sys.path.insert(0, REPO)
+    import bench
+    for mode, steps in (('fp32', 6), ('bf16', 7)):
+        c = bench.PMC_CONV[mode]
+        out = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'pmc_conv_bytes.py'),
+                              os.path.join(REPO, c['file']), str(steps)],
+                             capture_output=True, text=True, check=True).stdout
+        disp = float(re.search(r'= ([\d.]+) per step', out).group(1))
+        fetch = float(re.search(r'FETCH_SIZE x 2 = ([\d.]+) GB', out).group(1))
+        write = float(re.search(r'WRITE_SIZE     = ([\d.]+) GB', out).group(1))
+        assert disp == c['dispatches']
+        assert abs(fetch * 1e9 - c['fetch']) < 2e6 and abs(write * 1e9 - c['write']) < 2e6
+
+
 def _write_trace(path, steps=4):
     """Two queues; per step: 3 conv + 1 norm kernel on queue 1, 2 conv on queue 2,
     then the optimizer launch.  10 us kernels, 5 us gaps on queue 1."""
