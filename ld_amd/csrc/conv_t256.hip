@@ -17,10 +17,22 @@
 //     shift, padding as an out-of-range offset -> the DMA writes zeros) and no
 //     swizzle is needed: a fragment is 32 consecutive 16-byte rows per half-wave,
 //     which ds_read_b128 serves without bank conflicts.
-//   * two LDS stages of 64 KB (256 x 256); step u + 1 streams in while step u is
-//     multiplied; ONE barrier per 64-deep step, placed after the wave's own
-//     `s_waitcnt vmcnt(0)`: every wave's DMA of step u has landed and every wave
-//     has finished reading the stage that step u + 1 overwrites.
+//   * two LDS stages of 64 KB (256 x 256).  A step = four 16-deep sub-steps, each
+//     multiplying the fragments read during the previous one.  ONE barrier per
+//     step, between sub-steps 2 and 3: by then the wave's reads of the current stage
+//     are complete (lgkmcnt) and its share of the next step has landed (vmcnt), so
+//     the fourth sub-step runs over the reads of the next step's first fragments;
+//     the DMA of step u + 2 into the stage everybody just left is issued in three
+//     groups (behind the barrier, then under the next step's first two sub-steps)
+//     -- a burst of all 56 wave instructions of a CU queues on its address unit.
+//   * epilogue: fp32 outputs with EXCHANGED operand roles (SWAP, see the kernel):
+//     a lane then holds four consecutive positions of a channel; each 32 x 32 tile
+//     takes a turn through a wave-private LDS buffer so that a wave instruction
+//     stores eight whole 128-byte rows.  C8 outputs / C8 residuals / the stride-2
+//     data-gradient classes keep the 4-wave kernel's epilogue.
+// Measured (profiles/r06_t256_stamps.txt, r06_t256_head.json): head tower 256 -> 256
+// 3 x 3, J = 44 800: 680 -> 890 TFLOP/s; main loop 72 % MFMA-busy (the DMA costs 23 %
+// of it), epilogue at the HBM write rate, 234 tiles on 256 CUs.
 // Reference op: the conv layers of mmdet/models/dense_heads/gfl_head.py:102-133
 // (towers), necks/fpn.py:66-221, backbones/resnet.py:260-299, in the fp16 mode
 // mmcv auto_fp16 gives them.

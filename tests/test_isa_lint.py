@@ -160,3 +160,45 @@ def test_fused_bottleneck_rings_prefetch_and_no_spill(fused_asm):
     assert int(vgpr) <= 512, meta  # unified VGPR + AGPR file of one wave per SIMD
     agpr = re.findall(r'\.agpr_count:\s+(\d+)', fused_asm)
     assert agpr and max(int(a) for a in agpr) >= 128, agpr
+
+
+@pytest.fixture(scope='module')
+def t256_asm():
+    import isa_lint
+    src = os.path.join(REPO, 'ld_amd', 'csrc', 'conv_t256.hip')
+    if not os.path.exists(isa_lint.os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')):
+        pytest.skip('hipcc not available')
+    return isa_lint.device_asm(src)
+
+
+def test_t256_lds_dma_loop_shape_and_registers(t256_asm):
+    """Round 6, conv_t256.hip: every instance of the 8-wave LDS-DMA kernel keeps the
+    loop it was designed with -- operands arrive by `buffer_load_dwordx4 ... lds`
+    (never through VGPRs + ds_write), the ONLY vmcnt wait of the main loop is the
+    one in front of the step's barrier (hipcc must not add one in front of the
+    fragment reads: a second __shared__ object or a VGPR-destination load in the
+    loop makes it), the barrier count equals the unrolled step count, and nothing
+    spills with 128 / 96 accumulator registers."""
+    import re
+    names = re.findall(r'^(_Z\w*conv_t256_c8_kernel\w*):\s', t256_asm, re.M)
+    assert len(names) >= 12, names  # 4 tile shapes x (plain, swapped, stride-2 class)
+    for name in names:
+        body = t256_asm.split('\n' + name + ':', 1)[1].split('s_endpgm', 1)[0]
+        lines = body.split('\n')
+        mf = [i for i, l in enumerate(lines) if 'v_mfma_f32_32x32x16_bf16' in l]
+        loop = lines[mf[0]:mf[-1] + 1]
+        dma = [l for l in loop if 'buffer_load_dwordx4' in l and ' lds' in l]
+        assert len(dma) >= 8, (name, len(dma))  # two unrolled steps of >= 4 per wave
+        assert not any('ds_write' in l for l in loop), name
+        assert not any(l.strip().startswith(('global_load', 'flat_load')) for l in loop), name
+        waits = [l for l in loop if 's_waitcnt' in l and 'vmcnt' in l]
+        bars = [l for l in loop if l.strip().startswith('s_barrier')]
+        assert len(bars) == 2 and len(waits) == 2, (name, waits, bars)
+        assert all('vmcnt(0)' in w and 'lgkmcnt(0)' in w for w in waits), (name, waits)
+    meta = re.findall(r'\.name:\s+(\S*conv_t256_c8_kernel\S*)\n(?:.*\n)*?'
+                      r'\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?'
+                      r'\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)', t256_asm)
+    assert len(meta) >= 12
+    for name, scratch, vgpr, spill in meta:
+        assert int(spill) == 0 and int(scratch) == 0, (name, scratch, spill)
+        assert int(vgpr) <= 256, (name, vgpr)  # two waves per SIMD
