@@ -266,3 +266,61 @@ def test_auto_stepper_pipelined_equals_eager(launcher):
             st.step(seq[0], next_data=seq[1])  # not the batch the pipeline holds
     finally:
         Y.set_precision('fp32')
+
+
+def test_step_list_replays_a_two_stream_capture():
+    """ld_step_list_* on a small hand-made capture (not the train step): a fork onto a
+    side stream, work on both, a join, a memset and a kernel-copy -- the list keeps
+    the two lanes, orders them with events at the fork / join, and a replay on NEW
+    input data gives what eager execution gives; a captured torch copy (a 1-D memcpy
+    node this runtime cannot describe) is refused instead of replayed wrongly."""
+    import ctypes as C
+    from ld_amd import layers as Y
+    from ld_amd import lib as L
+    from ld_amd.train import _StepList
+    dev = torch.device('cuda:0')
+    x = torch.randn(1 << 20, device=dev)
+    out = torch.empty_like(x)
+    tmp = torch.empty_like(x)
+    side = torch.cuda.Stream(device=dev)
+    cap = torch.cuda.Stream(device=dev)
+
+    def work():
+        main = torch.cuda.current_stream(dev)
+        a = x * 2.0
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            b = a + 1.0
+            b = b * b
+        c = a * 3.0
+        tmp.zero_()                      # a memset node
+        Y.copy_into(tmp, c)              # ld_copy_d2d: a kernel node
+        main.wait_stream(side)
+        torch.add(b, tmp, out=out)
+
+    cap.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(cap):
+        work()                           # warm-up: allocator, lazy init
+    torch.cuda.current_stream(dev).wait_stream(cap)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g, stream=cap):
+        work()
+    sl = _StepList(g)
+    assert sl.info['lanes'] == 2 and sl.info['cross_lane_waits'] >= 2, sl.info
+    assert sl.info['memcpys'] == 0 and sl.info['kernels'] >= 6, sl.info
+    for seed in (1, 2, 3):
+        x.copy_(torch.randn(1 << 20, generator=torch.Generator().manual_seed(seed)).to(dev))
+        out.fill_(float('nan'))
+        sl.replay(dev)
+        torch.cuda.synchronize()
+        a = x * 2.0
+        want = (a + 1.0) * (a + 1.0) + a * 3.0
+        assert torch.equal(out, want), seed
+    # a torch copy inside a capture is a hipMemcpyAsync: refused by the builder
+    g2 = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g2, stream=cap):
+        tmp.copy_(x)
+        torch.add(tmp, 1.0, out=out)
+    rc = L.get_lib().ld_step_list_build(C.c_void_p(g2.raw_cuda_graph()), 4)
+    assert rc == -3, rc  # LD_EUNSUPPORTED
