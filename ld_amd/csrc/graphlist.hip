@@ -166,6 +166,9 @@ extern "C" int64_t ld_step_list_build(void* hip_graph, int max_lanes) {
     switch (n.type) {
       case hipGraphNodeTypeKernel:
         e = hipGraphKernelNodeGetParams(hn[i], &n.kp);
+        // arguments packed in `extra` (module-API launch): only hipModuleLaunchKernel
+        // takes that form
+        if (e == hipSuccess && !n.kp.kernelParams && n.kp.extra) n.module_fn = true;
         ++s->n_kernel;
         break;
       case hipGraphNodeTypeMemcpy:
