@@ -391,6 +391,15 @@ __global__ void gn_stats_final_kernel(const double* __restrict__ partial, Levels
 }
 
 // y = relu?( (x - mean) * rstd * gamma[c] + beta[c] )
+// y = xhat * gamma + beta, the product-sum PINNED as one fma.  Round 6: the lean
+// backward (ld_gn_backward_c8_lean) recomputes the ReLU mask y > 0 from x with this
+// same function instead of reading y back -- forward and backward must round the
+// same way whatever the compiler's contraction choice is at either site.
+__device__ __forceinline__ float gn_affine(float in, float mu, float rs, float ga,
+                                           float be) {
+  return __builtin_fmaf((in - mu) * rs, ga, be);
+}
+
 __global__ __launch_bounds__(256) void gn_apply_kernel(
     const float* __restrict__ x, Levels lv, int C, int G,
     const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
   const int l = level_of_pos(lv, p);
   const size_t o = ((size_t)n * G + c / (C / G)) * lv.num_levels + l;
   const size_t idx = (size_t)row * lv.P + p;
-  float v = (x[idx] - mean[o]) * rstd[o] * gamma[c] + beta[c];
+  float v = gn_affine(x[idx], mean[o], rstd[o], gamma[c], beta[c]);
   if (relu) v = fmaxf(v, 0.f);
   y[idx] = v;
 }
@@ -427,12 +436,12 @@ __global__ __launch_bounds__(256) void gn_apply4_kernel(
   if (l0 == l3) {
     const float mu = mean[ob + l0], rs = rstd[ob + l0];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out[k] = (in[k] - mu) * rs * ga + be;
+    for (int k = 0; k < 4; ++k) out[k] = gn_affine(in[k], mu, rs, ga, be);
   } else {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int l = level_of_pos(lv, p + k);
-      out[k] = (in[k] - mean[ob + l]) * rstd[ob + l] * ga + be;
+      out[k] = gn_affine(in[k], mean[ob + l], rstd[ob + l], ga, be);
     }
   }
   if (relu) {
@@ -607,20 +616,21 @@ __global__ __launch_bounds__(256) void gn_apply_c8_kernel(
     if (l0 == l3) {
       const float mu = mean[ob + l0], rs = rstd[ob + l0];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) out[e][k] = (in[k] - mu) * rs * ga + be;
+      for (int k = 0; k < 4; ++k) out[e][k] = gn_affine(in[k], mu, rs, ga, be);
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int l = level_of_pos(lv, p + k);
-        out[e][k] = (in[k] - mean[ob + l]) * rstd[ob + l] * ga + be;
+        out[e][k] = gn_affine(in[k], mean[ob + l], rstd[ob + l], ga, be);
       }
     }
     if (relu) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) out[e][k] = fmaxf(out[e][k], 0.f);
     }
-    *reinterpret_cast<float4*>(y + idx) =
-        make_float4(out[e][0], out[e][1], out[e][2], out[e][3]);
+    if (y)  // null: the C8 image is the only output (ld_gn_forward_c8, y == NULL)
+      *reinterpret_cast<float4*>(y + idx) =
+          make_float4(out[e][0], out[e][1], out[e][2], out[e][3]);
   }
   store_c8x4(y_c8 + (size_t)blk * lv.P + p, out);
 }
@@ -673,12 +683,17 @@ __device__ __forceinline__ void gn_pick(const GnRowTab& t, int l, float& mu, flo
     }
 }
 
+// MASK_X (the lean backward, bf16 mode): the ReLU mask y > 0 is recomputed from x
+// with the forward's own expression (gn_affine) instead of reading y -- 8 instead
+// of 12 bytes read per element; dx may be null (only the C8 image is consumed).
+template <bool MASK_X>
 __global__ __launch_bounds__(256) void gn_bwd_apply_c8_kernel(
     const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ x, Levels lv, int C, int G,
     const float* __restrict__ mean, const float* __restrict__ rstd,
-    const float* __restrict__ gamma, const float* __restrict__ gm, int relu,
-    float* __restrict__ dx, gn_uintx4* __restrict__ dx_c8) {
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ gm, int relu, float* __restrict__ dx,
+    gn_uintx4* __restrict__ dx_c8) {
   const int C8 = C >> 3;
   const int blk = blockIdx.y;
   const int c8 = blk % C8, n = blk / C8;
@@ -702,7 +717,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_c8_kernel(
     const size_t idx = ((size_t)n * C + c8 * 8 + e) * lv.P + p;
     t0[e] = *reinterpret_cast<const float4*>(dy + idx);
     t2[e] = *reinterpret_cast<const float4*>(x + idx);
-    t1[e] = *reinterpret_cast<const float4*>(yq + idx);  // unconditional: no branch
+    if (!MASK_X)
+      t1[e] = *reinterpret_cast<const float4*>(yq + idx);  // unconditional: no branch
   }
   float out[8][4];
 #pragma unroll
@@ -710,24 +726,31 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_c8_kernel(
     const int c = c8 * 8 + e;
     const size_t idx = ((size_t)n * C + c) * lv.P + p;
     const float ga = gamma[c];
+    float be = 0.f;
+    if (MASK_X) be = beta[c];
     if (!one_group) {
       gn_load_tab(tab, mean, rstd, gm, ((size_t)n * G + c / cpg) * L, L);
       gn_pick(tab, l0, mu0, rs0, f10, f20);
     }
     const float a_dy[4] = {t0[e].x, t0[e].y, t0[e].z, t0[e].w};
     const float a_x[4] = {t2[e].x, t2[e].y, t2[e].z, t2[e].w};
-    const float a_y[4] = {t1[e].x, t1[e].y, t1[e].z, t1[e].w};
+    float a_y[4] = {1.f, 1.f, 1.f, 1.f};
+    if (!MASK_X) {
+      a_y[0] = t1[e].x; a_y[1] = t1[e].y; a_y[2] = t1[e].z; a_y[3] = t1[e].w;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float mu = mu0, rs = rs0, fm1 = f10, fm2 = f20;
       if (l0 != l3) gn_pick(tab, level_of_pos(lv, p + k), mu, rs, fm1, fm2);
       float dz = a_dy[k];
+      if (MASK_X) a_y[k] = gn_affine(a_x[k], mu, rs, ga, be);
       if (relu && !(a_y[k] > 0.f)) dz = 0.f;
       const float xh = (a_x[k] - mu) * rs;
       out[e][k] = rs * (ga * dz - fm1 - xh * fm2);
     }
-    *reinterpret_cast<float4*>(dx + idx) =
-        make_float4(out[e][0], out[e][1], out[e][2], out[e][3]);
+    if (!MASK_X || dx)
+      *reinterpret_cast<float4*>(dx + idx) =
+          make_float4(out[e][0], out[e][1], out[e][2], out[e][3]);
   }
   store_c8x4(dx_c8 + (size_t)blk * lv.P + p, out);
 }
@@ -827,15 +850,22 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(
 // whose cost was their own latency (62 us per launch, 1.5 TB/s).  Writes slice 0
 // of every (row, level) directly -- no fold launch.  Per-thread accumulation
 // order differs from the sliced kernel (fp64 sums: ~1e-16 relative).
+template <bool MASK_X>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_row_kernel(
     const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ x, Levels lv, int C, int G,
-    const float* __restrict__ mean, const float* __restrict__ rstd, int relu,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
     double* __restrict__ sums) {
   const int L = lv.num_levels;
   const int row = blockIdx.x;  // n*C + c
   const int c = row % C, n = row / C;
   const size_t rbase = (size_t)row * lv.P;
+  float ga = 0.f, be = 0.f;
+  if (MASK_X) {  // the ReLU mask from x (gn_affine), not from y
+    ga = gamma[c];
+    be = beta[c];
+  }
   for (int l = 0; l < L; ++l) {
     const size_t o = ((size_t)n * G + c / (C / G)) * L + l;
     const float mu = mean[o], rs = rstd[o];
@@ -848,14 +878,18 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_row_kernel(
       const float4 g = *reinterpret_cast<const float4*>(dy + idx);
       const float4 xx = *reinterpret_cast<const float4*>(x + idx);
       float dz[4] = {g.x, g.y, g.z, g.w};
-      if (relu) {
+      const float xv[4] = {xx.x, xx.y, xx.z, xx.w};
+      if (relu && MASK_X) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (!(gn_affine(xv[k], mu, rs, ga, be) > 0.f)) dz[k] = 0.f;
+      } else if (relu) {
         const float4 yy = *reinterpret_cast<const float4*>(y + idx);
         if (!(yy.x > 0.f)) dz[0] = 0.f;
         if (!(yy.y > 0.f)) dz[1] = 0.f;
         if (!(yy.z > 0.f)) dz[2] = 0.f;
         if (!(yy.w > 0.f)) dz[3] = 0.f;
       }
-      const float xv[4] = {xx.x, xx.y, xx.z, xx.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         s1 += (double)dz[k];
@@ -869,9 +903,10 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_row_kernel(
       const int p = t < b0 - p0 ? p0 + t : b1 + (t - (b0 - p0));
       const size_t idx = rbase + p;
       float dz = dy[idx];
-      if (relu && !(y[idx] > 0.f)) dz = 0.f;
+      const float xe = x[idx];
+      if (relu && !((MASK_X ? gn_affine(xe, mu, rs, ga, be) : y[idx]) > 0.f)) dz = 0.f;
       s1 += (double)dz;
-      s2 += (double)(dz * ((x[idx] - mu) * rs));
+      s2 += (double)(dz * ((xe - mu) * rs));
     }
     block_sum2(s1, s2);
     if (threadIdx.x == 0) {
@@ -1559,8 +1594,8 @@ static int gn_forward_impl(const ld_levels_t* lv, const float* x, const float* g
                            void* workspace, size_t workspace_bytes,
                            ld_stream_t stream) {
   if (int e = check_levels(lv)) return e;
-  if (!x || !gamma || !beta || !y || !mean || !rstd || N < 1 || C < 1 || G < 1 ||
-      C % G)
+  if (!x || !gamma || !beta || (!y && !y_c8) || !mean || !rstd || N < 1 || C < 1 ||
+      G < 1 || C % G)
     return LD_EINVAL;
   if (!workspace || workspace_bytes < ld_gn_forward_workspace_bytes(lv, N, G))
     return LD_ENOSPACE;
@@ -1574,7 +1609,8 @@ static int gn_forward_impl(const ld_levels_t* lv, const float* x, const float* g
                      LD_STREAM, (const double*)workspace, k, N, C, G, eps, mean,
                      rstd);
   if (y_c8) {
-    if (k.P % 4 != 0 || C % 8 != 0 || ((uintptr_t)x | (uintptr_t)y) % 16 != 0)
+    if (k.P % 4 != 0 || C % 8 != 0 ||
+        ((uintptr_t)x | (uintptr_t)y | (uintptr_t)y_c8) % 16 != 0)
       return LD_EUNSUPPORTED;
     LD_LAUNCH(gn_apply_c8_kernel, dim3((k.P / 4 + 255) / 256, N * (C / 8)),
                        dim3(256), 0, LD_STREAM, x, k, C, G, mean, rstd, gamma, beta,
@@ -1620,17 +1656,22 @@ extern "C" size_t ld_gn_backward_workspace_bytes(const ld_levels_t* lv, int N,
          (size_t)N * C * lv->num_levels * 2 * sizeof(float);
 }
 
+// beta != null = the lean form (ld_gn_backward_c8_lean): the ReLU mask is recomputed
+// from x, y is not read (may be null), dx may be null (dx_c8 is then the only output)
 static int gn_backward_impl(const ld_levels_t* lv, const float* dy, const float* y,
-                            const float* x, const float* gamma, const float* mean,
+                            const float* x, const float* gamma, const float* beta,
+                            const float* mean,
                             const float* rstd, int N, int C, int G, int relu,
                             float* dx, void* dx_c8, float* dgamma, float* dbeta,
                             int accumulate, void* workspace, size_t workspace_bytes,
                             ld_stream_t stream) {
   if (int e = check_levels(lv)) return e;
-  if (!dy || !x || !gamma || !mean || !rstd || !dx || N < 1 || C < 1 || G < 1 ||
-      C % G)
+  const bool lean = beta != nullptr;
+  if (!dy || !x || !gamma || !mean || !rstd || (!dx && !(lean && dx_c8)) || N < 1 ||
+      C < 1 || G < 1 || C % G)
     return LD_EINVAL;
-  if (relu && !y) return LD_EINVAL;
+  if (relu && !y && !lean) return LD_EINVAL;
+  if (lean) y = dy;  // never dereferenced; keeps the alignment tests below uniform
   if (!workspace || workspace_bytes < ld_gn_backward_workspace_bytes(lv, N, C))
     return LD_ENOSPACE;
   const Levels k = make_levels(lv);
@@ -1639,9 +1680,13 @@ static int gn_backward_impl(const ld_levels_t* lv, const float* dy, const float*
   const int rl = N * C * k.num_levels, ngl = N * G * k.num_levels;
   const bool rowwise = k.P % 4 == 0 &&
                        ((uintptr_t)dy | (uintptr_t)x | (uintptr_t)(relu ? y : x)) % 16 == 0;
-  if (rowwise) {
-    LD_LAUNCH(gn_bwd_reduce_row_kernel, dim3(N * C), dim3(256), 0, LD_STREAM, dy,
-                       y, x, k, C, G, mean, rstd, relu, sums);
+  if (lean && !rowwise) return LD_EUNSUPPORTED;
+  if (rowwise && lean) {
+    LD_LAUNCH(gn_bwd_reduce_row_kernel<true>, dim3(N * C), dim3(256), 0, LD_STREAM,
+                       dy, y, x, k, C, G, mean, rstd, gamma, beta, relu, sums);
+  } else if (rowwise) {
+    LD_LAUNCH(gn_bwd_reduce_row_kernel<false>, dim3(N * C), dim3(256), 0, LD_STREAM,
+                       dy, y, x, k, C, G, mean, rstd, gamma, beta, relu, sums);
   } else {
     LD_LAUNCH(gn_bwd_reduce_kernel, dim3(rl * kGnBwdSplit), dim3(256), 0,
                        LD_STREAM, dy, y, x, k, C, G, mean, rstd, relu, sums);
@@ -1651,11 +1696,17 @@ static int gn_backward_impl(const ld_levels_t* lv, const float* dy, const float*
   LD_LAUNCH(gn_bwd_group_kernel, dim3((ngl + 255) / 256), dim3(256), 0,
                      LD_STREAM, sums, k, N, C, G, gamma, gm);
   const bool vec = k.P % 4 == 0 &&
-                   ((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx |
+                   ((uintptr_t)dy | (uintptr_t)x | (uintptr_t)(dx ? dx : x) |
                     (uintptr_t)(relu ? y : x)) % 16 == 0;
   const char* old_env = getenv("LD_NN_OLD");  // A/B: the round-5 kernels
   const bool use_old = old_env && old_env[0] == '1';
-  if (dx_c8 && use_old) {
+  if (lean) {
+    if (!dx_c8 || !vec || C % 8 != 0) return LD_EUNSUPPORTED;
+    LD_LAUNCH(gn_bwd_apply_c8_kernel<true>,
+                       dim3((k.P / 4 + 255) / 256, N * (C / 8)), dim3(256), 0,
+                       LD_STREAM, dy, y, x, k, C, G, mean, rstd, gamma, beta, gm, relu,
+                       dx, (gn_uintx4*)dx_c8);
+  } else if (dx_c8 && use_old) {
     if (!vec || C % 8 != 0) return LD_EUNSUPPORTED;
     LD_LAUNCH(old_r5::gn_bwd_apply_c8_kernel,
                        dim3((k.P / 4 + 255) / 256, N * (C / 8)), dim3(256), 0,
@@ -1667,10 +1718,10 @@ static int gn_backward_impl(const ld_levels_t* lv, const float* dy, const float*
                        gm, relu, dx);
   } else if (dx_c8) {
     if (!vec || C % 8 != 0) return LD_EUNSUPPORTED;
-    LD_LAUNCH(gn_bwd_apply_c8_kernel,
+    LD_LAUNCH(gn_bwd_apply_c8_kernel<false>,
                        dim3((k.P / 4 + 255) / 256, N * (C / 8)), dim3(256), 0,
-                       LD_STREAM, dy, y, x, k, C, G, mean, rstd, gamma, gm, relu, dx,
-                       (gn_uintx4*)dx_c8);
+                       LD_STREAM, dy, y, x, k, C, G, mean, rstd, gamma, beta, gm, relu,
+                       dx, (gn_uintx4*)dx_c8);
   } else if (vec)
     LD_LAUNCH(gn_bwd_apply_kernel<4>, dim3((k.P / 4 + 255) / 256, N * C),
                        dim3(256), 0, LD_STREAM, dy, y, x, k, C, G, mean, rstd, gamma,
@@ -1692,9 +1743,9 @@ extern "C" int ld_gn_backward(const ld_levels_t* lv, const float* dy, const floa
                               float* dx, float* dgamma, float* dbeta, int accumulate,
                               void* workspace, size_t workspace_bytes,
                               ld_stream_t stream) {
-  return gn_backward_impl(lv, dy, y, x, gamma, mean, rstd, N, C, G, relu, dx, nullptr,
-                          dgamma, dbeta, accumulate, workspace, workspace_bytes,
-                          stream);
+  return gn_backward_impl(lv, dy, y, x, gamma, nullptr, mean, rstd, N, C, G, relu, dx,
+                          nullptr, dgamma, dbeta, accumulate, workspace,
+                          workspace_bytes, stream);
 }
 
 extern "C" int ld_gn_backward_c8(const ld_levels_t* lv, const float* dy,
@@ -1705,9 +1756,27 @@ extern "C" int ld_gn_backward_c8(const ld_levels_t* lv, const float* dy,
                                  void* workspace, size_t workspace_bytes,
                                  ld_stream_t stream) {
   if (!dx_c8) return LD_EINVAL;
-  return gn_backward_impl(lv, dy, y, x, gamma, mean, rstd, N, C, G, relu, dx, dx_c8,
-                          dgamma, dbeta, accumulate, workspace, workspace_bytes,
+  return gn_backward_impl(lv, dy, y, x, gamma, nullptr, mean, rstd, N, C, G, relu, dx,
+                          dx_c8, dgamma, dbeta, accumulate, workspace, workspace_bytes,
                           stream);
+}
+
+// The lean GroupNorm (+ ReLU) backward of bf16 mode (round 6): y is not an operand
+// -- the ReLU mask is recomputed from x, mean, rstd, gamma, beta with the forward's
+// own expression (bit-identical to reading y back: tests/test_gpu_layers.py) -- and
+// dx (fp32) may be NULL when every consumer takes the C8 image dx_c8.  18 instead of
+// 30 bytes of HBM traffic per element over the two passes.
+extern "C" int ld_gn_backward_c8_lean(const ld_levels_t* lv, const float* dy,
+                                      const float* x, const float* gamma,
+                                      const float* beta, const float* mean,
+                                      const float* rstd, int N, int C, int G, int relu,
+                                      float* dx, void* dx_c8, float* dgamma,
+                                      float* dbeta, int accumulate, void* workspace,
+                                      size_t workspace_bytes, ld_stream_t stream) {
+  if (!dx_c8 || !beta) return LD_EINVAL;
+  return gn_backward_impl(lv, dy, nullptr, x, gamma, beta, mean, rstd, N, C, G, relu,
+                          dx, dx_c8, dgamma, dbeta, accumulate, workspace,
+                          workspace_bytes, stream);
 }
 
 extern "C" int ld_maxpool3x3s2(const float* x, int rows, int H, int W, float* y,

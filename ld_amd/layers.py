@@ -1069,12 +1069,16 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b,
     """Data / weight / bias gradients of a conv (shared by ConvFn and the fused
     ConvBnActFn).  x3: the saved input tensor, or -- x8 given -- its C8Act.
     Returns (dx, dw, db); dw / db are None when they went straight into the
-    gradient arena."""
+    gradient arena.  dy may be a C8Act (the BN backward wrote only the bf16 C8
+    image of the conv's output gradient): then both gradients must be C8
+    kernels, and the conv has no bias."""
     lib = L.get_lib()
     if x8 is not None:
         x3 = x8
     stride, pad, levels, has_bias = meta
-    dy = dy.contiguous()
+    dy8 = isinstance(dy, C8Act)
+    if not dy8:
+        dy = dy.contiguous()
     N, cin, _ = x3.shape
     cout, _, kh, kw = w.shape
     d, _ = conv_desc(N, cin, cout, kh, kw, stride, pad, levels)
@@ -1085,8 +1089,12 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b,
     # below use the same image
     c8w = need_w and _PRECISION[0] == 'bf16' and \
         _C8[0] and _WGRAD_C8[0] and cin % 32 == 0 and cout % 32 == 0
-    if c8w:
+    if c8w and not dy8:
         to_c8(dy)
+    if dy8 and ((need_w and not c8w) or (has_bias and need_b) or
+                (need_x and not _use_bf16(cout))):
+        raise L.LdError('conv backward: a C8-only output gradient needs the C8 '
+                        'data- and weight-gradient kernels and no bias')
     if x8 is not None and not c8w:
         raise L.LdError('a C8-only activation feeds this conv: its weight '
                         'gradient needs the C8 wgrad kernel (bf16 mode, '
@@ -1096,7 +1104,7 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b,
         _, wt_bwd = weight_images(w, True, bf16=bf16, need_fwd=False)
         dx = torch.empty((N, cin, d.Pin), dtype=torch.float32,
                          device=dy.device)
-        c8 = bf16 and _use_c8(cout, kh, stride, N * d.Pin, dy)
+        c8 = bf16 and (dy8 or _use_c8(cout, kh, stride, N * d.Pin, dy))
         tune = lib.ld_conv_bf16_tune_dgrad_c8 if c8 else \
             lib.ld_conv_bf16_tune_dgrad if bf16 else \
             lib.ld_conv_tune_dgrad
@@ -1106,7 +1114,7 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b,
             lib.ld_conv_bf16_dgrad_acc if bf16 else lib.ld_conv_dgrad_acc
         with _timed('conv_dgrad_bf16' if bf16 else 'conv_dgrad', d,
                     fused=(int(addend is not None), 0)):
-            dyin = to_c8(dy) if c8 else dy
+            dyin = dy.buf if dy8 else to_c8(dy) if c8 else dy
             _tune_once('c8_dgrad' if c8 else
                        'bf16_dgrad' if bf16 else 'dgrad', d, (),
                        lambda: tune(C.byref(d), L.ptr(dyin),
@@ -1152,7 +1160,8 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b,
         # (profiles/r05_bf16_wgrad_side_stream.txt).  LD_WGRAD_STREAM_BF16=0
         # restores the old placement.  fp32: 36.88 -> 35.98 ms eager
         # (profiles/r03_wgrad_side_stream.txt).
-        if sink is not None and _WGRAD_STREAM[0] and dy.is_cuda and \
+        if sink is not None and _WGRAD_STREAM[0] and \
+                dy.device.type == 'cuda' and \
                 KernelProfile.active is None and (
                     _PRECISION[0] != 'bf16' or _WGRAD_FORCE[0] or
                     _WGRAD_BF16_EAGER[0] or
@@ -1199,7 +1208,7 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b,
             # operand images are produced on the main stream (cached ones cost
             # nothing); the wgrad itself may go to the side stream
             xw, dyw = ((x3.buf if x8 is not None else to_c8(x3)),
-                       to_c8(dy)) if c8w else (x3, dy)
+                       dy.buf if dy8 else to_c8(dy)) if c8w else (x3, dy)
             if side is None:
                 _launch(ws, st)
             elif defer and not torch.cuda.is_current_stream_capturing():
@@ -1399,15 +1408,23 @@ _BN_BWD_C8 = [os.environ.get('LD_BN_BWD_C8', '1') == '1']
 
 
 def _bn_act_backward(dy, x3, y, scale, mean, rstd, relu, params, need_x,
-                     need_g, need_b, need_res):
+                     need_g, need_b, need_res, dx_c8_only=False):
     """Backward of eval-BN affine (+ residual) + ReLU (shared by BnActFn and the
     fused ConvBnActFn): x3 = the BN input (conv output), y = its output.
     Returns (dx, dres, dgamma, dbeta); the parameter gradients are None when
-    they went straight into the gradient arena."""
+    they went straight into the gradient arena.  ``dx_c8_only`` (bf16 mode, the
+    caller's conv takes C8 operands in both of its gradients): dx is written
+    ONLY as its C8 image and comes back as a C8Act -- the fp32 copy had no
+    reader (round 6: 4 of the launch's 22 bytes per element)."""
     lib = L.get_lib()
     dy = dy.contiguous()
     N, c, P = x3.shape
-    dx = torch.empty_like(x3) if need_x else None
+    dx8_only = bool(dx_c8_only and need_x and _BN_BWD_C8[0] and
+                    N * ((P // 4 + 63) // 64) <= 256 and
+                    all(t is None or t.data_ptr() % 16 == 0 for t in (dy, y, x3))
+                    and _C8[0] and _PRECISION[0] == 'bf16' and c % 32 == 0 and
+                    P % 4 == 0)
+    dx = torch.empty_like(x3) if need_x and not dx8_only else None
     dres = torch.empty_like(x3) if need_res else None
     pg, pb = params
     sg, sb = _sink(pg), _sink(pb)
@@ -1436,7 +1453,13 @@ def _bn_act_backward(dy, x3, y, scale, mean, rstd, relu, params, need_x,
     # aligned (a saved conv output or residual that is an offset view is not):
     # otherwise the plain kernel + a to_c8 launch where needed
     al16 = all(t is None or t.data_ptr() % 16 == 0 for t in (dy, y, x3, dx, dres))
-    if need_x and _BN_BWD_C8[0] and N * ((P // 4 + 63) // 64) <= 256 and al16:
+    if dx8_only and not al16:  # (a fresh dres is always aligned; stay correct)
+        dx, dx8_only = torch.empty_like(x3), False
+        al16 = dx.data_ptr() % 16 == 0
+    if dx8_only:
+        dx_c8 = torch.empty(N * c * P, dtype=torch.bfloat16, device=x3.device)
+    elif dx is not None and _BN_BWD_C8[0] and \
+            N * ((P // 4 + 63) // 64) <= 256 and al16:
         dx_c8 = _c8_side_output(dx)
     if dx_c8 is not None:
         L.check(lib.ld_bn_act_backward_c8(
@@ -1445,7 +1468,10 @@ def _bn_act_backward(dy, x3, y, scale, mean, rstd, relu, params, need_x,
             L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), acc,
             L.ptr(ws), ws.numel(), L.stream_ptr(x3.device)),
             'ld_bn_act_backward_c8')
-        _attach_c8(dx, dx_c8)
+        if dx8_only:
+            dx = C8Act(dx_c8, (N, c, P))
+        else:
+            _attach_c8(dx, dx_c8)
     else:
         L.check(lib.ld_bn_act_backward(
             L.ptr(dy), L.ptr(y), L.ptr(x3), L.ptr(scale), L.ptr(mean),
@@ -1511,9 +1537,15 @@ class ConvBnActFn(torch.autograd.Function):
         pw, pg, pb = ctx.params
         ng = ctx.needs_input_grad
         need_conv = ng[0] or ng[1]
+        # bf16 mode: both conv gradients read the C8 image of d(raw); its fp32
+        # copy is then never read -- do not write it
+        cout, cin = w.shape[0], w.shape[1]
+        c8_dead = _DRAW_C8_ONLY[0] and _PRECISION[0] == 'bf16' and _C8[0] and \
+            _WGRAD_C8[0] and cin % 32 == 0 and cout % 32 == 0 and \
+            (not ng[0] or _use_bf16(cout))
         draw, dres, dgamma, dbeta = _bn_act_backward(
             dz, raw, z, scale, mean, rstd, ctx.relu, (pg, pb), need_conv,
-            ng[2], ng[3], ctx.has_res and ng[7])
+            ng[2], ng[3], ctx.has_res and ng[7], dx_c8_only=c8_dead)
         # the identity path's gradient: deposited on the block input, where
         # conv1's data gradient (it runs later) sums it in its epilogue
         dres = fan_give(ctx.fan_res, dres)
@@ -1528,6 +1560,7 @@ class ConvBnActFn(torch.autograd.Function):
 
 
 _FUSE_CONV_BN = [os.environ.get('LD_FUSE_CONV_BN', '1') == '1']
+_DRAW_C8_ONLY = [os.environ.get('LD_DRAW_C8_ONLY', '1') == '1']
 
 
 def conv_bn_act(x3, w, gamma, beta, mean, var, eps, stride, pad, levels,

@@ -575,6 +575,42 @@ def test_bn_act_backward_c8_side_output(bf16_mode, relu, has_res):
     assert torch.equal(img, want)
 
 
+@pytest.mark.parametrize('has_res', [True, False])
+def test_conv_bn_backward_without_the_unread_fp32_gradient(bf16_mode, has_res):
+    """Round 6: in ConvBnActFn.backward (bf16 mode, C8 operands in both conv
+    gradients) nothing reads the fp32 copy of d(conv output) -- the BN backward
+    then writes only its C8 image (LD_DRAW_C8_ONLY, default on).  Every gradient
+    bit-identical to the path that also writes the fp32 copy."""
+    from ld_amd import layers as Y
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    N, cin, cout, H, W = 2, 64, 128, 20, 28
+    lv = ((H, W), )
+    base = [torch.randn(N, cin, H * W, generator=g),
+            torch.randn(cout, cin, 3, 3, generator=g) * 0.05,
+            torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g),
+            torch.randn(N, cout, H * W, generator=g)]
+    mean = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    var = (torch.rand(cout, generator=g) + 0.5).to(dev)
+    go = torch.randn(N, cout, H * W, generator=g).to(dev)
+    outs = []
+    for on in (False, True):
+        Y._DRAW_C8_ONLY[0] = on
+        try:
+            x, w, gamma, beta, res = (t.to(dev).requires_grad_(True) for t in base)
+            z, _ = Y.conv_bn_act(x, w, gamma, beta, mean, var, 1e-5, 1, 1, lv,
+                                 residual=res if has_res else None, relu=True)
+            z.backward(go)
+            torch.cuda.synchronize()
+        finally:
+            Y._DRAW_C8_ONLY[0] = True
+        outs.append((x.grad, w.grad, gamma.grad, beta.grad,
+                     res.grad if has_res else None))
+    for a, b in zip(*outs):
+        if a is not None:
+            assert torch.equal(a, b)
+
+
 def test_bf16_wgrad_vectorised_loads_same_bits(bf16_mode, monkeypatch):
     """The 16-byte-load variants of the wave-private bf16 weight gradient (dY
     always when Pout % 4 == 0, X too for 1x1 stride-1 convs) build the same LDS

@@ -1,0 +1,3 @@
+set -x
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_graph.py -x -q -m gpu 2>&1 | tail -5
