@@ -831,6 +831,17 @@ int ld_gn_backward_c8(const ld_levels_t* lv, const float* dy, const float* y,
                       const float* rstd, int N, int C, int G, int relu, float* dx,
                       void* dx_c8, float* dgamma, float* dbeta, int accumulate,
                       void* workspace, size_t workspace_bytes, ld_stream_t stream);
+/* The lean form of ld_gn_backward_c8 (round 6, bf16 mode): y is not an operand --
+ * the ReLU mask y > 0 is recomputed from x, mean, rstd, gamma, beta with the
+ * forward's own expression (bit-identical to reading y back) -- and dx (fp32) may
+ * be NULL when every consumer of the gradient takes the C8 image dx_c8.  18 instead
+ * of 30 bytes of HBM traffic per element.  ld_gn_forward_c8 accepts y == NULL the
+ * same way (only the C8 image of the output is written). */
+int ld_gn_backward_c8_lean(const ld_levels_t* lv, const float* dy, const float* x,
+                           const float* gamma, const float* beta, const float* mean,
+                           const float* rstd, int N, int C, int G, int relu, float* dx,
+                           void* dx_c8, float* dgamma, float* dbeta, int accumulate,
+                           void* workspace, size_t workspace_bytes, ld_stream_t stream);
 /* MaxPool2d(kernel 3, stride 2, pad 1) on rows = N*C planes (resnet.py:570);
  * forward only (the stem is frozen, frozen_stages=1). */
 int ld_maxpool3x3s2(const float* x, int rows, int H, int W, float* y,

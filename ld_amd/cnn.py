@@ -408,7 +408,10 @@ class ConvModule(nn.Module):
         if self.with_norm:
             constant_init(self.norm, 1, bias=0)
 
-    def forward3(self, x3, levels, activate=True, norm=True):
+    def forward3(self, x3, levels, activate=True, norm=True, c8_out=False):
+        """``c8_out``: the caller's next layer is another conv of this kind -- a
+        frozen conv + GN layer in bf16 mode may then return its output as a
+        layers.C8Act (no fp32 copy)."""
         act = activate and self.with_activation
         if act and not (norm and self.with_norm):
             # conv (+bias) -> ReLU (RetinaGFLHead's towers, norm_cfg=None)
@@ -421,6 +424,14 @@ class ConvModule(nn.Module):
                                           relu=True, emit_c8=True)
             y3, lv = c.forward3(x3, levels)
             return Y.relu(y3), lv
+        if norm and self.with_norm and type(self.conv) is Conv2d and \
+                self.conv.bias is None and type(self.norm) is GroupNorm:
+            # trainable tower layer: one autograd node in bf16 mode (the pair
+            # of launches otherwise) -- layers.conv_gn_act
+            c, n = self.conv, self.norm
+            return Y.conv_gn_act(x3, c.weight, n.weight, n.bias, n.num_groups,
+                                 n.eps, c.stride[0], c.padding[0], levels,
+                                 relu=act, c8_only=c8_out)
         y3, lv = self.conv.forward3(x3, levels)
         if norm and self.with_norm:
             n = self.norm

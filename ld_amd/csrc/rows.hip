@@ -304,5 +304,5 @@ extern "C" int ld_sum(const float* x, int64_t n, float* out, void* workspace,
   return (int)hipGetLastError();
 }
 
-extern "C" int ld_abi_version(void) { return 9; }
+extern "C" int ld_abi_version(void) { return 10; }
 extern "C" const char* ld_target_arch(void) { return "gfx950"; }

@@ -169,6 +169,17 @@ class LazyScalars(dict):
         return (dict, (dict(dict.items(self)), ))
 
 
+def _tower(convs, x3, levels):
+    """A stack of ConvModules on the level-concatenated tensor.  Every layer but
+    the last is told that its output feeds another conv of the stack (c8_out): a
+    frozen conv + GN layer in bf16 mode then keeps only the bf16 C8 image of its
+    output (the teacher's towers; cnn.ConvModule.forward3)."""
+    last = len(convs) - 1
+    for i, m in enumerate(convs):
+        x3, _ = m.forward3(x3, levels, c8_out=i < last)
+    return x3
+
+
 @HEADS.register_module()
 class GFLHead(nn.Module):
     """Constructor = AnchorHead.__init__ (anchor_head.py:31-96) +
@@ -262,10 +273,8 @@ class GFLHead(nn.Module):
         assert len(feats) == len(self.scales)
         x3, levels = self._pack(feats)
         cls_feat = reg_feat = x3
-        for m in self.cls_convs:
-            cls_feat, _ = m.forward3(cls_feat, levels)
-        for m in self.reg_convs:
-            reg_feat, _ = m.forward3(reg_feat, levels)
+        cls_feat = _tower(self.cls_convs, cls_feat, levels)
+        reg_feat = _tower(self.reg_convs, reg_feat, levels)
         cls3, _ = self.gfl_cls.forward3(cls_feat, levels)
         reg3, _ = self.gfl_reg.forward3(reg_feat, levels)
         scales = torch.stack([s.scale for s in self.scales])
@@ -618,10 +627,8 @@ class ATSSGFLHead(GFLHead):
         assert len(feats) == len(self.scales)
         x3, levels = self._pack(feats)
         cls_feat = reg_feat = x3
-        for m in self.cls_convs:
-            cls_feat, _ = m.forward3(cls_feat, levels)
-        for m in self.reg_convs:
-            reg_feat, _ = m.forward3(reg_feat, levels)
+        cls_feat = _tower(self.cls_convs, cls_feat, levels)
+        reg_feat = _tower(self.reg_convs, reg_feat, levels)
         cls3, _ = self.atss_cls.forward3(cls_feat, levels)
         reg3, _ = self.atss_reg.forward3(reg_feat, levels)
         ctr3, _ = self.atss_centerness.forward3(reg_feat, levels)
@@ -833,10 +840,8 @@ class FCOSGFLHead(nn.Module):
         assert len(feats) == len(self.scales)
         x3, levels = Y.pack_levels(feats)
         cls_feat = reg_feat = x3
-        for m in self.cls_convs:
-            cls_feat, _ = m.forward3(cls_feat, levels)
-        for m in self.reg_convs:
-            reg_feat, _ = m.forward3(reg_feat, levels)
+        cls_feat = _tower(self.cls_convs, cls_feat, levels)
+        reg_feat = _tower(self.reg_convs, reg_feat, levels)
         cls3, _ = self.conv_cls.forward3(cls_feat, levels)
         reg3, _ = self.conv_reg.forward3(reg_feat, levels)
         ctr3, _ = self.conv_centerness.forward3(reg_feat, levels)
@@ -1065,10 +1070,8 @@ class RetinaGFLHead(nn.Module):
         """retina_gfl_head.py:276-299, all levels in one launch per layer."""
         x3, levels = Y.pack_levels(feats)
         cls_feat = reg_feat = x3
-        for m in self.cls_convs:
-            cls_feat, _ = m.forward3(cls_feat, levels)
-        for m in self.reg_convs:
-            reg_feat, _ = m.forward3(reg_feat, levels)
+        cls_feat = _tower(self.cls_convs, cls_feat, levels)
+        reg_feat = _tower(self.reg_convs, reg_feat, levels)
         cls3, _ = self.atss_cls.forward3(cls_feat, levels)
         reg3, _ = self.atss_reg.forward3(reg_feat, levels)
         return Y.split_levels(cls3, levels), Y.split_levels(reg3, levels)
@@ -1289,10 +1292,8 @@ class GFocalHead(GFLHead):
         assert len(feats) == len(self.scales)
         x3, levels = self._pack(feats)
         cls_feat = reg_feat = x3
-        for m in self.cls_convs:
-            cls_feat, _ = m.forward3(cls_feat, levels)
-        for m in self.reg_convs:
-            reg_feat, _ = m.forward3(reg_feat, levels)
+        cls_feat = _tower(self.cls_convs, cls_feat, levels)
+        reg_feat = _tower(self.reg_convs, reg_feat, levels)
         cls3, _ = self.gfl_cls.forward3(cls_feat, levels)
         reg3, _ = self.gfl_reg.forward3(reg_feat, levels)
         scales = torch.stack([s.scale for s in self.scales])

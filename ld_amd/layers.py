@@ -1692,9 +1692,21 @@ def _attach_c8(t, buf):
 
 
 def _gn_forward_launch(lv, x3, gamma, beta, N, c, groups, eps, relu, y, stats):
+    """y = None: write ONLY the C8 image of the output (bf16 mode; returns the
+    image, or None when the geometry has no C8 form -- nothing was launched)."""
     lib = L.get_lib()
     need = lib.ld_gn_forward_workspace_bytes(C.byref(lv), N, groups)
     ws = workspace(x3.device, need, 'gn_fwd')
+    if y is None:
+        if _c8_side_output(x3) is None:
+            return None
+        y_c8 = torch.empty(x3.numel(), dtype=torch.bfloat16, device=x3.device)
+        L.check(lib.ld_gn_forward_c8(
+            C.byref(lv), L.ptr(x3), L.ptr(gamma), L.ptr(beta), N, c, groups,
+            eps, 1 if relu else 0, None, L.ptr(y_c8), L.ptr(stats[0]),
+            L.ptr(stats[1]), L.ptr(ws), ws.numel(),
+            L.stream_ptr(x3.device)), 'ld_gn_forward_c8')
+        return y_c8
     y_c8 = _c8_side_output(y) if x3.data_ptr() % 16 == 0 else None
     if y_c8 is not None:
         L.check(lib.ld_gn_forward_c8(
@@ -1711,11 +1723,77 @@ def _gn_forward_launch(lv, x3, gamma, beta, N, c, groups, eps, relu, y, stats):
                               L.stream_ptr(x3.device)), 'ld_gn_forward')
 
 
+_GN_LEAN = [os.environ.get('LD_GN_LEAN', '1') == '1']
+
+
+def _gn_backward(dy, x3, y, gamma, beta, stats, groups, levels, relu, params,
+                 need_g, need_b, dx_c8_only=False):
+    """Backward of GroupNorm (+ ReLU) on a level-concatenated tensor (shared by
+    GnActFn and the fused ConvGnActFn).  Returns (dx, dgamma, dbeta); the
+    parameter gradients are None when they went into the gradient arena.
+    bf16 mode (C8 side output possible): the lean kernels -- the ReLU mask is
+    recomputed from x instead of reading y back (bit-identical, LD_GN_LEAN=0 for
+    the old form) and, ``dx_c8_only``, dx exists only as its C8 image and comes
+    back as a C8Act."""
+    lib = L.get_lib()
+    dy = dy.contiguous()
+    N, c, P = x3.shape
+    lv = levels_desc(levels)
+    pg, pb = params
+    sg, sb = _sink(pg), _sink(pb)
+    direct = need_g and need_b and sg is not None and sb is not None
+    if direct:
+        dgamma, dbeta = sg, sb
+    else:
+        dgamma = torch.empty(c, dtype=torch.float32, device=x3.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=x3.device)
+    need = lib.ld_gn_backward_workspace_bytes(C.byref(lv), N, c)
+    ws = workspace(x3.device, need, 'gn')
+    aligned = all(t.data_ptr() % 16 == 0 for t in (dy, y, x3))
+    c8_ok = aligned and _C8[0] and _PRECISION[0] == 'bf16' and c % 32 == 0 and \
+        P % 4 == 0
+    lean = c8_ok and _GN_LEAN[0] and os.environ.get('LD_NN_OLD') != '1'
+    dx8_only = bool(lean and dx_c8_only)
+    dx = None if dx8_only else torch.empty_like(x3)
+    dx_c8 = torch.empty(N * c * P, dtype=torch.bfloat16, device=x3.device) \
+        if dx8_only else _c8_side_output(dx) if c8_ok else None
+    if lean:
+        L.check(lib.ld_gn_backward_c8_lean(
+            C.byref(lv), L.ptr(dy), L.ptr(x3), L.ptr(gamma), L.ptr(beta),
+            L.ptr(stats[0]), L.ptr(stats[1]), N, c, groups,
+            1 if relu else 0, L.ptr(dx), L.ptr(dx_c8), L.ptr(dgamma),
+            L.ptr(dbeta), 1 if direct else 0, L.ptr(ws), ws.numel(),
+            L.stream_ptr(x3.device)), 'ld_gn_backward_c8_lean')
+        if dx8_only:
+            dx = C8Act(dx_c8, (N, c, P))
+        else:
+            _attach_c8(dx, dx_c8)
+    elif dx_c8 is not None:
+        L.check(lib.ld_gn_backward_c8(
+            C.byref(lv), L.ptr(dy), L.ptr(y), L.ptr(x3), L.ptr(gamma),
+            L.ptr(stats[0]), L.ptr(stats[1]), N, c, groups,
+            1 if relu else 0, L.ptr(dx), L.ptr(dx_c8), L.ptr(dgamma),
+            L.ptr(dbeta), 1 if direct else 0, L.ptr(ws), ws.numel(),
+            L.stream_ptr(x3.device)), 'ld_gn_backward_c8')
+        _attach_c8(dx, dx_c8)
+    else:
+        L.check(lib.ld_gn_backward(
+            C.byref(lv), L.ptr(dy), L.ptr(y), L.ptr(x3), L.ptr(gamma),
+            L.ptr(stats[0]), L.ptr(stats[1]), N, c, groups,
+            1 if relu else 0, L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta),
+            1 if direct else 0, L.ptr(ws), ws.numel(),
+            L.stream_ptr(x3.device)), 'ld_gn_backward')
+    if direct:
+        dgamma = dbeta = None
+        _emit(pg)
+        _emit(pb)
+    return dx, dgamma, dbeta
+
+
 class GnActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x3, gamma, beta, groups, eps, levels, relu):
-        lib = L.get_lib()
         _dev_f32(x3, 'gn input')
         N, c, P = x3.shape
         lv = levels_desc(levels)
@@ -1724,7 +1802,7 @@ class GnActFn(torch.autograd.Function):
                             device=x3.device)
         _gn_forward_launch(lv, x3, gamma, beta, N, c, groups, eps, relu, y,
                            stats)
-        ctx.save_for_backward(x3, y, gamma, stats)
+        ctx.save_for_backward(x3, y, gamma, beta, stats)
         ctx.meta = (groups, levels, relu)
         ctx.params = (gamma, beta)
         _note_use(gamma, beta)
@@ -1732,46 +1810,105 @@ class GnActFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        lib = L.get_lib()
-        x3, y, gamma, stats = ctx.saved_tensors
+        x3, y, gamma, beta, stats = ctx.saved_tensors
         groups, levels, relu = ctx.meta
-        dy = dy.contiguous()
-        N, c, P = x3.shape
-        lv = levels_desc(levels)
-        dx = torch.empty_like(x3)
-        pg, pb = ctx.params
-        sg, sb = _sink(pg), _sink(pb)
-        direct = ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and \
-            sg is not None and sb is not None
-        if direct:
-            dgamma, dbeta = sg, sb
-        else:
-            dgamma = torch.empty(c, dtype=torch.float32, device=x3.device)
-            dbeta = torch.empty(c, dtype=torch.float32, device=x3.device)
-        need = lib.ld_gn_backward_workspace_bytes(C.byref(lv), N, c)
-        ws = workspace(x3.device, need, 'gn')
-        aligned = all(t.data_ptr() % 16 == 0 for t in (dy, y, x3))
-        dx_c8 = _c8_side_output(dx) if aligned else None
-        if dx_c8 is not None:
-            L.check(lib.ld_gn_backward_c8(
-                C.byref(lv), L.ptr(dy), L.ptr(y), L.ptr(x3), L.ptr(gamma),
-                L.ptr(stats[0]), L.ptr(stats[1]), N, c, groups,
-                1 if relu else 0, L.ptr(dx), L.ptr(dx_c8), L.ptr(dgamma),
-                L.ptr(dbeta), 1 if direct else 0, L.ptr(ws), ws.numel(),
-                L.stream_ptr(x3.device)), 'ld_gn_backward_c8')
-            _attach_c8(dx, dx_c8)
-        else:
-            L.check(lib.ld_gn_backward(
-                C.byref(lv), L.ptr(dy), L.ptr(y), L.ptr(x3), L.ptr(gamma),
-                L.ptr(stats[0]), L.ptr(stats[1]), N, c, groups,
-                1 if relu else 0, L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta),
-                1 if direct else 0, L.ptr(ws), ws.numel(),
-                L.stream_ptr(x3.device)), 'ld_gn_backward')
-        if direct:
-            dgamma = dbeta = None
-            _emit(pg)
-            _emit(pb)
+        dx, dgamma, dbeta = _gn_backward(
+            dy, x3, y, gamma, beta, stats, groups, levels, relu, ctx.params,
+            ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dx, dgamma, dbeta, None, None, None, None
+
+
+class ConvGnActFn(torch.autograd.Function):
+    """y = relu?(GroupNorm(conv(x, w))) for a TRAINABLE bias-free conv / GN pair
+    (the GFL head towers, gfl_head.py:102-133) as ONE autograd node (round 6, bf16
+    mode).  The launches are those of ConvFn + GnActFn, in the same order, on the
+    same operands; what the fusion buys is in the backward: the gradient of the
+    conv output never leaves this node, so it exists only as the bf16 C8 image
+    both conv gradients read (no fp32 copy: 4 of the GN backward's bytes per
+    element), and the conv output is not an autograd tensor."""
+
+    @staticmethod
+    def forward(ctx, x3, w, gamma, beta, groups, eps, stride, pad, levels, relu):
+        raw, out_levels = conv_forward_raw(x3, w, stride, pad, levels)
+        N, c, P = raw.shape
+        lv = levels_desc(out_levels)
+        y = torch.empty_like(raw)
+        stats = torch.empty((2, N, groups, len(out_levels)),
+                            dtype=torch.float32, device=raw.device)
+        _gn_forward_launch(lv, raw, gamma, beta, N, c, groups, eps, relu, y,
+                           stats)
+        ctx.x8 = x3 if isinstance(x3, C8Act) else None
+        ctx.save_for_backward(x3.buf if ctx.x8 is not None else x3, w, raw, y,
+                              gamma, beta, stats)
+        ctx.meta = (stride, pad, levels, False)
+        ctx.gn = (groups, out_levels, relu)
+        ctx.params = (w, gamma, beta)
+        ctx.fan = fan_in(ctx, 0, x3) if ctx.x8 is None else None
+        _note_use(w, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x3, w, raw, y, gamma, beta, stats = ctx.saved_tensors
+        pw, pg, pb = ctx.params
+        groups, out_levels, relu = ctx.gn
+        ng = ctx.needs_input_grad
+        cout, cin = w.shape[0], w.shape[1]
+        c8_dead = _DRAW_C8_ONLY[0] and _PRECISION[0] == 'bf16' and _C8[0] and \
+            _WGRAD_C8[0] and cin % 32 == 0 and cout % 32 == 0 and \
+            (not ng[0] or _use_bf16(cout))
+        draw, dgamma, dbeta = _gn_backward(
+            dy, raw, y, gamma, beta, stats, groups, out_levels, relu, (pg, pb),
+            ng[2], ng[3], dx_c8_only=c8_dead)
+        dx = dw = None
+        if ng[0] or ng[1]:
+            dx, dw, _ = _conv_backward(x3, ctx.x8, w, draw, ctx.meta,
+                                       (pw, None), ng[0], ng[1], False,
+                                       addend=fan_take(ctx.fan) if ng[0]
+                                       else None)
+        return (fan_give(ctx.fan, dx), dw, dgamma, dbeta, None, None, None,
+                None, None, None)
+
+
+_FUSE_CONV_GN = [os.environ.get('LD_FUSE_CONV_GN', '1') == '1']
+
+
+def conv_gn_act(x3, w, gamma, beta, groups, eps, stride, pad, levels, relu=True,
+                c8_only=False):
+    """Bias-free conv -> GroupNorm -> ReLU; returns (y3, out_levels).  bf16 mode:
+    one autograd node when something trains (ConvGnActFn); without a gradient
+    ``c8_only`` asks for the output as a C8Act (a caller whose next layer is
+    another C8 conv).  The conv2d + gn_act pair otherwise (fp32 mode,
+    LD_FUSE_CONV_GN=0)."""
+    N, cin, _ = x3.shape
+    cout, _, kh, kw = w.shape
+    _, out_levels = conv_desc(N, cin, cout, kh, kw, stride, pad, levels)
+    grad = torch.is_grad_enabled() and (
+        w.requires_grad or gamma.requires_grad or
+        (isinstance(x3, torch.Tensor) and x3.requires_grad))
+    if _FUSE_CONV_GN[0] and _PRECISION[0] == 'bf16' and cin >= 16 and grad:
+        return ConvGnActFn.apply(x3, w, gamma, beta, groups, eps, stride, pad,
+                                 levels, relu), out_levels
+    if _FUSE_CONV_GN[0] and _PRECISION[0] == 'bf16' and cin >= 16 and not grad:
+        # frozen layer (the teacher's towers): the conv output feeds only the
+        # norm -- no C8 image of it -- and, ``c8_only``, the layer's output
+        # exists only as its C8 image (the next conv's operand)
+        raw, _ = conv_forward_raw(x3, w, stride, pad, levels)
+        N, c, _ = raw.shape
+        lv = levels_desc(out_levels)
+        stats = torch.empty((2, N, groups, len(out_levels)),
+                            dtype=torch.float32, device=raw.device)
+        if c8_only:
+            img = _gn_forward_launch(lv, raw, gamma, beta, N, c, groups, eps,
+                                     relu, None, stats)
+            if img is not None:
+                return C8Act(img, raw.shape), out_levels
+        y = torch.empty_like(raw)
+        _gn_forward_launch(lv, raw, gamma, beta, N, c, groups, eps, relu, y,
+                           stats)
+        return y, out_levels
+    y3, out_levels = conv2d(x3, w, None, stride, pad, levels)
+    return gn_act(y3, gamma, beta, groups, eps, out_levels, relu), out_levels
 
 
 def gn_act(x3, gamma, beta, groups, eps, levels, relu=True):

@@ -181,7 +181,7 @@ def save_tune_table(path):
     return get_lib().ld_conv_tune_save(str(path).encode())
 
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 _G, _H, _M = C.POINTER(GeomT), C.POINTER(LossHpT), C.POINTER(MapsT)
 _CV, _EP, _LV = C.POINTER(ConvT), C.POINTER(ConvEpilogueT), C.POINTER(LevelsT)
@@ -357,6 +357,9 @@ SIGNATURES = {
     'ld_gn_backward_c8': (C.c_int, [_LV, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
                                     _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
                                     _vp, _sz, _vp]),
+    'ld_gn_backward_c8_lean': (C.c_int, [_LV, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
+                                         _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
+                                         _vp, _sz, _vp]),
     'ld_gn_backward_workspace_bytes': (_sz, [_LV, _i32, _i32]),
     'ld_gn_backward': (C.c_int, [_LV, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
                                  _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp,

@@ -508,6 +508,82 @@ def test_round6_norm_backward_kernels_bit_identical(cfg, mode, monkeypatch):
         Y.set_precision('fp32')
 
 
+@pytest.mark.parametrize('cfg', [(64, 8, True), (64, 32, True), (256, 32, True),
+                                 (64, 16, False)])
+def test_gn_lean_backward_bit_identical(cfg):
+    """Round 6, bf16 mode: the lean GroupNorm backward (ld_gn_backward_c8_lean)
+    recomputes the ReLU mask from x with the forward's own expression instead of
+    reading y -- dx, its C8 image, dgamma and dbeta carry the same bits as the
+    y-reading kernels (LD_GN_LEAN=0), on pyramids with level boundaries inside a
+    thread's four positions."""
+    from ld_amd import layers as Y
+    dev = _dev()
+    C, G, relu = cfg
+    levels = ((12, 20), (6, 10), (3, 5), (2, 3), (1, 3)) if C < 256 else \
+        ((100, 168), (50, 84), (25, 42), (13, 21), (7, 11))
+    P = sum(h * w for h, w in levels)
+    assert P % 4 == 0
+    g = torch.Generator().manual_seed(C * 3 + G)
+    x = (torch.randn(2, C, P, generator=g) * 2 + 0.5).to(dev)
+    gamma = (torch.randn(C, generator=g) * .7).to(dev)  # both signs
+    beta = torch.randn(C, generator=g).to(dev)
+    go = torch.randn(2, C, P, generator=g).to(dev)
+    Y.set_precision('bf16')
+    try:
+        outs = []
+        for lean in (False, True):
+            Y._GN_LEAN[0] = lean
+            xd, gd, bd = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+            y = Y.gn_act(xd, gd, bd, G, 1e-5, levels, relu)
+            seen = {}
+            xd.register_hook(lambda gr: seen.setdefault('dx', gr))
+            y.backward(go)
+            torch.cuda.synchronize()
+            img = Y._c8_cached(seen['dx'])
+            assert img is not None
+            outs.append((y.detach().clone(), xd.grad.clone(), gd.grad.clone(),
+                         bd.grad.clone(), img.clone()))
+        for a, b, what in zip(outs[0], outs[1], ('y', 'dx', 'dgamma', 'dbeta', 'dx C8')):
+            assert torch.equal(a, b), (cfg, what)
+    finally:
+        Y._GN_LEAN[0] = True
+        Y.set_precision('fp32')
+
+
+def test_fused_conv_gn_node_bit_identical_to_the_pair():
+    """Round 6, bf16 mode: ConvGnActFn (one autograd node per trainable tower
+    layer; the gradient of the conv output exists only as its C8 image) against
+    conv2d + gn_act: output and every gradient identical, two stacked layers so
+    that the second layer's data gradient feeds the first layer's GN backward."""
+    from ld_amd import layers as Y
+    dev = _dev()
+    levels = ((12, 20), (6, 10), (3, 5), (2, 3), (1, 3))
+    P = sum(h * w for h, w in levels)
+    g = torch.Generator().manual_seed(77)
+    C = 64
+    base = [torch.randn(2, C, P, generator=g)] + [
+        t for _ in range(2) for t in (torch.randn(C, C, 3, 3, generator=g) * 0.05,
+                                      torch.rand(C, generator=g) + .5,
+                                      torch.randn(C, generator=g) * .3)]
+    go = torch.randn(2, C, P, generator=g).to(dev)
+    Y.set_precision('bf16')
+    try:
+        outs = []
+        for fused in (False, True):
+            Y._FUSE_CONV_GN[0] = fused
+            t = [b.to(dev).requires_grad_(True) for b in base]
+            h, lv = Y.conv_gn_act(t[0], t[1], t[2], t[3], 32, 1e-5, 1, 1, levels)
+            y, _ = Y.conv_gn_act(h, t[4], t[5], t[6], 32, 1e-5, 1, 1, lv)
+            y.backward(go)
+            torch.cuda.synchronize()
+            outs.append([y.detach().clone()] + [v.grad.clone() for v in t])
+        for i, (a, b) in enumerate(zip(*outs)):
+            assert torch.equal(a, b), i
+    finally:
+        Y._FUSE_CONV_GN[0] = True
+        Y.set_precision('fp32')
+
+
 @pytest.mark.parametrize('fine,coarse', [((50, 84), (25, 42)),
                                          ((25, 25), (13, 13)),
                                          ((13, 21), (7, 11))])

@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 6, GPU session 10: lean GroupNorm backward (mask from x, no y read) + fused
+# conv+GN autograd node (C8-only gradient of the conv output): tests, A/B in the step
+mkdir -p gpurun_out; export TMPDIR=/tmp
+O=gpurun_out
+timeout 1500 python -m pytest tests/test_gpu_layers.py tests/test_gpu_bf16.py tests/test_gpu_e2e.py tests/test_gpu_graph.py -q -m gpu -x > $O/s10_pytest.log 2>&1; echo pytest rc=$?; tail -3 $O/s10_pytest.log
+for rep in 1 2 3; do
+echo "== bf16 default"; timeout 200 python tools/profile_step.py --mode bf16 --steps 40 --warmup 10 --pipeline 2>/dev/null | grep img/s
+echo "== bf16 LD_GN_LEAN=0 LD_FUSE_CONV_GN=0"; LD_GN_LEAN=0 LD_FUSE_CONV_GN=0 timeout 200 python tools/profile_step.py --mode bf16 --steps 40 --warmup 10 --pipeline 2>/dev/null | grep img/s
+echo "== bf16 LD_FUSE_CONV_GN=0"; LD_FUSE_CONV_GN=0 timeout 200 python tools/profile_step.py --mode bf16 --steps 40 --warmup 10 --pipeline 2>/dev/null | grep img/s
+done
