@@ -443,6 +443,10 @@ typedef struct {
    * (resnet.py:639-648 keeps BN in eval mode; its affine stays trainable).
    * NULL = not written. */
   float* y_raw;
+  /* ld_conv_bf16_forward_c8 only: that second output as a bf16 C8 image
+   * (N, Cout/8, Pout, 8) instead of fp32 (give one or the other) -- what
+   * ld_bn_act_backward_c8in reads for d(gamma); half the bytes (round 6). */
+  void* y_raw_c8;
 } ld_conv_epilogue_t;
 
 /* (Cout,Cin,KH,KW) parameter -> GEMM images: wt_fwd [tap][Cin_pad][Cout]
@@ -774,6 +778,18 @@ int ld_bn_act_backward_c8(const float* dy, const float* y, const float* x,
                           int N, int C, int P, int relu, float* dx, void* dx_c8,
                           float* dres, float* dgamma, float* dbeta, int accumulate,
                           void* workspace, size_t workspace_bytes, ld_stream_t stream);
+/* ld_bn_act_backward_c8 with the two saved activations given as bf16 C8 images
+ * (N, C/8, P, 8) instead of fp32 tensors (round 6): y_c8 = the image of the
+ * layer's output (only its sign is used, the ReLU mask; NULL without relu), x_c8 =
+ * the conv result before the affine as written through
+ * ld_conv_epilogue_t.y_raw_c8.  dx may be NULL (only dx_c8 is written).  8 instead
+ * of 12 bytes read per element; d(gamma) sees the bf16-rounded conv result. */
+int ld_bn_act_backward_c8in(const float* dy, const void* y_c8, const void* x_c8,
+                            const float* scale, const float* mean, const float* rstd,
+                            int N, int C, int P, int relu, float* dx, void* dx_c8,
+                            float* dres, float* dgamma, float* dbeta, int accumulate,
+                            void* workspace, size_t workspace_bytes,
+                            ld_stream_t stream);
 /* Deferred finalisation (round 5, see ld_wgrad_reduce_batch): with accumulate ==
  * LD_GRAD_DEFER the two BN backward entry points above write only their
  * per-workgroup fp64 partials ([C][nsplit] pairs (sum dz, sum dz*xhat), nsplit =

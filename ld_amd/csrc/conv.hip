@@ -2249,7 +2249,11 @@ int build_forward(const ld_conv_t* c, const float* x, const void* wt_fwd,
   k.y_c8 = ep ? ep->y_c8 : nullptr;
   k.res_c8 = ep ? ep->residual_c8 : nullptr;
   k.y_raw = ep ? ep->y_raw : nullptr;
+  k.raw_c8 = ep ? ep->y_raw_c8 : nullptr;
   if (k.y_raw && (k.bias || !y)) return LD_EINVAL;  // raw = acc: no bias, y needed
+  // the raw result as a C8 image: the C8-operand kernels only (family 2)
+  if (k.raw_c8 && (family != 2 || k.bias || k.y_raw || c->Cout % 8 != 0))
+    return LD_EINVAL;
   if ((k.y_c8 || k.res_c8) && (family == 0 || c->Cout % 8 != 0)) return LD_EINVAL;
   if (k.res_c8 && k.residual) return LD_EINVAL;
   if ((k.scale == nullptr) != (k.shift == nullptr)) return LD_EINVAL;

@@ -943,6 +943,14 @@ __global__ __launch_bounds__(256, 2) void conv_tile_c8_kernel(ConvK a) {
         if (MODE == 0 && c8out && row0 < Cout)
           *(uintx2*)((char*)a.y_c8 + c8base[j] + c8row) =
               __builtin_bit_cast(uintx2, __builtin_convertvector(q, bf16x4));
+        // the conv result before the affine as a C8 image (round 6: what the BN
+        // backward reads for d(gamma); 2 instead of 4 bytes per element)
+        if (MODE == 0 && a.raw_c8 && row0 < Cout) {
+          const floatx4_t rw = {acc[i][j][4 * g], acc[i][j][4 * g + 1],
+                                acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          *(uintx2*)((char*)a.raw_c8 + c8base[j] + c8row) =
+              __builtin_bit_cast(uintx2, __builtin_convertvector(rw, bf16x4));
+        }
       }
     }
   }

@@ -32,6 +32,7 @@ struct ConvK {  // kernel-side view of ld_conv_t + pointers
   void* y_c8;             // optional: also write y as (N, Cout/8, Pout, 8) bf16
   const void* res_c8;     // optional: residual as a C8 image (then residual == null)
   float* y_raw;           // optional second output: acc (+ bias) before the affine
+  void* raw_c8;           // ... or that output as a bf16 C8 image only (C8 kernels)
   unsigned x_bytes, wt_bytes;  // buffer-descriptor extents
   // MODE 1 (data-gradient of a stride-2 conv, one output-parity class per
   // launch): g.lv[].Hout/Wout/off_out describe the COMPACT grid of the class;

@@ -538,6 +538,12 @@ __global__ __launch_bounds__(512) void conv_t256_c8_kernel(ConvK a) {
         if (MODE == 0 && c8out && row0 < Cout)
           *(uintx2*)((char*)a.y_c8 + c8base[j] + c8row) =
               __builtin_bit_cast(uintx2, __builtin_convertvector(q, bf16x4));
+        if (MODE == 0 && a.raw_c8 && row0 < Cout) {  // as in conv_tile_c8_kernel
+          const floatx4_t rw = {acc[i][j][4 * g], acc[i][j][4 * g + 1],
+                                acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          *(uintx2*)((char*)a.raw_c8 + c8base[j] + c8row) =
+              __builtin_bit_cast(uintx2, __builtin_convertvector(rw, bf16x4));
+        }
       }
     }
   }
@@ -580,7 +586,8 @@ int ld_bf16_t256_launch(int mode, const ConvK& k, int BM, int BN, hipStream_t st
     const char* e = getenv("LD_CONV_T256_SWAP");
     return !(e && e[0] == '0');
   }();
-  const bool swap = allow_swap && mode == 0 && k.Pout % 4 == 0 && !k.y_c8 && !k.res_c8;
+  const bool swap = allow_swap && mode == 0 && k.Pout % 4 == 0 && !k.y_c8 && !k.res_c8 &&
+                    !k.raw_c8;
 #define LD_CASE(BM_, BN_, WM_, WN_)                                                \
   if (BM == BM_ && BN == BN_) {                                                    \
     if (mode == 1)                                                                 \

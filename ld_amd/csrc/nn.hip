@@ -593,6 +593,92 @@ __global__ __launch_bounds__(64) void bn_act_bwd_c8_kernel(
   }
 }
 
+// Round 6, the lean BN backward of bf16 mode: the two saved activations arrive as
+// the bf16 C8 images the forward wrote anyway -- y (only its sign is used: the ReLU
+// mask, identical to the fp32 test) and the conv result x before the affine (for
+// d(gamma); the conv epilogue writes it as a C8 image instead of fp32,
+// ld_conv_epilogue_t.y_raw_c8).  8 instead of 12 bytes read per element, and the
+// forward wrote 2 instead of 4 for x.  Same thread shape and the same expressions
+// as bn_act_bwd_c8_kernel; a thread's 8 channels x 4 positions of an image are 64
+// contiguous bytes.
+__global__ __launch_bounds__(64) void bn_act_bwd_c8in_kernel(
+    const float* __restrict__ dy, const gn_uintx4* __restrict__ y_img,
+    const gn_uintx4* __restrict__ x_img, const float* __restrict__ scale,
+    const float* __restrict__ mean, const float* __restrict__ rstd, int C, int P,
+    int relu, float* __restrict__ dx, float* __restrict__ dres,
+    gn_uintx4* __restrict__ dx_c8, double* __restrict__ partial, int nslots) {
+  const int C8 = C >> 3;
+  const int blk = blockIdx.y;  // n * C8 + c8
+  const int c8 = blk % C8, n = blk / C8;
+  const int p = (blockIdx.x * 64 + threadIdx.x) * 4;
+  const bool live = p < P;
+  const int pl = live ? p : 0;
+  float out[8][4];
+  double s1[8], s2[8];
+  float4 g8[8];
+  gn_uintx4 yq[4], xq[4];
+  const gn_uintx4* yp = relu ? y_img : x_img;  // unconditional loads, no branch
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    g8[e] = *reinterpret_cast<const float4*>(dy + ((size_t)n * C + c8 * 8 + e) * P + pl);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    yq[k] = yp[(size_t)blk * P + pl + k];
+    xq[k] = x_img[(size_t)blk * P + pl + k];
+  }
+  gn_floatx8 yf[4], xf[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    yf[k] = __builtin_convertvector(__builtin_bit_cast(gn_bf16x8, yq[k]), gn_floatx8);
+    xf[k] = __builtin_convertvector(__builtin_bit_cast(gn_bf16x8, xq[k]), gn_floatx8);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c8 * 8 + e;
+    const float s = scale[c];
+    s1[e] = 0.0;
+    s2[e] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[e][k] = 0.0f;
+    if (!live) continue;
+    const size_t idx = ((size_t)n * C + c) * P + p;
+    float dz[4] = {g8[e].x, g8[e].y, g8[e].z, g8[e].w};
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (!(yf[k][e] > 0.f)) dz[k] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[e][k] = dz[k] * s;
+    if (dx)
+      *reinterpret_cast<float4*>(dx + idx) =
+          make_float4(out[e][0], out[e][1], out[e][2], out[e][3]);
+    if (dres)
+      *reinterpret_cast<float4*>(dres + idx) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+    if (partial) {
+      const float mu = mean[c], rs = rstd[c];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s1[e] += (double)dz[k];
+        s2[e] += (double)(dz[k] * ((xf[k][e] - mu) * rs));
+      }
+    }
+  }
+  if (live) store_c8x4(dx_c8 + (size_t)blk * P + p, out);
+  if (partial) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double a = wave_sum_d(s1[e]), b = wave_sum_d(s2[e]);
+      if (threadIdx.x == 0) {
+        const int slot = n * gridDim.x + blockIdx.x;
+        const size_t at = ((size_t)(c8 * 8 + e) * nslots + slot) * 2;
+        partial[at + 0] = a;
+        partial[at + 1] = b;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void gn_apply_c8_kernel(
     const float* __restrict__ x, Levels lv, int C, int G,
     const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -1508,6 +1594,40 @@ extern "C" int ld_bn_act_backward_c8(const float* dy, const float* y, const floa
   LD_LAUNCH(bn_act_bwd_c8_kernel, dim3(xb, N * (C / 8)), dim3(64), 0, LD_STREAM,
                      dy, y, x, scale, mean, rstd, C, P, relu, dx, dres,
                      (gn_uintx4*)dx_c8, params ? (double*)workspace : nullptr, nslots);
+  if (params && accumulate != LD_GRAD_DEFER)
+    LD_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0,
+                       LD_STREAM, (const double*)workspace, C, nslots, dgamma, dbeta,
+                       accumulate);
+  return (int)hipGetLastError();
+}
+
+// ld_bn_act_backward_c8 with y and x given as bf16 C8 images (N, C/8, P, 8) instead
+// of fp32 tensors (round 6; y_c8 may be NULL without relu).  Same outputs, same
+// partial-slot layout (ld_bn_act_backward_nsplit(..., c8 = 1)); dgamma is computed
+// from the bf16-rounded conv result.
+extern "C" int ld_bn_act_backward_c8in(const float* dy, const void* y_c8,
+                                       const void* x_c8, const float* scale,
+                                       const float* mean, const float* rstd, int N,
+                                       int C, int P, int relu, float* dx, void* dx_c8,
+                                       float* dres, float* dgamma, float* dbeta,
+                                       int accumulate, void* workspace,
+                                       size_t workspace_bytes, ld_stream_t stream) {
+  if (!dy || !scale || !dx_c8 || !x_c8 || N < 1 || C < 1 || P < 1) return LD_EINVAL;
+  if (relu && !y_c8) return LD_EINVAL;
+  const bool params = dgamma || dbeta;
+  if (params && (!mean || !rstd)) return LD_EINVAL;
+  if (params && (!workspace ||
+                 workspace_bytes < ld_bn_act_backward_workspace_bytes(N, C, P)))
+    return LD_ENOSPACE;
+  const int xb = (P / 4 + 63) / 64, nslots = N * xb;
+  if (P % 4 != 0 || C % 8 != 0 || nslots > kBnSplitMax ||
+      ((uintptr_t)dy | (uintptr_t)(y_c8 ? y_c8 : dy) | (uintptr_t)x_c8 |
+       (uintptr_t)(dx ? dx : dy) | (uintptr_t)(dres ? dres : dy) | (uintptr_t)dx_c8) % 16)
+    return LD_EUNSUPPORTED;
+  LD_LAUNCH(bn_act_bwd_c8in_kernel, dim3(xb, N * (C / 8)), dim3(64), 0, LD_STREAM, dy,
+                     (const gn_uintx4*)y_c8, (const gn_uintx4*)x_c8, scale, mean, rstd, C,
+                     P, relu, dx, dres, (gn_uintx4*)dx_c8,
+                     params ? (double*)workspace : nullptr, nslots);
   if (params && accumulate != LD_GRAD_DEFER)
     LD_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0,
                        LD_STREAM, (const double*)workspace, C, nslots, dgamma, dbeta,

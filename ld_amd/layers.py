@@ -633,7 +633,7 @@ def _epilogue(bias=None, scale=None, shift=None, residual=None, relu=False,
 
 def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
                      shift=None, residual=None, relu=False, emit_c8=False,
-                     c8_only=False, y_raw=None):
+                     c8_only=False, y_raw=None, y_raw_c8=None):
     """One implicit-GEMM launch.  Returns (y3, out_levels).  ``emit_c8``: in
     bf16 mode also write the C8 image of y from the epilogue (for a y that goes
     straight into another conv: the frozen conv+BN+ReLU chains).  ``c8_only``:
@@ -676,6 +676,15 @@ def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
         ep.y_raw = y_raw.data_ptr()
         L.keep(y_raw)
     c8 = in8 or (bf16 and _use_c8(cin, kh, stride, N * d.Pout, x3))
+    if y_raw_c8 is not None:
+        # the pre-affine result as a bf16 C8 image (ConvBnActFn, lean form)
+        if not c8 or y_raw is not None or bias is not None or cout % 8 or \
+                y_raw_c8.numel() != N * cout * d.Pout or \
+                y_raw_c8.dtype != torch.bfloat16:
+            raise L.LdError('conv: y_raw_c8 needs the C8-operand kernel, no '
+                            'bias, no fp32 y_raw and an (N*Cout*Pout) bf16 buffer')
+        ep.y_raw_c8 = y_raw_c8.data_ptr()
+        L.keep(y_raw_c8)
     fn = lib.ld_conv_forward_smallc if smallc else (
         lib.ld_conv_bf16_forward_c8 if c8 else
         lib.ld_conv_bf16_forward if bf16 else lib.ld_conv_forward)
@@ -1408,16 +1417,22 @@ _BN_BWD_C8 = [os.environ.get('LD_BN_BWD_C8', '1') == '1']
 
 
 def _bn_act_backward(dy, x3, y, scale, mean, rstd, relu, params, need_x,
-                     need_g, need_b, need_res, dx_c8_only=False):
+                     need_g, need_b, need_res, dx_c8_only=False, c8in=None):
     """Backward of eval-BN affine (+ residual) + ReLU (shared by BnActFn and the
     fused ConvBnActFn): x3 = the BN input (conv output), y = its output.
     Returns (dx, dres, dgamma, dbeta); the parameter gradients are None when
     they went straight into the gradient arena.  ``dx_c8_only`` (bf16 mode, the
     caller's conv takes C8 operands in both of its gradients): dx is written
     ONLY as its C8 image and comes back as a C8Act -- the fp32 copy had no
-    reader (round 6: 4 of the launch's 22 bytes per element)."""
+    reader (round 6: 4 of the launch's 22 bytes per element).  ``c8in`` = (y image,
+    x image, (N, C, P)): the lean form -- x3 / y are None, the saved activations
+    are the bf16 C8 images the forward wrote (ld_bn_act_backward_c8in)."""
     lib = L.get_lib()
     dy = dy.contiguous()
+    if c8in is not None:
+        return _bn_act_backward_c8in(dy, c8in, scale, mean, rstd, relu, params,
+                                     need_x, need_g, need_b, need_res,
+                                     dx_c8_only)
     N, c, P = x3.shape
     dx8_only = bool(dx_c8_only and need_x and _BN_BWD_C8[0] and
                     N * ((P // 4 + 63) // 64) <= 256 and
@@ -1495,6 +1510,65 @@ def _bn_act_backward(dy, x3, y, scale, mean, rstd, relu, params, need_x,
     return dx, dres, dgamma, dbeta
 
 
+def _bn_act_backward_c8in(dy, c8in, scale, mean, rstd, relu, params, need_x,
+                          need_g, need_b, need_res, dx_c8_only):
+    """The lean BN (+ residual) + ReLU backward of bf16 mode: the saved output
+    and the saved conv result are bf16 C8 images (see _bn_act_backward)."""
+    lib = L.get_lib()
+    y_img, x_img, (N, c, P) = c8in
+    dev = dy.device
+    if dy.data_ptr() % 16:
+        dy = dy.clone()
+    dx = None if dx_c8_only or not need_x else torch.empty(
+        (N, c, P), dtype=torch.float32, device=dev)
+    dres = torch.empty((N, c, P), dtype=torch.float32, device=dev) \
+        if need_res else None
+    dx_c8 = torch.empty(N * c * P, dtype=torch.bfloat16, device=dev)
+    pg, pb = params
+    sg, sb = _sink(pg), _sink(pb)
+    direct = need_g and need_b and sg is not None and sb is not None
+    if direct:
+        dgamma, dbeta = sg, sb
+    else:
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev) \
+            if need_g else None
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev) \
+            if need_b else None
+    need = lib.ld_bn_act_backward_workspace_bytes(N, c, P)
+    defer = direct and _DEFER_ON[0]
+    if defer and any(j.dgamma == sg.data_ptr() for j, _ in _DEFER_B):
+        wgrad_join(dev)
+        flush_deferred()
+    ws = _defer_buffer(pg, '_ld_bn_partial', need, dev) if defer else \
+        workspace(dev, need, 'bn')
+    acc = L.LD_GRAD_DEFER if defer else 1 if direct else 0
+    L.check(lib.ld_bn_act_backward_c8in(
+        L.ptr(dy), L.ptr(y_img), L.ptr(x_img), L.ptr(scale), L.ptr(mean),
+        L.ptr(rstd), N, c, P, 1 if relu else 0, L.ptr(dx), L.ptr(dx_c8),
+        L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), acc, L.ptr(ws), ws.numel(),
+        L.stream_ptr(dev)), 'ld_bn_act_backward_c8in')
+    if dx is None and need_x:
+        dx = C8Act(dx_c8, (N, c, P))
+    elif dx is not None:
+        _attach_c8(dx, dx_c8)
+    if defer:
+        job = L.BnFinJobT()
+        job.partial, job.dgamma, job.dbeta = (ws.data_ptr(), sg.data_ptr(),
+                                              sb.data_ptr())
+        job.C, job.accumulate = c, 1
+        job.nsplit = lib.ld_bn_act_backward_nsplit(N, c, P, 1)
+        _DEFER_B.append((job, dev))
+        DEFER_STATS['bn_jobs'] += 1
+    if direct:
+        dgamma = dbeta = None
+        _emit(pg)
+        _emit(pb)
+    return dx, dres, dgamma, dbeta
+
+
+_BN_LEAN = [os.environ.get('LD_BN_LEAN', '1') == '1']
+
+
 class ConvBnActFn(torch.autograd.Function):
     """z = relu?(BN_eval(conv(x, w)) + residual) as ONE forward launch for a
     TRAINABLE conv / norm pair (round 3; VERDICT round 2, next #1b): the conv
@@ -1513,15 +1587,40 @@ class ConvBnActFn(torch.autograd.Function):
         scale, shift, rstd = bn_prepare(gamma, beta, mean, var, eps)
         N = x3.shape[0]
         cout, _, kh, kw = w.shape
-        d, _ = conv_desc(N, x3.shape[1], cout, kh, kw, stride, pad, levels)
-        raw = torch.empty((N, cout, d.Pout), dtype=torch.float32,
-                          device=w.device)
-        z, _ = conv_forward_raw(x3, w, stride, pad, levels, scale=scale,
-                                shift=shift, residual=residual, relu=relu,
-                                emit_c8=True, y_raw=raw)
+        cin = x3.shape[1]
+        d, _ = conv_desc(N, cin, cout, kh, kw, stride, pad, levels)
+        P = d.Pout
+        # bf16 mode, C8-operand conv: the lean form -- the conv result before the
+        # affine is kept as a bf16 C8 image (2 instead of 4 bytes per element,
+        # written and read), and the backward takes the ReLU mask from the C8
+        # image of z instead of reading z (round 6; LD_BN_LEAN=0: the fp32 form)
+        lean = _BN_LEAN[0] and _BN_BWD_C8[0] and \
+            _PRECISION[0] == 'bf16' and _C8[0] and _WGRAD_C8[0] and \
+            cin % 32 == 0 and cout % 32 == 0 and P % 4 == 0 and \
+            N * ((P // 4 + 63) // 64) <= 256 and \
+            (isinstance(x3, C8Act) or
+             _use_c8(cin, kh, stride, N * P, x3))
+        if lean:
+            raw = torch.empty(N * cout * P, dtype=torch.bfloat16,
+                              device=w.device)
+            z, _ = conv_forward_raw(x3, w, stride, pad, levels, scale=scale,
+                                    shift=shift, residual=residual, relu=relu,
+                                    emit_c8=True, y_raw_c8=raw)
+            zimg = _c8_cached(z)
+            if zimg is None:
+                raise L.LdError('ConvBnActFn: no C8 image on the output')
+        else:
+            raw = torch.empty((N, cout, P), dtype=torch.float32,
+                              device=w.device)
+            z, _ = conv_forward_raw(x3, w, stride, pad, levels, scale=scale,
+                                    shift=shift, residual=residual, relu=relu,
+                                    emit_c8=True, y_raw=raw)
+            zimg = z  # placeholder: same tensor, nothing extra is kept alive
+        ctx.lean = lean
+        ctx.oshape = (N, cout, P)
         ctx.x8 = x3 if isinstance(x3, C8Act) else None
         ctx.save_for_backward(x3.buf if ctx.x8 is not None else x3, w, raw, z,
-                              scale, mean, rstd)
+                              scale, mean, rstd, zimg)
         ctx.meta = (stride, pad, levels, False)
         ctx.relu = relu
         ctx.has_res = residual is not None
@@ -1533,7 +1632,7 @@ class ConvBnActFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz):
-        x3, w, raw, z, scale, mean, rstd = ctx.saved_tensors
+        x3, w, raw, z, scale, mean, rstd, zimg = ctx.saved_tensors
         pw, pg, pb = ctx.params
         ng = ctx.needs_input_grad
         need_conv = ng[0] or ng[1]
@@ -1543,9 +1642,15 @@ class ConvBnActFn(torch.autograd.Function):
         c8_dead = _DRAW_C8_ONLY[0] and _PRECISION[0] == 'bf16' and _C8[0] and \
             _WGRAD_C8[0] and cin % 32 == 0 and cout % 32 == 0 and \
             (not ng[0] or _use_bf16(cout))
-        draw, dres, dgamma, dbeta = _bn_act_backward(
-            dz, raw, z, scale, mean, rstd, ctx.relu, (pg, pb), need_conv,
-            ng[2], ng[3], ctx.has_res and ng[7], dx_c8_only=c8_dead)
+        if ctx.lean:
+            draw, dres, dgamma, dbeta = _bn_act_backward(
+                dz, None, None, scale, mean, rstd, ctx.relu, (pg, pb),
+                need_conv, ng[2], ng[3], ctx.has_res and ng[7],
+                dx_c8_only=c8_dead, c8in=(zimg, raw, ctx.oshape))
+        else:
+            draw, dres, dgamma, dbeta = _bn_act_backward(
+                dz, raw, z, scale, mean, rstd, ctx.relu, (pg, pb), need_conv,
+                ng[2], ng[3], ctx.has_res and ng[7], dx_c8_only=c8_dead)
         # the identity path's gradient: deposited on the block input, where
         # conv1's data gradient (it runs later) sums it in its epilogue
         dres = fan_give(ctx.fan_res, dres)

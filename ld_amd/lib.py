@@ -127,7 +127,7 @@ class ConvEpilogueT(C.Structure):
                 ('shift', C.c_void_p), ('residual', C.c_void_p),
                 ('relu', C.c_int32), ('reserved', C.c_int32),
                 ('y_c8', C.c_void_p), ('residual_c8', C.c_void_p),
-                ('y_raw', C.c_void_p)]
+                ('y_raw', C.c_void_p), ('y_raw_c8', C.c_void_p)]
 
 
 class LevelsT(C.Structure):
@@ -348,6 +348,9 @@ SIGNATURES = {
     'ld_bn_act_backward_c8': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32,
                                         _i32, _i32, _i32, _vp, _vp, _vp, _vp,
                                         _vp, _i32, _vp, _sz, _vp]),
+    'ld_bn_act_backward_c8in': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32,
+                                          _i32, _i32, _i32, _vp, _vp, _vp, _vp,
+                                          _vp, _i32, _vp, _sz, _vp]),
     'ld_bias_grad': (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     'ld_gn_forward_workspace_bytes': (_sz, [_LV, _i32, _i32]),
     'ld_gn_forward': (C.c_int, [_LV, _vp, _vp, _vp, _i32, _i32, _i32, _f32,

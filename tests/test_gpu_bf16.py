@@ -611,6 +611,52 @@ def test_conv_bn_backward_without_the_unread_fp32_gradient(bf16_mode, has_res):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('has_res,relu', [(True, True), (False, True), (False, False)])
+def test_conv_bn_lean_form_same_gradients(bf16_mode, has_res, relu):
+    """Round 6, ConvBnActFn in bf16 mode with a C8-operand conv: the lean form
+    keeps the conv result before the affine as a bf16 C8 image
+    (ld_conv_epilogue_t.y_raw_c8) and takes the ReLU mask from the C8 image of z
+    (ld_bn_act_backward_c8in).  Against the fp32 form (LD_BN_LEAN=0): z, dx, dw,
+    d(residual) and d(beta) carry the same bits (same mask, same sums); d(gamma)
+    sees the bf16-rounded conv result -- 2^-9 relative per term; with this test's
+    random-sign gradient the sum is itself of the order sqrt(n) terms, so the
+    relative difference stays at that 2^-9 level (measured 2.5e-3 of the largest
+    entry), the rounding every bf16 conv operand already carries."""
+    from ld_amd import layers as Y
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    N, cin, cout, H, W = 2, 64, 128, 20, 28
+    lv = ((H, W), )
+    base = [torch.randn(N, cin, H * W, generator=g),
+            torch.randn(cout, cin, 3, 3, generator=g) * 0.05,
+            torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g),
+            torch.randn(N, cout, H * W, generator=g)]
+    mean = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    var = (torch.rand(cout, generator=g) + 0.5).to(dev)
+    go = torch.randn(N, cout, H * W, generator=g).to(dev)
+    outs = []
+    for lean in (False, True):
+        Y._BN_LEAN[0] = lean
+        try:
+            x, w, gamma, beta, res = (t.to(dev).requires_grad_(True) for t in base)
+            Y.to_c8(x)  # an image on the input: the C8-operand conv is taken
+            z, _ = Y.conv_bn_act(x, w, gamma, beta, mean, var, 1e-5, 1, 1, lv,
+                                 residual=res if has_res else None, relu=relu)
+            z.backward(go)
+            torch.cuda.synchronize()
+        finally:
+            Y._BN_LEAN[0] = True
+        outs.append((z.detach(), x.grad, w.grad, beta.grad,
+                     res.grad if has_res else None, gamma.grad))
+    a, b = outs
+    for i in range(5):
+        if a[i] is not None:
+            assert torch.equal(a[i], b[i]), i
+    sc = float(a[5].abs().max())
+    assert float((a[5] - b[5]).abs().max()) <= 1e-2 * sc
+    assert not torch.equal(a[5], b[5])  # the lean form did run
+
+
 def test_bf16_wgrad_vectorised_loads_same_bits(bf16_mode, monkeypatch):
     """The 16-byte-load variants of the wave-private bf16 weight gradient (dY
     always when Pout % 4 == 0, X too for 1x1 stride-1 convs) build the same LDS
