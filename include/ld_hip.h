@@ -783,7 +783,9 @@ int ld_bn_act_backward_c8(const float* dy, const float* y, const float* x,
  * layer's output (only its sign is used, the ReLU mask; NULL without relu), x_c8 =
  * the conv result before the affine as written through
  * ld_conv_epilogue_t.y_raw_c8.  dx may be NULL (only dx_c8 is written).  8 instead
- * of 12 bytes read per element; d(gamma) sees the bf16-rounded conv result. */
+ * of 12 bytes read per element; d(gamma) sees the bf16-rounded conv result.  Needs
+ * C % 8 == 0 and P % 2 == 0 (four positions per thread when P % 4 == 0, two
+ * otherwise: the 25 x 42 stage). */
 int ld_bn_act_backward_c8in(const float* dy, const void* y_c8, const void* x_c8,
                             const float* scale, const float* mean, const float* rstd,
                             int N, int C, int P, int relu, float* dx, void* dx_c8,
@@ -793,7 +795,8 @@ int ld_bn_act_backward_c8in(const float* dy, const void* y_c8, const void* x_c8,
 /* Deferred finalisation (round 5, see ld_wgrad_reduce_batch): with accumulate ==
  * LD_GRAD_DEFER the two BN backward entry points above write only their
  * per-workgroup fp64 partials ([C][nsplit] pairs (sum dz, sum dz*xhat), nsplit =
- * ld_bn_act_backward_nsplit(N, C, P, c8)) into `workspace` -- which the caller
+ * ld_bn_act_backward_nsplit(N, C, P, c8), c8 = 0 for ld_bn_act_backward, 1 for
+ * ld_bn_act_backward_c8, 2 for ld_bn_act_backward_c8in) into `workspace` -- which the caller
  * then owns until ld_bn_bwd_finalize_batch has summed every job of a bucket in ONE
  * launch (16 channels per block, a job owns ceil(C / 16) blocks from first_block;
  * the arithmetic of the per-layer finalize launch: 37 launches per step fewer).

@@ -601,34 +601,36 @@ __global__ __launch_bounds__(64) void bn_act_bwd_c8_kernel(
 // forward wrote 2 instead of 4 for x.  Same thread shape and the same expressions
 // as bn_act_bwd_c8_kernel; a thread's 8 channels x 4 positions of an image are 64
 // contiguous bytes.
+template <int V>  // positions per thread: 4 (P % 4 == 0) or 2 (P % 2 == 0: 25 x 42)
 __global__ __launch_bounds__(64) void bn_act_bwd_c8in_kernel(
     const float* __restrict__ dy, const gn_uintx4* __restrict__ y_img,
     const gn_uintx4* __restrict__ x_img, const float* __restrict__ scale,
     const float* __restrict__ mean, const float* __restrict__ rstd, int C, int P,
     int relu, float* __restrict__ dx, float* __restrict__ dres,
     gn_uintx4* __restrict__ dx_c8, double* __restrict__ partial, int nslots) {
+  typedef float fvec __attribute__((ext_vector_type(V)));
   const int C8 = C >> 3;
   const int blk = blockIdx.y;  // n * C8 + c8
   const int c8 = blk % C8, n = blk / C8;
-  const int p = (blockIdx.x * 64 + threadIdx.x) * 4;
+  const int p = (blockIdx.x * 64 + threadIdx.x) * V;
   const bool live = p < P;
   const int pl = live ? p : 0;
-  float out[8][4];
+  float out[8][V];
   double s1[8], s2[8];
-  float4 g8[8];
-  gn_uintx4 yq[4], xq[4];
+  fvec g8[8];
+  gn_uintx4 yq[V], xq[V];
   const gn_uintx4* yp = relu ? y_img : x_img;  // unconditional loads, no branch
 #pragma unroll
   for (int e = 0; e < 8; ++e)
-    g8[e] = *reinterpret_cast<const float4*>(dy + ((size_t)n * C + c8 * 8 + e) * P + pl);
+    g8[e] = *reinterpret_cast<const fvec*>(dy + ((size_t)n * C + c8 * 8 + e) * P + pl);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < V; ++k) {
     yq[k] = yp[(size_t)blk * P + pl + k];
     xq[k] = x_img[(size_t)blk * P + pl + k];
   }
-  gn_floatx8 yf[4], xf[4];
+  gn_floatx8 yf[V], xf[V];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < V; ++k) {
     yf[k] = __builtin_convertvector(__builtin_bit_cast(gn_bf16x8, yq[k]), gn_floatx8);
     xf[k] = __builtin_convertvector(__builtin_bit_cast(gn_bf16x8, xq[k]), gn_floatx8);
   }
@@ -639,32 +641,42 @@ __global__ __launch_bounds__(64) void bn_act_bwd_c8in_kernel(
     s1[e] = 0.0;
     s2[e] = 0.0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out[e][k] = 0.0f;
+    for (int k = 0; k < V; ++k) out[e][k] = 0.0f;
     if (!live) continue;
     const size_t idx = ((size_t)n * C + c) * P + p;
-    float dz[4] = {g8[e].x, g8[e].y, g8[e].z, g8[e].w};
+    fvec dz = g8[e];
     if (relu) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int k = 0; k < V; ++k)
         if (!(yf[k][e] > 0.f)) dz[k] = 0.f;
     }
+    fvec o;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out[e][k] = dz[k] * s;
-    if (dx)
-      *reinterpret_cast<float4*>(dx + idx) =
-          make_float4(out[e][0], out[e][1], out[e][2], out[e][3]);
-    if (dres)
-      *reinterpret_cast<float4*>(dres + idx) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+    for (int k = 0; k < V; ++k) {
+      out[e][k] = dz[k] * s;
+      o[k] = out[e][k];
+    }
+    if (dx) *reinterpret_cast<fvec*>(dx + idx) = o;
+    if (dres) *reinterpret_cast<fvec*>(dres + idx) = dz;
     if (partial) {
       const float mu = mean[c], rs = rstd[c];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < V; ++k) {
         s1[e] += (double)dz[k];
         s2[e] += (double)(dz[k] * ((xf[k][e] - mu) * rs));
       }
     }
   }
-  if (live) store_c8x4(dx_c8 + (size_t)blk * P + p, out);
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      gn_floatx8 f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = out[e][k];
+      dx_c8[(size_t)blk * P + p + k] =
+          __builtin_bit_cast(gn_uintx4, __builtin_convertvector(f, gn_bf16x8));
+    }
+  }
   if (partial) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -1619,15 +1631,25 @@ extern "C" int ld_bn_act_backward_c8in(const float* dy, const void* y_c8,
   if (params && (!workspace ||
                  workspace_bytes < ld_bn_act_backward_workspace_bytes(N, C, P)))
     return LD_ENOSPACE;
-  const int xb = (P / 4 + 63) / 64, nslots = N * xb;
-  if (P % 4 != 0 || C % 8 != 0 || nslots > kBnSplitMax ||
-      ((uintptr_t)dy | (uintptr_t)(y_c8 ? y_c8 : dy) | (uintptr_t)x_c8 |
-       (uintptr_t)(dx ? dx : dy) | (uintptr_t)(dres ? dres : dy) | (uintptr_t)dx_c8) % 16)
+  // 4 positions per thread where the fp32 rows are 16-byte aligned (P % 4 == 0), 2
+  // where they are 8-byte aligned (P % 2 == 0: the 25 x 42 stage, P = 1050)
+  const int V = P % 4 == 0 ? 4 : 2;
+  const int xb = (P / V + 63) / 64, nslots = N * xb;
+  if (P % 2 != 0 || C % 8 != 0 || nslots > kBnSplitMax ||
+      ((uintptr_t)(y_c8 ? y_c8 : x_c8) | (uintptr_t)x_c8 | (uintptr_t)dx_c8) % 16 ||
+      ((uintptr_t)dy | (uintptr_t)(dx ? dx : dy) | (uintptr_t)(dres ? dres : dy)) %
+          (4 * V))
     return LD_EUNSUPPORTED;
-  LD_LAUNCH(bn_act_bwd_c8in_kernel, dim3(xb, N * (C / 8)), dim3(64), 0, LD_STREAM, dy,
-                     (const gn_uintx4*)y_c8, (const gn_uintx4*)x_c8, scale, mean, rstd, C,
-                     P, relu, dx, dres, (gn_uintx4*)dx_c8,
-                     params ? (double*)workspace : nullptr, nslots);
+  if (V == 4)
+    LD_LAUNCH(bn_act_bwd_c8in_kernel<4>, dim3(xb, N * (C / 8)), dim3(64), 0, LD_STREAM,
+                       dy, (const gn_uintx4*)y_c8, (const gn_uintx4*)x_c8, scale, mean,
+                       rstd, C, P, relu, dx, dres, (gn_uintx4*)dx_c8,
+                       params ? (double*)workspace : nullptr, nslots);
+  else
+    LD_LAUNCH(bn_act_bwd_c8in_kernel<2>, dim3(xb, N * (C / 8)), dim3(64), 0, LD_STREAM,
+                       dy, (const gn_uintx4*)y_c8, (const gn_uintx4*)x_c8, scale, mean,
+                       rstd, C, P, relu, dx, dres, (gn_uintx4*)dx_c8,
+                       params ? (double*)workspace : nullptr, nslots);
   if (params && accumulate != LD_GRAD_DEFER)
     LD_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0,
                        LD_STREAM, (const double*)workspace, C, nslots, dgamma, dbeta,
@@ -1639,6 +1661,9 @@ extern "C" int ld_bn_act_backward_c8in(const float* dy, const void* y_c8,
 // ld_bn_act_backward_c8 (c8 != 0) write for this geometry (host logic).
 extern "C" int ld_bn_act_backward_nsplit(int N, int C, int P, int c8) {
   if (N < 1 || C < 1 || P < 1) return 0;
+  // c8 == 1: ld_bn_act_backward_c8 (P % 4 == 0); c8 == 2: ld_bn_act_backward_c8in
+  // (4 positions per thread, or 2 when P % 4 != 0)
+  if (c8 == 2) return N * ((P / (P % 4 == 0 ? 4 : 2) + 63) / 64);
   return c8 ? N * ((P / 4 + 63) / 64) : bn_splits(N, C, P);
 }
 

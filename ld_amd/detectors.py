@@ -10,6 +10,7 @@ import torch.nn as nn
 
 from .config import Config, ConfigDict
 from .heads import LazyScalars
+from . import layers as Y
 from .layers import side_stream as _side_stream
 from .registry import (DETECTORS, build_backbone, build_detector, build_head,
                        build_neck)
@@ -79,7 +80,14 @@ class SingleStageDetector(nn.Module):
         self.bbox_head.init_weights()
 
     def extract_feat(self, img):
-        x = self.backbone(img)
+        if torch.is_grad_enabled():
+            # bf16 mode: the trainable trunk hands its activations from block to
+            # block (and to the neck's lateral convs) as bf16 C8 images only
+            # (layers.trunk_c8_scope; a no-op in fp32 mode)
+            with Y.trunk_c8_scope():
+                x = self.backbone(img)
+        else:
+            x = self.backbone(img)
         if self.with_neck:
             x = self.neck(x)
         return x

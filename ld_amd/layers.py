@@ -302,6 +302,9 @@ def to_c8(x3):
     if img is not None:
         C8_STATS['reused'] += 1
         return img
+    if _unwritten(x3):
+        raise L.LdError('to_c8: this activation exists only as a C8 image that '
+                        'is no longer attached to the tensor (trunk_c8_scope)')
     C8_STATS['converted'] += 1
     N, Cc, P = x3.shape
     out = torch.empty(N * Cc * P, dtype=torch.bfloat16, device=x3.device)
@@ -386,6 +389,42 @@ def c8_only_available(channels):
     return (_C8[0] and _PRECISION[0] == 'bf16' and
             os.environ.get('LD_TEACHER_C8_ONLY', '1') == '1' and
             all(c % 32 == 0 for c in channels))
+
+
+# ---- bf16 trunk between TRAINABLE blocks (round 6) ---------------------------
+# Inside this scope (the KD detector opens it around the student's backbone in
+# bf16 mode) a lean ConvBnActFn keeps its output z ONLY as the bf16 C8 image: the
+# fp32 tensor autograd needs as the node's output is allocated but never written
+# (``_ld_unwritten``), every consumer on the step takes the image -- the next conv
+# as its operand, the next block's conv3 as its residual (ld_conv_epilogue_t.
+# residual_c8: the identity path is then bf16 from block to block, as in the
+# reference's fp16 mode, mmcv auto_fp16 on the backbone), the BN backward as its
+# ReLU mask, the neck's lateral convs as their operand.  A consumer that would read
+# the fp32 values raises (conv_forward_raw, to_c8, _conv_backward): no silent
+# garbage.  LD_TRUNK_C8=0 keeps the fp32 copy.
+_TRUNK_C8 = [False]
+_TRUNK_C8_ON = [os.environ.get('LD_TRUNK_C8', '1') == '1']
+
+
+class trunk_c8_scope:
+
+    def __enter__(self):
+        self.prev = _TRUNK_C8[0]
+        _TRUNK_C8[0] = _TRUNK_C8_ON[0] and _PRECISION[0] == 'bf16' and _C8[0]
+
+    def __exit__(self, *exc):
+        _TRUNK_C8[0] = self.prev
+
+
+def _unwritten(t):
+    """Whether ``t`` (or the tensor it is a reshape view of) is an fp32
+    placeholder whose values were never written (trunk_c8_scope)."""
+    if not isinstance(t, torch.Tensor):
+        return False
+    if getattr(t, '_ld_unwritten', False):
+        return True
+    b = t._base
+    return b is not None and getattr(b, '_ld_unwritten', False)
 
 
 def _register(reg, t):
@@ -642,6 +681,9 @@ def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
     in8 = isinstance(x3, C8Act)
     if not in8:
         _dev_f32(x3, 'conv input')
+    if _unwritten(residual):
+        # a trunk activation that exists only as its C8 image (trunk_c8_scope)
+        residual = C8Act(to_c8(residual), residual.shape)
     N, cin, P = x3.shape
     cout, cin_w, kh, kw = w.shape
     if cin_w != cin:
@@ -676,6 +718,9 @@ def conv_forward_raw(x3, w, stride, pad, levels, bias=None, scale=None,
         ep.y_raw = y_raw.data_ptr()
         L.keep(y_raw)
     c8 = in8 or (bf16 and _use_c8(cin, kh, stride, N * d.Pout, x3))
+    if not c8 and _unwritten(x3):
+        raise L.LdError('conv: the input exists only as a C8 image '
+                        '(trunk_c8_scope) and this conv takes fp32 operands')
     if y_raw_c8 is not None:
         # the pre-affine result as a bf16 C8 image (ConvBnActFn, lean form)
         if not c8 or y_raw is not None or bias is not None or cout % 8 or \
@@ -1104,6 +1149,10 @@ def _conv_backward(x3, x8, w, dy, meta, params, need_x, need_w, need_b,
                 (need_x and not _use_bf16(cout))):
         raise L.LdError('conv backward: a C8-only output gradient needs the C8 '
                         'data- and weight-gradient kernels and no bias')
+    if need_w and not c8w and _unwritten(x3):
+        raise L.LdError('conv backward: the saved input exists only as a C8 '
+                        'image (trunk_c8_scope); its weight gradient needs the '
+                        'C8 wgrad kernel')
     if x8 is not None and not c8w:
         raise L.LdError('a C8-only activation feeds this conv: its weight '
                         'gradient needs the C8 wgrad kernel (bf16 mode, '
@@ -1517,7 +1566,7 @@ def _bn_act_backward_c8in(dy, c8in, scale, mean, rstd, relu, params, need_x,
     lib = L.get_lib()
     y_img, x_img, (N, c, P) = c8in
     dev = dy.device
-    if dy.data_ptr() % 16:
+    if dy.data_ptr() % 16:  # fresh allocations are 512-byte aligned
         dy = dy.clone()
     dx = None if dx_c8_only or not need_x else torch.empty(
         (N, c, P), dtype=torch.float32, device=dev)
@@ -1556,7 +1605,7 @@ def _bn_act_backward_c8in(dy, c8in, scale, mean, rstd, relu, params, need_x,
         job.partial, job.dgamma, job.dbeta = (ws.data_ptr(), sg.data_ptr(),
                                               sb.data_ptr())
         job.C, job.accumulate = c, 1
-        job.nsplit = lib.ld_bn_act_backward_nsplit(N, c, P, 1)
+        job.nsplit = lib.ld_bn_act_backward_nsplit(N, c, P, 2)
         _DEFER_B.append((job, dev))
         DEFER_STATS['bn_jobs'] += 1
     if direct:
@@ -1596,11 +1645,23 @@ class ConvBnActFn(torch.autograd.Function):
         # image of z instead of reading z (round 6; LD_BN_LEAN=0: the fp32 form)
         lean = _BN_LEAN[0] and _BN_BWD_C8[0] and \
             _PRECISION[0] == 'bf16' and _C8[0] and _WGRAD_C8[0] and \
-            cin % 32 == 0 and cout % 32 == 0 and P % 4 == 0 and \
-            N * ((P // 4 + 63) // 64) <= 256 and \
+            cin % 32 == 0 and cout % 32 == 0 and P % 2 == 0 and \
+            N * ((P // (4 if P % 4 == 0 else 2) + 63) // 64) <= 256 and \
             (isinstance(x3, C8Act) or
              _use_c8(cin, kh, stride, N * P, x3))
-        if lean:
+        if lean and _TRUNK_C8[0]:
+            # trunk_c8_scope: z only as its C8 image; the fp32 tensor returned to
+            # autograd is a placeholder nobody reads (see the scope's comment)
+            raw = torch.empty(N * cout * P, dtype=torch.bfloat16,
+                              device=w.device)
+            z8, _ = conv_forward_raw(x3, w, stride, pad, levels, scale=scale,
+                                     shift=shift, residual=residual, relu=relu,
+                                     c8_only=True, y_raw_c8=raw)
+            zimg = z8.buf
+            z = torch.empty((N, cout, P), dtype=torch.float32, device=w.device)
+            _attach_c8(z, zimg)
+            z._ld_unwritten = True
+        elif lean:
             raw = torch.empty(N * cout * P, dtype=torch.bfloat16,
                               device=w.device)
             z, _ = conv_forward_raw(x3, w, stride, pad, levels, scale=scale,

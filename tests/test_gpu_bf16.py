@@ -611,8 +611,9 @@ def test_conv_bn_backward_without_the_unread_fp32_gradient(bf16_mode, has_res):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('hw', [(20, 28), (25, 42)], ids=['p560', 'p1050'])
 @pytest.mark.parametrize('has_res,relu', [(True, True), (False, True), (False, False)])
-def test_conv_bn_lean_form_same_gradients(bf16_mode, has_res, relu):
+def test_conv_bn_lean_form_same_gradients(bf16_mode, has_res, relu, hw):
     """Round 6, ConvBnActFn in bf16 mode with a C8-operand conv: the lean form
     keeps the conv result before the affine as a bf16 C8 image
     (ld_conv_epilogue_t.y_raw_c8) and takes the ReLU mask from the C8 image of z
@@ -625,7 +626,7 @@ def test_conv_bn_lean_form_same_gradients(bf16_mode, has_res, relu):
     from ld_amd import layers as Y
     dev = _dev()
     g = torch.Generator().manual_seed(9)
-    N, cin, cout, H, W = 2, 64, 128, 20, 28
+    N, cin, cout, (H, W) = 2, 64, 128, hw  # 25 x 42: P % 4 == 2, two positions / thread
     lv = ((H, W), )
     base = [torch.randn(N, cin, H * W, generator=g),
             torch.randn(cout, cin, 3, 3, generator=g) * 0.05,
@@ -650,11 +651,64 @@ def test_conv_bn_lean_form_same_gradients(bf16_mode, has_res, relu):
                      res.grad if has_res else None, gamma.grad))
     a, b = outs
     for i in range(5):
-        if a[i] is not None:
-            assert torch.equal(a[i], b[i]), i
+        if a[i] is None:
+            continue
+        if i == 3 and (H * W) % 4:
+            # d(beta): the fp32 form of this geometry is the per-channel kernel,
+            # whose fp64 partial sums are grouped differently
+            assert float((a[i] - b[i]).abs().max()) <= 1e-6 * float(a[i].abs().max())
+            continue
+        assert torch.equal(a[i], b[i]), i
     sc = float(a[5].abs().max())
     assert float((a[5] - b[5]).abs().max()) <= 1e-2 * sc
     assert not torch.equal(a[5], b[5])  # the lean form did run
+
+
+def test_trunk_c8_scope_outputs_only_images(bf16_mode):
+    """Round 6, layers.trunk_c8_scope: a lean ConvBnActFn returns an fp32
+    placeholder that is never written; the next conv takes the C8 image as its
+    operand and as its residual, the backward takes the ReLU mask from it.  Against
+    the same two layers outside the scope: the first layer's image is identical, the
+    second differs only through the bf16 residual (<= one bf16 step of the
+    residual), gradients agree to bf16 operand precision; a consumer that would
+    read the fp32 values raises."""
+    from ld_amd import layers as Y
+    from ld_amd import lib as L
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    N, C, H, W = 2, 64, 20, 28
+    lv = ((H, W), )
+    base = [torch.randn(N, C, H * W, generator=g)] + [
+        t for _ in range(2) for t in (torch.randn(C, C, 3, 3, generator=g) * 0.05,
+                                      torch.rand(C, generator=g) + 0.5,
+                                      torch.randn(C, generator=g) * 0.2)]
+    mean = (torch.randn(C, generator=g) * 0.1).to(dev)
+    var = (torch.rand(C, generator=g) + 0.5).to(dev)
+    go = torch.randn(N, C, H * W, generator=g).to(dev)
+    outs = []
+    for scoped in (False, True):
+        t = [b.to(dev).requires_grad_(True) for b in base]
+        Y.to_c8(t[0])
+        import contextlib
+        with (Y.trunk_c8_scope() if scoped else contextlib.nullcontext()):
+            a, _ = Y.conv_bn_act(t[0], t[1], t[2], t[3], mean, var, 1e-5, 1, 1, lv)
+            b, _ = Y.conv_bn_act(a, t[4], t[5], t[6], mean, var, 1e-5, 1, 1, lv,
+                                 residual=a)
+        assert Y._unwritten(a) == scoped and Y._unwritten(b) == scoped
+        ia, ib = Y._c8_cached(a).clone(), Y._c8_cached(b).clone()
+        b.backward(go)
+        torch.cuda.synchronize()
+        outs.append((ia, ib, [v.grad.clone() for v in t]))
+        if scoped:
+            b._ld_c8 = None  # the image is gone: nothing may fall back to fp32
+            with pytest.raises(L.LdError, match='only as a C8 image'):
+                Y.to_c8(b)
+    (ia0, ib0, g0), (ia1, ib1, g1) = outs
+    assert torch.equal(ia0, ia1)
+    f0, f1 = ib0.float(), ib1.float()
+    assert float((f0 - f1).abs().max()) <= 2.0 ** -7 * float(f0.abs().max())
+    for u, v in zip(g0, g1):
+        assert float((u - v).abs().max()) <= 2e-2 * float(u.abs().max())
 
 
 def test_bf16_wgrad_vectorised_loads_same_bits(bf16_mode, monkeypatch):
