@@ -1893,7 +1893,7 @@ _GN_LEAN = [os.environ.get('LD_GN_LEAN', '1') == '1']
 
 
 def _gn_backward(dy, x3, y, gamma, beta, stats, groups, levels, relu, params,
-                 need_g, need_b, dx_c8_only=False):
+                 need_g, need_b, dx_c8_only=False, need_lean=False):
     """Backward of GroupNorm (+ ReLU) on a level-concatenated tensor (shared by
     GnActFn and the fused ConvGnActFn).  Returns (dx, dgamma, dbeta); the
     parameter gradients are None when they went into the gradient arena.
@@ -1919,6 +1919,10 @@ def _gn_backward(dy, x3, y, gamma, beta, stats, groups, levels, relu, params,
     c8_ok = aligned and _C8[0] and _PRECISION[0] == 'bf16' and c % 32 == 0 and \
         P % 4 == 0
     lean = c8_ok and _GN_LEAN[0] and os.environ.get('LD_NN_OLD') != '1'
+    if need_lean and not lean:
+        raise L.LdError('GroupNorm backward: the forward kept y only as its C8 '
+                        'image, the kernels that do not read y are not '
+                        'available for these operands')
     dx8_only = bool(lean and dx_c8_only)
     dx = None if dx8_only else torch.empty_like(x3)
     dx_c8 = torch.empty(N * c * P, dtype=torch.bfloat16, device=x3.device) \
@@ -1994,15 +1998,30 @@ class ConvGnActFn(torch.autograd.Function):
     element), and the conv output is not an autograd tensor."""
 
     @staticmethod
-    def forward(ctx, x3, w, gamma, beta, groups, eps, stride, pad, levels, relu):
+    def forward(ctx, x3, w, gamma, beta, groups, eps, stride, pad, levels, relu,
+                c8_out=False):
         raw, out_levels = conv_forward_raw(x3, w, stride, pad, levels)
         N, c, P = raw.shape
         lv = levels_desc(out_levels)
-        y = torch.empty_like(raw)
         stats = torch.empty((2, N, groups, len(out_levels)),
                             dtype=torch.float32, device=raw.device)
-        _gn_forward_launch(lv, raw, gamma, beta, N, c, groups, eps, relu, y,
-                           stats)
+        # ``c8_out`` (the caller's next layer is another conv of the stack): the
+        # lean backward does not read y and the next conv takes the C8 image --
+        # the fp32 output is then a placeholder that is never written
+        # (``_ld_unwritten``, see trunk_c8_scope)
+        img = None
+        if c8_out and _TRUNK_C8_ON[0] and _GN_LEAN[0] and \
+                os.environ.get('LD_NN_OLD') != '1':
+            img = _gn_forward_launch(lv, raw, gamma, beta, N, c, groups, eps,
+                                     relu, None, stats)
+        y = torch.empty_like(raw)
+        if img is not None:
+            _attach_c8(y, img)
+            y._ld_unwritten = True
+        else:
+            _gn_forward_launch(lv, raw, gamma, beta, N, c, groups, eps, relu, y,
+                               stats)
+        ctx.y_unwritten = img is not None
         ctx.x8 = x3 if isinstance(x3, C8Act) else None
         ctx.save_for_backward(x3.buf if ctx.x8 is not None else x3, w, raw, y,
                               gamma, beta, stats)
@@ -2025,7 +2044,7 @@ class ConvGnActFn(torch.autograd.Function):
             (not ng[0] or _use_bf16(cout))
         draw, dgamma, dbeta = _gn_backward(
             dy, raw, y, gamma, beta, stats, groups, out_levels, relu, (pg, pb),
-            ng[2], ng[3], dx_c8_only=c8_dead)
+            ng[2], ng[3], dx_c8_only=c8_dead, need_lean=ctx.y_unwritten)
         dx = dw = None
         if ng[0] or ng[1]:
             dx, dw, _ = _conv_backward(x3, ctx.x8, w, draw, ctx.meta,
@@ -2033,7 +2052,7 @@ class ConvGnActFn(torch.autograd.Function):
                                        addend=fan_take(ctx.fan) if ng[0]
                                        else None)
         return (fan_give(ctx.fan, dx), dw, dgamma, dbeta, None, None, None,
-                None, None, None)
+                None, None, None, None)
 
 
 _FUSE_CONV_GN = [os.environ.get('LD_FUSE_CONV_GN', '1') == '1']
@@ -2054,7 +2073,7 @@ def conv_gn_act(x3, w, gamma, beta, groups, eps, stride, pad, levels, relu=True,
         (isinstance(x3, torch.Tensor) and x3.requires_grad))
     if _FUSE_CONV_GN[0] and _PRECISION[0] == 'bf16' and cin >= 16 and grad:
         return ConvGnActFn.apply(x3, w, gamma, beta, groups, eps, stride, pad,
-                                 levels, relu), out_levels
+                                 levels, relu, c8_only), out_levels
     if _FUSE_CONV_GN[0] and _PRECISION[0] == 'bf16' and cin >= 16 and not grad:
         # frozen layer (the teacher's towers): the conv output feeds only the
         # norm -- no C8 image of it -- and, ``c8_only``, the layer's output

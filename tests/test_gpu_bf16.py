@@ -670,8 +670,8 @@ def test_trunk_c8_scope_outputs_only_images(bf16_mode):
     operand and as its residual, the backward takes the ReLU mask from it.  Against
     the same two layers outside the scope: the first layer's image is identical, the
     second differs only through the bf16 residual (<= one bf16 step of the
-    residual), gradients agree to bf16 operand precision; a consumer that would
-    read the fp32 values raises."""
+    residual), gradients agree to bf16 operand precision in the L2 norm; a consumer
+    that would read the fp32 values raises."""
     from ld_amd import layers as Y
     from ld_amd import lib as L
     dev = _dev()
@@ -707,8 +707,12 @@ def test_trunk_c8_scope_outputs_only_images(bf16_mode):
     assert torch.equal(ia0, ia1)
     f0, f1 = ib0.float(), ib1.float()
     assert float((f0 - f1).abs().max()) <= 2.0 ** -7 * float(f0.abs().max())
+    # (a residual that moves by a bf16 step flips the ReLU mask of the ~0.1 % of
+    # cells within that step of zero: those entries of dx move by a whole gradient
+    # term, sqrt(1e-3) ~ 3 % of the norm with this test's white-noise gradient --
+    # measured 2.2 %; the whole-step effect is test_bf16_train_step_vs_fp32_golden's)
     for u, v in zip(g0, g1):
-        assert float((u - v).abs().max()) <= 2e-2 * float(u.abs().max())
+        assert float((u - v).norm()) <= 5e-2 * float(u.norm())
 
 
 def test_bf16_wgrad_vectorised_loads_same_bits(bf16_mode, monkeypatch):

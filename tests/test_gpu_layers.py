@@ -569,16 +569,21 @@ def test_fused_conv_gn_node_bit_identical_to_the_pair():
     Y.set_precision('bf16')
     try:
         outs = []
-        for fused in (False, True):
+        # third variant: the first layer hands its output on ONLY as the C8 image
+        # (c8_only: the fp32 tensor is an unwritten placeholder, layers._unwritten)
+        for fused, c8_only in ((False, False), (True, False), (True, True)):
             Y._FUSE_CONV_GN[0] = fused
             t = [b.to(dev).requires_grad_(True) for b in base]
-            h, lv = Y.conv_gn_act(t[0], t[1], t[2], t[3], 32, 1e-5, 1, 1, levels)
+            h, lv = Y.conv_gn_act(t[0], t[1], t[2], t[3], 32, 1e-5, 1, 1, levels,
+                                  c8_only=c8_only)
+            assert Y._unwritten(h) == c8_only
             y, _ = Y.conv_gn_act(h, t[4], t[5], t[6], 32, 1e-5, 1, 1, lv)
             y.backward(go)
             torch.cuda.synchronize()
             outs.append([y.detach().clone()] + [v.grad.clone() for v in t])
-        for i, (a, b) in enumerate(zip(*outs)):
-            assert torch.equal(a, b), i
+        for other in outs[1:]:
+            for i, (a, b) in enumerate(zip(outs[0], other)):
+                assert torch.equal(a, b), i
     finally:
         Y._FUSE_CONV_GN[0] = True
         Y.set_precision('fp32')
