@@ -1864,7 +1864,8 @@ def _gn_forward_launch(lv, x3, gamma, beta, N, c, groups, eps, relu, y, stats):
     need = lib.ld_gn_forward_workspace_bytes(C.byref(lv), N, groups)
     ws = workspace(x3.device, need, 'gn_fwd')
     if y is None:
-        if _c8_side_output(x3) is None:
+        if not (_C8[0] and _PRECISION[0] == 'bf16' and c % 32 == 0 and
+                x3.shape[2] % 4 == 0 and x3.data_ptr() % 16 == 0):
             return None
         y_c8 = torch.empty(x3.numel(), dtype=torch.bfloat16, device=x3.device)
         L.check(lib.ld_gn_forward_c8(
@@ -1890,6 +1891,7 @@ def _gn_forward_launch(lv, x3, gamma, beta, N, c, groups, eps, relu, y, stats):
 
 
 _GN_LEAN = [os.environ.get('LD_GN_LEAN', '1') == '1']
+_GN_YSKIP = [os.environ.get('LD_GN_YSKIP', '1') == '1']
 
 
 def _gn_backward(dy, x3, y, gamma, beta, stats, groups, levels, relu, params,
@@ -2010,7 +2012,7 @@ class ConvGnActFn(torch.autograd.Function):
         # the fp32 output is then a placeholder that is never written
         # (``_ld_unwritten``, see trunk_c8_scope)
         img = None
-        if c8_out and _TRUNK_C8_ON[0] and _GN_LEAN[0] and \
+        if c8_out and _TRUNK_C8_ON[0] and _GN_YSKIP[0] and _GN_LEAN[0] and \
                 os.environ.get('LD_NN_OLD') != '1':
             img = _gn_forward_launch(lv, raw, gamma, beta, N, c, groups, eps,
                                      relu, None, stats)

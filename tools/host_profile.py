@@ -1,4 +1,6 @@
-"""cProfile of the host side of the train step (find Python launch overhead)."""
+"""cProfile of the host side of eager train steps (where the Python time of the
+~500 launches per step goes).
+    python tools/host_profile.py [fp32|bf16] [steps]"""
 import cProfile
 import os
 import pstats
@@ -7,27 +9,34 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ld_amd import model_zoo  # noqa: E402
-from ld_amd.train import SGDTrainer  # noqa: E402
 import bench  # noqa: E402
 from ld_amd import layers as Y  # noqa: E402
+from ld_amd import model_zoo  # noqa: E402
+from ld_amd.train import SGDTrainer  # noqa: E402
 
-if len(sys.argv) > 1:
-    Y.set_precision(sys.argv[1])  # fp32 | bf16
 
-dev = torch.device('cuda:0')
-det = model_zoo.build_seeded_ld_detector(50, 101, dev)
-tr = SGDTrainer(det, lr=0.0025)
-_, d = bench.make_batch(2, 7, 1234, dev)
-for _ in range(3):
-    tr.step(d)
-torch.cuda.synchronize()
-pr = cProfile.Profile()
-pr.enable()
-for _ in range(5):
-    tr.step(d)
-pr.disable()
-torch.cuda.synchronize()
-st = pstats.Stats(pr)
-st.sort_stats('tottime').print_stats(45)
-st.sort_stats('cumulative').print_stats(35)
+def main():
+    mode = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    dev = torch.device('cuda:0')
+    Y.set_precision(mode)
+    det = model_zoo.build_seeded_ld_detector(50, 101, dev)
+    tr = SGDTrainer(det, lr=model_zoo.OPTIMIZER['lr'])
+    b = [bench.make_batch(2, g, 4321 + g, dev)[1] for g in (7, 5)]
+    for i in range(6):
+        tr.step(b[i % 2], next_data=b[(i + 1) % 2])
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(steps):
+        tr.step(b[i % 2], next_data=b[(i + 1) % 2])
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats('tottime')
+    print(f'# {steps} eager {mode} steps; times are totals over the steps')
+    st.print_stats(45)
+
+
+if __name__ == '__main__':
+    main()
