@@ -290,7 +290,7 @@ PMC_CONV = {
     'fp32': dict(file='profiles/r06_pmc_traffic_conv_step_fp32_by_kernel.txt',
                  dispatches=324, fetch=24.261e9, write=9.625e9),
     'bf16': dict(file='profiles/r06_pmc_traffic_conv_step_bf16_by_kernel.txt',
-                 dispatches=282, fetch=11.024e9, write=9.081e9),
+                 dispatches=282, fetch=10.700e9, write=7.454e9),
 }
 
 
@@ -834,6 +834,12 @@ def main():
                 'ms_per_step_k_step_bracket': dtb / args.steps * 1e3,
                 'host_enqueue_ms_per_step': tenqb / args.steps * 1e3,
                 'last_loss': lossb, 'dtype': 'bf16 operands / f32 accumulate',
+                'stepper': 'eager (Python issues every launch)',
+                # round 6: the GPU side of this step fell to ~10.9 ms, the eager
+                # host loop needs 9-11 ms on one core: where the two meet this leg
+                # is HOST-bound (enqueue time == step time) and noisy with the host;
+                # the same step re-issued by the C launch loop is step_list.bf16
+                'host_bound': bool(tenqb >= 0.95 * dtb),
             }
             if roofb is not None:
                 if gflop_per_img is not None:
