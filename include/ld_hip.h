@@ -861,23 +861,6 @@ int ld_gn_backward_c8_lean(const ld_levels_t* lv, const float* dy, const float* 
                            const float* rstd, int N, int C, int G, int relu, float* dx,
                            void* dx_c8, float* dgamma, float* dbeta, int accumulate,
                            void* workspace, size_t workspace_bytes, ld_stream_t stream);
-/* GroupNorm (+ ReLU) whose INPUT is given only as the bf16 C8 image
- * (N, C/8, P, 8) of the conv result (round 6, bf16 mode: the tower conv then writes
- * 2 instead of 4 bytes per element and the four norm passes read half as much).
- * Needs C == 8 * G (a group = one C8 block), P % 4 == 0, 16-byte aligned tensors
- * (LD_EUNSUPPORTED otherwise).  The norm sees the conv result rounded to bf16.
- * Forward: y (fp32) may be NULL, y_c8 is always written; workspace =
- * ld_gn_forward_workspace_bytes.  Backward: the lean form (ReLU mask recomputed
- * from the image, dx may be NULL); workspace = ld_gn_backward_workspace_bytes. */
-int ld_gn_forward_c8in(const ld_levels_t* lv, const void* x_c8, const float* gamma,
-                       const float* beta, int N, int C, int G, float eps, int relu,
-                       float* y, void* y_c8, float* mean, float* rstd, void* workspace,
-                       size_t workspace_bytes, ld_stream_t stream);
-int ld_gn_backward_c8in(const ld_levels_t* lv, const float* dy, const void* x_c8,
-                        const float* gamma, const float* beta, const float* mean,
-                        const float* rstd, int N, int C, int G, int relu, float* dx,
-                        void* dx_c8, float* dgamma, float* dbeta, int accumulate,
-                        void* workspace, size_t workspace_bytes, ld_stream_t stream);
 /* MaxPool2d(kernel 3, stride 2, pad 1) on rows = N*C planes (resnet.py:570);
  * forward only (the stem is frozen, frozen_stages=1). */
 int ld_maxpool3x3s2(const float* x, int rows, int H, int W, float* y,

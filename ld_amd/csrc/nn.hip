@@ -1099,219 +1099,6 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     dx[idx] = out[0];
 }
 
-// ---- GroupNorm on a C8-image INPUT (round 6) ---------------------------------
-// The conv that feeds a tower's norm then writes its result ONLY as the bf16 C8
-// image (half the bytes of the fp32 tensor, written once and read by the statistics
-// pass, the apply pass and both backward passes).  C / G == 8: a group IS one C8
-// block, i.e. one contiguous (P, 8) bf16 slab per (image, group).  The norm sees
-// the conv result rounded to bf16 -- the rounding its OUTPUT gets anyway on the way
-// into the next conv.  Forward and backward use the same fp32 value of each element
-// (the converted image), so the lean backward's recomputed ReLU mask is exact.
-__global__ __launch_bounds__(256) void gn_stats_partial_c8in_kernel(
-    const gn_uintx4* __restrict__ x8, Levels lv, int G, double* __restrict__ partial) {
-  const int L = lv.num_levels;
-  int per_ng = 0;
-#pragma unroll
-  for (int i = 0; i < LD_MAX_LEVELS; ++i)
-    if (i < L) per_ng += gn_slices(lv.off[i + 1] - lv.off[i]);
-  const int ng = blockIdx.x / per_ng;
-  int sp = blockIdx.x - ng * per_ng, l = 0;
-#pragma unroll
-  for (int i = 0; i < LD_MAX_LEVELS - 1; ++i) {
-    const int c = i < L ? gn_slices(lv.off[i + 1] - lv.off[i]) : 0;
-    if (l == i && i + 1 < L && sp >= c) {
-      sp -= c;
-      l = i + 1;
-    }
-  }
-  const int ngl = ng * L + l;  // ng = n * G + g
-  const int A = lv.off[l + 1] - lv.off[l];
-  const gn_uintx4* base = x8 + (size_t)ng * lv.P + lv.off[l];
-  const int per = gn_slice_len(A);
-  const int beg = sp * per, end = min(A, beg + per);
-  double s = 0.0, q = 0.0;
-  for (int p = beg + threadIdx.x; p < end; p += 256) {
-    const gn_floatx8 f =
-        __builtin_convertvector(__builtin_bit_cast(gn_bf16x8, base[p]), gn_floatx8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const double v = f[e];
-      s += v;
-      q += v * v;
-    }
-  }
-  block_sum2(s, q);
-  if (threadIdx.x == 0) {
-    double* const slot = partial + ((size_t)ngl * kGnSplit + sp) * 2;
-    slot[0] = s;
-    slot[1] = q;
-  }
-}
-
-struct GnLvTab {
-  float mu[LD_MAX_LEVELS], rs[LD_MAX_LEVELS];
-};
-__device__ __forceinline__ void gn_lv_load(GnLvTab& t, const float* __restrict__ mean,
-                                           const float* __restrict__ rstd, size_t ob,
-                                           int L) {
-#pragma unroll
-  for (int l = 0; l < LD_MAX_LEVELS; ++l) {
-    const size_t o = ob + (l < L ? l : 0);  // wave-uniform: scalar loads
-    t.mu[l] = mean[o];
-    t.rs[l] = rstd[o];
-  }
-}
-__device__ __forceinline__ void gn_lv_pick(const GnLvTab& t, int l, float& mu, float& rs) {
-  mu = t.mu[0];
-  rs = t.rs[0];
-#pragma unroll
-  for (int i = 1; i < LD_MAX_LEVELS; ++i)
-    if (l == i) {
-      mu = t.mu[i];
-      rs = t.rs[i];
-    }
-}
-
-__global__ __launch_bounds__(256) void gn_apply_c8in_kernel(
-    const gn_uintx4* __restrict__ x8, Levels lv, int C,
-    const float* __restrict__ mean, const float* __restrict__ rstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-    float* __restrict__ y, gn_uintx4* __restrict__ y_c8) {
-  const int C8 = C >> 3;
-  const int blk = blockIdx.y;  // n * C8 + c8 = n * G + g
-  const int c8 = blk % C8, n = blk / C8;
-  const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (p >= lv.P) return;
-  const int L = lv.num_levels;
-  const int l0 = level_of_pos(lv, p), l3 = level_of_pos(lv, p + 3);
-  GnLvTab tab;
-  gn_lv_load(tab, mean, rstd, (size_t)blk * L, L);
-  gn_uintx4 q[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) q[k] = x8[(size_t)blk * lv.P + p + k];
-  float out[8][4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    float mu, rs;
-    gn_lv_pick(tab, l0 == l3 ? l0 : level_of_pos(lv, p + k), mu, rs);
-    const gn_floatx8 f =
-        __builtin_convertvector(__builtin_bit_cast(gn_bf16x8, q[k]), gn_floatx8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = gn_affine(f[e], mu, rs, gamma[c8 * 8 + e], beta[c8 * 8 + e]);
-      if (relu) v = fmaxf(v, 0.f);
-      out[e][k] = v;
-    }
-  }
-  if (y) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-      *reinterpret_cast<float4*>(y + ((size_t)n * C + c8 * 8 + e) * lv.P + p) =
-          make_float4(out[e][0], out[e][1], out[e][2], out[e][3]);
-  }
-  store_c8x4(y_c8 + (size_t)blk * lv.P + p, out);
-}
-
-// backward pass A on the C8 input: one workgroup per (image, group, position slice)
-// and all levels; a thread = one position x the group's 8 channels (one 16-byte
-// image row + 8 coalesced dy cells).  Writes slice `sp` of every (row, level):
-// gn_bwd_fold_kernel sums the slices.
-__global__ __launch_bounds__(256) void gn_bwd_reduce_c8in_kernel(
-    const float* __restrict__ dy, const gn_uintx4* __restrict__ x8, Levels lv, int C,
-    const float* __restrict__ mean, const float* __restrict__ rstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-    double* __restrict__ sums) {
-  const int C8 = C >> 3, L = lv.num_levels;
-  const int sp = blockIdx.x % kGnBwdSplit, blk = blockIdx.x / kGnBwdSplit;
-  const int c8 = blk % C8, n = blk / C8;
-  float ga[8], be[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    ga[e] = gamma[c8 * 8 + e];
-    be[e] = beta[c8 * 8 + e];
-  }
-  for (int l = 0; l < L; ++l) {
-    const int A = lv.off[l + 1] - lv.off[l];
-    const int per = max((A + kGnBwdSplit - 1) / kGnBwdSplit, 1024);
-    const int beg = sp * per, end = min(A, beg + per);
-    const float mu = mean[(size_t)blk * L + l], rs = rstd[(size_t)blk * L + l];
-    double s1[8], s2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.0;
-    for (int p = beg + threadIdx.x; p < end; p += 256) {
-      const int pos = lv.off[l] + p;
-      const gn_floatx8 f = __builtin_convertvector(
-          __builtin_bit_cast(gn_bf16x8, x8[(size_t)blk * lv.P + pos]), gn_floatx8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float dz = dy[((size_t)n * C + c8 * 8 + e) * lv.P + pos];
-        if (relu && !(gn_affine(f[e], mu, rs, ga[e], be[e]) > 0.f)) dz = 0.f;
-        s1[e] += (double)dz;
-        s2[e] += (double)(dz * ((f[e] - mu) * rs));
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      block_sum2(s1[e], s2[e]);
-      if (threadIdx.x == 0) {
-        const size_t at =
-            (((size_t)(n * C + c8 * 8 + e) * L + l) * kGnBwdSplit + sp) * 2;
-        sums[at + 0] = s1[e];
-        sums[at + 1] = s2[e];
-      }
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void gn_bwd_apply_c8in_kernel(
-    const float* __restrict__ dy, const gn_uintx4* __restrict__ x8, Levels lv, int C,
-    const float* __restrict__ mean, const float* __restrict__ rstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ gm, int relu, float* __restrict__ dx,
-    gn_uintx4* __restrict__ dx_c8) {
-  const int C8 = C >> 3;
-  const int blk = blockIdx.y;
-  const int c8 = blk % C8, n = blk / C8;
-  const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (p >= lv.P) return;
-  const int L = lv.num_levels;
-  const int l0 = level_of_pos(lv, p), l3 = level_of_pos(lv, p + 3);
-  GnRowTab tab;
-  gn_load_tab(tab, mean, rstd, gm, (size_t)blk * L, L);
-  float4 t0[8];
-  gn_uintx4 q[4];
-#pragma unroll
-  for (int e = 0; e < 8; ++e)
-    t0[e] = *reinterpret_cast<const float4*>(dy + ((size_t)n * C + c8 * 8 + e) * lv.P + p);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) q[k] = x8[(size_t)blk * lv.P + p + k];
-  float out[8][4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    float mu, rs, fm1, fm2;
-    gn_pick(tab, l0 == l3 ? l0 : level_of_pos(lv, p + k), mu, rs, fm1, fm2);
-    const gn_floatx8 f =
-        __builtin_convertvector(__builtin_bit_cast(gn_bf16x8, q[k]), gn_floatx8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float ga = gamma[c8 * 8 + e];
-      const float a_dy = k == 0 ? t0[e].x : k == 1 ? t0[e].y : k == 2 ? t0[e].z : t0[e].w;
-      float dz = a_dy;
-      if (relu && !(gn_affine(f[e], mu, rs, ga, beta[c8 * 8 + e]) > 0.f)) dz = 0.f;
-      const float xh = (f[e] - mu) * rs;
-      out[e][k] = rs * (ga * dz - fm1 - xh * fm2);
-    }
-  }
-  if (dx) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-      *reinterpret_cast<float4*>(dx + ((size_t)n * C + c8 * 8 + e) * lv.P + p) =
-          make_float4(out[e][0], out[e][1], out[e][2], out[e][3]);
-  }
-  store_c8x4(dx_c8 + (size_t)blk * lv.P + p, out);
-}
-
-
 namespace old_r5 {
 template <int V>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
@@ -2135,76 +1922,6 @@ extern "C" int ld_gn_backward_c8_lean(const ld_levels_t* lv, const float* dy,
   return gn_backward_impl(lv, dy, nullptr, x, gamma, beta, mean, rstd, N, C, G, relu,
                           dx, dx_c8, dgamma, dbeta, accumulate, workspace,
                           workspace_bytes, stream);
-}
-
-// GroupNorm (+ ReLU) of a conv result given ONLY as its bf16 C8 image (round 6, see
-// the kernels): C / G == 8, P % 4 == 0, 16-byte aligned tensors.  y (fp32) may be
-// NULL; y_c8 is always written.  Workspace: ld_gn_forward_workspace_bytes.
-extern "C" int ld_gn_forward_c8in(const ld_levels_t* lv, const void* x_c8,
-                                  const float* gamma, const float* beta, int N, int C,
-                                  int G, float eps, int relu, float* y, void* y_c8,
-                                  float* mean, float* rstd, void* workspace,
-                                  size_t workspace_bytes, ld_stream_t stream) {
-  if (int e = check_levels(lv)) return e;
-  if (!x_c8 || !gamma || !beta || !y_c8 || !mean || !rstd || N < 1 || C < 8 || G < 1)
-    return LD_EINVAL;
-  if (!workspace || workspace_bytes < ld_gn_forward_workspace_bytes(lv, N, G))
-    return LD_ENOSPACE;
-  const Levels k = make_levels(lv);
-  if (C != G * 8 || k.P % 4 != 0 ||
-      ((uintptr_t)x_c8 | (uintptr_t)(y ? y : (float*)y_c8) | (uintptr_t)y_c8) % 16 != 0)
-    return LD_EUNSUPPORTED;
-  const int ngl = N * G * k.num_levels;
-  int per_ng = 0;
-  for (int l = 0; l < k.num_levels; ++l) per_ng += gn_slices(k.off[l + 1] - k.off[l]);
-  LD_LAUNCH(gn_stats_partial_c8in_kernel, dim3(N * G * per_ng), dim3(256), 0, LD_STREAM,
-                     (const gn_uintx4*)x_c8, k, G, (double*)workspace);
-  LD_LAUNCH(gn_stats_final_kernel, dim3((ngl + 255) / 256), dim3(256), 0,
-                     LD_STREAM, (const double*)workspace, k, N, C, G, eps, mean,
-                     rstd);
-  LD_LAUNCH(gn_apply_c8in_kernel, dim3((k.P / 4 + 255) / 256, N * (C / 8)), dim3(256),
-                     0, LD_STREAM, (const gn_uintx4*)x_c8, k, C, mean, rstd, gamma,
-                     beta, relu, y, (gn_uintx4*)y_c8);
-  return (int)hipGetLastError();
-}
-
-// ... and its backward: the lean form (ReLU mask recomputed from the image, dx
-// optional).  Workspace: ld_gn_backward_workspace_bytes.
-extern "C" int ld_gn_backward_c8in(const ld_levels_t* lv, const float* dy,
-                                   const void* x_c8, const float* gamma,
-                                   const float* beta, const float* mean,
-                                   const float* rstd, int N, int C, int G, int relu,
-                                   float* dx, void* dx_c8, float* dgamma, float* dbeta,
-                                   int accumulate, void* workspace,
-                                   size_t workspace_bytes, ld_stream_t stream) {
-  if (int e = check_levels(lv)) return e;
-  if (!dy || !x_c8 || !gamma || !beta || !mean || !rstd || !dx_c8 || N < 1 || C < 8 ||
-      G < 1)
-    return LD_EINVAL;
-  if (!workspace || workspace_bytes < ld_gn_backward_workspace_bytes(lv, N, C))
-    return LD_ENOSPACE;
-  const Levels k = make_levels(lv);
-  if (C != G * 8 || k.P % 4 != 0 ||
-      ((uintptr_t)dy | (uintptr_t)x_c8 | (uintptr_t)(dx ? dx : dy) | (uintptr_t)dx_c8) %
-              16 != 0)
-    return LD_EUNSUPPORTED;
-  double* sums = (double*)workspace;
-  float* gm = (float*)((char*)workspace + gn_bwd_sums_bytes(k.num_levels, N, C));
-  const int rl = N * C * k.num_levels, ngl = N * G * k.num_levels;
-  LD_LAUNCH(gn_bwd_reduce_c8in_kernel, dim3(N * (C / 8) * kGnBwdSplit), dim3(256), 0,
-                     LD_STREAM, dy, (const gn_uintx4*)x_c8, k, C, mean, rstd, gamma, beta,
-                     relu, sums);
-  LD_LAUNCH(gn_bwd_fold_kernel, dim3((rl + 255) / 256), dim3(256), 0, LD_STREAM, sums,
-                     rl);
-  LD_LAUNCH(gn_bwd_group_kernel, dim3((ngl + 255) / 256), dim3(256), 0, LD_STREAM, sums,
-                     k, N, C, G, gamma, gm);
-  LD_LAUNCH(gn_bwd_apply_c8in_kernel, dim3((k.P / 4 + 255) / 256, N * (C / 8)),
-                     dim3(256), 0, LD_STREAM, dy, (const gn_uintx4*)x_c8, k, C, mean, rstd,
-                     gamma, beta, gm, relu, dx, (gn_uintx4*)dx_c8);
-  if (dgamma && dbeta)
-    LD_LAUNCH(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, LD_STREAM, sums,
-                       N, C, k.num_levels, dgamma, dbeta, accumulate);
-  return (int)hipGetLastError();
 }
 
 extern "C" int ld_maxpool3x3s2(const float* x, int rows, int H, int W, float* y,

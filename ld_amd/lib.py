@@ -363,11 +363,6 @@ SIGNATURES = {
     'ld_gn_backward_c8_lean': (C.c_int, [_LV, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
                                          _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
                                          _vp, _sz, _vp]),
-    'ld_gn_forward_c8in': (C.c_int, [_LV, _vp, _vp, _vp, _i32, _i32, _i32, _f32,
-                                     _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'ld_gn_backward_c8in': (C.c_int, [_LV, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
-                                      _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
-                                      _vp, _sz, _vp]),
     'ld_gn_backward_workspace_bytes': (_sz, [_LV, _i32, _i32]),
     'ld_gn_backward': (C.c_int, [_LV, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
                                  _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp,
