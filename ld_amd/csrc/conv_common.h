@@ -188,8 +188,16 @@ void ld_tune_store(const LdTuneKey& key, const LdTuneCfg& cfg);
 
 namespace {
 inline LdTuneKey make_tune_key(int mode, int family, const ConvK& k) {
+  // a residual is a residual whether it arrives as fp32 or as a C8 image (round 6: the
+  // trainable trunk hands C8 images on, and its conv3 launches must keep finding their
+  // tuned rows); LD_TUNE_KEY_RESC8=0: the key of rounds 2-5 (fp32 residual only)
+  static const bool resc8 = [] {
+    const char* e = getenv("LD_TUNE_KEY_RESC8");
+    return !(e && e[0] == '0');
+  }();
+  const bool res = k.residual != nullptr || (resc8 && k.res_c8 != nullptr);
   return LdTuneKey{{mode, k.Cin, k.Cout, k.KH, k.KW, k.g.stride, k.g.pad, k.J,
                     k.g.num_levels, k.g.lv[0].Hin, k.g.lv[0].Win, k.ph, k.pw, k.relu,
-                    k.residual != nullptr && !k.tune_plain, k.scale != nullptr, family, 0}};
+                    res && !k.tune_plain, k.scale != nullptr, family, 0}};
 }
 }  // namespace
