@@ -1,11 +1,9 @@
 #!/bin/bash
-# round 6, last session: PMC traffic of the bf16 conv kernels and the judged numbers again
+# round 6, last session: the judged numbers again
 # on the build with the re-tuned C8 shape table (bench line, bf16 profiles, step lists,
 # smoke, whole GPU suite)
 mkdir -p gpurun_out; export TMPDIR=/tmp
 O=gpurun_out; R=$GRAFT_REPO_ROOT
-PMC_BY_KERNEL=1 timeout 900 tools/pmc_traffic.sh r06_conv_step_bf16_by_kernel "conv_|bottleneck" -- python $R/tools/profile_step.py --mode bf16 --serial --steps 4 --warmup 2 > $O/r6pmc_bf16.log 2>&1
-python tools/pmc_conv_bytes.py $O/pmc_traffic_r06_conv_step_bf16_by_kernel.txt 7
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r06_bench_final.json 2> $O/r06f_bench.err; echo bench rc=$?
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/r06f_serialb -o step -- python $R/tools/profile_step.py --mode bf16 --serial --steps 8 --warmup 2 > $R/$O/r06f_serialb.log 2>&1)
 f=$(find $O/r06f_serialb -name '*kernel_stats.csv' | head -1); cp "$f" $O/r06_rocprof_kernel_stats_bf16_serial.csv; rm -rf $O/r06f_serialb
