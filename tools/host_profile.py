@@ -1,5 +1,7 @@
 """cProfile of the host side of eager train steps (where the Python time of the
-~500 launches per step goes).
+~500 launches per step goes).  The autograd engine is held to the calling thread
+(torch.autograd.set_multithreading_enabled(False)) so that the backward's Python
+shows up in the profile.
     python tools/host_profile.py [fp32|bf16] [steps]"""
 import cProfile
 import os
@@ -27,15 +29,21 @@ def main():
         tr.step(b[i % 2], next_data=b[(i + 1) % 2])
     torch.cuda.synchronize()
     pr = cProfile.Profile()
-    pr.enable()
-    for i in range(steps):
-        tr.step(b[i % 2], next_data=b[(i + 1) % 2])
-    pr.disable()
+    with torch.autograd.set_multithreading_enabled(False):
+        for i in range(2):
+            tr.step(b[i % 2], next_data=b[(i + 1) % 2])
+        torch.cuda.synchronize()
+        pr.enable()
+        for i in range(steps):
+            tr.step(b[i % 2], next_data=b[(i + 1) % 2])
+        pr.disable()
     torch.cuda.synchronize()
     st = pstats.Stats(pr)
     st.sort_stats('tottime')
     print(f'# {steps} eager {mode} steps; times are totals over the steps')
-    st.print_stats(45)
+    st.print_stats(60)
+    st.sort_stats('cumulative')
+    st.print_stats(35)
 
 
 if __name__ == '__main__':
