@@ -97,7 +97,9 @@ def test_bf16_conv_fwd_bwd(case, wgrad, bf16_mode, monkeypatch):
     y, _ = Y.conv2d(xd, wd, bd, stride, pad, levels)
     _close(y, ref, what=name + ' fwd')
     y.backward(go.to(dev))
-    if cout % 16 == 0:
+    if cout % 16 == 0 or Y._PAD_DGRAD[0]:
+        # (round 6: a reduction that is not a multiple of 16 -- 68 output
+        # channels -- runs the bf16 kernel on a zero-padded dY)
         _close(xd.grad, xr.grad, what=name + ' dgrad')
     else:  # the fp32 kernel ran (reduction not a multiple of 16): exact operands
         xe = x.clone().requires_grad_(True)
@@ -713,6 +715,38 @@ def test_trunk_c8_scope_outputs_only_images(bf16_mode):
     # measured 2.2 %; the whole-step effect is test_bf16_train_step_vs_fp32_golden's)
     for u, v in zip(g0, g1):
         assert float((u - v).norm()) <= 5e-2 * float(u.norm())
+
+
+def test_padded_data_gradient_for_68_output_channels(bf16_mode):
+    """Round 6: the data gradient of a conv whose Cout is not a multiple of 16
+    (gfl_reg, 68 corner logits) takes the bf16 kernel on a zero-padded dY (the
+    weight image is zero-padded to 16 channels anyway) instead of the fp32 kernel.
+    Against the fp32 kernel (LD_PAD_DGRAD=0): equal to bf16 operand rounding; the
+    weight and bias gradients do not change at all."""
+    from ld_amd import layers as Y
+    dev = _dev()
+    g = torch.Generator().manual_seed(31)
+    levels = ((12, 20), (6, 10), (3, 5), (2, 3), (1, 2))
+    P = sum(h * w for h, w in levels)
+    base = [torch.randn(2, 256, P, generator=g),
+            torch.randn(68, 256, 3, 3, generator=g) * 0.02,
+            torch.randn(68, generator=g)]
+    go = torch.randn(2, 68, P, generator=g).to(dev)
+    outs = []
+    for pad in (False, True):
+        Y._PAD_DGRAD[0] = pad
+        try:
+            x, w, b = (t.to(dev).requires_grad_(True) for t in base)
+            y, _ = Y.conv2d(x, w, b, 1, 1, levels)
+            y.backward(go)
+            torch.cuda.synchronize()
+        finally:
+            Y._PAD_DGRAD[0] = True
+        outs.append((y.detach(), x.grad, w.grad, b.grad))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    assert not torch.equal(a[1], b[1])
+    assert float((a[1] - b[1]).norm()) <= 1e-2 * float(a[1].norm())
 
 
 def test_bf16_wgrad_vectorised_loads_same_bits(bf16_mode, monkeypatch):
