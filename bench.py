@@ -290,7 +290,7 @@ PMC_CONV = {
     'fp32': dict(file='profiles/r06_pmc_traffic_conv_step_fp32_by_kernel.txt',
                  dispatches=324, fetch=24.261e9, write=9.625e9),
     'bf16': dict(file='profiles/r06_pmc_traffic_conv_step_bf16_by_kernel.txt',
-                 dispatches=282, fetch=10.685e9, write=7.455e9),
+                 dispatches=282, fetch=10.691e9, write=7.453e9),
 }
 
 
